@@ -1,0 +1,388 @@
+"""CPU oracle for the DepthG correlation-loss hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a restatement, written from the maths in SURVEY.md section 9, of what the
+reference computes on the path `ContrastiveCorrelationLoss.forward` and its helpers.  It is
+the *checker* used by `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py`.  Nothing in the product package (`depthg_amd/`) may import it.
+
+Pinning: the reference ships no tests, known-answer vectors or fixtures for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference itself,
+imported on CPU in the build container by `tests/golden/make_fixtures.py` and stored as
+`tests/golden/*.npz`.  `tests/test_oracle_golden.py` checks every function below against them.
+
+Arithmetic is float32 on torch-CPU / numpy, like the reference.  The third-party pieces the
+reference leans on (`F.normalize`, `einsum`, `F.grid_sample`, `F.interpolate`,
+`F.adaptive_avg_pool2d`, numpy argmax/minimum) are restated from their published definitions
+instead of being called, so that the HIP kernels have an explicit formula to follow.
+
+Every function cites the reference lines it follows (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+EPS_NORM = 1e-10  # src/modules.py:790
+
+
+# --------------------------------------------------------------------------------------
+# A1  norm                                                             src/modules.py:789-790
+# --------------------------------------------------------------------------------------
+def norm(t: torch.Tensor) -> torch.Tensor:
+    """L2-normalise over dim 1: t / max(||t||_2, 1e-10)."""
+    n = t.square().sum(dim=1, keepdim=True).sqrt()
+    return t / n.clamp_min(EPS_NORM)
+
+
+# --------------------------------------------------------------------------------------
+# A2/A3  tensor_correlation / depth_correlation                        src/modules.py:797-814
+# --------------------------------------------------------------------------------------
+def tensor_correlation(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """out[n,h,w,i,j] = sum_c a[n,c,h,w] * b[n,c,i,j]  (a batched (P x C)(C x P) product)."""
+    n, c, h, w = a.shape
+    _, _, i, j = b.shape
+    am = a.reshape(n, c, h * w).transpose(1, 2)  # (n, P1, c)
+    bm = b.reshape(n, c, i * j)                  # (n, c, P2)
+    return torch.bmm(am, bm).reshape(n, h, w, i, j)
+
+
+depth_correlation = tensor_correlation  # same contraction with c == 1 (src/modules.py:812-814)
+
+
+# --------------------------------------------------------------------------------------
+# A6  sample = grid_sample(t, coords.permute(0,2,1,3), bilinear, border, align_corners=True)
+#                                                                      src/modules.py:822-825
+# --------------------------------------------------------------------------------------
+def bilinear_taps(coords: torch.Tensor, h: int, w: int):
+    """Tap positions/weights of `sample` for coords (B,S,S,2) in [-1,1].
+
+    Returns (x0, y0, x1, y1, wx1, wy1) each shaped (B,S,S) *in output order* (i, j), i.e.
+    already including the (0,2,1,3) permute: output position (i, j) reads
+    x = coords[b, j, i, 0] (width axis), y = coords[b, j, i, 1] (height axis)  (quirk Q3).
+    Unnormalise with align_corners=True: ((c + 1) / 2) * (size - 1); clip to [0, size-1]
+    (padding_mode='border'); taps floor / floor+1, the +1 tap is dropped when outside.
+    """
+    g = coords.permute(0, 2, 1, 3).to(torch.float32)
+    x = ((g[..., 0] + 1.0) / 2.0) * float(w - 1)
+    y = ((g[..., 1] + 1.0) / 2.0) * float(h - 1)
+    x = x.clamp(0.0, float(w - 1))
+    y = y.clamp(0.0, float(h - 1))
+    x0 = x.floor()
+    y0 = y.floor()
+    wx1 = x - x0
+    wy1 = y - y0
+    x0 = x0.long()
+    y0 = y0.long()
+    return x0, y0, x0 + 1, y0 + 1, wx1, wy1
+
+
+def sample(t: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """t (B,K,h,w), coords (B,S,S,2) -> (B,K,S,S)."""
+    b, k, h, w = t.shape
+    x0, y0, x1, y1, wx1, wy1 = bilinear_taps(coords, h, w)
+    wx0 = 1.0 - wx1
+    wy0 = 1.0 - wy1
+    s1, s2 = x0.shape[1], x0.shape[2]
+    flat = t.reshape(b, k, h * w)
+
+    def tap(yy, xx, wgt):
+        inside = ((xx <= w - 1) & (yy <= h - 1)).to(t.dtype)
+        idx = (yy.clamp(max=h - 1) * w + xx.clamp(max=w - 1)).reshape(b, 1, s1 * s2).expand(b, k, s1 * s2)
+        v = torch.gather(flat, 2, idx).reshape(b, k, s1, s2)
+        return v * (wgt * inside).unsqueeze(1)
+
+    out = tap(y0, x0, wy0 * wx0) + tap(y0, x1, wy0 * wx1) + tap(y1, x0, wy1 * wx0) + tap(y1, x1, wy1 * wx1)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# F.interpolate(d, size, mode='bilinear', align_corners=True)          src/modules.py:1261-1262
+# --------------------------------------------------------------------------------------
+def interpolate_bilinear_ac(d: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    b, c, hin, win = d.shape
+    hout, wout = size
+
+    def axis(nin, nout):
+        scale = np.float32(nin - 1) / np.float32(nout - 1) if nout > 1 else np.float32(0.0)
+        src = torch.arange(nout, dtype=torch.float32) * float(scale)
+        i0 = src.floor().long().clamp(max=nin - 1)
+        i1 = torch.where(i0 < nin - 1, i0 + 1, i0)
+        l1 = src - i0.to(torch.float32)
+        return i0, i1, 1.0 - l1, l1
+
+    y0, y1, ly0, ly1 = axis(hin, hout)
+    x0, x1, lx0, lx1 = axis(win, wout)
+    top = d[:, :, y0][:, :, :, x0] * lx0 + d[:, :, y0][:, :, :, x1] * lx1
+    bot = d[:, :, y1][:, :, :, x0] * lx0 + d[:, :, y1][:, :, :, x1] * lx1
+    return top * ly0.view(1, 1, -1, 1) + bot * ly1.view(1, 1, -1, 1)
+
+
+# --------------------------------------------------------------------------------------
+# F.adaptive_avg_pool2d(depth, (h, w))                                 src/modules.py:1003
+# --------------------------------------------------------------------------------------
+def adaptive_avg_pool2d(d: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    b, c, hin, win = d.shape
+    hout, wout = size
+    out = torch.empty(b, c, hout, wout, dtype=d.dtype)
+    for i in range(hout):
+        ys, ye = (i * hin) // hout, -((-(i + 1) * hin) // hout)
+        for j in range(wout):
+            xs, xe = (j * win) // wout, -((-(j + 1) * win) // wout)
+            out[:, :, i, j] = d[:, :, ys:ye, xs:xe].sum(dim=(2, 3)) / float((ye - ys) * (xe - xs))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A9  depth2points                                                     src/modules.py:988-996
+# --------------------------------------------------------------------------------------
+def fov_factor(fov: float = 90.0) -> torch.Tensor:
+    """2*tan(fov/2) with fov taken in RADIANS (quirk Q5), float32."""
+    return 2.0 * torch.tan(torch.tensor([fov], dtype=torch.float32) / 2.0)
+
+
+def depth2points(depth: torch.Tensor, fov: float = 30.0, far: float = 5.0) -> torch.Tensor:
+    """depth (h,w) -> (3,h,w) = [X, Y, Z];  X,Y = factor*d*(idx - n/2)/n, Z = -d*far."""
+    h, w = depth.shape[-2], depth.shape[-1]
+    factor = fov_factor(fov).to(depth.dtype)
+    rows = torch.arange(h).view(h, 1).expand(h, w)
+    cols = torch.arange(w).view(1, w).expand(h, w)
+    y = factor * depth * (rows - h / 2.0) / h
+    x = factor * depth * (cols - w / 2.0) / w
+    return torch.stack([x, y, -depth * far])
+
+
+# --------------------------------------------------------------------------------------
+# A10  fps                                                             src/modules.py:939-985
+# --------------------------------------------------------------------------------------
+def fps(points, n_samples: int) -> np.ndarray:
+    """Farthest point sampling, start at index 0, squared-L2 in float32, first-max ties.
+
+    Returns the `n_samples` selected indices in selection order.  Restated without
+    `np.delete`: a boolean `left` mask plays the role of `points_left`; since the reference's
+    `points_left` stays in ascending order, "first max over points_left" == "lowest original
+    index among the maxima of the unselected points".
+    """
+    pts = np.asarray(points, dtype=np.float32)
+    n = pts.shape[0]
+    left = np.ones(n, dtype=bool)
+    dists = np.full(n, np.inf, dtype=np.float64)
+    out = np.zeros(n_samples, dtype=np.int64)
+    out[0] = 0
+    left[0] = False
+    for i in range(1, n_samples):
+        last = pts[out[i - 1]]
+        diff = last[None, :] - pts
+        sq = diff * diff
+        d = (sq[:, 0] + sq[:, 1]) + sq[:, 2]          # float32, x,y,z order
+        dists = np.where(left, np.minimum(d.astype(np.float64), dists), dists)
+        masked = np.where(left, dists, -np.inf)
+        sel = int(np.argmax(masked))
+        out[i] = sel
+        left[sel] = False
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# A11  farthest_point_sampling_depth                                   src/modules.py:999-1037
+# --------------------------------------------------------------------------------------
+def farthest_point_sampling_depth(feat_hw: Tuple[int, int], depth: torch.Tensor, n_samples: int,
+                                  return_inds: bool = False):
+    """depth (B,1,H,W) -> coords (B,S,S,2) in [0,(h-1)/h]: row/h in [...,0], col/w in [...,1].
+
+    The selected *set* is re-emitted in row-major order (quirk Q4).  The caller maps *2-1.
+    """
+    h, w = feat_hw
+    d = adaptive_avg_pool2d(depth, (h, w))
+    coords_all = []
+    inds_all = []
+    for i in range(d.shape[0]):
+        pc = depth2points(d[i, 0], fov=90.0).permute(1, 2, 0).reshape(-1, 3)
+        inds = fps(pc.numpy(), n_samples ** 2)
+        inds_all.append(inds)
+        srt = np.sort(inds)
+        rows = torch.from_numpy((srt // w).astype(np.float32)) / h
+        cols = torch.from_numpy((srt % w).astype(np.float32)) / w
+        coords_all.append(torch.stack([rows, cols], dim=-1).reshape(n_samples, n_samples, 2))
+    coords = torch.stack(coords_all, dim=0)
+    if return_inds:
+        return coords, np.stack(inds_all)
+    return coords
+
+
+# --------------------------------------------------------------------------------------
+# A8  super_perm                                                       src/modules.py:1184-1188
+# --------------------------------------------------------------------------------------
+def super_perm(size: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """randperm with fixed points bumped by one, modulo size (may contain duplicates, Q6)."""
+    perm = torch.randperm(size, generator=generator, dtype=torch.long)
+    return super_perm_from(perm)
+
+
+def super_perm_from(perm: torch.Tensor) -> torch.Tensor:
+    size = perm.numel()
+    bumped = torch.where(perm == torch.arange(size), perm + 1, perm)
+    return bumped % size
+
+
+# --------------------------------------------------------------------------------------
+# A4  helper                                                           src/modules.py:1231-1254
+# --------------------------------------------------------------------------------------
+def clamp_bounds(cfg) -> Tuple[float, Optional[float]]:
+    lo = 0.0 if cfg.zero_clamp else -9999.0
+    hi = 0.8 if cfg.stabalize else None
+    return lo, hi
+
+
+def helper(cfg, f1, f2, c1, c2, shift):
+    with torch.no_grad():
+        fd = tensor_correlation(norm(f1), norm(f2))
+        if cfg.pointwise:
+            old_mean = fd.mean()
+            fd = fd - fd.mean(dim=(3, 4), keepdim=True)
+            fd = fd - fd.mean() + old_mean
+    cd = tensor_correlation(norm(c1), norm(c2))
+    lo, hi = clamp_bounds(cfg)
+    loss = -cd.clamp(lo, hi) * (fd - shift)
+    return loss, cd
+
+
+# --------------------------------------------------------------------------------------
+# A5  depth_feature_correlation                                        src/modules.py:1256-1278
+# --------------------------------------------------------------------------------------
+def depth_feature_correlation(cfg, c1, c2, d1, d2, shift):
+    cd = tensor_correlation(norm(c1), norm(c2))
+    d1 = interpolate_bilinear_ac(d1, tuple(c1.shape[2:]))
+    d2 = interpolate_bilinear_ac(d2, tuple(c2.shape[2:]))
+    dd = depth_correlation(norm(d1), norm(d2))
+    lo, hi = clamp_bounds(cfg)
+    loss = -cd.clamp(lo, hi) * (dd - shift)
+    return loss, dd
+
+
+# --------------------------------------------------------------------------------------
+# A7  ContrastiveCorrelationLoss.forward                               src/modules.py:1280-1367
+# --------------------------------------------------------------------------------------
+def draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos):
+    """Coordinate selection, default branches only (src/modules.py:1290-1321)."""
+    b = orig_feats.shape[0]
+    s = cfg.feature_samples
+    if getattr(cfg, "use_salience", False) or cfg.depth_sampling == "simple":
+        raise NotImplementedError("non-default samplers are outside the hot path (SURVEY section 2 row 3)")
+    if cfg.depth_sampling in ("fps", "fps_depth_feat"):
+        hw = tuple(orig_feats.shape[-2:])
+        c1 = farthest_point_sampling_depth(hw, depth, s) * 2 - 1
+        c2 = farthest_point_sampling_depth(tuple(orig_feats_pos.shape[-2:]), depth_pos, s) * 2 - 1
+        return c1, c2
+    c1 = torch.rand(b, s, s, 2) * 2 - 1
+    c2 = torch.rand(b, s, s, 2) * 2 - 1
+    return c1, c2
+
+
+def forward(cfg, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth=None, depth_pos=None,
+            coords1=None, coords2=None, perms: Optional[Sequence[torch.Tensor]] = None):
+    """Returns the reference's 6- or 8-tuple.  coords/perms may be injected (RNG parity)."""
+    if coords1 is None or coords2 is None:
+        coords1, coords2 = draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos)
+    feats = sample(orig_feats, coords1)
+    code = sample(orig_code, coords1)
+    feats_pos = sample(orig_feats_pos, coords2)
+    code_pos = sample(orig_code_pos, coords2)
+
+    pos_intra_loss, pos_intra_cd = helper(cfg, feats, feats, code, code, cfg.pos_intra_shift)
+    pos_inter_loss, pos_inter_cd = helper(cfg, feats, feats_pos, code, code_pos, cfg.pos_inter_shift)
+    if cfg.depth_feat_correlation_loss:
+        depth_feat_loss, depth_feat_cd = depth_feature_correlation(cfg, code, code, depth, depth, cfg.depth_feat_shift)
+
+    neg_losses, neg_cds = [], []
+    for k in range(cfg.neg_samples):
+        perm = perms[k] if perms is not None else super_perm(orig_feats.shape[0])
+        feats_neg = sample(orig_feats[perm], coords2)
+        code_neg = sample(orig_code[perm], coords2)
+        l, c = helper(cfg, feats, feats_neg, code, code_neg, cfg.neg_inter_shift)
+        neg_losses.append(l)
+        neg_cds.append(c)
+    neg_inter_loss = torch.cat(neg_losses, dim=0)
+    neg_inter_cd = torch.cat(neg_cds, dim=0)
+
+    if cfg.depth_feat_correlation_loss:
+        return (pos_intra_loss.mean(), pos_intra_cd, pos_inter_loss.mean(), pos_inter_cd,
+                neg_inter_loss, neg_inter_cd, depth_feat_loss.mean(), depth_feat_cd)
+    return (pos_intra_loss.mean(), pos_intra_cd, pos_inter_loss.mean(), pos_inter_cd,
+            neg_inter_loss, neg_inter_cd)
+
+
+# --------------------------------------------------------------------------------------
+# A13  caller arithmetic                                    src/train_segmentation.py:303-350
+# --------------------------------------------------------------------------------------
+def total_loss(cfg, out) -> torch.Tensor:
+    pos_intra, pos_inter, neg = out[0].mean(), out[2].mean(), out[4].mean()
+    if cfg.depth_feat_correlation_loss:
+        balance = cfg.lhp_weight if (getattr(cfg, "lhp", False) and getattr(cfg, "lhp_weight_balance", False)) else 0.0
+        return (cfg.pos_inter_weight * pos_inter + cfg.pos_intra_weight * pos_intra +
+                cfg.neg_inter_weight * neg + cfg.depth_feat_weight * out[6].mean()) * (cfg.correspondence_weight - balance)
+    return (cfg.pos_inter_weight * pos_inter + cfg.pos_intra_weight * pos_intra +
+            cfg.neg_inter_weight * neg) * cfg.correspondence_weight
+
+
+# --------------------------------------------------------------------------------------
+# A12  decay schedules                 src/depth_decay_modules.py:4-65, train_segmentation.py:356-375
+# --------------------------------------------------------------------------------------
+def decay_value(kind: str, init, rate: float, update_every: int, min_value, step: int):
+    k = step // update_every
+    if k == 0:
+        return init
+    v = max(init * rate ** k, min_value) if kind == "exp" else max(init - k * rate, min_value)
+    return type(init)(v) if type(v) != type(init) else v
+
+
+def legacy_decay_step(cfg, loss_cfg, global_step: int) -> None:
+    """Mutates cfg / loss_cfg exactly like src/train_segmentation.py:356-375 (incl. quirk Q9)."""
+    if cfg.depth_loss_decay and global_step % cfg.decay_every_steps == 0 and global_step > 0:
+        cfg.depth_feat_weight = cfg.depth_feat_weight * cfg.depth_loss_decay_factor
+        if not cfg.fix_depth_feat_shift:
+            cfg.depth_feat_shift = cfg.depth_feat_shift * cfg.depth_loss_decay_factor
+    if cfg.fps_until_step > 0 and global_step >= cfg.fps_until_step:
+        loss_cfg.depth_sampling = "none"
+        loss_cfg.feature_samples = cfg.post_fps_samples
+    if cfg.fps_sample_decay and global_step % cfg.fps_sample_decay_every_steps == 0:
+        loss_cfg.feature_samples = int(loss_cfg.feature_samples * cfg.fps_sample_decay_factor)
+        if loss_cfg.feature_samples < cfg.fps_min_samples:
+            loss_cfg.feature_samples = cfg.fps_min_samples
+
+
+# --------------------------------------------------------------------------------------
+# helpers shared by tests / bench (not reference functions)
+# --------------------------------------------------------------------------------------
+def default_cfg(**over) -> SimpleNamespace:
+    """Hot-path keys with the defaults of src/configs/local_config.yml."""
+    cfg = SimpleNamespace(
+        feature_samples=11, use_salience=False, depth_sampling="none", fps_gpu=False,
+        pointwise=True, zero_clamp=True, stabalize=False,
+        pos_intra_shift=0.08, pos_inter_shift=0.02, neg_inter_shift=0.66, neg_samples=5,
+        depth_feat_correlation_loss=True, depth_feat_shift=0.03,
+        pos_intra_weight=0.67, pos_inter_weight=0.25, neg_inter_weight=0.63, depth_feat_weight=0.19,
+        correspondence_weight=1.0, lhp=False, lhp_weight=0.2, lhp_weight_balance=False,
+        depth_loss_decay=False, depth_loss_decay_factor=1.0, decay_every_steps=300,
+        fix_depth_feat_shift=False, fps_until_step=0, post_fps_samples=11, fps_sample_decay=False,
+        fps_sample_decay_every_steps=300, fps_sample_decay_factor=0.9, fps_min_samples=0)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def identity_coords(b: int, s: int) -> torch.Tensor:
+    """coords (B,S,S,2) such that `sample` reads pixel (y=j', x=i') ... the dense S==h grid.
+
+    coords[b, u, v, 0] = lin[v], coords[b, u, v, 1] = lin[u]: with the permute inside `sample`
+    output (i, j) reads x = coords[b, j, i, 0] = lin[i], y = coords[b, j, i, 1] = lin[j]
+    -> out[b,:,i,j] = t[b,:,j,i] (an exact spatial transpose, quirk Q3).
+    """
+    lin = torch.linspace(-1.0, 1.0, s)
+    c = torch.empty(b, s, s, 2)
+    c[..., 0] = lin.view(1, 1, s)
+    c[..., 1] = lin.view(1, s, 1)
+    return c

@@ -1,0 +1,156 @@
+"""Pins the CPU oracle (oracle/depthg_oracle.py) against vectors captured from the reference
+itself (tests/golden/*.npz, made by tests/golden/make_fixtures.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FORWARD_CASES, cfg_from_fixture, load_golden
+from oracle import depthg_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, atol=1e-6, rtol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), atol=atol, rtol=rtol)
+
+
+def test_norm(golden_functions):
+    g = golden_functions
+    close(O.norm(T(g["norm_in"])), g["norm_out"], atol=1e-7)
+
+
+def test_tensor_correlation(golden_functions):
+    g = golden_functions
+    close(O.tensor_correlation(T(g["corr_a"]), T(g["corr_b"])), g["corr_out"])
+
+
+def test_sample(golden_functions):
+    g = golden_functions
+    close(O.sample(T(g["sample_t"]), T(g["sample_coords"])), g["sample_out"], atol=2e-6)
+
+
+def test_interpolate(golden_functions):
+    g = golden_functions
+    close(O.interpolate_bilinear_ac(T(g["interp_in"]), (11, 11)), g["interp_out_11"], atol=1e-4, rtol=1e-6)
+
+
+def test_adaptive_pool_nondivisible(golden_functions):
+    g = golden_functions
+    close(O.adaptive_avg_pool2d(T(g["fpsd2_depth"]), (14, 14)), g["pool2_out"], atol=1e-5)
+
+
+def test_depth2points_and_factor(golden_functions):
+    g = golden_functions
+    assert O.fov_factor(90.0).numpy().tobytes() == g["fov_factor"].tobytes()
+    out = O.depth2points(T(g["d2p_depth"]), fov=90)
+    assert np.array_equal(out.numpy(), g["d2p_out"])  # bit exact: same fp32 op order
+
+
+def test_fps_indices(golden_functions):
+    g = golden_functions
+    assert np.array_equal(O.fps(g["fps_points"], 36), g["fps_inds36"])
+    assert np.array_equal(O.fps(g["fps_points_flat"], 25), g["fps_inds_flat25"])  # tie-breaking
+
+
+def test_fps_depth_coords(golden_functions):
+    g = golden_functions
+    for S in (6, 11):
+        c = O.farthest_point_sampling_depth((14, 14), T(g["fpsd_depth"]), S)
+        assert np.array_equal(c.numpy(), g[f"fpsd_coords_S{S}"])
+    c = O.farthest_point_sampling_depth((14, 14), T(g["fpsd2_depth"]), 5)
+    assert np.array_equal(c.numpy(), g["fpsd2_coords_S5"])
+
+
+def test_super_perm(golden_functions):
+    g = golden_functions
+    assert np.array_equal(O.super_perm_from(T(g["randperm_8"])).numpy(), g["superperm_8"])
+    assert np.array_equal(O.super_perm_from(torch.zeros(1, dtype=torch.long)).numpy(), g["superperm_1"])
+    p = g["superperm_8"]
+    assert not np.any(p == np.arange(8))
+
+
+@pytest.mark.parametrize("name,over", [("pw", {}), ("nopw", {"pointwise": False}), ("nozc", {"zero_clamp": False}),
+                                       ("stab", {"stabalize": True})])
+def test_helper(golden_functions, name, over):
+    g = golden_functions
+    cfg = O.default_cfg(**over)
+    loss, cd = O.helper(cfg, T(g["helper_f1"]), T(g["helper_f2"]), T(g["helper_c1"]), T(g["helper_c2"]), 0.3)
+    close(loss, g[f"helper_{name}_loss"], atol=2e-6)
+    close(cd, g[f"helper_{name}_cd"], atol=2e-6)
+
+
+def test_depth_feature_correlation(golden_functions):
+    g = golden_functions
+    cfg = O.default_cfg()
+    c1 = T(g["helper_c1"])
+    loss, dd = O.depth_feature_correlation(cfg, c1, c1, T(g["dfc_depth"]), T(g["dfc_depth"]), 0.03)
+    close(loss, g["dfc_loss"], atol=2e-6)
+    close(dd, g["dfc_dd"], atol=1e-6)
+    assert set(np.unique(g["dfc_dd"])) <= {0.0, 1.0}  # quirk Q1
+
+
+@pytest.mark.parametrize("case", FORWARD_CASES)
+def test_forward_against_reference(case):
+    fx = load_golden(f"forward_{case}.npz")
+    cfg = cfg_from_fixture(fx)
+    code = T(fx["code"]).requires_grad_(True)
+    code_pos = T(fx["code_pos"]).requires_grad_(True)
+    perms = [T(p) for p in fx["perms"]]
+    out = O.forward(cfg, T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), T(fx["depth_pos"]),
+                    coords1=T(fx["coords1"]), coords2=T(fx["coords2"]), perms=perms)
+    close(out[0], fx["pos_intra_loss"], atol=1e-7, rtol=1e-5)
+    close(out[2], fx["pos_inter_loss"], atol=1e-7, rtol=1e-5)
+    close(out[4].mean(), fx["neg_inter_loss_mean"], atol=1e-7, rtol=1e-5)
+    close(out[1].mean(), fx["pos_intra_cd_mean"], atol=1e-7, rtol=1e-5)
+    close(out[5].mean(), fx["neg_inter_cd_mean"], atol=1e-7, rtol=1e-5)
+    sub = int(fx["sub"])
+    names = [("pos_intra_cd", 1), ("pos_inter_cd", 3), ("neg_inter_loss", 4), ("neg_inter_cd", 5)]
+    if cfg.depth_feat_correlation_loss:
+        close(out[6], fx["depth_feat_loss"], atol=1e-7, rtol=1e-5)
+        names.append(("depth_feat_cd", 7))
+    for n, i in names:
+        got = out[i] if bool(fx["store_full"]) else out[i].reshape(-1)[::sub]
+        close(got, fx[n], atol=3e-6, rtol=1e-5)
+    total = O.total_loss(cfg, out)
+    close(total, fx["total"], atol=1e-7, rtol=1e-5)
+    total.backward()
+    gs = max(np.abs(fx["grad_code"]).max(), 1e-12)
+    close(code.grad, fx["grad_code"], atol=2e-6 * gs + 1e-9, rtol=1e-4)
+    close(code_pos.grad, fx["grad_code_pos"], atol=2e-6 * max(np.abs(fx["grad_code_pos"]).max(), 1e-12) + 1e-9, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["c1_fps", "zerodepth_fps", "S9", "S12"])
+def test_forward_fps_coords_regenerated(case):
+    """coords drawn by the oracle's own FPS (not injected) equal the reference's."""
+    fx = load_golden(f"forward_{case}.npz")
+    cfg = cfg_from_fixture(fx)
+    c1, c2 = O.draw_coords(cfg, T(fx["feats"]), T(fx["feats_pos"]), T(fx["depth"]), T(fx["depth_pos"]))
+    assert np.array_equal(c1.numpy(), fx["coords1"])
+    assert np.array_equal(c2.numpy(), fx["coords2"])
+
+
+def test_decay_table_and_traces():
+    d = load_golden("decay.npz")
+    for kind, init, is_int, rate, every, mn, step, val, val_int in d["table"]:
+        init_v = int(init) if is_int else float(init)
+        mn_v = int(mn) if is_int else float(mn)
+        v = O.decay_value("exp" if kind == 0 else "lin", init_v, float(rate), int(every), mn_v, int(step))
+        assert float(v) == pytest.approx(float(val), rel=1e-12, abs=1e-15)
+        assert isinstance(v, int) == bool(val_int)
+    import ast
+    for key in d:
+        if not key.startswith("trace_"):
+            continue
+        name = key[len("trace_"):]
+        r = ast.literal_eval(str(d[f"recipe_{name}"]))
+        cfg = O.default_cfg(**{k: v for k, v in r.items() if k != "max_steps"})
+        want = {int(row[0]): row[1:] for row in d[key]}
+        for step in range(int(r["max_steps"])):
+            O.legacy_decay_step(cfg, cfg, step)
+            if step in want:
+                w = want[step]
+                assert cfg.depth_feat_weight == pytest.approx(w[0], rel=1e-12)
+                assert cfg.depth_feat_shift == pytest.approx(w[1], rel=1e-12)
+                assert cfg.feature_samples == int(w[2])
+                assert (cfg.depth_sampling != "none") == bool(w[3])
