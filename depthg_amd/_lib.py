@@ -1,0 +1,59 @@
+"""ctypes loader for libdepthg_hip.so (C ABI: include/depthg_corr.h).  Fails loudly when the
+library is missing: there is no CPU or eager fallback for the product path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdepthg_hip.so")
+
+DG_OUT_COUNT = 8
+DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS = (1 << i for i in range(6))
+
+EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
+           "dg_corr_materialize", "dg_fps_workspace_bytes", "dg_fps_coords"]
+
+
+class CorrDesc(ctypes.Structure):
+    """struct dg_corr_desc"""
+    _fields_ = [("B", ctypes.c_int32), ("C", ctypes.c_int32), ("D", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("S", ctypes.c_int32), ("n_neg", ctypes.c_int32),
+                ("depth_h", ctypes.c_int32), ("depth_w", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                ("shift_intra", ctypes.c_float), ("shift_inter", ctypes.c_float), ("shift_neg", ctypes.c_float),
+                ("shift_depth", ctypes.c_float)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"depthg_amd: {LIB_PATH} not found. Build it with `make -C depthg_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, cp = ctypes.c_void_p, ctypes.POINTER(CorrDesc)
+    lib.dg_version.restype = ctypes.c_int
+    lib.dg_last_error.restype = ctypes.c_char_p
+    lib.dg_corr_workspace_bytes.restype = ctypes.c_size_t
+    lib.dg_corr_workspace_bytes.argtypes = [cp]
+    lib.dg_corr_forward.restype = ctypes.c_int
+    lib.dg_corr_forward.argtypes = [cp] + [vp] * 10 + [ctypes.c_size_t, vp]
+    lib.dg_corr_backward.restype = ctypes.c_int
+    lib.dg_corr_backward.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
+    lib.dg_corr_materialize.restype = ctypes.c_int
+    lib.dg_corr_materialize.argtypes = [cp, ctypes.c_int32, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_fps_workspace_bytes.restype = ctypes.c_size_t
+    lib.dg_fps_workspace_bytes.argtypes = [ctypes.c_int32] * 3
+    lib.dg_fps_coords.restype = ctypes.c_int
+    lib.dg_fps_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"depthg_amd: {what} failed ({rc}): {msg}")

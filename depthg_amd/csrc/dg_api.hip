@@ -1,0 +1,341 @@
+// C ABI of the gfx950 DepthG correlation-loss library (declared in include/depthg_corr.h).
+// Host-side orchestration only: workspace carving, job tables, kernel launches on the caller's stream.
+#include "dg_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+
+// ---- error reporting
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define DG_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(DG_ERR_LAUNCH, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int dg_version(void) { return DG_VERSION; }
+extern "C" const char* dg_last_error(void) { return g_err; }
+
+// ---- workspace plan
+static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Plan {
+    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, nwaves, nrb;
+    bool shared, depth, grad, pointwise;
+    size_t nhwc_f[2], nhwc_c[2];
+    size_t Fk[DG_MAX_NEG + 2], Ck[DG_MAX_NEG + 2], Cp[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2];
+    size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2];
+    size_t nz;
+    size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
+    size_t part[DG_MAX_NEG + 3];
+    size_t total;
+};
+
+static int make_plan(const dg_corr_desc* d, Plan& p) {
+    if (!d) return fail(DG_ERR_INVALID, "null descriptor");
+    if (d->B < 1 || d->C < 1 || d->D < 1 || d->h < 1 || d->w < 1 || d->S < 1)
+        return fail(DG_ERR_INVALID, "non-positive dimension in descriptor");
+    if (d->n_neg < 0 || d->n_neg > DG_MAX_NEG) return fail(DG_ERR_UNSUPPORTED, "n_neg=%d outside [0,%d]", d->n_neg, DG_MAX_NEG);
+    if (d->C > 768) return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels not supported", d->C);
+    if (d->D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", d->D);
+    if ((size_t)d->h * d->w > 16384) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large", d->h, d->w);
+    p.B = d->B; p.C = d->C; p.D = d->D; p.h = d->h; p.w = d->w; p.S = d->S; p.N = d->n_neg;
+    p.P = d->S * d->S;
+    p.Ppad = (int)up(p.P, 32);
+    p.KF = d->C <= 128 ? 128 : (d->C <= 384 ? 384 : 768);
+    p.KD = d->D <= 96 ? 96 : 128;
+    p.C4 = (int)up(d->C, 4); p.D4 = (int)up(d->D, 4);
+    p.T = 2 + p.N;
+    p.shared = (d->flags & DG_SHARED_COORDS) != 0;
+    p.depth = (d->flags & DG_DEPTH_TERM) != 0;
+    p.grad = (d->flags & DG_NEED_GRAD) != 0;
+    p.pointwise = (d->flags & DG_POINTWISE) != 0;
+    p.nops = p.shared ? 2 : p.T;
+    p.nwaves = (p.KF == 768 || p.KD == 128 || p.Ppad <= 128) ? 4 : 8;
+    p.nrb = (p.Ppad + p.nwaves * 32 - 1) / (p.nwaves * 32);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
+    const size_t HW = (size_t)p.h * p.w, B = p.B;
+    for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(B * HW * p.C4 * 4); p.nhwc_c[i] = take(B * HW * p.D4 * 4); }
+    for (int i = 0; i < p.nops; ++i) {
+        p.Fk[i] = take(B * p.Ppad * p.KF * 2);
+        p.Ck[i] = take(B * p.Ppad * p.KD * 2);
+        p.Cp[i] = take(B * p.KD * p.Ppad * 2);
+        p.inv[i] = take(B * p.Ppad * 4);
+        p.colpart[i] = take(B * (p.Ppad / 32) * p.KF * 4);
+    }
+    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * 4); }
+    p.nz = take(B * p.Ppad * 4);
+    for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
+    for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
+    p.total = off;
+    return DG_OK;
+}
+
+extern "C" size_t dg_corr_workspace_bytes(const dg_corr_desc* desc) {
+    Plan p;
+    if (make_plan(desc, p) != DG_OK) return 0;
+    return p.total;
+}
+
+// operand index used as the S operand (pass A) of pair-set t, and its batch map
+static inline int op_of(const Plan& p, int t) { return t < 2 ? t : (p.shared ? 0 : t); }
+static inline const int64_t* map_of(const Plan& p, int t, const int64_t* perms) {
+    return (t >= 2 && p.shared) ? perms + (size_t)(t - 2) * p.B : nullptr;
+}
+
+static void clamp_bounds(const dg_corr_desc* d, float& lo, float& hi) {
+    lo = (d->flags & DG_ZERO_CLAMP) ? 0.0f : -9999.0f;
+    hi = (d->flags & DG_STABALIZE) ? 0.8f : __builtin_inff();
+}
+
+static float shift_of(const dg_corr_desc* d, int t) { return t == 0 ? d->shift_intra : (t == 1 ? d->shift_inter : d->shift_neg); }
+
+// Fills one helper job.  passB: the stationary operand is operand 2 of pair-set t.
+static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, bool passB, const int64_t* perms) {
+    DgJob j;
+    memset(&j, 0, sizeof(j));
+    const int o2 = op_of(p, t);
+    const int64_t* m2 = map_of(p, t, perms);
+    auto U16 = [&](size_t off) { return reinterpret_cast<const uint16_t*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    if (!passB) {
+        j.Rf = U16(p.Fk[0]); j.Rc = U16(p.Ck[0]); j.RcInv = F32(p.inv[0]); j.ridx = nullptr;
+        j.Sf = U16(p.Fk[o2]); j.Sc = U16(p.Ck[o2]); j.ScP = U16(p.Cp[o2]); j.sidx = m2;
+        j.center_on_lane = 1;
+    } else {
+        j.Rf = U16(p.Fk[o2]); j.Rc = U16(p.Ck[o2]); j.RcInv = F32(p.inv[o2]); j.ridx = m2;
+        j.Sf = U16(p.Fk[0]); j.Sc = U16(p.Ck[0]); j.ScP = U16(p.Cp[0]); j.sidx = nullptr;
+        j.center_on_lane = 0;
+    }
+    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.rsum = F32(p.rsum[t]); }
+    j.shift = shift_of(d, t);
+    j.kind = DG_JOB_HELPER;
+    return j;
+}
+
+static DgJob depth_job(const Plan& p, const dg_corr_desc* d, char* ws) {
+    DgJob j;
+    memset(&j, 0, sizeof(j));
+    auto U16 = [&](size_t off) { return reinterpret_cast<const uint16_t*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    j.Rc = U16(p.Ck[0]); j.Sc = U16(p.Ck[0]); j.ScP = U16(p.Cp[0]); j.RcInv = F32(p.inv[0]);
+    j.nzR = F32(p.nz); j.nzS = F32(p.nz);
+    j.shift = d->shift_depth;
+    j.kind = DG_JOB_DEPTH;
+    j.center_on_lane = 1;
+    return j;
+}
+
+static void corr_args_base(const Plan& p, const dg_corr_desc* d, DgCorrArgs& a) {
+    memset(&a, 0, sizeof(a));
+    a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.nrb = p.nrb; a.D = p.D;
+    clamp_bounds(d, a.lo, a.hi);
+    a.inv_BP = 1.0f / ((float)p.B * (float)p.P);
+}
+
+extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                               const float* orig_code, const float* orig_code_pos, const float* depth,
+                               const float* coords1, const float* coords2, const int64_t* perms,
+                               float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    Plan p;
+    int rc = make_plan(desc, p);
+    if (rc != DG_OK) return rc;
+    if (!orig_feats || !orig_feats_pos || !orig_code || !orig_code_pos || !coords1 || !coords2 || !out_scalars || !workspace)
+        return fail(DG_ERR_INVALID, "null tensor pointer");
+    if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", p.N);
+    if (p.depth && (!depth || desc->depth_h < 1 || desc->depth_w < 1))
+        return fail(DG_ERR_INVALID, "DG_DEPTH_TERM set but depth is missing (the reference raises on depth=None too)");
+    if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* ws = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    auto U16 = [&](size_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
+    const int HW = p.h * p.w;
+
+    // 1. channel-last copies of the four maps (the gather reads whole channel vectors per tap)
+    DG_HIP(dg_launch_transpose(orig_feats, F32(p.nhwc_f[0]), p.B, p.C, HW, p.C4, stream));
+    DG_HIP(dg_launch_transpose(orig_feats_pos, F32(p.nhwc_f[1]), p.B, p.C, HW, p.C4, stream));
+    DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
+    DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
+
+    // 2. sample + normalise + bf16 operand layouts
+    {
+        DgGatherArgs g;
+        memset(&g, 0, sizeof(g));
+        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad;
+        int nj = 0;
+        for (int o = 0; o < p.nops; ++o) {
+            const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
+            const float* coords = o == 0 ? coords1 : coords2;
+            const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
+            DgGatherJob& f = g.jobs[nj++];
+            f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
+            f.outK = U16(p.Fk[o]); f.outP = nullptr; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
+            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF;
+            DgGatherJob& c = g.jobs[nj++];
+            c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
+            c.outK = U16(p.Ck[o]); c.outP = U16(p.Cp[o]); c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
+            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD;
+        }
+        g.njobs = nj;
+        DG_HIP(dg_launch_gather(g, p.KF, stream));
+    }
+    if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
+
+    // 3. row means of fd (pointwise centering as a rank-1 correction)
+    if (p.pointwise) {
+        DgRowmeanArgs r;
+        memset(&r, 0, sizeof(r));
+        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.njobs = p.T;
+        for (int t = 0; t < p.T; ++t) {
+            r.jobs[t].A = U16(p.Fk[0]); r.jobs[t].aidx = nullptr;
+            r.jobs[t].colpart = F32(p.colpart[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
+            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rsum = F32(p.rsum[t]);
+        }
+        DG_HIP(dg_launch_rowmean(r, stream));
+    }
+
+    // 4. fused correlation passes
+    DgCorrArgs a;
+    corr_args_base(p, desc, a);
+    int nj = 0;
+    for (int t = 0; t < p.T; ++t) {
+        DgJob j = helper_job(p, desc, ws, t, false, perms);
+        j.part = F32(p.part[t]);
+        j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
+        a.jobs[nj++] = j;
+    }
+    if (p.depth) {
+        DgJob j = depth_job(p, desc, ws);
+        j.part = F32(p.part[p.T]);
+        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
+        a.jobs[nj++] = j;
+    }
+    const int njA = nj;
+    if (p.grad)
+        for (int t = 0; t < p.T; ++t) {
+            DgJob j = helper_job(p, desc, ws, t, true, perms);
+            j.dR = F32(p.dRB[t]);
+            a.jobs[nj++] = j;
+        }
+    a.njobs = nj;
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad, stream));
+
+    // 5. scalar outputs
+    DgFinishArgs f;
+    memset(&f, 0, sizeof(f));
+    const double numel = (double)p.B * p.P * p.P;
+    for (int j = 0; j < njA; ++j) {
+        f.part[j] = a.jobs[j].part;
+        f.nblk[j] = p.B * p.nrb;
+        if (j < p.T) {
+            f.slot_loss[j] = j < 2 ? j : DG_OUT_LOSS_NEG;
+            f.slot_cd[j] = j < 2 ? DG_OUT_CD_INTRA + j : DG_OUT_CD_NEG;
+            f.scale[j] = (float)(1.0 / (j < 2 ? numel : numel * p.N));
+        } else {
+            f.slot_loss[j] = DG_OUT_LOSS_DEPTH; f.slot_cd[j] = -1; f.scale[j] = (float)(1.0 / numel);
+        }
+    }
+    f.njobs = njA;
+    f.nz = p.depth ? F32(p.nz) : nullptr;
+    f.B = p.B; f.P = p.P; f.Ppad = p.Ppad;
+    f.out = out_scalars;
+    DG_HIP(dg_launch_finish(f, stream));
+    return DG_OK;
+}
+
+extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scalars, const float* coords1,
+                                const float* coords2, const int64_t* perms, float* grad_code, float* grad_code_pos,
+                                void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    Plan p;
+    int rc = make_plan(desc, p);
+    if (rc != DG_OK) return rc;
+    if (!p.grad) return fail(DG_ERR_INVALID, "dg_corr_backward needs a descriptor with DG_NEED_GRAD (as used in forward)");
+    if (!grad_scalars || !coords1 || !coords2 || !grad_code || !grad_code_pos || !workspace) return fail(DG_ERR_INVALID, "null pointer");
+    if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", p.N);
+    if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    char* ws = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<const float*>(ws + off); };
+    DgScatterArgs s;
+    memset(&s, 0, sizeof(s));
+    const float f = (float)(1.0 / ((double)p.B * p.P * p.P));
+    const float fn = p.N > 0 ? f / (float)p.N : 0.f;
+    int n = 0;
+    auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest) {
+        s.src[n].buf = F32(buf); s.src[n].route = route; s.src[n].gidx = gidx; s.src[n].coords_sel = csel;
+        s.src[n].factor = factor; s.src[n].dest = dest; ++n;
+    };
+    add(p.dRA[0], nullptr, 0, 0, f, 0);
+    add(p.dRB[0], nullptr, 0, 0, f, 0);
+    add(p.dRA[1], nullptr, 1, 0, f, 0);
+    add(p.dRB[1], nullptr, 1, 1, f, 1);
+    for (int k = 0; k < p.N; ++k) {
+        add(p.dRA[2 + k], nullptr, 2, 0, fn, 0);
+        add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0);
+    }
+    if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0);
+    s.nsrc = n;
+    s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
+    s.out[0] = grad_code; s.out[1] = grad_code_pos;
+    s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
+    int DC = 32;
+    while (DC > 1 && (size_t)DC * (p.h * p.w + 1) * 4 > 150 * 1024) DC >>= 1;
+    if ((size_t)DC * (p.h * p.w + 1) * 4 > 150 * 1024) return fail(DG_ERR_UNSUPPORTED, "feature map too large for the LDS scatter");
+    s.DC = DC;
+    DG_HIP(dg_launch_scatter(s, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, float* out_cd, float* out_loss,
+                                   void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    Plan p;
+    int rc = make_plan(desc, p);
+    if (rc != DG_OK) return rc;
+    if (!workspace) return fail(DG_ERR_INVALID, "null workspace");
+    if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    if (which < -1 || which >= p.T) return fail(DG_ERR_INVALID, "which=%d outside [-1,%d)", which, p.T);
+    if (which == -1 && !p.depth) return fail(DG_ERR_INVALID, "depth term not enabled in descriptor");
+    if (which >= 2 && p.shared) return fail(DG_ERR_UNSUPPORTED, "materialising negatives needs the perms; not available with DG_SHARED_COORDS");
+    if (!out_cd && !out_loss) return DG_OK;
+    char* ws = static_cast<char*>(workspace);
+    DgCorrArgs a;
+    corr_args_base(p, desc, a);
+    DgJob j = which == -1 ? depth_job(p, desc, ws) : helper_job(p, desc, ws, which, true, nullptr);
+    j.center_on_lane = 0;   // stationary = operand 2 -> stores are contiguous along q
+    if (which == -1) { /* R = S = code at coords1, dd symmetric */ }
+    j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
+    a.jobs[0] = j; a.njobs = 1;
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, false, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
+    (void)B; (void)h; (void)w;
+    return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform
+}
+
+extern "C" int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_w, int32_t h, int32_t w,
+                             int32_t S, float* out_coords, int32_t* out_inds, void* workspace, size_t workspace_bytes,
+                             dg_stream_t stream_) {
+    (void)workspace; (void)workspace_bytes;
+    if (!depth || !out_coords) return fail(DG_ERR_INVALID, "null pointer");
+    if (B < 1 || h < 1 || w < 1 || S < 1 || depth_h < h || depth_w < w) return fail(DG_ERR_INVALID, "bad FPS dimensions");
+    if (S * S > h * w) return fail(DG_ERR_INVALID, "cannot sample %d points from a %dx%d map", S * S, h, w);
+    if ((size_t)h * w * 20 > 150 * 1024) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the LDS sampler", h, w);
+    // 2*tan(fov/2) with fov = 90 taken in radians (reference quirk, src/modules.py:989,1016), float32 bits
+    const uint32_t bits = 0x404f54cbu;
+    float factor;
+    memcpy(&factor, &bits, 4);
+    DG_HIP(dg_launch_fps(depth, B, depth_h, depth_w, h, w, S, factor, out_coords, out_inds, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's operator surface for the correlation loss.
+
+`ContrastiveCorrelationLoss(cfg)` is a drop-in for the reference class of the same name
+(src/modules.py:1221-1367): same constructor, a mutable `.cfg` that is re-read on every call
+(the caller rewrites `cfg.depth_sampling`, `cfg.feature_samples`, `cfg.depth_feat_shift` between
+steps, src/train_segmentation.py:356-375), no parameters, same positional/keyword call signature
+and the same 6- / 8-tuple.  All arithmetic runs in the HIP library behind include/depthg_corr.h;
+there is no eager/CPU fallback (a missing library or a CPU tensor raises).
+
+Extra, build-side cfg keys (all optional, read with getattr):
+    dg_outputs      "full" (default): tuple elements 1,3,4,5,7 are the reference's un-reduced
+                    (.., S,S,S,S) tensors, written by dg_corr_materialize;
+                    "reduced": they are 1-element tensors holding the mean (so the caller's
+                    `.mean()` / logging keeps working) and nothing of size (B,P,P) ever reaches HBM.
+    dg_dense_grid   True: with feature_samples == h == w use the identity grid for coords1 and
+                    coords2 (SURVEY.md section 8(d) dense runs) instead of torch.rand.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def super_perm(size: int, device) -> torch.Tensor:
+    """randperm with fixed points bumped by one, modulo size (src/modules.py:1184-1188; quirk Q6)."""
+    perm = torch.randperm(size, device=device, dtype=torch.long)
+    perm = torch.where(perm == torch.arange(size, device=device), perm + 1, perm)
+    return perm % size
+
+
+def identity_coords(b: int, s: int, device) -> torch.Tensor:
+    """coords such that sample() reads every pixel of an s x s map exactly once (transposed, quirk Q3)."""
+    lin = torch.linspace(-1.0, 1.0, s, device=device)
+    c = torch.empty(b, s, s, 2, device=device)
+    c[..., 0] = lin.view(1, 1, s)
+    c[..., 1] = lin.view(1, s, 1)
+    return c
+
+
+class _CorrLossFunction(torch.autograd.Function):
+    """out[8] = fused loss scalars; backward = dg_corr_backward with the upstream of out[0:4]."""
+
+    @staticmethod
+    def forward(ctx, orig_code, orig_code_pos, orig_feats, orig_feats_pos, depth, coords1, coords2, perms, desc, holder):
+        ws = ops.alloc_workspace(desc, orig_feats.device)
+        out = ops.corr_forward(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
+                               perms, ws)
+        holder["workspace"] = ws
+        ctx.desc, ctx.ws, ctx.shape = desc, ws, tuple(orig_code.shape)
+        ctx.save_for_backward(coords1, coords2, perms)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        coords1, coords2, perms = ctx.saved_tensors
+        if not (ctx.desc.flags & ops._lib.DG_NEED_GRAD):
+            raise RuntimeError("depthg_amd: backward called on a forward that ran without gradient pieces")
+        gs = gout[:4].to(torch.float32).contiguous()
+        g_code, g_code_pos = ops.corr_backward(ctx.desc, gs, coords1, coords2, perms, ctx.ws, ctx.shape)
+        return g_code, g_code_pos, None, None, None, None, None, None, None, None
+
+
+class ContrastiveCorrelationLoss(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    # -- coordinate selection, src/modules.py:1287-1321 -------------------------------------------
+    def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos):
+        cfg = self.cfg
+        B, S = orig_feats.shape[0], int(cfg.feature_samples)
+        dev = orig_feats.device
+        coord_shape = [B, S, S, 2]
+        if getattr(cfg, "use_salience", False):
+            raise NotImplementedError("depthg_amd: use_salience sampling is outside the hot path (SURVEY.md 8(f) N4)")
+        mode = cfg.depth_sampling
+        if mode == "simple":
+            raise NotImplementedError("depthg_amd: depth_sampling='simple' is outside the hot path (SURVEY.md 8(f) N4)")
+        if mode in ("fps", "fps_depth_feat"):   # 'fps_depth_feat' == 'fps' in the reference (quirk Q13)
+            if depth is None or depth_pos is None:
+                raise AttributeError("depth_sampling='fps' needs depth and depth_pos (the reference fails on None too, quirk Q8)")
+            c1 = ops.fps_coords(depth, orig_feats.shape[-2:], S)
+            c2 = ops.fps_coords(depth_pos, orig_feats_pos.shape[-2:], S)
+            assert tuple(c1.shape) == tuple(c2.shape) == tuple(coord_shape), f"{c1.shape} != {c2.shape} != {coord_shape}"
+            return c1, c2, False
+        if getattr(cfg, "dg_dense_grid", False) and S == orig_feats.shape[-2] == orig_feats.shape[-1]:
+            c = identity_coords(B, S, dev)
+            return c, c, True
+        c1 = torch.rand(coord_shape, device=dev) * 2 - 1
+        c2 = torch.rand(coord_shape, device=dev) * 2 - 1
+        return c1, c2, False
+
+    def forward(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos,
+                depth=None, depth_pos=None):
+        coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
+                                                     depth, depth_pos)
+        B = orig_feats.shape[0]
+        perms = [super_perm(B, orig_feats.device) for _ in range(int(self.cfg.neg_samples))]
+        return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
+                                 shared_coords=shared)
+
+    # -- everything after the RNG draws (explicit coords / perms: parity tests, DP shards) ----------
+    def forward_with(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
+                     shared_coords=False):
+        cfg = self.cfg
+        B, C, h, w = orig_feats.shape
+        D = orig_code.shape[1]
+        S, N = int(cfg.feature_samples), int(cfg.neg_samples)
+        depth_term = bool(cfg.depth_feat_correlation_loss)
+        if depth_term and depth is None:
+            raise AttributeError("depth_feat_correlation_loss=True needs `depth` (reference: interpolate(None) raises)")
+        dev = orig_feats.device
+        feats = ops._f32c(orig_feats, "orig_feats")
+        feats_pos = ops._f32c(orig_feats_pos, "orig_feats_pos")
+        depth_c = ops._f32c(depth, "depth") if depth_term else None
+        coords1 = ops._f32c(coords1, "coords1")
+        coords2 = ops._f32c(coords2, "coords2")
+        if isinstance(perms, (list, tuple)):
+            perms_t = torch.stack([p.to(device=dev, dtype=torch.long) for p in perms]) if N > 0 else \
+                torch.zeros(0, B, dtype=torch.long, device=dev)
+        else:
+            perms_t = perms.to(device=dev, dtype=torch.long)
+        perms_t = perms_t.contiguous()
+        assert perms_t.shape == (N, B), f"perms shape {tuple(perms_t.shape)} != {(N, B)}"
+        need_grad = torch.is_grad_enabled() and (orig_code.requires_grad or orig_code_pos.requires_grad)
+        desc = ops.make_desc(B, C, D, h, w, S, N, pointwise=bool(cfg.pointwise), zero_clamp=bool(cfg.zero_clamp),
+                             stabalize=bool(cfg.stabalize), depth_term=depth_term, need_grad=need_grad,
+                             shared_coords=bool(shared_coords),
+                             shifts=(cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift,
+                                     cfg.depth_feat_shift if depth_term else 0.0),
+                             depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0))
+        holder = {}
+        code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
+        code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
+        out = _CorrLossFunction.apply(code_in.contiguous(), code_pos_in.contiguous(), feats, feats_pos, depth_c,
+                                      coords1, coords2, perms_t, desc, holder)
+        ws = holder["workspace"]
+        self.last_scalars = out.detach()
+
+        mode = getattr(cfg, "dg_outputs", "full")
+        if mode == "reduced":
+            res = (out[0], out[4:5].detach(), out[1], out[5:6].detach(), out[2:3], out[6:7].detach())
+            if depth_term:
+                res = res + (out[3], out[7:8].detach())
+            return res
+        if mode != "full":
+            raise ValueError(f"cfg.dg_outputs must be 'full' or 'reduced', got {mode!r}")
+        # reference-shaped outputs (src/modules.py:1352-1367); cd tensors carry no gradient (the caller only logs them)
+        if shared_coords and N > 0:
+            raise RuntimeError("depthg_amd: dg_outputs='full' is not available with the shared dense grid; use 'reduced'")
+        intra_cd, _ = ops.corr_materialize(desc, 0, ws)
+        inter_cd, _ = ops.corr_materialize(desc, 1, ws)
+        neg_cd, neg_loss = [], []
+        for k in range(N):
+            c, l = ops.corr_materialize(desc, 2 + k, ws, want_cd=True, want_loss=True)
+            neg_cd.append(c)
+            neg_loss.append(l)
+        if N > 0:
+            neg_cd_t = torch.cat(neg_cd, dim=0)
+            # un-reduced negative loss: values from the kernel; gradient routed through its mean (exact for the
+            # uniform upstreams that .mean()/.sum() produce, which is how the caller consumes it,
+            # src/train_segmentation.py:303)
+            neg_loss_t = torch.cat(neg_loss, dim=0) + (out[2] - out[2].detach())
+        else:
+            neg_cd_t = torch.zeros(0, S, S, S, S, device=dev)
+            neg_loss_t = neg_cd_t.clone()
+        res = (out[0], intra_cd, out[1], inter_cd, neg_loss_t, neg_cd_t)
+        if depth_term:
+            dd, _ = ops.corr_materialize(desc, -1, ws)
+            res = res + (out[3], dd)
+        return res

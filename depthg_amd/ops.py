@@ -1,0 +1,99 @@
+"""Tensor-level wrappers over the C ABI (raw device pointers + the current HIP stream).
+torch is used for device memory and streams only."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CorrDesc
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"depthg_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
+              shifts, depth_hw=(0, 0)):
+    flags = 0
+    flags |= _lib.DG_POINTWISE if pointwise else 0
+    flags |= _lib.DG_ZERO_CLAMP if zero_clamp else 0
+    flags |= _lib.DG_STABALIZE if stabalize else 0
+    flags |= _lib.DG_DEPTH_TERM if depth_term else 0
+    flags |= _lib.DG_NEED_GRAD if need_grad else 0
+    flags |= _lib.DG_SHARED_COORDS if shared_coords else 0
+    return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
+                    float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]))
+
+
+def workspace_bytes(desc):
+    n = _lib.load().dg_corr_workspace_bytes(ctypes.byref(desc))
+    if n == 0:
+        _lib.check(-1, "dg_corr_workspace_bytes")
+    return n
+
+
+def alloc_workspace(desc, device):
+    return torch.empty(workspace_bytes(desc), dtype=torch.uint8, device=device)
+
+
+def corr_forward(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, perms, workspace):
+    """Returns fp32 [8] device tensor (order: DG_OUT_* of include/depthg_corr.h)."""
+    lib = _lib.load()
+    dev = feats.device
+    out = torch.empty(_lib.DG_OUT_COUNT, dtype=torch.float32, device=dev)
+    rc = lib.dg_corr_forward(ctypes.byref(desc), _ptr(feats), _ptr(feats_pos), _ptr(code), _ptr(code_pos), _ptr(depth),
+                             _ptr(coords1), _ptr(coords2), _ptr(perms), _ptr(out), _ptr(workspace),
+                             workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_forward")
+    return out
+
+
+def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_code):
+    lib = _lib.load()
+    dev = grad_scalars.device
+    g_code = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    g_code_pos = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    rc = lib.dg_corr_backward(ctypes.byref(desc), _ptr(grad_scalars), _ptr(coords1), _ptr(coords2), _ptr(perms),
+                              _ptr(g_code), _ptr(g_code_pos), _ptr(workspace), workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_backward")
+    return g_code, g_code_pos
+
+
+def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False):
+    lib = _lib.load()
+    dev = workspace.device
+    shape = (desc.B, desc.S, desc.S, desc.S, desc.S)
+    cd = torch.empty(shape, dtype=torch.float32, device=dev) if want_cd else None
+    loss = torch.empty(shape, dtype=torch.float32, device=dev) if want_loss else None
+    rc = lib.dg_corr_materialize(ctypes.byref(desc), int(which), _ptr(cd), _ptr(loss), _ptr(workspace),
+                                 workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_materialize")
+    return cd, loss
+
+
+def fps_coords(depth, feat_hw, n_samples, return_inds=False):
+    """depth (B,1,H,W) on GPU -> coords (B,S,S,2) in [-1,1) (already *2-1)."""
+    lib = _lib.load()
+    depth = _f32c(depth, "depth")
+    B, _, H, W = depth.shape
+    h, w = int(feat_hw[0]), int(feat_hw[1])
+    S = int(n_samples)
+    coords = torch.empty(B, S, S, 2, dtype=torch.float32, device=depth.device)
+    inds = torch.empty(B, S * S, dtype=torch.int32, device=depth.device) if return_inds else None
+    ws = torch.empty(lib.dg_fps_workspace_bytes(B, h, w), dtype=torch.uint8, device=depth.device)
+    rc = lib.dg_fps_coords(_ptr(depth), B, H, W, h, w, S, _ptr(coords), _ptr(inds), _ptr(ws), ws.numel(),
+                           _stream(depth.device))
+    _lib.check(rc, "dg_fps_coords")
+    return (coords, inds) if return_inds else coords

@@ -1,0 +1,151 @@
+/*
+ * depthg_corr.h - C ABI of the MI355X (gfx950) implementation of DepthG's feature-correlation
+ * loss hot path.  Plain C: pointers and sizes only, no torch types.
+ *
+ * The reference (leonsick/depthg) has no FFI; the boundary it offers for this path is the
+ * Python nn.Module `ContrastiveCorrelationLoss` (src/modules.py:1221-1367).  The host-side
+ * mirror of that module lives in depthg_amd/loss.py and binds these entry points with ctypes
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *  - the callee never allocates or frees: scratch comes from a caller-sized workspace whose
+ *    size is returned by dg_corr_workspace_bytes();
+ *  - every launch goes to the given hipStream_t and is asynchronous w.r.t. the host;
+ *  - return value 0 = ok, negative = error (dg_last_error() gives text); no exceptions.
+ *  - re-entrant, no global mutable state besides the thread-local last-error string.
+ */
+#ifndef DEPTHG_CORR_H
+#define DEPTHG_CORR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_VERSION 100
+
+/* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
+#define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
+#define DG_ZERO_CLAMP     (1u << 1)  /* cfg.zero_clamp: clamp min 0 instead of -9999 (modules.py:1243-1246) */
+#define DG_STABALIZE      (1u << 2)  /* cfg.stabalize: clamp max 0.8 (modules.py:1249-1250) */
+#define DG_DEPTH_TERM     (1u << 3)  /* cfg.depth_feat_correlation_loss (modules.py:1334-1336) */
+#define DG_NEED_GRAD      (1u << 4)  /* also produce d/d orig_code, d/d orig_code_pos pieces */
+#define DG_SHARED_COORDS  (1u << 5)  /* coords1[n] == coords2[m] for all n, m (dense grid): negatives reuse
+                                        the prepared operand of `feats`/`code` through the batch permutation */
+
+#define DG_MAX_NEG 8
+
+/* error codes */
+#define DG_OK               0
+#define DG_ERR_INVALID     -1
+#define DG_ERR_UNSUPPORTED -2
+#define DG_ERR_WORKSPACE   -3
+#define DG_ERR_LAUNCH      -4
+
+typedef void* dg_stream_t; /* hipStream_t */
+
+/* Shape/cfg descriptor of one loss call (one `ContrastiveCorrelationLoss.forward`). */
+typedef struct dg_corr_desc {
+    int32_t B;        /* batch (per rank) */
+    int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 */
+    int32_t D;        /* code channels = cfg.dim; <= 128 */
+    int32_t h, w;     /* feature-map size of orig_feats / orig_code */
+    int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated */
+    int32_t n_neg;    /* cfg.neg_samples (<= DG_MAX_NEG) */
+    int32_t depth_h, depth_w; /* size of the depth map (image resolution); 0 if no depth */
+    uint32_t flags;
+    float shift_intra, shift_inter, shift_neg, shift_depth; /* cfg.pos_intra_shift ... cfg.depth_feat_shift */
+} dg_corr_desc;
+
+/* indices into out_scalars[] of dg_corr_forward */
+enum {
+    DG_OUT_LOSS_INTRA = 0, /* pos_intra_loss.mean()           (tuple element 0) */
+    DG_OUT_LOSS_INTER = 1, /* pos_inter_loss.mean()           (element 2) */
+    DG_OUT_LOSS_NEG   = 2, /* neg_inter_loss.mean()           (mean of element 4) */
+    DG_OUT_LOSS_DEPTH = 3, /* depth_feat_loss.mean()          (element 6) */
+    DG_OUT_CD_INTRA   = 4, /* pos_intra_cd.mean()             (mean of element 1) */
+    DG_OUT_CD_INTER   = 5, /* pos_inter_cd.mean()             (mean of element 3) */
+    DG_OUT_CD_NEG     = 6, /* neg_inter_cd.mean()             (mean of element 5) */
+    DG_OUT_DD         = 7, /* depth_feat_cd.mean() (= mean of dd, element 7) */
+    DG_OUT_COUNT      = 8
+};
+
+int dg_version(void);
+const char* dg_last_error(void);
+
+/* Bytes of workspace dg_corr_forward/backward/materialize need for this descriptor. */
+size_t dg_corr_workspace_bytes(const dg_corr_desc* desc);
+
+/*
+ * Forward of the whole loss (replaces ContrastiveCorrelationLoss.forward after the coordinate
+ * draw, src/modules.py:1323-1367): sample() of feats/code at coords1, feats_pos/code_pos and the
+ * n_neg negatives at coords2 (modules.py:822-825), norm() (modules.py:789-790), the
+ * feature/code correlations (modules.py:797-809), pointwise centering, clamp, shift and the
+ * mean reductions of helper() (modules.py:1231-1254) and of depth_feature_correlation()
+ * (modules.py:1256-1278).
+ *
+ *  orig_feats, orig_feats_pos : fp32 (B,C,h,w) contiguous NCHW
+ *  orig_code,  orig_code_pos  : fp32 (B,D,h,w)
+ *  depth                      : fp32 (B,1,depth_h,depth_w) or NULL (required with DG_DEPTH_TERM)
+ *  coords1, coords2           : fp32 (B,S,S,2) in [-1,1]  (what the reference passes to sample())
+ *  perms                      : int64 (n_neg,B) = super_perm() draws (modules.py:1184-1188,1341)
+ *  out_scalars                : fp32 [DG_OUT_COUNT]
+ * With DG_NEED_GRAD the unit-upstream gradient pieces are left in the workspace for
+ * dg_corr_backward, which must be called with the SAME desc, coords, perms and workspace.
+ */
+int dg_corr_forward(const dg_corr_desc* desc,
+                    const float* orig_feats, const float* orig_feats_pos,
+                    const float* orig_code, const float* orig_code_pos,
+                    const float* depth,
+                    const float* coords1, const float* coords2, const int64_t* perms,
+                    float* out_scalars,
+                    void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * Backward (replaces autograd through helper()/sample(), SURVEY.md section 9 "Gradient"):
+ *  grad_scalars : fp32 [4] device = upstream gradients of the four loss means
+ *                 (DG_OUT_LOSS_INTRA..DG_OUT_LOSS_DEPTH order)
+ *  grad_code, grad_code_pos : fp32 (B,D,h,w), overwritten.
+ */
+int dg_corr_backward(const dg_corr_desc* desc,
+                     const float* grad_scalars,
+                     const float* coords1, const float* coords2, const int64_t* perms,
+                     float* grad_code, float* grad_code_pos,
+                     void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * Optional full tensors the reference returns un-reduced (src/modules.py:1352-1367), computed
+ * from the operands dg_corr_forward left in the workspace.  which: 0 = pos_intra, 1 = pos_inter,
+ * 2+k = negative k, -1 = depth term.  out_cd / out_loss: fp32 (B,S,S,S,S) or NULL.
+ * For which == -1 out_cd receives dd (tuple element 7).
+ */
+int dg_corr_materialize(const dg_corr_desc* desc, int32_t which,
+                        float* out_cd, float* out_loss,
+                        void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * Depth-guided sample locations (replaces farthest_point_sampling_depth, src/modules.py:999-1037,
+ * with depth2points :988-996 and fps :939-985): adaptive_avg_pool2d of depth to (h,w), pinhole
+ * back-projection with fov=90 (radians, quirk Q5), farthest point sampling of S*S points starting
+ * at index 0, re-emitted in row-major order.
+ *  depth      : fp32 (B,1,depth_h,depth_w)
+ *  out_coords : fp32 (B,S,S,2), already mapped *2-1 as the caller does (modules.py:1305-1308)
+ *  out_inds   : int32 (B,S*S) selection order (may be NULL)
+ *  workspace  : >= dg_fps_workspace_bytes(B,h,w) bytes
+ */
+size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w);
+int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_w,
+                  int32_t h, int32_t w, int32_t S,
+                  float* out_coords, int32_t* out_inds,
+                  void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/* Self-test of the MFMA fragment maps this library relies on (returns 0 when they hold). Test aid. */
+int dg_selftest_mfma(void* workspace, size_t workspace_bytes, dg_stream_t stream, int32_t* out_host_mismatch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPTHG_CORR_H */
