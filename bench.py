@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: correlation-loss steps/sec at B=32, C=384, 28x28 (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 launched by the driver through torch.distributed.run, one rank per GPU, RCCL).
+
+A "step" = one forward + backward of the DepthG correlation loss, starting from the fp32 feature /
+code maps as the featurizer hands them over, resident in HBM:
+    sample() of feats/code (dense 28x28 identity grid) -> norm() -> 7 pair-sets of helper()
+    (1 intra, 1 inter, 5 negatives) + depth_feature_correlation() -> 4 loss means + 4 cd means ->
+    d/d orig_code, d/d orig_code_pos (through norm() and sample()),
+    and, for N > 1, one RCCL all-reduce of a head-gradient-sized fp32 buffer (201,740 elements =
+    DinoFeaturizer cluster1+cluster2 at C=384, dim=70).
+Batch is sharded data-parallel: every rank runs B=32 of its own synthetic images (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HEADLINE = dict(B=32, C=384, D=70, h=28, w=28, S=28, n_neg=5, depth_hw=224)
+HEAD_GRAD_ELEMS = 201_740          # cluster1 (26,950) + cluster2 (174,790) parameters, reference src/modules.py:75-88
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16/f16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def make_cfg(**over):
+    from types import SimpleNamespace
+    # COCO-Stuff ViT-S recipe of the reference (paper_reproduction.sh:5) on top of src/configs/local_config.yml
+    cfg = SimpleNamespace(
+        feature_samples=HEADLINE["S"], use_salience=False, depth_sampling="none", fps_gpu=False, pointwise=True,
+        zero_clamp=True, stabalize=False, pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761,
+        neg_samples=HEADLINE["n_neg"], depth_feat_correlation_loss=True, depth_feat_shift=0.03,
+        pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19,
+        correspondence_weight=1.0, dg_outputs="reduced", dg_dense_grid=True)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def synth_inputs(B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    H = HEADLINE
+    f = torch.randn(B, H["C"], H["h"], H["w"], generator=g)
+    fp = torch.randn(B, H["C"], H["h"], H["w"], generator=g)
+    c = torch.randn(B, H["D"], H["h"], H["w"], generator=g)
+    cp = torch.randn(B, H["D"], H["h"], H["w"], generator=g)
+    d = torch.randint(0, 256, (B, 1, H["depth_hw"], H["depth_hw"]), generator=g).float()
+    dp = torch.randint(0, 256, (B, 1, H["depth_hw"], H["depth_hw"]), generator=g).float()
+    return [t.to(device) for t in (f, fp, c, cp, d, dp)]
+
+
+def algorithmic_gflop(B, P, C, D, n_neg):
+    """one correlation = 2*B*P^2*K flop; recompute is not counted."""
+    corr = lambda k: 2.0 * B * P * P * k / 1e9
+    fwd = (2 + n_neg) * corr(C) + (3 + n_neg) * corr(D) + corr(1)
+    bwd = 2 * (3 + n_neg) * corr(D)
+    return fwd, bwd
+
+
+def total_of(cfg, out):
+    return (cfg.pos_inter_weight * out[2] + cfg.pos_intra_weight * out[0] + cfg.neg_inter_weight * out[4].mean() +
+            cfg.depth_feat_weight * out[6]) * cfg.correspondence_weight
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the headline
+    workload: same C, D, S, pair-sets and backward, smaller batch; scaled to steps/s of the full batch."""
+    from oracle import depthg_oracle as O
+    H = HEADLINE
+    Bs = 8
+    ncores = min(os.cpu_count() or 1, 16)      # torch-CPU bmm/elementwise stop scaling (and thrash) beyond this
+    torch.set_num_threads(ncores)
+    cfg = O.default_cfg(feature_samples=H["S"], pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761,
+                        depth_feat_shift=0.03, pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7,
+                        depth_feat_weight=0.19)
+    f, fp, c, cp, d, dp = synth_inputs(Bs, 4321, "cpu")
+    coords = O.identity_coords(Bs, H["S"])
+    g = torch.Generator().manual_seed(7)
+    perms = [O.super_perm(Bs, g) for _ in range(H["n_neg"])]
+    times = []
+    t_start = time.time()
+    for rep in range(40):
+        c1 = c.clone().requires_grad_(True)
+        cp1 = cp.clone().requires_grad_(True)
+        t0 = time.time()
+        out = O.forward(cfg, f, fp, c1, cp1, d, dp, coords1=coords, coords2=coords, perms=perms)
+        O.total_loss(cfg, out).backward()
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget and len(times) >= 2:
+            break
+    timed = times[1:] if len(times) > 1 else times      # first repetition is the warm-up
+    t = min(timed)
+    return {"value": (Bs / H["B"]) / t, "unit": "steps/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle forward+backward at B={Bs} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
+                      f"{H['n_neg']} negatives, {ncores} threads, min of {len(timed)} timed reps = {t:.2f} s; "
+                      f"value = ({Bs}/{H['B']}) / t"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from depthg_amd.parallel import GradBucket
+
+    H = HEADLINE
+    cfg = make_cfg()
+    loss_fn = ContrastiveCorrelationLoss(cfg)
+    f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev)
+    c.requires_grad_(True)
+    cp.requires_grad_(True)
+    bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
+
+    def step():
+        c.grad = None
+        cp.grad = None
+        out = loss_fn(f, fp, None, None, c, cp, d, dp)
+        total = total_of(cfg, out)
+        total.backward()
+        if world > 1:
+            # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size
+            # filled from this step's d/d code, all-reduced (sum) over xGMI and scaled by 1/world
+            bucket.fill_from(c.grad)
+            bucket.allreduce_mean_()
+        return total
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed   # every rank completes `steps` steps of its own B=32 shard
+
+    # ---- roofline of the dominant kernel (k_corr_main), measured live with HIP events on the launch stream
+    desc, perms_t, ws = loss_fn.last_call
+    reps = 20
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        ops.corr_relaunch_main(desc, perms_t, ws)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        ops.corr_relaunch_main(desc, perms_t, ws)
+    ev1.record()
+    torch.cuda.synchronize()
+    kern_ms = ev0.elapsed_time(ev1) / reps
+    fwd_gf, bwd_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
+    achieved = (fwd_gf + bwd_gf) / 1e3 / (kern_ms / 1e3)   # TFLOP/s
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "k_corr_main", "kernel_ms": round(kern_ms, 4),
+                "algorithmic_gflop_per_launch": round(fwd_gf + bwd_gf, 2)}
+
+    if rank == 0:
+        line = {
+            "metric": "correlation-loss steps/sec at B=32,C=384,28x28 (fwd+bwd, per-GPU batch 32)",
+            "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 (feats) / f16 (code) MFMA inputs, f32 accumulate", "data": "synthetic",
+            "config": {"workload": "headline: B=32/GPU, C=384, D=70, 28x28 dense grid (S=28, P=784), 5 negatives, "
+                                   "depth term on, pointwise, zero_clamp; fwd + bwd to orig_code/orig_code_pos",
+                       "global_batch": H["B"] * world, "parallelism": f"dp{world}",
+                       "allreduce_elems": HEAD_GRAD_ELEMS if world > 1 else 0},
+            "loss_total": float(total.detach()),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

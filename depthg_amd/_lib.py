@@ -10,7 +10,7 @@ DG_OUT_COUNT = 8
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS = (1 << i for i in range(6))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
-           "dg_corr_materialize", "dg_fps_workspace_bytes", "dg_fps_coords"]
+           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -45,6 +45,8 @@ def load():
     lib.dg_corr_backward.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.dg_corr_materialize.restype = ctypes.c_int
     lib.dg_corr_materialize.argtypes = [cp, ctypes.c_int32, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_corr_relaunch_main.restype = ctypes.c_int
+    lib.dg_corr_relaunch_main.argtypes = [cp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_fps_workspace_bytes.restype = ctypes.c_size_t
     lib.dg_fps_workspace_bytes.argtypes = [ctypes.c_int32] * 3
     lib.dg_fps_coords.restype = ctypes.c_int

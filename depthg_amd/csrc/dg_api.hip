@@ -143,6 +143,35 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, DgCorrArgs& a) 
     a.inv_BP = 1.0f / ((float)p.B * (float)p.P);
 }
 
+// Job table of the fused correlation launch: pass A (stationary = operand 1) for every pair-set and the
+// depth term, then (with gradients) pass B (stationary = operand 2).  Returns the number of pass-A jobs.
+static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a) {
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    corr_args_base(p, desc, a);
+    int nj = 0;
+    for (int t = 0; t < p.T; ++t) {
+        DgJob j = helper_job(p, desc, ws, t, false, perms);
+        j.part = F32(p.part[t]);
+        j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
+        a.jobs[nj++] = j;
+    }
+    if (p.depth) {
+        DgJob j = depth_job(p, desc, ws);
+        j.part = F32(p.part[p.T]);
+        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
+        a.jobs[nj++] = j;
+    }
+    const int njA = nj;
+    if (p.grad)
+        for (int t = 0; t < p.T; ++t) {
+            DgJob j = helper_job(p, desc, ws, t, true, perms);
+            j.dR = F32(p.dRB[t]);
+            a.jobs[nj++] = j;
+        }
+    a.njobs = nj;
+    return njA;
+}
+
 extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                                const float* orig_code, const float* orig_code_pos, const float* depth,
                                const float* coords1, const float* coords2, const int64_t* perms,
@@ -181,11 +210,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             DgGatherJob& f = g.jobs[nj++];
             f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
             f.outK = U16(p.Fk[o]); f.outP = nullptr; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
-            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF;
+            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.fp16 = 0;
             DgGatherJob& c = g.jobs[nj++];
             c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
             c.outK = U16(p.Ck[o]); c.outP = U16(p.Cp[o]); c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
-            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD;
+            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.fp16 = 1;
         }
         g.njobs = nj;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
@@ -207,28 +236,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
 
     // 4. fused correlation passes
     DgCorrArgs a;
-    corr_args_base(p, desc, a);
-    int nj = 0;
-    for (int t = 0; t < p.T; ++t) {
-        DgJob j = helper_job(p, desc, ws, t, false, perms);
-        j.part = F32(p.part[t]);
-        j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
-        a.jobs[nj++] = j;
-    }
-    if (p.depth) {
-        DgJob j = depth_job(p, desc, ws);
-        j.part = F32(p.part[p.T]);
-        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
-        a.jobs[nj++] = j;
-    }
-    const int njA = nj;
-    if (p.grad)
-        for (int t = 0; t < p.T; ++t) {
-            DgJob j = helper_job(p, desc, ws, t, true, perms);
-            j.dR = F32(p.dRB[t]);
-            a.jobs[nj++] = j;
-        }
-    a.njobs = nj;
+    const int njA = build_corr_jobs(p, desc, ws, perms, a);
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad, stream));
 
     // 5. scalar outputs
@@ -316,6 +324,21 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
     a.jobs[0] = j; a.njobs = 1;
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, false, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+// Measurement aid: re-launch ONLY the fused correlation kernel on the operands a previous dg_corr_forward
+// (same desc / perms / workspace) left in the workspace.  Idempotent (rewrites the same outputs).
+extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* perms, void* workspace,
+                                     size_t workspace_bytes, dg_stream_t stream_) {
+    Plan p;
+    int rc = make_plan(desc, p);
+    if (rc != DG_OK) return rc;
+    if (!workspace || workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace missing or too small");
+    if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null");
+    DgCorrArgs a;
+    build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a);
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

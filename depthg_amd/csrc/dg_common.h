@@ -8,6 +8,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define DG_EPS_NORM 1e-10f  // F.normalize eps, reference src/modules.py:790
 #define DG_TILE 32          // positions per MFMA tile edge (v_mfma_f32_32x32x16_bf16)
@@ -29,10 +31,10 @@ enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 // "S" = streamed operand (tiles of 32 positions through LDS).
 struct DgJob {
     const uint16_t* Rf;   // bf16 [B][Ppad][KF]  normalised feats, K-major   (null for DG_JOB_DEPTH)
-    const uint16_t* Rc;   // bf16 [B][Ppad][KD]  normalised code,  K-major
+    const uint16_t* Rc;   // fp16 [B][Ppad][KD]  normalised code,  K-major (fp16: 4x finer than bf16, range is [-1,1])
     const uint16_t* Sf;   // bf16 [B][Ppad][KF]
-    const uint16_t* Sc;   // bf16 [B][Ppad][KD]
-    const uint16_t* ScP;  // bf16 [B][KD][Ppad]  normalised code, P-major, dg_perm32-permuted per 32-block
+    const uint16_t* Sc;   // fp16 [B][Ppad][KD]
+    const uint16_t* ScP;  // fp16 [B][KD][Ppad]  normalised code, P-major, dg_perm32-permuted per 32-block
     const float* rvec;    // fp32 [B][Ppad] row means a_p . bbar (indexed by operand-1 position) or null
     const float* rsum;    // fp32 [B] per-image sums of rvec over valid p (for m0) or null
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
@@ -84,6 +86,8 @@ struct DgGatherJob {
     float* inv_norm;         // [B][Ppad] or null
     float* colpart;          // [B][Ppad/32][Kpad] per-tile column sums of the normalised rows or null
     int32_t K, K4, Kpad;
+    int32_t fp16;            // 1: write IEEE half (code operands), 0: bf16 (feats operands)
+    int32_t pad_;
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {

@@ -17,6 +17,9 @@
 __device__ __forceinline__ bf16x8 lds_read_frag(const char* base, int byte_off) {
     return *reinterpret_cast<const bf16x8*>(base + byte_off);
 }
+__device__ __forceinline__ f16x8 lds_read_frag_h(const char* base, int byte_off) {
+    return *reinterpret_cast<const f16x8*>(base + byte_off);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 
     // ---- stationary operand fragments -> registers
     bf16x8 Rf[NKF];
-    bf16x8 Rc[NKD];
+    f16x8 Rc[NKD];
     if (!depth_job) {
         const uint16_t* src = job.Rf + ((size_t)nR * Ppad + pr) * KF + 8 * h;
 #pragma unroll
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
     {
         const uint16_t* src = job.Rc + ((size_t)nR * Ppad + pr) * KD + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < NKD; ++ks) Rc[ks] = *reinterpret_cast<const bf16x8*>(src + 16 * ks);
+        for (int ks = 0; ks < NKD; ++ks) Rc[ks] = *reinterpret_cast<const f16x8*>(src + 16 * ks);
     }
 
     // ---- per-job scalars
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
                 const char* base = tile + L::OFF_SC + r * L::SC_STRIDE + h * 16;
 #pragma unroll
                 for (int ks = 0; ks < NKD; ++ks)
-                    Yc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read_frag(base, ks * 32), Rc[ks], Yc, 0, 0, 0);
+                    Yc = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_read_frag_h(base, ks * 32), Rc[ks], Yc, 0, 0, 0);
             }
             // ---- epilogue: element i of the accumulator is (tile row s = (i&3)+8*(i>>2)+4*h, column r)
             const float* rvs = reinterpret_cast<const float*>(tile + L::OFF_RV);
@@ -193,17 +196,17 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
             }
             if (GRAD) {
                 // ---- dR[r][:] += sum_s G[s][r] * ScP[s][:]   (accumulator tile as A operand)
-                bf16x8 ga[2];
+                f16x8 ga[2];
 #pragma unroll
                 for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ga[sp][j] = (__bf16)g[8 * sp + j];
+                    for (int j = 0; j < 8; ++j) ga[sp][j] = (_Float16)g[8 * sp + j];
 #pragma unroll
                 for (int f = 0; f < NDF; ++f) {
                     const char* base = tile + L::OFF_SP + (32 * f + r) * L::SP_STRIDE + h * 16;
 #pragma unroll
                     for (int sp = 0; sp < 2; ++sp)
-                        dR[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[sp], lds_read_frag(base, sp * 32), dR[f], 0, 0, 0);
+                        dR[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[sp], lds_read_frag_h(base, sp * 32), dR[f], 0, 0, 0);
                 }
             }
         }
@@ -234,8 +237,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const uint16_t raw = job.Rc[((size_t)nR * Ppad + rr) * KD + 32 * f + r];
-                const float x = __uint_as_float((uint32_t)raw << 16);
+                const float x = (float)reinterpret_cast<const _Float16*>(job.Rc)[((size_t)nR * Ppad + rr) * KD + 32 * f + r];
                 xv[f][i] = x;
                 dot[i] = fmaf(x, dR[f][i], dot[i]);
             }

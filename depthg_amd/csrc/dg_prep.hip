@@ -101,9 +101,15 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             if (k < Kpad) {
                 float4 u = make_float4(v[m].x * inv, v[m].y * inv, v[m].z * inv, v[m].w * inv);
                 colacc[m][0] += u.x; colacc[m][1] += u.y; colacc[m][2] += u.z; colacc[m][3] += u.w;
-                bf16x4 o;
-                o[0] = (__bf16)u.x; o[1] = (__bf16)u.y; o[2] = (__bf16)u.z; o[3] = (__bf16)u.w;
-                *reinterpret_cast<bf16x4*>(J.outK + ((size_t)n * a.Ppad + p) * Kpad + k) = o;
+                uint2 o;
+                if (J.fp16) {
+                    f16x4 t; t[0] = (_Float16)u.x; t[1] = (_Float16)u.y; t[2] = (_Float16)u.z; t[3] = (_Float16)u.w;
+                    o = *reinterpret_cast<uint2*>(&t);
+                } else {
+                    bf16x4 t; t[0] = (__bf16)u.x; t[1] = (__bf16)u.y; t[2] = (__bf16)u.z; t[3] = (__bf16)u.w;
+                    o = *reinterpret_cast<uint2*>(&t);
+                }
+                *reinterpret_cast<uint2*>(J.outK + ((size_t)n * a.Ppad + p) * Kpad + k) = o;
                 if (J.outP) {
                     const int pp = dg_perm32(pi);
                     const uint16_t* ob = reinterpret_cast<const uint16_t*>(&o);

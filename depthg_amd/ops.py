@@ -97,3 +97,11 @@ def fps_coords(depth, feat_hw, n_samples, return_inds=False):
                            _stream(depth.device))
     _lib.check(rc, "dg_fps_coords")
     return (coords, inds) if return_inds else coords
+
+
+def corr_relaunch_main(desc, perms, workspace):
+    """Measurement aid: launch only the fused correlation kernel again (operands already in `workspace`)."""
+    lib = _lib.load()
+    rc = lib.dg_corr_relaunch_main(ctypes.byref(desc), _ptr(perms), _ptr(workspace), workspace.numel(),
+                                   _stream(workspace.device))
+    _lib.check(rc, "dg_corr_relaunch_main")

@@ -1,0 +1,70 @@
+"""Data-parallel glue for the correlation loss (new in the build; the reference trains on one device,
+src/train_segmentation.py:683-714).
+
+One process per GPU, batch-sharded: every rank evaluates the loss on its local shard (shard-local
+`old_mean` and negatives, i.e. what DDP would do with the reference module - SURVEY.md section 8(e)).
+The only exchange step is one all-reduce (sum, then * 1/world) of a single flat fp32 buffer holding the
+trainable head gradients; torch.distributed's "nccl" backend is RCCL over xGMI on ROCm, "gloo" is used by
+the CPU tests.  Messages are <= 3 MB, i.e. latency-bound: one bucket, one collective per step.
+"""
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+
+def shard_range(global_batch: int, world: int, rank: int):
+    """Contiguous [lo, hi) slice of the global batch owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class GradBucket:
+    """One flat fp32 buffer for all head gradients; `allreduce_mean_` averages it over the process group."""
+
+    def __init__(self, numel: int, device, dist_module=None, group=None):
+        self.flat = torch.zeros(int(numel), dtype=torch.float32, device=device)
+        self.dist = dist_module
+        self.group = group
+        self._views: List[torch.Tensor] = []
+
+    @classmethod
+    def for_parameters(cls, params: Sequence[torch.Tensor], dist_module=None, group=None):
+        params = [p for p in params if p.requires_grad]
+        b = cls(sum(p.numel() for p in params), params[0].device, dist_module, group)
+        off = 0
+        for p in params:
+            b._views.append(b.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        b._params = params
+        return b
+
+    def pack(self):
+        """Copy p.grad of the registered parameters into the flat buffer (zeros for missing grads)."""
+        for p, v in zip(self._params, self._views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+
+    def unpack(self):
+        for p, v in zip(self._params, self._views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+    def fill_from(self, t: torch.Tensor):
+        """Benchmark stand-in: fill the bucket from the leading elements of a gradient tensor."""
+        src = t.reshape(-1)
+        n = min(src.numel(), self.flat.numel())
+        self.flat[:n].copy_(src[:n])
+
+    def allreduce_mean_(self):
+        if self.dist is None:
+            return self.flat
+        world = self.dist.get_world_size(self.group)
+        if world > 1:
+            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.flat.mul_(1.0 / world)
+        return self.flat

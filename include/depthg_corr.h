@@ -142,8 +142,12 @@ int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_
                   float* out_coords, int32_t* out_inds,
                   void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
-/* Self-test of the MFMA fragment maps this library relies on (returns 0 when they hold). Test aid. */
-int dg_selftest_mfma(void* workspace, size_t workspace_bytes, dg_stream_t stream, int32_t* out_host_mismatch);
+/*
+ * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a
+ * previous dg_corr_forward with the same desc / perms / workspace prepared.  Idempotent.
+ */
+int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* perms,
+                          void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 #ifdef __cplusplus
 }

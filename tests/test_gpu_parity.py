@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden vectors and the CPU oracle.
+Run on the GPU box: python -m pytest tests -m gpu.
+
+Tolerances (stated here, measured in DESIGN.md):
+  * feats enter the MFMA as bf16 and code as fp16 (normalised, |x| <= 1), fp32 accumulation; fd errors are
+    ~2^-9 relative per operand element and average out in the loss means.
+  * loss means: <= 1e-4 relative at the headline size (north_star); on the tiny golden cases (3e4 elements,
+    near-cancelling sums; the terms are O(1e-2), some means cancel down to O(1e-4)) <= 2e-3 relative + 1e-5 absolute.
+  * cd / dd elements: <= 1e-3 absolute (fp16 operands).  loss elements: <= 4e-3 absolute.
+  * gradients: relative L2 error <= 3e-2, cosine >= 0.9995.  The gradient is DISCONTINUOUS in cd (clamp mask
+    1[lo <= cd <= hi]): a fraction phi of elements with |cd| below the cd rounding error flips its mask and the
+    error of the (incoherent) sum scales like sqrt(phi); fp16 code operands give phi ~ 5e-4 -> ~2 %.  With
+    zero_clamp off (no mask) the same kernels agree to ~1e-3 (case `nozeroclamp`).
+  * FPS coordinates and indices: bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FORWARD_CASES, cfg_from_fixture, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked tests need an MI355X; there is no fallback path")
+    return torch.device("cuda:0")
+
+
+def _run_fixture(fx, dev, **cfg_over):
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    cfg = cfg_from_fixture(fx, **cfg_over)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    loss = ContrastiveCorrelationLoss(cfg)
+    code, code_pos = T(fx["code"]).requires_grad_(True), T(fx["code_pos"]).requires_grad_(True)
+    out = loss.forward_with(T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), T(fx["coords1"]),
+                            T(fx["coords2"]), T(fx["perms"]))
+    total = O.total_loss(cfg, out)
+    total.backward()
+    torch.cuda.synchronize()
+    return cfg, out, total, code.grad, code_pos.grad
+
+
+def _relclose(got, want, rtol, atol, what):
+    got, want = float(got), float(want)
+    assert abs(got - want) <= rtol * abs(want) + atol, f"{what}: got {got:.9e} want {want:.9e} rel {abs(got-want)/abs(want):.2e}"
+
+
+@pytest.mark.parametrize("case", FORWARD_CASES)
+def test_golden_forward_backward(case, dev):
+    fx = load_golden(f"forward_{case}.npz")
+    cfg, out, total, g_code, g_code_pos = _run_fixture(fx, dev)
+    RT, AT = 2e-3, 1e-5
+    _relclose(out[0], fx["pos_intra_loss"], RT, AT, "pos_intra_loss")
+    _relclose(out[2], fx["pos_inter_loss"], RT, AT, "pos_inter_loss")
+    _relclose(out[4].mean(), fx["neg_inter_loss_mean"], RT, AT, "neg_inter_loss.mean")
+    _relclose(out[1].mean(), fx["pos_intra_cd_mean"], RT, 1e-5, "pos_intra_cd.mean")
+    _relclose(out[3].mean(), fx["pos_inter_cd_mean"], RT, 1e-5, "pos_inter_cd.mean")
+    _relclose(out[5].mean(), fx["neg_inter_cd_mean"], RT, 1e-5, "neg_inter_cd.mean")
+    if cfg.depth_feat_correlation_loss:
+        _relclose(out[6], fx["depth_feat_loss"], RT, AT, "depth_feat_loss")
+        _relclose(out[7].mean(), fx["depth_feat_cd_mean"], 1e-6, 1e-7, "dd mean")
+    _relclose(total, fx["total"], 5e-3, 1e-5, "total")
+    sub = int(fx["sub"])
+    pick = (lambda t: t.detach().cpu().numpy()) if bool(fx["store_full"]) else \
+        (lambda t: t.detach().reshape(-1)[::sub].cpu().numpy())
+    assert np.abs(pick(out[1]) - fx["pos_intra_cd"]).max() < 1e-3
+    assert np.abs(pick(out[3]) - fx["pos_inter_cd"]).max() < 1e-3
+    assert np.abs(pick(out[5]) - fx["neg_inter_cd"]).max() < 1e-3
+    assert np.abs(pick(out[4]) - fx["neg_inter_loss"]).max() < 4e-3
+    if cfg.depth_feat_correlation_loss:
+        assert np.array_equal(pick(out[7]), fx["depth_feat_cd"])      # dd in {0,1}: exact
+    for got, want, name in ((g_code, fx["grad_code"], "grad_code"), (g_code_pos, fx["grad_code_pos"], "grad_code_pos")):
+        got = got.cpu().numpy().astype(np.float64)
+        want = want.astype(np.float64)
+        rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+        cos = (got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want))
+        tol = 3e-3 if not cfg.zero_clamp else 3e-2
+        assert rel < tol and cos > 0.9995, f"{name}: rel-l2 {rel:.3e} cos {cos:.6f}"
+
+
+def test_reduced_outputs_match_full(dev):
+    fx = load_golden("forward_c1_none.npz")
+    _, out_f, total_f, g_f, gp_f = _run_fixture(fx, dev)
+    _, out_r, total_r, g_r, gp_r = _run_fixture(fx, dev, dg_outputs="reduced")
+    assert float(total_f) == pytest.approx(float(total_r), rel=1e-6)
+    # LDS float atomics in the scatter make the last bits order-dependent
+    assert torch.allclose(g_f, g_r, rtol=1e-4, atol=1e-9) and torch.allclose(gp_f, gp_r, rtol=1e-4, atol=1e-9)
+    assert out_r[4].numel() == 1 and float(out_r[1]) == pytest.approx(float(out_f[1].mean()), rel=1e-4)
+
+
+def test_fps_bit_exact(dev, golden_functions):
+    from depthg_amd import ops
+    g = golden_functions
+    for S in (6, 11):
+        c, inds = ops.fps_coords(torch.from_numpy(g["fpsd_depth"]).to(dev), (14, 14), S, return_inds=True)
+        assert np.array_equal(c.cpu().numpy(), g[f"fpsd_coords_S{S}"] * 2 - 1)
+    c = ops.fps_coords(torch.from_numpy(g["fpsd2_depth"]).to(dev), (14, 14), 5)
+    assert np.array_equal(c.cpu().numpy(), g["fpsd2_coords_S5"] * 2 - 1)
+    # selection ORDER against the oracle (the reference discards it, quirk Q4, but it pins the argmax tie-breaking)
+    from oracle import depthg_oracle as O
+    d = torch.from_numpy(g["fpsd_depth"])
+    _, want = O.farthest_point_sampling_depth((14, 14), d, 6, return_inds=True)
+    _, got = ops.fps_coords(d.to(dev), (14, 14), 6, return_inds=True)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_fps_flat_depth_ties(dev):
+    """constant depth: many exactly equal distances -> first-max tie-breaking must match numpy's."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    d = torch.full((2, 1, 112, 112), 3.0)
+    want = O.farthest_point_sampling_depth((14, 14), d, 5) * 2 - 1
+    got = ops.fps_coords(d.to(dev), (14, 14), 5)
+    assert np.array_equal(got.cpu().numpy(), want.numpy())
+
+
+def test_module_rng_path_fps_and_rand(dev):
+    """RNG-driven entry point (coords drawn inside): fps coords equal the reference's; output tuple arity."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    fx = load_golden("forward_c1_fps.npz")
+    cfg = cfg_from_fixture(fx)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    loss = ContrastiveCorrelationLoss(cfg)
+    c1, c2, shared = loss._draw_coords(T(fx["feats"]), T(fx["feats_pos"]), None, None, T(fx["depth"]), T(fx["depth_pos"]))
+    assert not shared
+    assert np.array_equal(c1.cpu().numpy(), fx["coords1"]) and np.array_equal(c2.cpu().numpy(), fx["coords2"])
+    out = loss(T(fx["feats"]), T(fx["feats_pos"]), None, None, T(fx["code"]), T(fx["code_pos"]), T(fx["depth"]), T(fx["depth_pos"]))
+    assert len(out) == 8 and out[4].shape == (5 * 2, 11, 11, 11, 11) and out[1].shape == (2, 11, 11, 11, 11)
+    cfg.depth_sampling = "none"
+    cfg.depth_feat_correlation_loss = False
+    out = loss(T(fx["feats"]), T(fx["feats_pos"]), None, None, T(fx["code"]), T(fx["code_pos"]), None, None)
+    assert len(out) == 6
+
+
+@pytest.mark.parametrize("B,C,D,hw,S,N", [(3, 384, 70, 28, 28, 2), (2, 768, 100, 28, 11, 3), (4, 384, 90, 28, 12, 5),
+                                          (2, 96, 32, 16, 16, 1)])
+def test_oracle_seeded_shapes(B, C, D, hw, S, N, dev):
+    """HIP vs CPU oracle on seeded inputs: ViT-S/ViT-B widths, P not a multiple of 32, dense 28x28."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(100 + S)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float()
+    d[:, :, :9, :7] = 0.0
+    c1 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    c2 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dg_outputs="reduced")
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
+                                                       [p.to(dev) for p in perms])
+    O.total_loss(cfg, out).backward()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 2e-3, 1e-5, f"tuple[{i}]")
+    for i in (1, 3, 5, 7):
+        _relclose(out[i].mean(), ref[i].mean(), 2e-3, 1e-5, f"tuple[{i}] mean")
+    for got, want in ((cg.grad, cr.grad), (cpg.grad, cpr.grad)):
+        rel = (got.cpu() - want).norm() / want.norm()
+        assert rel < 3e-2, float(rel)
+
+
+def test_headline_size_properties(dev):
+    """B=32, C=384, 28x28 dense grid (BASELINE.json headline): size-independent properties.
+    (a) dense shared-grid mode == general gather mode on the same identity coords;
+    (b) loss means linear in the shifts: L(shift) - L(0) = shift * mean(clamp(cd));
+    (c) gradient is linear in the upstream weights."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.loss import identity_coords
+    from oracle import depthg_oracle as O
+    B, C, D, hw = 32, 384, 70, 28
+    g = torch.Generator().manual_seed(1234)
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+    d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float().to(dev)
+    perms = [O.super_perm(B, g).to(dev) for _ in range(5)]
+    coords = identity_coords(B, hw, dev)
+    cfg = O.default_cfg(feature_samples=hw, dg_outputs="reduced")
+
+    def run(cfg, shared, weights=(0.67, 0.25, 0.63, 0.19)):
+        cg, cpg = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+        out = ContrastiveCorrelationLoss(cfg).forward_with(f, fp, cg, cpg, d, coords, coords, perms, shared_coords=shared)
+        tot = weights[0] * out[0] + weights[1] * out[2] + weights[2] * out[4].mean() + weights[3] * out[6]
+        tot.backward()
+        return [float(out[i].mean()) for i in range(8)], cg.grad, cpg.grad
+
+    s_shared, g_shared, gp_shared = run(cfg, True)
+    s_gen, g_gen, gp_gen = run(cfg, False)
+    for a, b in zip(s_shared, s_gen):
+        assert a == pytest.approx(b, rel=1e-6, abs=1e-9)
+    assert (g_shared - g_gen).norm() <= 1e-5 * g_gen.norm()
+    # (b) zero-clamped cd >= 0: with shift -> 0 the loss changes by shift * mean(clamp(cd)) for each term
+    cfg0 = O.default_cfg(feature_samples=hw, dg_outputs="reduced", pos_intra_shift=0.0, pos_inter_shift=0.0,
+                         neg_inter_shift=0.0, depth_feat_shift=0.0)
+    s0, _, _ = run(cfg0, True)
+    cfg1 = O.default_cfg(feature_samples=hw, dg_outputs="reduced", pos_intra_shift=0.5, pos_inter_shift=0.5,
+                         neg_inter_shift=0.5, depth_feat_shift=0.5)
+    s1, _, _ = run(cfg1, True)
+    for i in (0, 2, 4, 6):
+        delta_a = (s_shared[i] - s0[i]) / [cfg.pos_intra_shift, 0, cfg.pos_inter_shift, 0, cfg.neg_inter_shift, 0, cfg.depth_feat_shift][i]
+        delta_b = (s1[i] - s0[i]) / 0.5
+        assert delta_a == pytest.approx(delta_b, rel=2e-3)
+        assert delta_b > 0
+    # (c) linearity of the backward in the upstream weights
+    _, g2, gp2 = run(cfg, True, weights=(1.34, 0.5, 1.26, 0.38))
+    assert (g2 - 2 * g_shared).norm() <= 1e-5 * g2.norm() and (gp2 - 2 * gp_shared).norm() <= 1e-5 * gp2.norm()
+
+
+def test_headline_loss_vs_oracle_subset(dev):
+    """Headline width on a batch the CPU oracle finishes in seconds (B=4, C=384, 28x28 dense, 5 negatives):
+    loss means within 1e-4 relative (north_star tolerance)."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.loss import identity_coords
+    from oracle import depthg_oracle as O
+    B, C, D, hw = 4, 384, 70, 28
+    g = torch.Generator().manual_seed(4321)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float()
+    perms = [O.super_perm(B, g) for _ in range(5)]
+    cfg = O.default_cfg(feature_samples=hw, dg_outputs="reduced")
+    coords = O.identity_coords(B, hw)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=coords, coords2=coords, perms=perms)
+    tot_ref = O.total_loss(cfg, ref)
+    tot_ref.backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), coords.to(dev),
+                                                       coords.to(dev), [p.to(dev) for p in perms], shared_coords=True)
+    tot = O.total_loss(cfg, out)
+    tot.backward()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 1e-4, 0.0, f"loss term {i}")
+    _relclose(tot, tot_ref, 1e-4, 0.0, "weighted total")
+    rel = (cg.grad.cpu() - cr.grad).norm() / cr.grad.norm()
+    assert rel < 3e-2, float(rel)
+
+
+def test_error_paths(dev):
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    cfg = O.default_cfg(feature_samples=4)
+    loss = ContrastiveCorrelationLoss(cfg)
+    f = torch.randn(2, 16, 8, 8, device=dev)
+    c = torch.randn(2, 8, 8, 8, device=dev)
+    with pytest.raises(AttributeError):      # depth term on, depth=None (reference: interpolate(None) raises)
+        loss(f, f, None, None, c, c, None, None)
+    with pytest.raises(RuntimeError):        # CPU tensors: no fallback path
+        loss.forward_with(f.cpu(), f.cpu(), c.cpu(), c.cpu(), torch.ones(2, 1, 16, 16), torch.zeros(2, 4, 4, 2),
+                          torch.zeros(2, 4, 4, 2), [torch.zeros(2, dtype=torch.long)] * 5)
+    big = torch.randn(1, 1024, 4, 4, device=dev)
+    with pytest.raises(RuntimeError, match="not supported"):
+        loss.forward_with(big, big, c[:1, :, :4, :4], c[:1, :, :4, :4], torch.ones(1, 1, 16, 16, device=dev),
+                          torch.zeros(1, 4, 4, 2, device=dev), torch.zeros(1, 4, 4, 2, device=dev),
+                          [torch.zeros(1, dtype=torch.long, device=dev)] * 5)

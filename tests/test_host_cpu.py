@@ -1,0 +1,122 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/depthg_corr.h declares, descriptor
+validation, the host-side schedules, and that the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_exports_every_declared_symbol():
+    from depthg_amd import _lib
+    header = open(os.path.join(ROOT, "include", "depthg_corr.h")).read()
+    declared = set(re.findall(r"\b(dg_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/depthg_corr.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert lib.dg_version() == 100
+
+
+def test_descriptor_validation_and_workspace():
+    from depthg_amd import ops
+    kw = dict(pointwise=True, zero_clamp=True, stabalize=False, depth_term=True, need_grad=True, shared_coords=False,
+              shifts=(0.1, 0.2, 0.3, 0.4), depth_hw=(224, 224))
+    small = ops.workspace_bytes(ops.make_desc(2, 64, 70, 14, 14, 11, 5, **kw))
+    big = ops.workspace_bytes(ops.make_desc(32, 384, 70, 28, 28, 28, 5, **kw))
+    assert 0 < small < big < 2 ** 31
+    shared = ops.workspace_bytes(ops.make_desc(32, 384, 70, 28, 28, 28, 5, **{**kw, "shared_coords": True}))
+    assert shared < big
+    for bad in (dict(C=769), dict(D=129), dict(n_neg=9), dict(B=0)):
+        args = dict(B=2, C=64, D=70, h=14, w=14, S=11, n_neg=5)
+        args.update(bad)
+        with pytest.raises(RuntimeError):
+            ops.workspace_bytes(ops.make_desc(*args.values(), **kw))
+
+
+def test_struct_layout_matches_header():
+    from depthg_amd._lib import CorrDesc
+    assert ctypes.sizeof(CorrDesc) == 14 * 4
+    assert [f[0] for f in CorrDesc._fields_][:10] == ["B", "C", "D", "h", "w", "S", "n_neg", "depth_h", "depth_w", "flags"]
+
+
+def test_product_path_refuses_cpu_tensors():
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    loss = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=4))
+    assert list(loss.parameters()) == []          # src/train_segmentation.py:136 iterates .parameters()
+    f, c = torch.randn(2, 16, 8, 8), torch.randn(2, 8, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        loss.forward_with(f, f, c, c, torch.ones(2, 1, 16, 16), torch.zeros(2, 4, 4, 2), torch.zeros(2, 4, 4, 2),
+                          [torch.zeros(2, dtype=torch.long)] * 5)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "depthg_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src, f"{fn} mentions the oracle"
+
+
+def test_decay_schedules_match_reference():
+    from depthg_amd import depth_decay as DD
+    d = load_golden("decay.npz")
+    for kind, init, is_int, rate, every, mn, step, val, val_int in d["table"]:
+        cls = DD.get_depth_scheduler("exp" if kind == 0 else "lin")
+        init_v, mn_v = (int(init), int(mn)) if is_int else (float(init), float(mn))
+        v = cls(init_v, float(rate), int(every), mn_v).return_update(int(step))
+        assert float(v) == pytest.approx(float(val), rel=1e-12, abs=1e-15) and isinstance(v, int) == bool(val_int)
+    with pytest.raises(NotImplementedError):
+        DD.get_depth_scheduler("cos")
+    with pytest.raises(AssertionError):
+        DD.ExponentialDecay(1.0, 0.5, 10, 0)      # int/float mismatch, like the reference's assert
+
+
+def test_legacy_decay_traces():
+    import ast
+    from types import SimpleNamespace
+    from depthg_amd.depth_decay import legacy_decay_step
+    d = load_golden("decay.npz")
+    for key in [k for k in d if k.startswith("trace_")]:
+        r = ast.literal_eval(str(d["recipe_" + key[len("trace_"):]]))
+        cfg = SimpleNamespace(fix_depth_feat_shift=False, fps_until_step=0, post_fps_samples=11, fps_min_samples=0)
+        for k, v in r.items():
+            setattr(cfg, k, v)
+        want = {int(row[0]): row[1:] for row in d[key]}
+        for step in range(int(r["max_steps"])):
+            legacy_decay_step(cfg, cfg, step)
+            if step in want:
+                w = want[step]
+                assert cfg.depth_feat_weight == pytest.approx(w[0], rel=1e-12)
+                assert cfg.depth_feat_shift == pytest.approx(w[1], rel=1e-12)
+                assert cfg.feature_samples == int(w[2]) and (cfg.depth_sampling != "none") == bool(w[3])
+
+
+def test_super_perm_properties():
+    from depthg_amd.loss import super_perm
+    torch.manual_seed(0)
+    for n in (1, 2, 5, 32):
+        for _ in range(20):
+            p = super_perm(n, "cpu")
+            assert p.shape == (n,) and int(p.min()) >= 0 and int(p.max()) < n
+            if n > 1:
+                assert not bool((p == torch.arange(n)).any())
+    assert super_perm(1, "cpu").tolist() == [0]      # quirk Q6
+    g = load_golden("functions.npz")
+    torch.manual_seed(3)
+    assert np.array_equal(super_perm(8, "cpu").numpy(), g["superperm_8"])   # same RNG consumption as the reference
+
+
+def test_shard_range_covers_batch():
+    from depthg_amd.parallel import shard_range
+    for gb, world in ((64, 8), (10, 4), (3, 8)):
+        spans = [shard_range(gb, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
