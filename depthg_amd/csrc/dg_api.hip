@@ -6,7 +6,6 @@
 #include <cstdio>
 #include <cstring>
 
-
 // ---- error reporting
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -29,14 +28,15 @@ extern "C" const char* dg_last_error(void) { return g_err; }
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
-    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, nwaves, nrb;
+    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, nwaves, nrb, nchunk, blob;
     bool shared, depth, grad, pointwise;
     size_t nhwc_f[2], nhwc_c[2];
-    size_t Fk[DG_MAX_NEG + 2], Ck[DG_MAX_NEG + 2], Cp[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2];
+    size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2];
     size_t nz;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
+    size_t comb[2], jobsum;
     size_t total;
 };
 
@@ -62,21 +62,24 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.nops = p.shared ? 2 : p.T;
     p.nwaves = (p.KF == 768 || p.KD == 128 || p.Ppad <= 128) ? 4 : 8;
     p.nrb = (p.Ppad + p.nwaves * 32 - 1) / (p.nwaves * 32);
+    p.nchunk = (p.Ppad + DG_RM_ROWS - 1) / DG_RM_ROWS;
+    p.blob = DgBlob(p.KF, p.KD).bytes;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
     const size_t HW = (size_t)p.h * p.w, B = p.B;
     for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(B * HW * p.C4 * 4); p.nhwc_c[i] = take(B * HW * p.D4 * 4); }
     for (int i = 0; i < p.nops; ++i) {
-        p.Fk[i] = take(B * p.Ppad * p.KF * 2);
-        p.Ck[i] = take(B * p.Ppad * p.KD * 2);
-        p.Cp[i] = take(B * p.KD * p.Ppad * 2);
+        p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
         p.colpart[i] = take(B * (p.Ppad / 32) * p.KF * 4);
+        p.bbar[i] = take(B * p.KF * 4);
     }
-    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * 4); }
+    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * p.nchunk * 4); }
     p.nz = take(B * p.Ppad * 4);
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
+    for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
+    p.jobsum = take((DG_MAX_JOBS + 1) * 2 * 8);
     p.total = off;
     return DG_OK;
 }
@@ -106,18 +109,17 @@ static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, b
     memset(&j, 0, sizeof(j));
     const int o2 = op_of(p, t);
     const int64_t* m2 = map_of(p, t, perms);
-    auto U16 = [&](size_t off) { return reinterpret_cast<const uint16_t*>(ws + off); };
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     if (!passB) {
-        j.Rf = U16(p.Fk[0]); j.Rc = U16(p.Ck[0]); j.RcInv = F32(p.inv[0]); j.ridx = nullptr;
-        j.Sf = U16(p.Fk[o2]); j.Sc = U16(p.Ck[o2]); j.ScP = U16(p.Cp[o2]); j.sidx = m2;
+        j.Rop = ws + p.op[0]; j.RcInv = F32(p.inv[0]); j.ridx = nullptr;
+        j.Sop = ws + p.op[o2]; j.sidx = m2;
         j.center_on_lane = 1;
     } else {
-        j.Rf = U16(p.Fk[o2]); j.Rc = U16(p.Ck[o2]); j.RcInv = F32(p.inv[o2]); j.ridx = m2;
-        j.Sf = U16(p.Fk[0]); j.Sc = U16(p.Ck[0]); j.ScP = U16(p.Cp[0]); j.sidx = nullptr;
+        j.Rop = ws + p.op[o2]; j.RcInv = F32(p.inv[o2]); j.ridx = m2;
+        j.Sop = ws + p.op[0]; j.sidx = nullptr;
         j.center_on_lane = 0;
     }
-    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.rsum = F32(p.rsum[t]); }
+    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.rsum = F32(p.rsum[t]); j.nrsum = p.B * p.nchunk; }
     j.shift = shift_of(d, t);
     j.kind = DG_JOB_HELPER;
     return j;
@@ -126,9 +128,8 @@ static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, b
 static DgJob depth_job(const Plan& p, const dg_corr_desc* d, char* ws) {
     DgJob j;
     memset(&j, 0, sizeof(j));
-    auto U16 = [&](size_t off) { return reinterpret_cast<const uint16_t*>(ws + off); };
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    j.Rc = U16(p.Ck[0]); j.Sc = U16(p.Ck[0]); j.ScP = U16(p.Cp[0]); j.RcInv = F32(p.inv[0]);
+    j.Rop = ws + p.op[0]; j.Sop = ws + p.op[0]; j.RcInv = F32(p.inv[0]);
     j.nzR = F32(p.nz); j.nzS = F32(p.nz);
     j.shift = d->shift_depth;
     j.kind = DG_JOB_DEPTH;
@@ -136,29 +137,26 @@ static DgJob depth_job(const Plan& p, const dg_corr_desc* d, char* ws) {
     return j;
 }
 
-static void corr_args_base(const Plan& p, const dg_corr_desc* d, DgCorrArgs& a) {
+static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCorrArgs& a) {
     memset(&a, 0, sizeof(a));
     a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.nrb = p.nrb; a.D = p.D;
     clamp_bounds(d, a.lo, a.hi);
     a.inv_BP = 1.0f / ((float)p.B * (float)p.P);
+    a.dummy = ws + p.op[0];
 }
 
-// Job table of the fused correlation launch: pass A (stationary = operand 1) for every pair-set and the
-// depth term, then (with gradients) pass B (stationary = operand 2).  Returns the number of pass-A jobs.
-static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a) {
+// Job table of the fused correlation launch: pass A (stationary = operand 1) for every pair-set, then (with
+// gradients) pass B (stationary = operand 2), the cheap depth job last.  Pass-A jobs come first: returns their count
+// (the depth job, when present, is the last job of the table and is also a pass-A job for the loss sums).
+static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a,
+                           int* depth_index) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    corr_args_base(p, desc, a);
+    corr_args_base(p, desc, ws, a);
     int nj = 0;
     for (int t = 0; t < p.T; ++t) {
         DgJob j = helper_job(p, desc, ws, t, false, perms);
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
-        a.jobs[nj++] = j;
-    }
-    if (p.depth) {
-        DgJob j = depth_job(p, desc, ws);
-        j.part = F32(p.part[p.T]);
-        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
         a.jobs[nj++] = j;
     }
     const int njA = nj;
@@ -168,6 +166,14 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
             j.dR = F32(p.dRB[t]);
             a.jobs[nj++] = j;
         }
+    *depth_index = -1;
+    if (p.depth) {
+        DgJob j = depth_job(p, desc, ws);
+        j.part = F32(p.part[p.T]);
+        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
+        *depth_index = nj;
+        a.jobs[nj++] = j;
+    }
     a.njobs = nj;
     return njA;
 }
@@ -188,7 +194,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char* ws = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    auto U16 = [&](size_t off) { return reinterpret_cast<uint16_t*>(ws + off); };
     const int HW = p.h * p.w;
 
     // 1. channel-last copies of the four maps (the gather reads whole channel vectors per tap)
@@ -197,11 +202,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
     DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
 
-    // 2. sample + normalise + bf16 operand layouts
+    // 2. sample + normalise + operand blobs
     {
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
-        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad;
+        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
         int nj = 0;
         for (int o = 0; o < p.nops; ++o) {
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
@@ -209,12 +214,12 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
             DgGatherJob& f = g.jobs[nj++];
             f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
-            f.outK = U16(p.Fk[o]); f.outP = nullptr; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
-            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.fp16 = 0;
+            f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
+            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
             DgGatherJob& c = g.jobs[nj++];
             c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
-            c.outK = U16(p.Ck[o]); c.outP = U16(p.Cp[o]); c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
-            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.fp16 = 1;
+            c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
+            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
         }
         g.njobs = nj;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
@@ -223,12 +228,17 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
 
     // 3. row means of fd (pointwise centering as a rank-1 correction)
     if (p.pointwise) {
+        DgColmeanArgs c;
+        memset(&c, 0, sizeof(c));
+        c.nops = p.nops; c.B = p.B; c.P = p.P; c.Ppad = p.Ppad; c.KF = p.KF;
+        for (int o = 0; o < p.nops; ++o) { c.colpart[o] = F32(p.colpart[o]); c.bbar[o] = F32(p.bbar[o]); }
+        DG_HIP(dg_launch_colmean(c, stream));
         DgRowmeanArgs r;
         memset(&r, 0, sizeof(r));
-        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.njobs = p.T;
+        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.nchunk = p.nchunk;
         for (int t = 0; t < p.T; ++t) {
-            r.jobs[t].A = U16(p.Fk[0]); r.jobs[t].aidx = nullptr;
-            r.jobs[t].colpart = F32(p.colpart[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
+            r.jobs[t].A = ws + p.op[0]; r.jobs[t].aidx = nullptr;
+            r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
             r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rsum = F32(p.rsum[t]);
         }
         DG_HIP(dg_launch_rowmean(r, stream));
@@ -236,27 +246,32 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
 
     // 4. fused correlation passes
     DgCorrArgs a;
-    const int njA = build_corr_jobs(p, desc, ws, perms, a);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad, stream));
+    int depth_index;
+    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad ? 1 : 0, stream));
 
     // 5. scalar outputs
     DgFinishArgs f;
     memset(&f, 0, sizeof(f));
     const double numel = (double)p.B * p.P * p.P;
-    for (int j = 0; j < njA; ++j) {
-        f.part[j] = a.jobs[j].part;
-        f.nblk[j] = p.B * p.nrb;
-        if (j < p.T) {
-            f.slot_loss[j] = j < 2 ? j : DG_OUT_LOSS_NEG;
-            f.slot_cd[j] = j < 2 ? DG_OUT_CD_INTRA + j : DG_OUT_CD_NEG;
-            f.scale[j] = (float)(1.0 / (j < 2 ? numel : numel * p.N));
-        } else {
-            f.slot_loss[j] = DG_OUT_LOSS_DEPTH; f.slot_cd[j] = -1; f.scale[j] = (float)(1.0 / numel);
-        }
+    int nf = 0;
+    for (int j = 0; j < njA; ++j, ++nf) {
+        f.part[nf] = a.jobs[j].part;
+        f.nblk[nf] = p.B * p.nrb;
+        f.slot_loss[nf] = j < 2 ? j : DG_OUT_LOSS_NEG;
+        f.slot_cd[nf] = j < 2 ? DG_OUT_CD_INTRA + j : DG_OUT_CD_NEG;
+        f.scale[nf] = (float)(1.0 / (j < 2 ? numel : numel * p.N));
     }
-    f.njobs = njA;
+    if (depth_index >= 0) {
+        f.part[nf] = a.jobs[depth_index].part;
+        f.nblk[nf] = p.B * p.nrb;
+        f.slot_loss[nf] = DG_OUT_LOSS_DEPTH; f.slot_cd[nf] = -1; f.scale[nf] = (float)(1.0 / numel);
+        ++nf;
+    }
+    f.njobs = nf;
     f.nz = p.depth ? F32(p.nz) : nullptr;
     f.B = p.B; f.P = p.P; f.Ppad = p.Ppad;
+    f.jobsum = reinterpret_cast<double*>(ws + p.jobsum);
     f.out = out_scalars;
     DG_HIP(dg_launch_finish(f, stream));
     return DG_OK;
@@ -273,7 +288,7 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", p.N);
     if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
     char* ws = static_cast<char*>(workspace);
-    auto F32 = [&](size_t off) { return reinterpret_cast<const float*>(ws + off); };
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     DgScatterArgs s;
     memset(&s, 0, sizeof(s));
     const float f = (float)(1.0 / ((double)p.B * p.P * p.P));
@@ -291,9 +306,10 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
         add(p.dRA[2 + k], nullptr, 2, 0, fn, 0);
         add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0);
     }
-    if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0);
+    if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
     s.nsrc = n;
     s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
+    s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
     s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
     int DC = 32;
@@ -317,13 +333,13 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     if (!out_cd && !out_loss) return DG_OK;
     char* ws = static_cast<char*>(workspace);
     DgCorrArgs a;
-    corr_args_base(p, desc, a);
+    corr_args_base(p, desc, ws, a);
+    // stationary = operand 2 (on MFMA lanes) -> the stores of one accumulator register are contiguous along q
     DgJob j = which == -1 ? depth_job(p, desc, ws) : helper_job(p, desc, ws, which, true, nullptr);
-    j.center_on_lane = 0;   // stationary = operand 2 -> stores are contiguous along q
-    if (which == -1) { /* R = S = code at coords1, dd symmetric */ }
+    j.center_on_lane = 0;
     j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
     a.jobs[0] = j; a.njobs = 1;
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, false, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, 2, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 
@@ -337,8 +353,9 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     if (!workspace || workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace missing or too small");
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null");
     DgCorrArgs a;
-    build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad, static_cast<hipStream_t>(stream_)));
+    int depth_index;
+    build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad ? 1 : 0, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -6,13 +6,11 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define DG_EPS_NORM 1e-10f  // F.normalize eps, reference src/modules.py:790
-#define DG_TILE 32          // positions per MFMA tile edge (v_mfma_f32_32x32x16_bf16)
 
 // Position permutation inside each 32-position block of the P-major code operand, chosen so that
 // the B fragment of the gradient product (k order = accumulator row order of a 32x32 MFMA tile,
@@ -23,6 +21,43 @@ __host__ __device__ inline int dg_perm32(int pl) {
     return (2 * s + hh) * 8 + 4 * u + v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Operand layout in HBM ("blob" layout).  A prepared operand = the normalised sampled feats (bf16) and
+// code (fp16) of one tensor pair, stored per image n and per tile of 32 positions as ONE contiguous blob
+// that is byte-for-byte the LDS image the correlation kernel wants, so that staging a tile is a linear
+// global->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) with no registers involved:
+//   F part  [32 positions q][GF granules]  bf16, granule g of row q stored at slot q*GF + (g ^ (q & 15))
+//           (XOR swizzle: the 16 lanes of a ds_read_b128 group read distinct rows at one k -> distinct banks)
+//   C part  [GD granules][32 positions]    fp16, K-major code, granule-major (conflict-free as is)
+//   P part  [4 granules c][KD channels d]  fp16, P-major code: granule c of channel d holds the positions
+//           with dg_perm32(pl) in [8c, 8c+8)
+// granule = 16 bytes = 8 elements.  KF in {128,384,768} (GF multiple of 16), KD in {96,128}.
+struct DgBlob {
+    int GF, GD, KD;
+    int off_c, off_p, bytes;
+    __host__ __device__ DgBlob(int KF, int KD_) : GF(KF / 8), GD(KD_ / 8), KD(KD_) {
+        off_c = 32 * GF * 16;
+        off_p = off_c + GD * 32 * 16;
+        bytes = off_p + 4 * KD * 16;
+    }
+    __host__ __device__ int f(int q, int g) const { return (q * GF + (g ^ (q & 15))) * 16; }
+    __host__ __device__ int c(int q, int g) const { return off_c + (g * 32 + q) * 16; }
+    __host__ __device__ int p(int d, int cc) const { return off_p + (cc * KD + d) * 16; }
+};
+
+template <int NKF, int NKD>
+struct BlobT {
+    static constexpr int KF = NKF * 16, KD = NKD * 16, GF = KF / 8, GD = KD / 8;
+    static constexpr int OFF_C = 32 * GF * 16;
+    static constexpr int OFF_P = OFF_C + GD * 32 * 16;
+    static constexpr int BYTES = OFF_P + 4 * KD * 16;
+    static constexpr int CHUNKS = BYTES / 1024;          // 1 KiB DMA pieces
+    static constexpr int CHUNK_C0 = OFF_C / 1024;        // first chunk of the C part
+    static constexpr int CHUNK_P0 = OFF_P / 1024;
+    static_assert(BYTES % 1024 == 0 && OFF_C % 1024 == 0 && OFF_P % 1024 == 0, "blob parts must be KiB multiples");
+    static_assert(GF % 16 == 0, "swizzle needs 16-granule groups");
+};
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 
@@ -30,13 +65,10 @@ enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 // "R" = stationary operand (its positions live on MFMA lanes / output rows of the gradient),
 // "S" = streamed operand (tiles of 32 positions through LDS).
 struct DgJob {
-    const uint16_t* Rf;   // bf16 [B][Ppad][KF]  normalised feats, K-major   (null for DG_JOB_DEPTH)
-    const uint16_t* Rc;   // fp16 [B][Ppad][KD]  normalised code,  K-major (fp16: 4x finer than bf16, range is [-1,1])
-    const uint16_t* Sf;   // bf16 [B][Ppad][KF]
-    const uint16_t* Sc;   // fp16 [B][Ppad][KD]
-    const uint16_t* ScP;  // fp16 [B][KD][Ppad]  normalised code, P-major, dg_perm32-permuted per 32-block
+    const char* Rop;      // operand blobs [B][Ppad/32][blob bytes] of the stationary operand
+    const char* Sop;      // ... of the streamed operand
     const float* rvec;    // fp32 [B][Ppad] row means a_p . bbar (indexed by operand-1 position) or null
-    const float* rsum;    // fp32 [B] per-image sums of rvec over valid p (for m0) or null
+    const float* rsum;    // fp32 [nrsum] partial sums of rvec over valid p (for m0) or null
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
     const float* nzS;
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
@@ -49,7 +81,7 @@ struct DgJob {
     float shift;
     int32_t kind;
     int32_t center_on_lane;  // 1: R is operand 1 (rvec / nzR indexed by lane); 0: R is operand 2 (rvec by tile row)
-    int32_t pad_;
+    int32_t nrsum;           // number of rsum partials (B * chunks)
 };
 
 #define DG_MAX_JOBS 24
@@ -62,6 +94,7 @@ struct DgCorrArgs {
     int32_t D;            // real code channels
     float lo, hi;         // clamp bounds
     float inv_BP;         // 1 / (B*P)
+    const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
 };
 
 // ---- argument blocks of the helper kernels (one definition shared by kernels and host API)
@@ -74,6 +107,7 @@ struct DgFinishArgs {
     int32_t njobs;
     const float* nz;                 // [B][Ppad] or null
     int32_t B, P, Ppad;
+    double* jobsum;                  // [DG_MAX_JOBS + 1][2] scratch (stage 1 -> stage 2)
     float* out;                      // [DG_OUT_COUNT]
 };
 
@@ -81,31 +115,36 @@ struct DgGatherJob {
     const float* src;        // NHWC fp32 [B][h*w][K4]
     const float* coords;     // [B][S][S][2]
     const int64_t* srcidx;   // batch map (image n is read from src[srcidx[n]]) or null
-    uint16_t* outK;          // bf16 [B][Ppad][Kpad]
-    uint16_t* outP;          // bf16 [B][Kpad][Ppad] permuted (code operands) or null
-    float* inv_norm;         // [B][Ppad] or null
-    float* colpart;          // [B][Ppad/32][Kpad] per-tile column sums of the normalised rows or null
+    char* blob;              // operand blobs [B][Ppad/32][blob bytes]
+    float* inv_norm;         // [B][Ppad] or null (code)
+    float* colpart;          // [B][Ppad/32][Kpad] per-tile column sums of the normalised rows or null (feats)
     int32_t K, K4, Kpad;
-    int32_t fp16;            // 1: write IEEE half (code operands), 0: bf16 (feats operands)
-    int32_t pad_;
+    int32_t is_code;         // 1: fp16 code (C and P parts), 0: bf16 feats (F part)
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
     DgGatherJob jobs[DG_MAX_GATHER];
-    int32_t njobs, B, h, w, S, P, Ppad;
+    int32_t njobs, B, h, w, S, P, Ppad, KF, KD;
 };
 
+struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_tiles colpart[o][n][tile][k]
+    const float* colpart[DG_MAX_NEG + 2];
+    float* bbar[DG_MAX_NEG + 2];
+    int32_t nops, B, P, Ppad, KF;
+};
+
+#define DG_RM_ROWS 64       // rows per block of k_rowmean
 struct DgRowmeanJob {
-    const uint16_t* A;        // bf16 [B][Ppad][KF] operand-1 feats
-    const float* colpart;     // [B][Ppad/32][KF] column sums of the operand-2 feats
+    const char* A;            // operand-1 blobs
+    const float* bbar;        // [B][KF] mean normalised feats of operand 2
     const int64_t* aidx;      // batch maps (null = identity)
     const int64_t* bidx;
     float* rvec;              // [B][Ppad]
-    float* rsum;              // [B]
+    float* rsum;              // [B][nchunk]
 };
 struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
-    int32_t njobs, B, P, Ppad, KF;
+    int32_t njobs, B, P, Ppad, KF, KD, nchunk;
 };
 
 struct DgScatterSrc {
@@ -123,16 +162,18 @@ struct DgScatterArgs {
     const float* coords1;
     const float* coords2;
     const float* gscal;    // [4] upstream gradients (device)
+    float* comb[2];        // [B][Ppad][DP] combined direct sources per destination (scratch)
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
     int32_t B, D, DP, h, w, S, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
 };
 
 // launchers (defined next to their kernels)
-hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, bool grad, hipStream_t stream);
+hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W, int S, int Ppad, hipStream_t s);
+hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,

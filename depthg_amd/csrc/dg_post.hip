@@ -21,83 +21,81 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
     w00 = wy0 * wx0; w01 = wy0 * wx1; w10 = wy1 * wx0; w11 = wy1 * wx1;
 }
 
-// grid (ceil(D/DC), B, 2), block 256, dynamic LDS DC*(h*w+1)*4
-__global__ __launch_bounds__(256) void k_scatter_grad(const DgScatterArgs a) {
+// Stage 1: comb[dest][b][p][:] = sum over the direct sources of `dest` of factor * upstream * buf[b][p][:]
+// (elementwise, float4).  grid (ceil(B*Ppad*DP/4 / 256), 2).
+__global__ __launch_bounds__(256) void k_grad_combine(const DgScatterArgs a) {
+    const int dest = blockIdx.y;
+    const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.nsrc; ++s) {
+        const DgScatterSrc& q = a.src[s];
+        if (q.dest != dest || q.route != nullptr) continue;
+        const float sc = q.factor * a.gscal[q.gidx];
+        const float4 v = reinterpret_cast<const float4*>(q.buf)[i];
+        acc.x = fmaf(sc, v.x, acc.x); acc.y = fmaf(sc, v.y, acc.y); acc.z = fmaf(sc, v.z, acc.z); acc.w = fmaf(sc, v.w, acc.w);
+    }
+    reinterpret_cast<float4*>(a.comb[dest])[i] = acc;
+}
+
+#define SCAT_THREADS 512
+__device__ __forceinline__ void scatter_rows(float* acc, int stride, const float* buf, float sc, const float* coords,
+                                             int nimg, int d, int dl, int pl, int pstep, const DgScatterArgs& a) {
+    const int S = a.S;
+    for (int p = pl; p < a.P; p += pstep) {
+        const int i = p / S, j = p - i * S;
+        int x0, y0; bool inx, iny; float w00, w01, w10, w11;
+        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w00, w01, w10, w11);
+        if (d < a.D) {
+            const float v = sc * buf[((size_t)nimg * a.Ppad + p) * a.DP + d];
+            float* base = acc + dl * stride + y0 * a.w + x0;
+            if (w00 != 0.f) __hip_atomic_fetch_add(base, v * w00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (inx && w01 != 0.f) __hip_atomic_fetch_add(base + 1, v * w01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (iny && w10 != 0.f) __hip_atomic_fetch_add(base + a.w, v * w10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (inx && iny && w11 != 0.f) __hip_atomic_fetch_add(base + a.w + 1, v * w11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// Stage 2: grid (ceil(D/DC), B, 2), block SCAT_THREADS, dynamic LDS DC*(h*w+1)*4: one destination image and
+// channel chunk per block, accumulated in LDS, written once.
+__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
     extern __shared__ float acc[];
     const int tid = threadIdx.x;
     const int dc0 = blockIdx.x * a.DC, bdst = blockIdx.y, dest = blockIdx.z;
     const int HW = a.h * a.w, stride = HW + 1;
-    for (int i = tid; i < a.DC * stride; i += 256) acc[i] = 0.f;
+    for (int i = tid; i < a.DC * stride; i += SCAT_THREADS) acc[i] = 0.f;
     __syncthreads();
-    const int dl = tid & (a.DC - 1), pl = tid / a.DC, pstep = 256 / a.DC;
+    const int dl = tid & (a.DC - 1), pl = tid / a.DC, pstep = SCAT_THREADS / a.DC;
     const int d = dc0 + dl;
-    const int S = a.S;
-    // pass 1: sources that scatter image bdst -> destination bdst (combined before the scatter, per coords set)
-    for (int cs = 0; cs < 2; ++cs) {
-        float scale[DG_MAX_SCATTER];
-        bool any = false;
-        for (int s = 0; s < a.nsrc; ++s) {
-            const DgScatterSrc& q = a.src[s];
-            const bool use = q.dest == dest && q.route == nullptr && q.coords_sel == cs;
-            scale[s] = use ? q.factor * a.gscal[q.gidx] : 0.f;
-            any |= use;
-        }
-        if (!any) continue;
-        const float* coords = cs == 0 ? a.coords1 : a.coords2;
-        for (int p = pl; p < a.P; p += pstep) {
-            float v = 0.f;
-            if (d < a.D)
-                for (int s = 0; s < a.nsrc; ++s)
-                    if (scale[s] != 0.f) v = fmaf(scale[s], a.src[s].buf[((size_t)bdst * a.Ppad + p) * a.DP + d], v);
-            const int i = p / S, j = p - i * S;
-            int x0, y0; bool inx, iny; float w00, w01, w10, w11;
-            dg_taps(coords + (((size_t)bdst * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w00, w01, w10, w11);
-            if (d < a.D) {
-                float* base = acc + dl * stride + y0 * a.w + x0;
-                if (w00 != 0.f) __hip_atomic_fetch_add(base, v * w00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (inx && w01 != 0.f) __hip_atomic_fetch_add(base + 1, v * w01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (iny && w10 != 0.f) __hip_atomic_fetch_add(base + a.w, v * w10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (inx && iny && w11 != 0.f) __hip_atomic_fetch_add(base + a.w + 1, v * w11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    }
-    // pass 2: routed sources (negatives): image n scatters into destination route[n] with n's coords
+    // direct sources (already combined): image bdst -> destination bdst; coords1 for grad_code, coords2 for grad_code_pos
+    scatter_rows(acc, stride, a.comb[dest], 1.0f, dest == 0 ? a.coords1 : a.coords2, bdst, d, dl, pl, pstep, a);
+    // routed sources (negatives): image n scatters into destination route[n] with n's coords
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
         const float sc = q.factor * a.gscal[q.gidx];
         const float* coords = q.coords_sel == 0 ? a.coords1 : a.coords2;
-        for (int n = 0; n < a.B; ++n) {
-            if ((int)q.route[n] != bdst) continue;
-            for (int p = pl; p < a.P; p += pstep) {
-                const int i = p / S, j = p - i * S;
-                int x0, y0; bool inx, iny; float w00, w01, w10, w11;
-                dg_taps(coords + (((size_t)n * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w00, w01, w10, w11);
-                if (d < a.D) {
-                    const float v = sc * q.buf[((size_t)n * a.Ppad + p) * a.DP + d];
-                    float* base = acc + dl * stride + y0 * a.w + x0;
-                    if (w00 != 0.f) __hip_atomic_fetch_add(base, v * w00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (inx && w01 != 0.f) __hip_atomic_fetch_add(base + 1, v * w01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (iny && w10 != 0.f) __hip_atomic_fetch_add(base + a.w, v * w10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (inx && iny && w11 != 0.f) __hip_atomic_fetch_add(base + a.w + 1, v * w11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
+        for (int n = 0; n < a.B; ++n)
+            if ((int)q.route[n] == bdst) scatter_rows(acc, stride, q.buf, sc, coords, n, d, dl, pl, pstep, a);
     }
     __syncthreads();
     float* out = a.out[dest];
-    for (int i = tid; i < a.DC * HW; i += 256) {
+    for (int i = tid; i < a.DC * HW; i += SCAT_THREADS) {
         const int dd = i / HW, pix = i - dd * HW;
         if (dc0 + dd < a.D) out[((size_t)bdst * a.D + dc0 + dd) * HW + pix] = acc[dd * stride + pix];
     }
 }
 
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
+    const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
+    hipLaunchKernelGGL(k_grad_combine, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, s, a);
     const int smem = a.DC * (a.h * a.w + 1) * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_grad), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     dim3 grid((a.D + a.DC - 1) / a.DC, a.B, 2);
-    hipLaunchKernelGGL(k_scatter_grad, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL(k_scatter_grad, grid, dim3(SCAT_THREADS), smem, s, a);
     return hipGetLastError();
 }
 

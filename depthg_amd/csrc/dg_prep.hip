@@ -2,7 +2,7 @@
 //   k_nchw_to_nhwc   (B,K,h,w) fp32 -> (B,h*w,K4) fp32, K4 = round_up(K,4), zero padded
 //   k_gather_norm    sample() + norm() of the reference (src/modules.py:822-825, 789-790):
 //                    bilinear gather at coords (grid_sample, border, align_corners=True),
-//                    L2-normalise over channels, write bf16 K-major (+ P-major, 1/norm, column sums)
+//                    L2-normalise over channels, write the tile blobs (+ 1/norm, column sums)
 //   k_depth_nz       depth -> F.interpolate(size=(S,S), bilinear, align_corners=True) -> norm over
 //                    the single channel (src/modules.py:1261-1265): d / max(|d|, 1e-10)
 //   k_rowmean        r[n][p] = a[n][p] . mean_q b[n][q]   (row means of fd for `pointwise`,
@@ -34,11 +34,13 @@ hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int H
 
 // ------------------------------------------------------------------------------------------
 
-// block = 256 threads = 4 waves; block handles 32 consecutive positions (one permutation block),
-// wave w handles positions w, w+4, ...; lane l handles channels 4l + 256 m.
+// block = 256 threads = 4 waves; block handles 32 consecutive positions (one operand tile),
+// wave w handles positions w, w+4, ...; lane l handles channels 4l + 256 m.  Output goes straight into
+// the tile blob (dg_common.h): feats -> F part (bf16, swizzled rows), code -> C part (fp16, granule-major)
+// and P part (fp16, P-major, dg_perm32 order; transposed through LDS).
 template <int MAXM>
 __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
-    __shared__ __attribute__((aligned(16))) uint16_t ptile[128 * 32];   // [Kpad<=128][32] for outP
+    __shared__ __attribute__((aligned(16))) uint16_t ptile[128 * 32];   // [KD<=128][32] for the P part
     __shared__ float colred[4][MAXM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
@@ -47,6 +49,8 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const float* img = J.src + (size_t)ns * a.h * a.w * K4;
     const int S = a.S;
+    const DgBlob L(a.KF, a.KD);
+    char* blob = J.blob + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
 
     float colacc[MAXM][4];
 #pragma unroll
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
         if (p < a.P) {
             // output position (i, j) = (p / S, p % S) reads x = coords[n][j][i][0], y = coords[n][j][i][1]
             const int i = p / S, j = p - i * S;
-            const float* c = a.jobs[blockIdx.z].coords + (((size_t)n * S + j) * S + i) * 2;
+            const float* c = J.coords + (((size_t)n * S + j) * S + i) * 2;
             float x = ((c[0] + 1.f) / 2.f) * (float)(a.w - 1);
             float y = ((c[1] + 1.f) / 2.f) * (float)(a.h - 1);
             x = fminf(fmaxf(x, 0.f), (float)(a.w - 1));
@@ -69,8 +73,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             const float x0f = floorf(x), y0f = floorf(y);
             const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const int x0 = (int)x0f, y0 = (int)y0f;
-            const int x1 = x0 + 1, y1 = y0 + 1;
-            const bool inx = x1 <= a.w - 1, iny = y1 <= a.h - 1;
+            const bool inx = x0 + 1 <= a.w - 1, iny = y0 + 1 <= a.h - 1;
             const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
             const float* p00 = img + ((size_t)y0 * a.w + x0) * K4;
             const float* p01 = p00 + K4;
@@ -102,19 +105,18 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
                 float4 u = make_float4(v[m].x * inv, v[m].y * inv, v[m].z * inv, v[m].w * inv);
                 colacc[m][0] += u.x; colacc[m][1] += u.y; colacc[m][2] += u.z; colacc[m][3] += u.w;
                 uint2 o;
-                if (J.fp16) {
+                if (J.is_code) {
                     f16x4 t; t[0] = (_Float16)u.x; t[1] = (_Float16)u.y; t[2] = (_Float16)u.z; t[3] = (_Float16)u.w;
                     o = *reinterpret_cast<uint2*>(&t);
-                } else {
-                    bf16x4 t; t[0] = (__bf16)u.x; t[1] = (__bf16)u.y; t[2] = (__bf16)u.z; t[3] = (__bf16)u.w;
-                    o = *reinterpret_cast<uint2*>(&t);
-                }
-                *reinterpret_cast<uint2*>(J.outK + ((size_t)n * a.Ppad + p) * Kpad + k) = o;
-                if (J.outP) {
+                    *reinterpret_cast<uint2*>(blob + L.c(pi, k >> 3) + (k & 7) * 2) = o;
                     const int pp = dg_perm32(pi);
                     const uint16_t* ob = reinterpret_cast<const uint16_t*>(&o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ptile[(k + e) * 32 + pp] = ob[e];
+                } else {
+                    bf16x4 t; t[0] = (__bf16)u.x; t[1] = (__bf16)u.y; t[2] = (__bf16)u.z; t[3] = (__bf16)u.w;
+                    o = *reinterpret_cast<uint2*>(&t);
+                    *reinterpret_cast<uint2*>(blob + L.f(pi, k >> 3) + (k & 7) * 2) = o;
                 }
             }
         }
@@ -133,12 +135,12 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             J.colpart[((size_t)n * (a.Ppad / 32) + pt) * Kpad + k] = s;
         }
     }
-    if (J.outP) {
-        // rows d of the P-major operand: 32 positions = 64 bytes = 4 granules per row
+    if (J.is_code) {
+        // P part: channel d, granule cc = 8 permuted positions = 16 bytes
         for (int id = tid; id < Kpad * 4; id += 256) {
-            const int d = id >> 2, g = id & 3;
-            uint4 val = *reinterpret_cast<const uint4*>(&ptile[d * 32 + g * 8]);
-            *reinterpret_cast<uint4*>(J.outP + ((size_t)n * Kpad + d) * a.Ppad + pt * 32 + g * 8) = val;
+            const int d = id >> 2, cc = id & 3;
+            uint4 val = *reinterpret_cast<const uint4*>(&ptile[d * 32 + cc * 8]);
+            *reinterpret_cast<uint4*>(blob + L.p(d, cc)) = val;
         }
     }
 }
@@ -184,34 +186,51 @@ hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W
 
 // ------------------------------------------------------------------------------------------
 
-// grid (B, njobs), block 256.
+// bbar[o][n][k] = (1/P) sum over tiles of the per-tile column sums.  grid (B, nops), block 256.
+__global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
+    const int n = blockIdx.x, o = blockIdx.y, nt = a.Ppad / 32;
+    const float invP = 1.f / (float)a.P;
+    for (int k = threadIdx.x; k < a.KF; k += 256) {
+        float s = 0.f;
+        for (int t = 0; t < nt; ++t) s += a.colpart[o][((size_t)n * nt + t) * a.KF + k];
+        a.bbar[o][(size_t)n * a.KF + k] = s * invP;
+    }
+}
+
+hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_colmean, dim3(a.B, a.nops), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// r[n][p] = a[n][p] . bbar[n]; grid (nchunk, B, njobs), block 256: DG_RM_ROWS rows per block, one row per
+// wave step; lanes walk the 16-byte granule slots of the swizzled F rows.
 __global__ __launch_bounds__(256) void k_rowmean(const DgRowmeanArgs a) {
     __shared__ float bbar[768];
     __shared__ float wsum[4];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const DgRowmeanJob& J = a.jobs[blockIdx.y];
-    const int KF = a.KF, nt = a.Ppad / 32;
+    const int ch = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const DgRowmeanJob& J = a.jobs[blockIdx.z];
+    const int KF = a.KF, GF = KF / 8, nt = a.Ppad / 32;
+    const DgBlob L(a.KF, a.KD);
     const int na = J.aidx ? (int)J.aidx[n] : n;
     const int nb = J.bidx ? (int)J.bidx[n] : n;
-    const float invP = 1.f / (float)a.P;
-    for (int k = tid; k < KF; k += 256) {
-        float s = 0.f;
-        for (int t = 0; t < nt; ++t) s += J.colpart[((size_t)nb * nt + t) * KF + k];
-        bbar[k] = s * invP;
-    }
+    for (int k = tid; k < KF; k += 256) bbar[k] = J.bbar[(size_t)nb * KF + k];
     __syncthreads();
     float tot = 0.f;
-    for (int p = wid; p < a.Ppad; p += 4) {
+    for (int pi = wid; pi < DG_RM_ROWS; pi += 4) {
+        const int p = ch * DG_RM_ROWS + pi;
+        if (p >= a.Ppad) break;
         float d = 0.f;
         if (p < a.P) {
-            const uint16_t* row = J.A + ((size_t)na * a.Ppad + p) * KF;
-            for (int k = 8 * lane; k < KF; k += 512) {
-                uint4 raw = *reinterpret_cast<const uint4*>(row + k);
+            const int q = p & 31;
+            const char* row = J.A + ((size_t)na * nt + (p >> 5)) * L.bytes + (size_t)q * GF * 16;
+            for (int slot = lane; slot < GF; slot += 64) {
+                const int g = slot ^ (q & 15);            // slot holds granule g (involution)
+                uint4 raw = *reinterpret_cast<const uint4*>(row + slot * 16);
                 const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    d = fmaf(__uint_as_float(wds[e] << 16), bbar[k + 2 * e], d);
-                    d = fmaf(__uint_as_float(wds[e] & 0xffff0000u), bbar[k + 2 * e + 1], d);
+                    d = fmaf(__uint_as_float(wds[e] << 16), bbar[8 * g + 2 * e], d);
+                    d = fmaf(__uint_as_float(wds[e] & 0xffff0000u), bbar[8 * g + 2 * e + 1], d);
                 }
             }
 #pragma unroll
@@ -221,10 +240,10 @@ __global__ __launch_bounds__(256) void k_rowmean(const DgRowmeanArgs a) {
     }
     if (lane == 0) wsum[wid] = tot;
     __syncthreads();
-    if (tid == 0) J.rsum[n] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) J.rsum[(size_t)n * a.nchunk + ch] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rowmean, dim3(a.B, a.njobs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_rowmean, dim3(a.nchunk, a.B, a.njobs), dim3(256), 0, s, a);
     return hipGetLastError();
 }
