@@ -32,7 +32,7 @@ struct Plan {
     bool shared, depth, grad, pointwise;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
-    size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2];
+    size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2], m0[DG_MAX_NEG + 2];
     size_t nz;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
@@ -74,7 +74,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.colpart[i] = take(B * (p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
     }
-    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * p.nchunk * 4); }
+    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * p.nchunk * 4); p.m0[t] = take(4); }
     p.nz = take(B * p.Ppad * 4);
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
@@ -119,7 +119,7 @@ static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, b
         j.Sop = ws + p.op[0]; j.sidx = nullptr;
         j.center_on_lane = 0;
     }
-    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.rsum = F32(p.rsum[t]); j.nrsum = p.B * p.nchunk; }
+    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.m0 = F32(p.m0[t]); }
     j.shift = shift_of(d, t);
     j.kind = DG_JOB_HELPER;
     return j;
@@ -239,7 +239,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         for (int t = 0; t < p.T; ++t) {
             r.jobs[t].A = ws + p.op[0]; r.jobs[t].aidx = nullptr;
             r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
-            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rsum = F32(p.rsum[t]);
+            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rsum = F32(p.rsum[t]); r.m0[t] = F32(p.m0[t]);
         }
         DG_HIP(dg_launch_rowmean(r, stream));
     }

@@ -68,7 +68,7 @@ struct DgJob {
     const char* Rop;      // operand blobs [B][Ppad/32][blob bytes] of the stationary operand
     const char* Sop;      // ... of the streamed operand
     const float* rvec;    // fp32 [B][Ppad] row means a_p . bbar (indexed by operand-1 position) or null
-    const float* rsum;    // fp32 [nrsum] partial sums of rvec over valid p (for m0) or null
+    const float* m0;      // fp32 [1] mean of rvec over all valid (n, p) = old_mean of the reference (modules.py:1237) or null
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
     const float* nzS;
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
@@ -81,7 +81,7 @@ struct DgJob {
     float shift;
     int32_t kind;
     int32_t center_on_lane;  // 1: R is operand 1 (rvec / nzR indexed by lane); 0: R is operand 2 (rvec by tile row)
-    int32_t nrsum;           // number of rsum partials (B * chunks)
+    int32_t pad_;
 };
 
 #define DG_MAX_JOBS 24
@@ -95,6 +95,7 @@ struct DgCorrArgs {
     float lo, hi;         // clamp bounds
     float inv_BP;         // 1 / (B*P)
     const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
+    int32_t debug;        // developer ablation bits (0 in production)
 };
 
 // ---- argument blocks of the helper kernels (one definition shared by kernels and host API)
@@ -144,6 +145,7 @@ struct DgRowmeanJob {
 };
 struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
+    float* m0[DG_MAX_NEG + 2];   // [1] per job: sum(rsum) / (B*P), filled by k_m0 after k_rowmean
     int32_t njobs, B, P, Ppad, KF, KD, nchunk;
 };
 

@@ -15,6 +15,7 @@
 // Reference semantics reproduced here: helper() src/modules.py:1231-1254,
 // depth_feature_correlation() :1256-1278 (job kind DG_JOB_DEPTH), norm() :789-790 (backward part).
 #include "dg_common.h"
+#include <cstdlib>
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -99,7 +100,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x16& Yf, const f32x16& Yc
     }
 }
 
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, int KIND>
+template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE, int KIND>
 __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, GF = BL::GF;
@@ -107,6 +108,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr int DP = KD;                  // padded code width of dR
     constexpr int BUF = BL::BYTES + 256;    // blob + 32 rvec floats + 32 nz floats
     constexpr int RCB = BL::OFF_P - BL::OFF_C;   // bytes of one C part (the stationary code rows of one wave)
+    constexpr int NBUF = BL::BYTES > 48 * 1024 ? 2 : 3;   // LDS buffers; tiles are fetched NBUF-1 ahead
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,7 +126,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     // ---- stationary operand: feats fragments -> registers, code rows -> LDS (DMA of the C part of its blob)
     const char* Rblob = job.Rop + ((size_t)nR * ntiles + (wave_active ? rtile : 0)) * BL::BYTES;
     constexpr bool RCREG = NWAVES == 4;   // 4-wave blocks run one wave per SIMD (512 registers): keep the code rows there
-    char* rc_lds = smem + 2 * BUF + wid * RCB;
+    char* rc_lds = smem + NBUF * BUF + wid * RCB;
     const uint32_t smem_a = lds_addr(smem);
     f16x8 Rc[RCREG ? NKD : 1];
     if (RCREG) {
@@ -135,7 +137,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         }
     } else {
         for (int c = 0; c < RCB / 1024; ++c)
-            dma16(Rblob + BL::OFF_C + c * 1024 + lane * 16, smem_a + 2 * BUF + wid * RCB + c * 1024);
+            dma16(Rblob + BL::OFF_C + c * 1024 + lane * 16, smem_a + NBUF * BUF + wid * RCB + c * 1024);
     }
     bf16x8 Rf[NKF];
     if (KIND != KIND_DEPTH) {
@@ -150,16 +152,11 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 
     // ---- per-job scalars
     float c0 = -job.shift;    // fd'' - shift = Yf - rowmean + (m0 - shift)
-    if (KIND != KIND_DEPTH && job.rvec) {
-        float ms = 0.f;
-        for (int b = 0; b < job.nrsum; ++b) ms += job.rsum[b];
-        c0 += ms * args.inv_BP;
-    }
+    if (KIND != KIND_DEPTH && job.rvec) c0 += job.m0[0];
     float c0_lane = c0, nz_lane = 0.f;
     if (KIND == KIND_LANE && job.rvec) c0_lane -= job.rvec[(size_t)n * Ppad + pr];
     if (KIND == KIND_DEPTH) nz_lane = job.nzR[(size_t)n * Ppad + pr];
     const float lo = args.lo, hi = args.hi;
-    const bool simple = (lo == 0.f) && (hi > 1e30f);
     const bool has_vec = job.rvec != nullptr;     // no pointwise centering -> the row vector is all zeros
 
     // ---- tile staging by LDS-DMA (1 KiB per wave instruction, linear in HBM and in LDS)
@@ -176,6 +173,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         if (KIND != KIND_LANE && wid == NWAVES - 1)     // 32 floats of the tile rows (lanes 32-63 write a copy behind them)
             dma4(vsrc + t * 32 + (lane & 31), dst + BL::BYTES);
     };
+    // DMA instructions this wave issues per tile (wave-uniform): the counted wait leaves exactly one tile in flight
+    const int my_dma = (C_END - C_BEGIN - wid + NWAVES - 1) / NWAVES + ((KIND != KIND_LANE && wid == NWAVES - 1) ? 1 : 0);
 
     f32x16 dR[NDF];
 #pragma unroll
@@ -188,18 +187,47 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 #pragma unroll
     for (int j = 0; j < 8; ++j) swz[j] = ((2 * j + h) ^ (r & 15)) << 4;
 
+    // NBUF LDS buffers, tiles are fetched NBUF-1 ahead: with 3 buffers the DMAs of tile t+1 stay in flight at the top
+    // of iteration t (counted vmcnt), with 2 buffers everything outstanding is tile t itself
     issue(0, 0);
+    if (NBUF == 3 && ntiles > 1) issue(1, 1);
+    int bcur = 0;
     for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the other buffer is free again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
+        if (NBUF == 3 && t + 1 < ntiles) {
+            switch (my_dma) {
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+                case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
-        const char* tile = smem + (t & 1) * BUF;
+        if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);   // the buffer tile t-1 used
+        const char* tile = smem + bcur * BUF;
+        bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
 
         if (wave_active) {
             // ---- correlations on the matrix cores
             f32x16 Yf = f32x16{}, Yc = f32x16{};
-            if (KIND != KIND_DEPTH) {
+            if (KIND != KIND_DEPTH && !(args.debug & 2)) {
                 // granule 2ks+h of row r sits at slot (2ks+h) ^ (r&15): the XOR only touches the low 4 bits, so the
                 // 8 k-steps of a 16-granule group share 8 per-lane offsets and the group index is an immediate
                 const char* base = tile + r * (GF * 16);
@@ -221,9 +249,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             }
             const float* rvs = reinterpret_cast<const float*>(tile + BL::BYTES);
             float g[16];
-            if (simple) tile_epilogue<KIND, true, MAT>(Yf, Yc, rvs, rvs, h, c0, c0_lane, nz_lane, lo, hi, lsum, csum, g, job, out_base, t * 32, P, q_ok, has_vec);
-            else        tile_epilogue<KIND, false, MAT>(Yf, Yc, rvs, rvs, h, c0, c0_lane, nz_lane, lo, hi, lsum, csum, g, job, out_base, t * 32, P, q_ok, has_vec);
-            if (GRAD) {
+            tile_epilogue<KIND, SIMPLE, MAT>(Yf, Yc, rvs, rvs, h, c0, c0_lane, nz_lane, lo, hi, lsum, csum, g, job, out_base, t * 32, P, q_ok, has_vec);
+            if (GRAD && !(args.debug & 4)) {
                 // ---- dR[r][:] += sum_s G[s][r] * ScP[s][:]   (accumulator tile as A operand)
                 f16x8 ga[2];
 #pragma unroll
@@ -244,7 +271,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     }
 
     // ---- partial sums of this block (deterministic two-level reduction; finished by k_corr_finish)
-    float* red = reinterpret_cast<float*>(smem + 2 * BUF + (RCREG ? 0 : NWAVES * RCB));
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RCB));
     lsum = wave_sum(lsum);
     csum = wave_sum(csum);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
@@ -290,7 +317,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     }
 }
 
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT>
+template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE>
 __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF] + Rc[NWAVES][C part] + red[NWAVES][2]
     // ---- XCD-aware block order: blocks that share an XCD (orig % 8) get a contiguous range of logical ids,
@@ -301,15 +328,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    const int per_job = args.B * args.nrb;
-    const int jid = bid / per_job;
-    bid -= jid * per_job;
-    const int n = bid / args.nrb;
-    const int rb = bid - n * args.nrb;
+    const int per_img = args.njobs * args.nrb;      // image-major: the jobs of one image stream the same operand blobs
+    const int n = bid / per_img;
+    bid -= n * per_img;
+    const int jid = bid / args.nrb;
+    const int rb = bid - jid * args.nrb;
     const DgJob& job = args.jobs[jid];
-    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, GRAD, MAT, KIND_DEPTH>(args, job, n, rb, smem);
-    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, GRAD, MAT, KIND_ROW>(args, job, n, rb, smem);
-    else if (!MAT) corr_body<NKF, NKD, NWAVES, GRAD, MAT, KIND_LANE>(args, job, n, rb, smem);
+    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_DEPTH>(args, job, n, rb, smem);
+    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_ROW>(args, job, n, rb, smem);
+    else if (!MAT) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_LANE>(args, job, n, rb, smem);
 }
 
 // ---- final reduction of the per-block partial sums into the 8 output scalars (two tiny launches)
@@ -350,26 +377,35 @@ __global__ void k_corr_finish2(const DgFinishArgs a) {
 }
 
 // ---- launch helpers (host) ------------------------------------------------------------------
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT>
+template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE>
 static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     using BL = BlobT<NKF, NKD>;
-    const int smem = 2 * (BL::BYTES + 256) + (NWAVES == 4 ? 0 : NWAVES * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
-    auto kern = k_corr_main<NKF, NKD, NWAVES, GRAD, MAT>;
+    const int nbuf = BL::BYTES > 48 * 1024 ? 2 : 3;
+    const int smem = nbuf * (BL::BYTES + 256) + (NWAVES == 4 ? 0 : NWAVES * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
+    auto kern = k_corr_main<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     const int grid = args.njobs * args.B * args.nrb;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem, stream, args);
+    DgCorrArgs a2 = args;
+    if (const char* e = getenv("DG_DEBUG")) a2.debug = atoi(e);   // developer ablation switches (timing only, results invalid)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem, stream, a2);
     return hipGetLastError();
 }
 
 // KF in {128, 384, 768}, KD in {96, 128}; waves per block chosen by the caller (4 or 8).
 // mode: 0 = loss only, 1 = loss + gradients, 2 = materialise cd / loss tensors.
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream) {
+    const bool simple = args.lo == 0.f && args.hi > 1e30f;   // zero_clamp without stabalize: clamp(cd) == cd * mask
 #define DG_CASE(NKF_, NKD_, NW_)                                                                     \
     if (KF == NKF_ * 16 && KD == NKD_ * 16 && nwaves == NW_) {                                       \
-        if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, true, false>(args, stream);             \
-        if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, false, true>(args, stream);             \
-        return launch_corr_t<NKF_, NKD_, NW_, false, false>(args, stream);                           \
+        if (simple) {                                                                                \
+            if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, true, false, true>(args, stream);   \
+            if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, false, true, true>(args, stream);   \
+            return launch_corr_t<NKF_, NKD_, NW_, false, false, true>(args, stream);                 \
+        }                                                                                            \
+        if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, true, false, false>(args, stream);      \
+        if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, false, true, false>(args, stream);      \
+        return launch_corr_t<NKF_, NKD_, NW_, false, false, false>(args, stream);                    \
     }
     DG_CASE(8, 6, 4) DG_CASE(8, 6, 8) DG_CASE(8, 8, 4)
     DG_CASE(24, 6, 4) DG_CASE(24, 6, 8) DG_CASE(24, 8, 4)

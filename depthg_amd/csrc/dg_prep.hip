@@ -243,7 +243,22 @@ __global__ __launch_bounds__(256) void k_rowmean(const DgRowmeanArgs a) {
     if (tid == 0) J.rsum[(size_t)n * a.nchunk + ch] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// m0[t] = mean over valid (n, p) of rvec = the reference's fd.mean() before centering (fixed summation order)
+__global__ __launch_bounds__(256) void k_m0(const DgRowmeanArgs a) {
+    __shared__ float wsum[4];
+    const DgRowmeanJob& J = a.jobs[blockIdx.x];
+    const int tid = threadIdx.x, n = a.B * a.nchunk;
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) s += J.rsum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) a.m0[blockIdx.x][0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / ((float)a.B * (float)a.P);
+}
+
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_rowmean, dim3(a.nchunk, a.B, a.njobs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_m0, dim3(a.njobs), dim3(256), 0, s, a);
     return hipGetLastError();
 }
