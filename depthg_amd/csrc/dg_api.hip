@@ -28,7 +28,7 @@ extern "C" const char* dg_last_error(void) { return g_err; }
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
-    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, nwaves, nrb, nchunk, blob;
+    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, nchunk, blob;
     bool shared, depth, grad, pointwise;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
@@ -60,8 +60,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.grad = (d->flags & DG_NEED_GRAD) != 0;
     p.pointwise = (d->flags & DG_POINTWISE) != 0;
     p.nops = p.shared ? 2 : p.T;
-    p.nwaves = (p.KF == 768 || p.KD == 128 || p.Ppad <= 128) ? 4 : 8;
-    p.nrb = (p.Ppad + p.nwaves * 32 - 1) / (p.nwaves * 32);
+    p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
+    p.nrb = (p.Ppad + p.rf * 32 - 1) / (p.rf * 32);
     p.nchunk = (p.Ppad + DG_RM_ROWS - 1) / DG_RM_ROWS;
     p.blob = DgBlob(p.KF, p.KD).bytes;
     size_t off = 0;
@@ -248,7 +248,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     DgCorrArgs a;
     int depth_index;
     const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad ? 1 : 0, stream));
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream));
 
     // 5. scalar outputs
     DgFinishArgs f;
@@ -339,7 +339,7 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     j.center_on_lane = 0;
     j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
     a.jobs[0] = j; a.njobs = 1;
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, 2, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, 2, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 
@@ -355,7 +355,7 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     DgCorrArgs a;
     int depth_index;
     build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.nwaves, p.grad ? 1 : 0, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -90,7 +90,7 @@ struct DgCorrArgs {
     DgJob jobs[DG_MAX_JOBS];
     int32_t njobs;
     int32_t B, P, Ppad;
-    int32_t nrb;          // row blocks per image = ceil(Ppad / (NWAVES*32))
+    int32_t nrb;          // row blocks per image = ceil(Ppad / (waves per block * 32))
     int32_t D;            // real code channels
     float lo, hi;         // clamp bounds
     float inv_BP;         // 1 / (B*P)

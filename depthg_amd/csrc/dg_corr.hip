@@ -1,16 +1,18 @@
 // Fused correlation-loss kernel for gfx950 (MI355X).
 //
-// One workgroup = NWAVES waves; each wave keeps 32 positions of the stationary operand "R"
-// (normalised feats bf16 + code fp16 rows) in registers and walks over the streamed operand "S" in
-// tiles of 32 positions.  A tile is one contiguous blob in HBM (dg_common.h) that is DMA'd into LDS
-// (global_load_lds_dwordx4) one tile ahead of the computation; one workgroup barrier per tile.
-// Per 32x32 tile and wave:
-//     Yf[s][r] = sum_k Sf[s][k] Rf[r][k]     (KF/16 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)
-//     Yc[s][r] = sum_d Sc[s][d] Rc[r][d]     (KD/16 x v_mfma_f32_32x32x16_f16)
+// One workgroup = NWAVES waves (8 = two per SIMD for the ViT-S widths; more than 256 registers per wave makes
+// hipcc shuttle MFMA operands between the AGPR and VGPR halves, measured slower); each wave keeps RF x 32
+// positions of the stationary operand "R" (normalised feats, bf16) in registers and walks over the streamed
+// operand "S" in tiles of 32 positions.  A tile is one contiguous blob in HBM (dg_common.h) that is DMA'd
+// into LDS (global_load_lds_dwordx4) two tiles ahead of the computation; one workgroup barrier per tile.
+// Per 32x32 tile and row fragment:
+//     Yc[s][r] = sum_d Sc[s][d] Rc[r][d]     (KD/16 x v_mfma_f32_32x32x16_f16, fp32 accumulate)
+//     Yf[s][r] = sum_k Sf[s][k] Rf[r][k]     (KF/16 x v_mfma_f32_32x32x16_bf16)
 //     epilogue (registers only): centering, shift, clamp, loss / cd partial sums, G = dLoss/dcd
 //     dR[r][:] += sum_s G[s][r] ScP[s][:]    (accumulator tile reused as the A operand, 2*KD/32 MFMAs)
-// The (B,P,P) tensors fd / cd / loss of the reference (src/modules.py:1231-1254) are never
-// written to HBM unless a caller asks for them (materialise path).
+// With RF = 2 the epilogue VALU work of fragment 0 is interleaved with the MFMA chain of fragment 1.
+// The (B,P,P) tensors fd / cd / loss of the reference (src/modules.py:1231-1254) are never written to HBM
+// unless a caller asks for them (materialise path).
 //
 // Reference semantics reproduced here: helper() src/modules.py:1231-1254,
 // depth_feature_correlation() :1256-1278 (job kind DG_JOB_DEPTH), norm() :789-790 (backward part).
@@ -26,8 +28,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 // LDS-DMA: every lane gives its own global source address; the wave writes 64 x 16 (or 64 x 4) contiguous
 // bytes at the wave-uniform LDS address.  Issued through inline asm so that hipcc neither drains it with
-// vmcnt(0) before unrelated LDS reads nor counts it; completion is enforced by the explicit
-// "s_waitcnt vmcnt(0)" + s_barrier at the top of the tile loop (cdna guide 5.7: M0 written in the same statement).
+// vmcnt(0) before unrelated LDS reads nor counts it; completion is enforced by the explicit counted
+// "s_waitcnt vmcnt" + s_barrier at the top of the tile loop (cdna guide 5.7: M0 written in the same statement).
 __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -37,6 +39,33 @@ __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // over-waits, never under-waits
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -53,62 +82,48 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 enum { KIND_LANE = 0, KIND_ROW = 1, KIND_DEPTH = 2 };   // centering vector on lanes (R = operand 1) / on tile rows / depth term
+typedef int v4i __attribute__((ext_vector_type(4)));
+#ifndef PF
+#define PF 4       // LDS fragment reads kept in flight per wave
+#endif
 
-// epilogue of one 32x32 tile: element i of the accumulators is (tile row s = (i&3)+8*(i>>2)+4*h, column r)
-template <int KIND, bool SIMPLE, bool MAT>
-__device__ __forceinline__ void tile_epilogue(const f32x16& Yf, const f32x16& Yc, const float* rvs, const float* nzs, int h,
-                                              float c0, float c0_lane, float nz_lane, float lo, float hi,
-                                              float& lsum, float& csum, float (&g)[16],
-                                              const DgJob& job, size_t out_base, int p0, int P, bool q_ok, bool has_vec) {
-#pragma unroll
-    for (int i4 = 0; i4 < 4; ++i4) {
-        // rows 8*i4 + 4*h + (0..3): the per-row vector comes as one 16-byte LDS read
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KIND == KIND_ROW && has_vec) v4 = *reinterpret_cast<const float4*>(rvs + 8 * i4 + 4 * h);
-        if (KIND == KIND_DEPTH) v4 = *reinterpret_cast<const float4*>(nzs + 8 * i4 + 4 * h);
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = 4 * i4 + e;
-            float fdv;
-            if (KIND == KIND_DEPTH)     fdv = fmaf(nz_lane, vv[e], c0);
-            else if (KIND == KIND_ROW)  fdv = Yf[i] + (c0 - vv[e]);
-            else                        fdv = Yf[i] + c0_lane;
-            const float cdv = Yc[i];
-            csum += cdv;
-            float gi, li;
-            if (SIMPLE) {                    // zero_clamp, no stabalize: clamp(cd) = cd * mask
-                gi = cdv >= 0.f ? -fdv : 0.f;
-                li = gi * cdv;               // = -clamp(cd) * (fd - shift)
-                lsum -= li;
-            } else {
-                const float cl = fminf(fmaxf(cdv, lo), hi);
-                lsum = fmaf(cl, fdv, lsum);
-                gi = (cdv >= lo && cdv <= hi) ? -fdv : 0.f;
-                li = -cl * fdv;
-            }
-            g[i] = gi;
-            if (MAT) {   // R = operand 2 on lanes -> stores contiguous along q
-                const int p = p0 + 8 * i4 + 4 * h + e;
-                if (q_ok && p < P) {
-                    const size_t o = out_base + (size_t)p * P;
-                    if (job.out_cd) job.out_cd[o] = KIND == KIND_DEPTH ? nz_lane * vv[e] : cdv;
-                    if (job.out_loss) job.out_loss[o] = li;
-                }
-            }
-        }
+// One accumulator element of a 32x32 tile: (fd, cd) -> loss term, G = dLoss/dcd.  vv = per-tile-row value
+// (row mean for KIND_ROW, depth indicator for KIND_DEPTH).
+template <int KIND, bool SIMPLE>
+__device__ __forceinline__ float epi_elem(float yf, float cdv, float vv, float c0, float c0_lane, float nz_lane,
+                                          float lo, float hi, float& lsum, float& csum, float& li) {
+    float fdv;
+    if (KIND == KIND_DEPTH)     fdv = fmaf(nz_lane, vv, c0);
+    else if (KIND == KIND_ROW)  fdv = yf + (c0 - vv);
+    else                        fdv = yf + c0_lane;
+    csum += cdv;
+    float gi;
+    if (SIMPLE) {                    // zero_clamp, no stabalize: clamp(cd) = cd * mask
+        gi = cdv >= 0.f ? -fdv : 0.f;
+        li = gi * cdv;               // = -clamp(cd) * (fd - shift)
+        lsum -= li;
+    } else {
+        const float cl = fminf(fmaxf(cdv, lo), hi);
+        lsum = fmaf(cl, fdv, lsum);
+        gi = (cdv >= lo && cdv <= hi) ? -fdv : 0.f;
+        li = -cl * fdv;
     }
+    return gi;
 }
 
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE, int KIND>
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND>
 __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, GF = BL::GF;
     constexpr int NDF = KD / 32;            // 32-wide output fragments of dR
     constexpr int DP = KD;                  // padded code width of dR
-    constexpr int BUF = BL::BYTES + 256;    // blob + 32 rvec floats + 32 nz floats
-    constexpr int RCB = BL::OFF_P - BL::OFF_C;   // bytes of one C part (the stationary code rows of one wave)
+    constexpr int BUF = BL::BYTES + 256;    // blob + 32 per-row floats (+ copy)
+    constexpr int RCB = BL::OFF_P - BL::OFF_C;   // bytes of one C part (the stationary code rows of one fragment)
     constexpr int NBUF = BL::BYTES > 48 * 1024 ? 2 : 3;   // LDS buffers; tiles are fetched NBUF-1 ahead
+    constexpr bool RCREG = BL::BYTES > 48 * 1024;         // LDS full (ViT-B): stationary code rows live in registers
+    constexpr int NSF = KIND == KIND_DEPTH ? 0 : NKF;     // feature k-steps per tile
+    constexpr int NS = NKD + NSF;                         // MFMA steps of one Y chain
+    static_assert(!RCREG || RF == 1, "register-resident code rows only with one fragment per wave");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,46 +133,62 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const int nR = job.ridx ? (int)job.ridx[n] : n;
     const int nS = job.sidx ? (int)job.sidx[n] : n;
 
-    const int rtile = rb * NWAVES + wid;             // 32-row tile of R owned by this wave
-    const bool wave_active = rtile < ntiles;
-    const int row0 = rtile * 32;
-    const int pr = wave_active ? row0 + r : 0;       // stationary position of this lane (clamped for idle waves)
+    // ---- the RF 32-row tiles of R owned by this wave
+    const int rtile0 = (rb * NWAVES + wid) * RF;
+    bool act[RF];
+    int pr[RF];
+    const char* Rblob[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        act[f] = rtile0 + f < ntiles;                       // wave-uniform
+        pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;         // stationary position of this lane (clamped when idle)
+        Rblob[f] = job.Rop + ((size_t)nR * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
+    }
+    const bool wave_active = act[0];
 
     // ---- stationary operand: feats fragments -> registers, code rows -> LDS (DMA of the C part of its blob)
-    const char* Rblob = job.Rop + ((size_t)nR * ntiles + (wave_active ? rtile : 0)) * BL::BYTES;
-    constexpr bool RCREG = NWAVES == 4;   // 4-wave blocks run one wave per SIMD (512 registers): keep the code rows there
-    char* rc_lds = smem + NBUF * BUF + wid * RCB;
     const uint32_t smem_a = lds_addr(smem);
+    char* rc_lds = smem + NBUF * BUF + wid * (RF * RCB);
     f16x8 Rc[RCREG ? NKD : 1];
     if (RCREG) {
 #pragma unroll
         for (int ks = 0; ks < NKD; ++ks) {
-            Rc[ks] = *reinterpret_cast<const f16x8*>(Rblob + BL::OFF_C + ((2 * ks + h) * 32 + r) * 16);
+            Rc[ks] = *reinterpret_cast<const f16x8*>(Rblob[0] + BL::OFF_C + ((2 * ks + h) * 32 + r) * 16);
             asm volatile("" : "+v"(Rc[ks]));
         }
     } else {
-        for (int c = 0; c < RCB / 1024; ++c)
-            dma16(Rblob + BL::OFF_C + c * 1024 + lane * 16, smem_a + NBUF * BUF + wid * RCB + c * 1024);
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+            for (int c = 0; c < RCB / 1024; ++c)
+                dma16(Rblob[f] + BL::OFF_C + c * 1024 + lane * 16, smem_a + NBUF * BUF + (wid * RF + f) * RCB + c * 1024);
     }
-    bf16x8 Rf[NKF];
+    bf16x8 Rf[RF][NSF > 0 ? NSF : 1];
     if (KIND != KIND_DEPTH) {
 #pragma unroll
-        for (int ks = 0; ks < NKF; ++ks)
-            Rf[ks] = *reinterpret_cast<const bf16x8*>(Rblob + (r * GF + ((2 * ks + h) ^ (r & 15))) * 16);
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+            for (int ks = 0; ks < NKF; ++ks)
+                Rf[f][ks] = *reinterpret_cast<const bf16x8*>(Rblob[f] + (r * GF + ((2 * ks + h) ^ (r & 15))) * 16);
         // make hipcc wait for these loads HERE: its counted vmcnt waits at their first use inside the tile loop
         // would also count (and drain) the tile DMAs it does not know about
 #pragma unroll
-        for (int ks = 0; ks < NKF; ++ks) asm volatile("" : "+v"(Rf[ks]));
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+            for (int ks = 0; ks < NKF; ++ks) asm volatile("" : "+v"(Rf[f][ks]));
     }
 
     // ---- per-job scalars
     float c0 = -job.shift;    // fd'' - shift = Yf - rowmean + (m0 - shift)
     if (KIND != KIND_DEPTH && job.rvec) c0 += job.m0[0];
-    float c0_lane = c0, nz_lane = 0.f;
-    if (KIND == KIND_LANE && job.rvec) c0_lane -= job.rvec[(size_t)n * Ppad + pr];
-    if (KIND == KIND_DEPTH) nz_lane = job.nzR[(size_t)n * Ppad + pr];
+    float c0_lane[RF], nz_lane[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        c0_lane[f] = c0; nz_lane[f] = 0.f;
+        if (KIND == KIND_LANE && job.rvec) c0_lane[f] -= job.rvec[(size_t)n * Ppad + pr[f]];
+        if (KIND == KIND_DEPTH) nz_lane[f] = job.nzR[(size_t)n * Ppad + pr[f]];
+    }
     const float lo = args.lo, hi = args.hi;
-    const bool has_vec = job.rvec != nullptr;     // no pointwise centering -> the row vector is all zeros
+    const bool has_vec = KIND == KIND_DEPTH || (KIND == KIND_ROW && job.rvec != nullptr);
 
     // ---- tile staging by LDS-DMA (1 KiB per wave instruction, linear in HBM and in LDS)
     const char* Sbase = job.Sop + (size_t)nS * ntiles * BL::BYTES + lane * 16;
@@ -166,112 +197,144 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     if (KIND == KIND_DEPTH) vsrc = job.nzS + (size_t)n * Ppad;
     constexpr int C_BEGIN = KIND == KIND_DEPTH ? BL::CHUNK_C0 : 0;
     constexpr int C_END = GRAD ? BL::CHUNKS : BL::CHUNK_P0;
+    constexpr int PIECES = (C_END - C_BEGIN + NWAVES - 1) / NWAVES;
     auto issue = [&](int t, int b) {
         const char* src = Sbase + (size_t)t * BL::BYTES;
         const uint32_t dst = smem_a + b * BUF;
-        for (int c = C_BEGIN + wid; c < C_END; c += NWAVES) dma16(src + c * 1024, dst + c * 1024);
-        if (KIND != KIND_LANE && wid == NWAVES - 1)     // 32 floats of the tile rows (lanes 32-63 write a copy behind them)
+        // every wave issues the same number of pieces (a ragged tail re-fetches the last piece: same bytes, same
+        // place), so the counted wait below is a compile-time constant
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) {
+            const int c = min(C_BEGIN + wid + k * NWAVES, C_END - 1);
+            dma16(src + c * 1024, dst + c * 1024);
+        }
+        if (KIND != KIND_LANE)     // 32 floats of the tile rows; all waves write the same bytes (lanes 32-63: a copy behind)
             dma4(vsrc + t * 32 + (lane & 31), dst + BL::BYTES);
     };
-    // DMA instructions this wave issues per tile (wave-uniform): the counted wait leaves exactly one tile in flight
-    const int my_dma = (C_END - C_BEGIN - wid + NWAVES - 1) / NWAVES + ((KIND != KIND_LANE && wid == NWAVES - 1) ? 1 : 0);
+    constexpr int my_dma = PIECES + (KIND != KIND_LANE ? 1 : 0);   // DMA instructions per wave and tile
 
-    f32x16 dR[NDF];
+    f32x16 dR[RF][NDF];
 #pragma unroll
-    for (int f = 0; f < NDF; ++f) dR[f] = f32x16{};
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int d = 0; d < NDF; ++d) dR[f][d] = f32x16{};
     float lsum = 0.f, csum = 0.f;
-    const size_t out_base = (size_t)n * P * P + pr;
-    const bool q_ok = pr < P;
 
-    int swz[8];
+    int swz[8];     // granule 2ks+h of tile row r sits at slot (2ks+h) ^ (r&15); the XOR only touches the low 4 bits
 #pragma unroll
     for (int j = 0; j < 8; ++j) swz[j] = ((2 * j + h) ^ (r & 15)) << 4;
+    const int frow = r * (GF * 16), crow = (h * 32 + r) * 16;
 
-    // NBUF LDS buffers, tiles are fetched NBUF-1 ahead: with 3 buffers the DMAs of tile t+1 stay in flight at the top
-    // of iteration t (counted vmcnt), with 2 buffers everything outstanding is tile t itself
     issue(0, 0);
     if (NBUF == 3 && ntiles > 1) issue(1, 1);
     int bcur = 0;
     for (int t = 0; t < ntiles; ++t) {
         // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
-        if (NBUF == 3 && t + 1 < ntiles) {
-            switch (my_dma) {
-                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-                case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-                case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma : 0);
         __builtin_amdgcn_s_barrier();
-        if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);   // the buffer tile t-1 used
+        if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
         const char* tile = smem + bcur * BUF;
         bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
+        if (!wave_active) continue;
 
-        if (wave_active) {
-            // ---- correlations on the matrix cores
-            f32x16 Yf = f32x16{}, Yc = f32x16{};
-            if (KIND != KIND_DEPTH && !(args.debug & 2)) {
-                // granule 2ks+h of row r sits at slot (2ks+h) ^ (r&15): the XOR only touches the low 4 bits, so the
-                // 8 k-steps of a 16-granule group share 8 per-lane offsets and the group index is an immediate
-                const char* base = tile + r * (GF * 16);
+        f32x16 Yf[RF], Yc[RF];
 #pragma unroll
-                for (int ks = 0; ks < NKF; ++ks) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + swz[ks & 7] + (ks >> 3) * 256);
-                    Yf = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Rf[ks], Yf, 0, 0, 0);
-                }
-            }
-            {
-                const char* base = tile + BL::OFF_C + (h * 32 + r) * 16;
-                const char* rbase = rc_lds + (h * 32 + r) * 16;
+        for (int f = 0; f < RF; ++f) { Yf[f] = f32x16{}; Yc[f] = f32x16{}; }
+        // per-tile-row vector (rows 8*i4 + 4*h + e): 4 x 16-byte LDS reads, shared by the fragments
+        float vv[16];
 #pragma unroll
-                for (int ks = 0; ks < NKD; ++ks) {
-                    const f16x8 a = *reinterpret_cast<const f16x8*>(base + ks * 1024);
-                    const f16x8 b = RCREG ? Rc[ks] : *reinterpret_cast<const f16x8*>(rbase + ks * 1024);
-                    Yc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, Yc, 0, 0, 0);
-                }
-            }
+        for (int i = 0; i < 16; ++i) vv[i] = 0.f;
+        if (KIND != KIND_LANE && has_vec) {
             const float* rvs = reinterpret_cast<const float*>(tile + BL::BYTES);
-            float g[16];
-            tile_epilogue<KIND, SIMPLE, MAT>(Yf, Yc, rvs, rvs, h, c0, c0_lane, nz_lane, lo, hi, lsum, csum, g, job, out_base, t * 32, P, q_ok, has_vec);
-            if (GRAD && !(args.debug & 4)) {
-                // ---- dR[r][:] += sum_s G[s][r] * ScP[s][:]   (accumulator tile as A operand)
-                f16x8 ga[2];
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp)
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(rvs + 8 * i4 + 4 * h);
+                vv[4 * i4] = v4.x; vv[4 * i4 + 1] = v4.y; vv[4 * i4 + 2] = v4.z; vv[4 * i4 + 3] = v4.w;
+            }
+        }
+        f16x8 ga[RF][2];                   // G as the A operand of the gradient product: k-step sp holds elements 8sp..8sp+7
+        auto epi = [&](int f, int i) {     // accumulator element i = (tile row (i&3)+8*(i>>2)+4*h, lane column r)
+            float li;
+            ga[f][i >> 3][i & 7] = (_Float16)epi_elem<KIND, SIMPLE>(Yf[f][i], Yc[f][i], vv[i], c0, c0_lane[f], nz_lane[f], lo, hi, lsum, csum, li);
+            if (MAT) {   // R = operand 2 on lanes -> stores contiguous along q
+                const int p = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (act[f] && pr[f] < P && p < P) {
+                    const size_t o = ((size_t)n * P + p) * P + pr[f];
+                    if (job.out_cd) job.out_cd[o] = KIND == KIND_DEPTH ? nz_lane[f] * vv[i] : Yc[f][i];
+                    if (job.out_loss) job.out_loss[o] = li;
+                }
+            }
+        };
+
+        // ---- one Y chain = NSF feature k-steps then NKD code k-steps.  The A operands (S fragments) run through an
+        //      explicit ring of PF registers that is refilled right after each MFMA, so that PF LDS reads are always in
+        //      flight; scheduling fences pin that order (left alone hipcc serialises read -> wait -> MFMA here).
+        auto a_ptr = [&](int st) -> const v4i* {
+            return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
+                            : reinterpret_cast<const v4i*>(tile + BL::OFF_C + crow + (st - NSF) * 1024);
+        };
+        auto chain = [&](const int f, auto&& between) {
+            v4i ra[PF], rb[2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ga[sp][j] = (_Float16)g[8 * sp + j];
+            for (int i = 0; i < PF; ++i) if (i < NS) ra[i] = *a_ptr(i);
+            if (!RCREG) {
 #pragma unroll
-                for (int f = 0; f < NDF; ++f) {
-                    const char* base = tile + BL::OFF_P + (h * KD + 32 * f + r) * 16;
+                for (int k = 0; k < 2; ++k) rb[k] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + k * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        const f16x8 b = *reinterpret_cast<const f16x8*>(base + sp * (2 * KD * 16));
-                        dR[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[sp], b, dR[f], 0, 0, 0);
-                    }
+            for (int st = 0; st < NS; ++st) {
+                const v4i cur = ra[st % PF];
+                if (st < NSF) {
+                    Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
+                } else {
+                    const int k = st - NSF;
+                    const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
+                    Yc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur), b, Yc[f], 0, 0, 0);
+                    if (!RCREG && k + 2 < NKD) rb[k & 1] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + (k + 2) * 1024);
+                }
+                if (st + PF < NS) ra[st % PF] = *a_ptr(st + PF);
+                between(st);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        chain(0, [](int) {});
+        if (RF == 2 && act[RF - 1]) {
+            // second fragment: its MFMA chain carries the epilogue (VALU) of fragment 0 in its gaps
+            chain(RF - 1, [&](int st) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i * NS / 16 == st) epi(0, i);
+            });
+#pragma unroll
+            for (int i = 0; i < 16; ++i) epi(RF - 1, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) epi(0, i);
+            if (RF == 2) {      // idle second fragment (ragged last row block): contributes nothing
+                ga[RF - 1][0] = f16x8{}; ga[RF - 1][1] = f16x8{};
+            }
+        }
+        if (GRAD && !(args.debug & 4)) {
+            // ---- dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
+#pragma unroll
+            for (int d = 0; d < NDF; ++d) {
+                const char* base = tile + BL::OFF_P + (h * KD + 32 * d + r) * 16;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(base + sp * (2 * KD * 16));
+#pragma unroll
+                    for (int f = 0; f < RF; ++f)
+                        dR[f][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[f][sp], b, dR[f][d], 0, 0, 0);
                 }
             }
         }
     }
 
     // ---- partial sums of this block (deterministic two-level reduction; finished by k_corr_finish)
-    float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RCB));
+    // (rows of an inactive second fragment are all-zero operands? no: they are clamped copies -> excluded here)
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RF * RCB));
     lsum = wave_sum(lsum);
     csum = wave_sum(csum);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
@@ -284,59 +347,63 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     }
 
     // ---- normalisation backward and store:  dc = (dx - x <x,dx>) / max(||c||, eps)
-    if (GRAD && job.dR && wave_active) {
-        // dR[f][i] is (stationary row rr = row0 + (i&3)+8*(i>>2)+4*h, code channel d = 32 f + r)
-        float dot[16];
+    if (GRAD && job.dR) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dot[i] = 0.f;
+        for (int f = 0; f < RF; ++f) {
+            if (!act[f]) continue;
+            // dR[f][d][i] is (stationary row rr = row0 + (i&3)+8*(i>>2)+4*h, code channel 32 d + r)
+            const int row0 = (rtile0 + f) * 32;
+            const char* xb = RCREG ? Rblob[f] + BL::OFF_C : rc_lds + f * RCB;
+            float dot[16];
 #pragma unroll
-        for (int f = 0; f < NDF; ++f)
+            for (int i = 0; i < 16; ++i) dot[i] = 0.f;
+#pragma unroll
+            for (int d = 0; d < NDF; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
+                    const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                    dot[i] = fmaf(x, dR[f][d][i], dot[i]);
+                }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int q = (i & 3) + 8 * (i >> 2) + 4 * h, d = 32 * f + r;
-                const char* xb = RCREG ? Rblob + BL::OFF_C : rc_lds;
-                const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((d >> 3) * 32 + q) * 16 + (d & 7) * 2);
-                dot[i] = fmaf(x, dR[f][i], dot[i]);
-            }
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * h, rr = row0 + q;
+                if (rr < P) {
+                    const float inv = job.RcInv[(size_t)nR * Ppad + rr];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = (i & 3) + 8 * (i >> 2) + 4 * h, rr = row0 + q;
-            if (rr < P) {
-                const float inv = job.RcInv[(size_t)nR * Ppad + rr];
-#pragma unroll
-                for (int f = 0; f < NDF; ++f) {
-                    const int d = 32 * f + r;
-                    const char* xb = RCREG ? Rblob + BL::OFF_C : rc_lds;
-                    const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((d >> 3) * 32 + q) * 16 + (d & 7) * 2);
-                    job.dR[((size_t)n * Ppad + rr) * DP + d] = (dR[f][i] - x * dot[i]) * inv;
+                    for (int d = 0; d < NDF; ++d) {
+                        const int ch = 32 * d + r;
+                        const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                        job.dR[((size_t)n * Ppad + rr) * DP + ch] = (dR[f][d][i] - x * dot[i]) * inv;
+                    }
                 }
             }
         }
     }
 }
 
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE>
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE>
 __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF] + Rc[NWAVES][C part] + red[NWAVES][2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] + Rc[NWAVES][RF][C part] + red[NWAVES][2]
     // ---- XCD-aware block order: blocks that share an XCD (orig % 8) get a contiguous range of logical ids,
-    //      so the row blocks of one (pair-set, image) stream the same S blobs through one L2.
+    //      image-major inside: all pair-sets of one image (which stream the same operand blobs) meet in one L2.
     int bid;
     {
         const int nwg = gridDim.x, orig = blockIdx.x;
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    const int per_img = args.njobs * args.nrb;      // image-major: the jobs of one image stream the same operand blobs
+    const int per_img = args.njobs * args.nrb;
     const int n = bid / per_img;
     bid -= n * per_img;
     const int jid = bid / args.nrb;
     const int rb = bid - jid * args.nrb;
     const DgJob& job = args.jobs[jid];
-    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_DEPTH>(args, job, n, rb, smem);
-    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_ROW>(args, job, n, rb, smem);
-    else if (!MAT) corr_body<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE, KIND_LANE>(args, job, n, rb, smem);
+    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH>(args, job, n, rb, smem);
+    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW>(args, job, n, rb, smem);
+    else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE>(args, job, n, rb, smem);
 }
 
 // ---- final reduction of the per-block partial sums into the 8 output scalars (two tiny launches)
@@ -377,37 +444,37 @@ __global__ void k_corr_finish2(const DgFinishArgs a) {
 }
 
 // ---- launch helpers (host) ------------------------------------------------------------------
-template <int NKF, int NKD, int NWAVES, bool GRAD, bool MAT, bool SIMPLE>
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE>
 static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     using BL = BlobT<NKF, NKD>;
-    const int nbuf = BL::BYTES > 48 * 1024 ? 2 : 3;
-    const int smem = nbuf * (BL::BYTES + 256) + (NWAVES == 4 ? 0 : NWAVES * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
-    auto kern = k_corr_main<NKF, NKD, NWAVES, GRAD, MAT, SIMPLE>;
+    const bool big = BL::BYTES > 48 * 1024;
+    const int smem = (big ? 2 : 3) * (BL::BYTES + 256) + (big ? 0 : NWAVES * RF * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
+    auto kern = k_corr_main<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     const int grid = args.njobs * args.B * args.nrb;
     DgCorrArgs a2 = args;
-    if (const char* e = getenv("DG_DEBUG")) a2.debug = atoi(e);   // developer ablation switches (timing only, results invalid)
+    if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only, results invalid)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem, stream, a2);
     return hipGetLastError();
 }
 
-// KF in {128, 384, 768}, KD in {96, 128}; waves per block chosen by the caller (4 or 8).
-// mode: 0 = loss only, 1 = loss + gradients, 2 = materialise cd / loss tensors.
+// KF in {128, 384, 768}, KD in {96, 128}; nwaves = waves per block (8: two per SIMD, 256 registers each; 4: one per
+// SIMD).  mode: 0 = loss only, 1 = loss + gradients, 2 = materialise cd / loss tensors.
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream) {
     const bool simple = args.lo == 0.f && args.hi > 1e30f;   // zero_clamp without stabalize: clamp(cd) == cd * mask
-#define DG_CASE(NKF_, NKD_, NW_)                                                                     \
-    if (KF == NKF_ * 16 && KD == NKD_ * 16 && nwaves == NW_) {                                       \
-        if (simple) {                                                                                \
-            if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, true, false, true>(args, stream);   \
-            if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, false, true, true>(args, stream);   \
-            return launch_corr_t<NKF_, NKD_, NW_, false, false, true>(args, stream);                 \
-        }                                                                                            \
-        if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, true, false, false>(args, stream);      \
-        if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, false, true, false>(args, stream);      \
-        return launch_corr_t<NKF_, NKD_, NW_, false, false, false>(args, stream);                    \
+#define DG_CASE(NKF_, NKD_, NW_)                                                                        \
+    if (KF == NKF_ * 16 && KD == NKD_ * 16 && nwaves == NW_) {                                          \
+        if (simple) {                                                                                   \
+            if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, 1, true, false, true>(args, stream);   \
+            if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, 1, false, true, true>(args, stream);   \
+            return launch_corr_t<NKF_, NKD_, NW_, 1, false, false, true>(args, stream);                 \
+        }                                                                                               \
+        if (mode == 1) return launch_corr_t<NKF_, NKD_, NW_, 1, true, false, false>(args, stream);      \
+        if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, 1, false, true, false>(args, stream);      \
+        return launch_corr_t<NKF_, NKD_, NW_, 1, false, false, false>(args, stream);                    \
     }
-    DG_CASE(8, 6, 4) DG_CASE(8, 6, 8) DG_CASE(8, 8, 4)
+    DG_CASE(8, 6, 4) DG_CASE(8, 8, 4)
     DG_CASE(24, 6, 4) DG_CASE(24, 6, 8) DG_CASE(24, 8, 4)
     DG_CASE(48, 6, 4) DG_CASE(48, 8, 4)
 #undef DG_CASE
