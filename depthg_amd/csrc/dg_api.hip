@@ -312,10 +312,8 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
     s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
-    int DC = 32;
-    while (DC > 1 && (size_t)DC * (p.h * p.w + 1) * 4 > 150 * 1024) DC >>= 1;
-    if ((size_t)DC * (p.h * p.w + 1) * 4 > 150 * 1024) return fail(DG_ERR_UNSUPPORTED, "feature map too large for the LDS scatter");
-    s.DC = DC;
+    if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);
+    s.DC = 8;
     DG_HIP(dg_launch_scatter(s, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }

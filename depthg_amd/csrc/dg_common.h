@@ -167,6 +167,7 @@ struct DgScatterArgs {
     float* comb[2];        // [B][Ppad][DP] combined direct sources per destination (scratch)
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
     int32_t B, D, DP, h, w, S, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
+    int32_t debug;         // developer ablation bits (0 in production)
 };
 
 // launchers (defined next to their kernels)

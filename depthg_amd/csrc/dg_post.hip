@@ -1,11 +1,12 @@
 // Backward tail and depth-guided sampling kernels:
 //   k_scatter_grad  grid_sample backward (bilinear, border, align_corners=True; the adjoint of
 //                   sample(), reference src/modules.py:822-825) of the per-pair-set code gradients,
-//                   combined with the upstream gradients of the four loss means, accumulated per
-//                   destination image in LDS (no global atomics), written as (B,D,h,w) fp32.
+//                   combined with the upstream gradients of the four loss means; formulated as a GATHER
+//                   over an inverse tap map built in LDS (no floating-point atomics), written as (B,D,h,w) fp32.
 //   k_fps_coords    farthest_point_sampling_depth (src/modules.py:999-1037) = adaptive_avg_pool2d
 //                   -> depth2points(fov=90 rad, :988-996) -> fps (:939-985) -> row-major coords*2-1.
 #include "dg_common.h"
+#include <cstdlib>
 
 
 __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, int& y0, bool& inx, bool& iny,
@@ -39,62 +40,151 @@ __global__ __launch_bounds__(256) void k_grad_combine(const DgScatterArgs a) {
     reinterpret_cast<float4*>(a.comb[dest])[i] = acc;
 }
 
-#define SCAT_THREADS 512
-__device__ __forceinline__ void scatter_rows(float* acc, int stride, const float* buf, float sc, const float* coords,
-                                             int nimg, int d, int dl, int pl, int pstep, const DgScatterArgs& a) {
-    const int S = a.S;
-    for (int p = pl; p < a.P; p += pstep) {
-        const int i = p / S, j = p - i * S;
-        int x0, y0; bool inx, iny; float w00, w01, w10, w11;
-        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w00, w01, w10, w11);
-        if (d < a.D) {
-            const float v = sc * buf[((size_t)nimg * a.Ppad + p) * a.DP + d];
-            float* base = acc + dl * stride + y0 * a.w + x0;
-            if (w00 != 0.f) __hip_atomic_fetch_add(base, v * w00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (inx && w01 != 0.f) __hip_atomic_fetch_add(base + 1, v * w01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (iny && w10 != 0.f) __hip_atomic_fetch_add(base + a.w, v * w10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (inx && iny && w11 != 0.f) __hip_atomic_fetch_add(base + a.w + 1, v * w11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-}
+#define SCAT_THREADS 1024
+#define SCAT_DC 8            // channels per block
+#define SCAT_PX (SCAT_THREADS / SCAT_DC)
+#define SCAT_MAXPASS 32      // supports h*w <= SCAT_PX * SCAT_MAXPASS = 4096 pixels
 
-// Stage 2: grid (ceil(D/DC), B, 2), block SCAT_THREADS, dynamic LDS DC*(h*w+1)*4: one destination image and
-// channel chunk per block, accumulated in LDS, written once.
+// Stage 2: adjoint of sample() without floating-point atomics.  One block = one destination image, SCAT_DC channels.
+// For every source image that lands in this destination the block builds, in LDS, the inverse of the bilinear tap
+// map (pixel -> list of (position, weight), CSR: count, exclusive scan, fill) and then every thread GATHERS its
+// (pixel, channel) outputs: reads are rows of the fp32 gradient buffers, accumulation is in registers.
+// grid (ceil(D / SCAT_DC), B, 2), block SCAT_THREADS, dynamic LDS = (2*hw + 1) ints + 4*P (float + ushort) + stage.
 __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
-    extern __shared__ float acc[];
-    const int tid = threadIdx.x;
-    const int dc0 = blockIdx.x * a.DC, bdst = blockIdx.y, dest = blockIdx.z;
-    const int HW = a.h * a.w, stride = HW + 1;
-    for (int i = tid; i < a.DC * stride; i += SCAT_THREADS) acc[i] = 0.f;
-    __syncthreads();
-    const int dl = tid & (a.DC - 1), pl = tid / a.DC, pstep = SCAT_THREADS / a.DC;
-    const int d = dc0 + dl;
+    extern __shared__ __attribute__((aligned(16))) char sg[];
+    const int tid = threadIdx.x, HW = a.h * a.w, P = a.P, S = a.S;
+    int* cnt = reinterpret_cast<int*>(sg);                 // [HW] taps per pixel (then fill cursor)
+    int* off = cnt + HW;                                   // [HW + 1] exclusive scan
+    float* ewgt = reinterpret_cast<float*>(off + HW + 1);  // [4P] weights
+    unsigned short* eidx = reinterpret_cast<unsigned short*>(ewgt + 4 * P);   // [4P] positions
+    __shared__ int wtot[SCAT_THREADS / 64];
+    const int dc0 = blockIdx.x * SCAT_DC, bdst = blockIdx.y, dest = blockIdx.z;
+    const int dl = tid & (SCAT_DC - 1), px = tid / SCAT_DC, d = dc0 + dl;
+    const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
+    float acc[SCAT_MAXPASS];
+#pragma unroll
+    for (int i = 0; i < SCAT_MAXPASS; ++i) acc[i] = 0.f;
+
+    auto one_source = [&](const float* buf, float sc, const float* coords, int nimg) {
+        // ---- count taps per pixel
+        for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;
+        __syncthreads();
+        int x0 = 0, y0 = 0; bool inx = false, iny = false; float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        const int p = tid;                         // one position per thread per round (P <= 1024 per round)
+        for (int pb = 0; pb < P; pb += SCAT_THREADS) {
+            const int pp = pb + p;
+            if (pp < P) {
+                const int i = pp / S, j = pp - i * S;
+                dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+                const int pix = y0 * a.w + x0;
+                if (w4[0] != 0.f) atomicAdd(&cnt[pix], 1);
+                if (inx && w4[1] != 0.f) atomicAdd(&cnt[pix + 1], 1);
+                if (iny && w4[2] != 0.f) atomicAdd(&cnt[pix + a.w], 1);
+                if (inx && iny && w4[3] != 0.f) atomicAdd(&cnt[pix + a.w + 1], 1);
+            }
+        }
+        __syncthreads();
+        // ---- exclusive scan of cnt -> off (each thread owns a contiguous run of pixels)
+        const int per = (HW + SCAT_THREADS - 1) / SCAT_THREADS;
+        const int b0 = min(tid * per, HW), b1 = min(b0 + per, HW);
+        int run = 0;
+        for (int i = b0; i < b1; ++i) run += cnt[i];
+        int incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += wtot[wv];
+        int o2 = base + incl - run;
+        for (int i = b0; i < b1; ++i) { const int c = cnt[i]; off[i] = o2; o2 += c; }
+        __syncthreads();
+        for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;       // becomes the fill cursor
+        __syncthreads();
+        // ---- fill the lists
+        for (int pb = 0; pb < P; pb += SCAT_THREADS) {
+            const int pp = pb + p;
+            if (pp < P) {
+                const int i = pp / S, j = pp - i * S;
+                dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+                const int pix = y0 * a.w + x0;
+                auto put = [&](int q, float wgt) {
+                    const int slot = off[q] + atomicAdd(&cnt[q], 1);
+                    ewgt[slot] = wgt; eidx[slot] = (unsigned short)pp;
+                };
+                if (w4[0] != 0.f) put(pix, w4[0]);
+                if (inx && w4[1] != 0.f) put(pix + 1, w4[1]);
+                if (iny && w4[2] != 0.f) put(pix + a.w, w4[2]);
+                if (inx && iny && w4[3] != 0.f) put(pix + a.w + 1, w4[3]);
+            }
+        }
+        __syncthreads();
+        // ---- gather
+        if (d < a.D) {
+            const float* src = buf + (size_t)nimg * a.Ppad * a.DP + d;
+#pragma unroll
+            for (int ps = 0; ps < SCAT_MAXPASS; ++ps) {
+                const int pix = ps * SCAT_PX + px;
+                if (ps < npass && pix < HW) {
+                    const int e0 = off[pix], e1 = e0 + cnt[pix];
+                    float sum = 0.f;
+                    for (int e = e0; e < e1; ++e) sum = fmaf(ewgt[e], src[(size_t)eidx[e] * a.DP], sum);
+                    acc[ps] = fmaf(sc, sum, acc[ps]);
+                }
+            }
+        }
+        __syncthreads();
+    };
+
     // direct sources (already combined): image bdst -> destination bdst; coords1 for grad_code, coords2 for grad_code_pos
-    scatter_rows(acc, stride, a.comb[dest], 1.0f, dest == 0 ? a.coords1 : a.coords2, bdst, d, dl, pl, pstep, a);
+    one_source(a.comb[dest], 1.0f, dest == 0 ? a.coords1 : a.coords2, bdst);
     // routed sources (negatives): image n scatters into destination route[n] with n's coords
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
         const float sc = q.factor * a.gscal[q.gidx];
         const float* coords = q.coords_sel == 0 ? a.coords1 : a.coords2;
-        for (int n = 0; n < a.B; ++n)
-            if ((int)q.route[n] == bdst) scatter_rows(acc, stride, q.buf, sc, coords, n, d, dl, pl, pstep, a);
+        for (int n0 = 0; n0 < a.B; n0 += 64) {           // which images route here: one ballot per 64 images
+            const int nn = n0 + (tid & 63);
+            const bool hit = nn < a.B && (int)q.route[nn] == bdst;
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int n = n0 + __builtin_ctzll(m);
+                m &= m - 1;
+                one_source(q.buf, sc, coords, n);
+            }
+        }
+    }
+    // ---- write (B,D,h,w): transpose through LDS so that the stores run along the pixels
+    float* stage = reinterpret_cast<float*>(sg);     // [SCAT_DC][HW + 1]
+#pragma unroll
+    for (int ps = 0; ps < SCAT_MAXPASS; ++ps) {
+        const int pix = ps * SCAT_PX + px;
+        if (ps < npass && pix < HW) stage[dl * (HW + 1) + pix] = acc[ps];
     }
     __syncthreads();
     float* out = a.out[dest];
-    for (int i = tid; i < a.DC * HW; i += SCAT_THREADS) {
+    for (int i = tid; i < SCAT_DC * HW; i += SCAT_THREADS) {
         const int dd = i / HW, pix = i - dd * HW;
-        if (dc0 + dd < a.D) out[((size_t)bdst * a.D + dc0 + dd) * HW + pix] = acc[dd * stride + pix];
+        if (dc0 + dd < a.D) out[((size_t)bdst * a.D + dc0 + dd) * HW + pix] = stage[dd * (HW + 1) + pix];
     }
+}
+
+size_t dg_scatter_lds_bytes(int HW, int P) {
+    const size_t lists = (size_t)(2 * HW + 1) * 4 + (size_t)4 * P * 6 + 16;
+    const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
+    return lists > stage ? lists : stage;
 }
 
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
     hipLaunchKernelGGL(k_grad_combine, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, s, a);
-    const int smem = a.DC * (a.h * a.w + 1) * 4;
+    const int HW = a.h * a.w;
+    if (HW > SCAT_PX * SCAT_MAXPASS || a.P > 65535) return hipErrorInvalidValue;
+    const int smem = (int)dg_scatter_lds_bytes(HW, a.P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_grad), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    dim3 grid((a.D + a.DC - 1) / a.DC, a.B, 2);
+    dim3 grid((a.D + SCAT_DC - 1) / SCAT_DC, a.B, 2);
     hipLaunchKernelGGL(k_scatter_grad, grid, dim3(SCAT_THREADS), smem, s, a);
     return hipGetLastError();
 }
