@@ -68,12 +68,12 @@ def total_of(cfg, out):
             cfg.depth_feat_weight * out[6]) * cfg.correspondence_weight
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=15.0):
     """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the headline
     workload: same C, D, S, pair-sets and backward, smaller batch; scaled to steps/s of the full batch."""
     from oracle import depthg_oracle as O
     H = HEADLINE
-    Bs = 8
+    Bs = H["B"]      # the full headline batch: ~0.4 s per repetition on 16 threads, repeated for ~15 s
     ncores = min(os.cpu_count() or 1, 16)      # torch-CPU bmm/elementwise stop scaling (and thrash) beyond this
     torch.set_num_threads(ncores)
     cfg = O.default_cfg(feature_samples=H["S"], pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761,

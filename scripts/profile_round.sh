@@ -1,0 +1,36 @@
+#!/bin/bash
+# Produces the per-round evidence kept under profiles/: kernel-trace stats of the bench command and the HBM-traffic
+# PMC passes of the fused kernel (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM").
+# usage (on the GPU box): scripts/profile_round.sh r01
+tag=${1:-r01}
+export TMPDIR=/tmp
+out=/root/repo/gpurun_out/$tag
+mkdir -p $out
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
+cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
+( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
+python3 - <<PY
+import csv, glob, collections, json
+res = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    f = glob.glob("$out/%s/*/*counter_collection.csv" % name)[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    for k, v in acc.items():
+        if k.startswith(("k_", "void k_")):
+            res.setdefault(k, {}).update({c: val / len(disp[k]) for c, val in v.items()})
+main = [k for k in res if "k_corr_main" in k][0]
+m = res[main]
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide stream -> x2
+m["hbm_read_bytes_corrected"] = 2 * m["FETCH_SIZE"] * 1024
+m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
+m["hbm_traffic_bytes_per_launch"] = m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]
+json.dump(res, open("$out/${tag}_pmc_per_launch.json", "w"), indent=1, sort_keys=True)
+print(main, json.dumps(m, indent=1))
+PY
+head -14 $out/${tag}_kernel_stats.csv | cut -c1-150
+cat $out/bench_under_rocprof.json

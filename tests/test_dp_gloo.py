@@ -1,0 +1,102 @@
+"""Data-parallel path on CPU: world_size 2, gloo, one process per rank (the reference has no DP).
+
+Parity definition: every rank evaluates the loss on ITS shard (shard-local old_mean and negatives); the post-all-reduce
+head gradient equals the mean over ranks of the per-shard gradients.  The loss itself is evaluated with the CPU oracle
+here (the HIP path needs a GPU; the same GradBucket is driven by bench.py on RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import depthg_oracle as O
+from depthg_amd.parallel import GradBucket, shard_range
+
+B_GLOBAL, C, D, HW, S, N = 4, 16, 8, 8, 4, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_problem():
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(B_GLOBAL, C, HW, HW, generator=g)
+    feats_pos = torch.randn(B_GLOBAL, C, HW, HW, generator=g)
+    depth = torch.randint(0, 256, (B_GLOBAL, 1, 4 * HW, 4 * HW), generator=g).float()
+    w = torch.randn(D, C, 1, 1, generator=g) * 0.3      # stand-in 1x1-conv head (cluster1, reference src/modules.py:80-81)
+    bias = torch.zeros(D)
+    coords1 = torch.rand(B_GLOBAL, S, S, 2, generator=g) * 2 - 1
+    coords2 = torch.rand(B_GLOBAL, S, S, 2, generator=g) * 2 - 1
+    return feats, feats_pos, depth, w, bias, coords1, coords2
+
+
+def _shard_grads(rank, world):
+    """Oracle loss on the shard of `rank`; returns (dW, dbias)."""
+    feats, feats_pos, depth, w, bias, coords1, coords2 = _make_problem()
+    lo, hi = shard_range(B_GLOBAL, world, rank)
+    w = w.clone().requires_grad_(True)
+    bias = bias.clone().requires_grad_(True)
+    f, fp, d = feats[lo:hi], feats_pos[lo:hi], depth[lo:hi]
+    code = torch.nn.functional.conv2d(f, w, bias)
+    code_pos = torch.nn.functional.conv2d(fp, w, bias)
+    g = torch.Generator().manual_seed(100 + rank)       # shard-local negatives
+    perms = [O.super_perm(hi - lo, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N)
+    out = O.forward(cfg, f, fp, code, code_pos, d, d, coords1=coords1[lo:hi], coords2=coords2[lo:hi], perms=perms)
+    O.total_loss(cfg, out).backward()
+    return w.grad.detach(), bias.grad.detach()
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    gw, gb = _shard_grads(rank, world)
+    w = torch.nn.Parameter(torch.zeros_like(gw)); w.grad = gw.clone()
+    b = torch.nn.Parameter(torch.zeros_like(gb)); b.grad = gb.clone()
+    bucket = GradBucket.for_parameters([w, b], dist)
+    bucket.pack()
+    bucket.allreduce_mean_()
+    bucket.unpack()
+    # every rank holds bit-identical averaged gradients afterwards
+    gathered = [torch.zeros_like(bucket.flat) for _ in range(world)]
+    dist.all_gather(gathered, bucket.flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered)
+    if rank == 0:
+        ret["w"] = w.grad.clone()
+        ret["b"] = b.grad.clone()
+        ret["same"] = same
+        ret["numel"] = bucket.flat.numel()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allreduce_matches_mean_of_shard_gradients():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want_w = sum(_shard_grads(r, world)[0] for r in range(world)) / world
+    want_b = sum(_shard_grads(r, world)[1] for r in range(world)) / world
+    assert ret["same"]
+    assert ret["numel"] == D * C + D
+    assert torch.allclose(ret["w"], want_w, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(ret["b"], want_b, rtol=1e-6, atol=1e-9)
+    assert float(want_w.abs().max()) > 0
+
+
+def test_bucket_single_process_is_identity():
+    p = torch.nn.Parameter(torch.arange(6.0).view(2, 3))
+    p.grad = torch.ones(2, 3) * 3
+    bucket = GradBucket.for_parameters([p], None)
+    bucket.pack()
+    bucket.allreduce_mean_()
+    bucket.unpack()
+    assert torch.equal(p.grad, torch.ones(2, 3) * 3)
