@@ -83,6 +83,9 @@ __device__ __forceinline__ float half_sum(float v) {
 
 enum { KIND_LANE = 0, KIND_ROW = 1, KIND_DEPTH = 2 };   // centering vector on lanes (R = operand 1) / on tile rows / depth term
 typedef int v4i __attribute__((ext_vector_type(4)));
+#ifndef DG_STAGGER
+#define DG_STAGGER 1
+#endif
 #ifndef PF
 #define PF 4       // LDS fragment reads kept in flight per wave
 #endif
@@ -124,6 +127,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr int NSF = KIND == KIND_DEPTH ? 0 : NKF;     // feature k-steps per tile
     constexpr int NS = NKD + NSF;                         // MFMA steps of one Y chain
     static_assert(!RCREG || RF == 1, "register-resident code rows only with one fragment per wave");
+    constexpr bool STAG = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,21 +229,45 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     for (int j = 0; j < 8; ++j) swz[j] = ((2 * j + h) ^ (r & 15)) << 4;
     const int frow = r * (GF * 16), crow = (h * 32 + r) * 16;
 
-    issue(0, 0);
-    if (NBUF == 3 && ntiles > 1) issue(1, 1);
-    int bcur = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
-        wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma : 0);
-        __builtin_amdgcn_s_barrier();
-        if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
-        const char* tile = smem + bcur * BUF;
-        bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
-        if (!wave_active) continue;
+    f32x16 Yf[RF], Yc[RF];       // live across the barrier in the staggered schedule
 
-        f32x16 Yf[RF], Yc[RF];
+    // ---- one Y chain = NSF feature k-steps then NKD code k-steps.  The A operands (S fragments) run through an
+    //      explicit ring of PF registers that is refilled right after each MFMA, so that PF LDS reads are always in
+    //      flight; scheduling fences pin that order (left alone hipcc serialises read -> wait -> MFMA here).
+    auto chain = [&](const char* tile, const int f, auto&& between) {
+        auto a_ptr = [&](int st) -> const v4i* {
+            return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
+                            : reinterpret_cast<const v4i*>(tile + BL::OFF_C + crow + (st - NSF) * 1024);
+        };
+        Yf[f] = f32x16{}; Yc[f] = f32x16{};
+        v4i ra[PF], rb[2];
 #pragma unroll
-        for (int f = 0; f < RF; ++f) { Yf[f] = f32x16{}; Yc[f] = f32x16{}; }
+        for (int i = 0; i < PF; ++i) if (i < NS) ra[i] = *a_ptr(i);
+        if (!RCREG) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) rb[k] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + k * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const v4i cur = ra[st % PF];
+            if (st < NSF) {
+                Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
+            } else {
+                const int k = st - NSF;
+                const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
+                Yc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur), b, Yc[f], 0, 0, 0);
+                if (!RCREG && k + 2 < NKD) rb[k & 1] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + (k + 2) * 1024);
+            }
+            if (st + PF < NS) ra[st % PF] = *a_ptr(st + PF);
+            between(st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- everything after the Y chains of tile t: epilogue (VALU) and the gradient MFMAs.  For RF == 2 the epilogue of
+    //      fragment 0 is carried in the gaps of fragment 1's chain (chain1 = true).
+    auto post = [&](const char* tile, const int t, const bool chain1) {
         // per-tile-row vector (rows 8*i4 + 4*h + e): 4 x 16-byte LDS reads, shared by the fragments
         float vv[16];
 #pragma unroll
@@ -265,50 +293,17 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 }
             }
         };
-
-        // ---- one Y chain = NSF feature k-steps then NKD code k-steps.  The A operands (S fragments) run through an
-        //      explicit ring of PF registers that is refilled right after each MFMA, so that PF LDS reads are always in
-        //      flight; scheduling fences pin that order (left alone hipcc serialises read -> wait -> MFMA here).
-        auto a_ptr = [&](int st) -> const v4i* {
-            return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
-                            : reinterpret_cast<const v4i*>(tile + BL::OFF_C + crow + (st - NSF) * 1024);
-        };
-        auto chain = [&](const int f, auto&& between) {
-            v4i ra[PF], rb[2];
-#pragma unroll
-            for (int i = 0; i < PF; ++i) if (i < NS) ra[i] = *a_ptr(i);
-            if (!RCREG) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) rb[k] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + k * 1024);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                const v4i cur = ra[st % PF];
-                if (st < NSF) {
-                    Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
-                } else {
-                    const int k = st - NSF;
-                    const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
-                    Yc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur), b, Yc[f], 0, 0, 0);
-                    if (!RCREG && k + 2 < NKD) rb[k & 1] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + (k + 2) * 1024);
-                }
-                if (st + PF < NS) ra[st % PF] = *a_ptr(st + PF);
-                between(st);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-
-        chain(0, [](int) {});
-        if (RF == 2 && act[RF - 1]) {
-            // second fragment: its MFMA chain carries the epilogue (VALU) of fragment 0 in its gaps
-            chain(RF - 1, [&](int st) {
+        if (RF == 2 && chain1) {
+            chain(tile, RF - 1, [&](int st) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if (i * NS / 16 == st) epi(0, i);
             });
 #pragma unroll
             for (int i = 0; i < 16; ++i) epi(RF - 1, i);
+        } else if (args.debug & 16) {   // developer ablation: no epilogue VALU (results invalid)
+#pragma unroll
+            for (int f = 0; f < RF; ++f) { ga[f][0] = __builtin_bit_cast(f16x8, Yf[f][0] > 1e30f ? v4i{1, 1, 1, 1} : v4i{0, 0, 0, 0}); ga[f][1] = ga[f][0]; lsum += Yc[f][0]; }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) epi(0, i);
@@ -317,7 +312,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             }
         }
         if (GRAD && !(args.debug & 4)) {
-            // ---- dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
+            // dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
 #pragma unroll
             for (int d = 0; d < NDF; ++d) {
                 const char* base = tile + BL::OFF_P + (h * KD + 32 * d + r) * 16;
@@ -329,6 +324,53 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                         dR[f][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[f][sp], b, dR[f][d], 0, 0, 0);
                 }
             }
+        }
+    };
+
+    if (STAG) {
+        // Staggered schedule (two waves per SIMD): waves NWAVES/2.. run half a tile behind their SIMD partners - they do
+        // the epilogue + gradient MFMAs of tile t-1 first and then the Y chain of tile t - so that one wave's VALU
+        // epilogue runs under the other's MFMA chain instead of both alternating in lockstep behind the tile barrier.
+        // Tile t-1 must stay in LDS during iteration t, so tiles are fetched one (not two) ahead.
+        const bool late = wid >= NWAVES / 2;
+        issue(0, 0);
+        auto top = [&](int t) {          // identical in both halves: same barriers, same DMA issue points
+            wait_vmcnt(0);
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < ntiles && !(args.debug & 1)) issue(t + 1, (t + 1) % 3);
+        };
+        if (!late) {
+            for (int t = 0; t < ntiles; ++t) {
+                top(t);
+                const char* tile = smem + (t % 3) * BUF;
+                if (wave_active) { chain(tile, 0, [](int) {}); post(tile, t, false); }
+            }
+        } else {
+            top(0);
+            if (wave_active) chain(smem, 0, [](int) {});
+            for (int t = 1; t < ntiles; ++t) {
+                top(t);
+                if (wave_active) {
+                    post(smem + ((t - 1) % 3) * BUF, t - 1, false);
+                    chain(smem + (t % 3) * BUF, 0, [](int) {});
+                }
+            }
+            if (wave_active) post(smem + ((ntiles - 1) % 3) * BUF, ntiles - 1, false);
+        }
+    } else {
+        issue(0, 0);
+        if (NBUF == 3 && ntiles > 1) issue(1, 1);
+        int bcur = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
+            wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma : 0);
+            __builtin_amdgcn_s_barrier();
+            if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
+            const char* tile = smem + bcur * BUF;
+            bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
+            if (!wave_active) continue;
+            chain(tile, 0, [](int) {});
+            post(tile, t, RF == 2 && act[RF - 1]);
         }
     }
 
