@@ -36,7 +36,7 @@ struct Plan {
     size_t nz;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
-    size_t comb[2], jobsum;
+    size_t comb[2], jobsum, taps;
     size_t total;
 };
 
@@ -80,6 +80,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
     p.jobsum = take((DG_MAX_JOBS + 1) * 2 * 8);
+    p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     p.total = off;
     return DG_OK;
 }
@@ -310,6 +311,7 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     s.nsrc = n;
     s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
     s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
+    s.taps = ws + p.taps;
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
     s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
     if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);

@@ -165,10 +165,16 @@ struct DgScatterArgs {
     const float* coords2;
     const float* gscal;    // [4] upstream gradients (device)
     float* comb[2];        // [B][Ppad][DP] combined direct sources per destination (scratch)
+    char* taps;            // [2 coords sets][B] inverse tap records (dg_taps_record_bytes each)
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
     int32_t B, D, DP, h, w, S, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
     int32_t debug;         // developer ablation bits (0 in production)
 };
+
+// bytes of one inverse-tap record: off[HW+1] ints, 4P weights, 4P positions (ushort), padded to 16
+__host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
+    return (((size_t)(HW + 1) * 4 + (size_t)4 * P * 6) + 15) / 16 * 16;
+}
 
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);

@@ -45,105 +45,141 @@ __global__ __launch_bounds__(256) void k_grad_combine(const DgScatterArgs a) {
 #define SCAT_PX (SCAT_THREADS / SCAT_DC)
 #define SCAT_MAXPASS 32      // supports h*w <= SCAT_PX * SCAT_MAXPASS = 4096 pixels
 
-// Stage 2: adjoint of sample() without floating-point atomics.  One block = one destination image, SCAT_DC channels.
-// For every source image that lands in this destination the block builds, in LDS, the inverse of the bilinear tap
-// map (pixel -> list of (position, weight), CSR: count, exclusive scan, fill) and then every thread GATHERS its
-// (pixel, channel) outputs: reads are rows of the fp32 gradient buffers, accumulation is in registers.
-// grid (ceil(D / SCAT_DC), B, 2), block SCAT_THREADS, dynamic LDS = (2*hw + 1) ints + 4*P (float + ushort) + stage.
-__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
+// Inverse of the bilinear tap map of sample(), once per (coords set, image): for every pixel the list of
+// (position, weight) that read it, as CSR in global memory (off[HW+1], then 4P weights, then 4P positions).
+// Lists are sorted by position, so the gather below sums in a fixed order (bit-reproducible gradients).
+// grid (B, 2), block SCAT_THREADS, dynamic LDS (2*HW + 1) ints + 4P floats + 4P ushorts.
+__global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sg[];
     const int tid = threadIdx.x, HW = a.h * a.w, P = a.P, S = a.S;
+    const int nimg = blockIdx.x, cs = blockIdx.y;
+    const float* coords = cs == 0 ? a.coords1 : a.coords2;
     int* cnt = reinterpret_cast<int*>(sg);                 // [HW] taps per pixel (then fill cursor)
     int* off = cnt + HW;                                   // [HW + 1] exclusive scan
-    float* ewgt = reinterpret_cast<float*>(off + HW + 1);  // [4P] weights
-    unsigned short* eidx = reinterpret_cast<unsigned short*>(ewgt + 4 * P);   // [4P] positions
+    float* ewgt = reinterpret_cast<float*>(off + HW + 1);  // [4P]
+    unsigned short* eidx = reinterpret_cast<unsigned short*>(ewgt + 4 * P);   // [4P]
     __shared__ int wtot[SCAT_THREADS / 64];
+    for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;
+    __syncthreads();
+    int x0 = 0, y0 = 0; bool inx = false, iny = false; float w4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pp = tid; pp < P; pp += SCAT_THREADS) {
+        const int i = pp / S, j = pp - i * S;
+        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        const int pix = y0 * a.w + x0;
+        if (w4[0] != 0.f) atomicAdd(&cnt[pix], 1);
+        if (inx && w4[1] != 0.f) atomicAdd(&cnt[pix + 1], 1);
+        if (iny && w4[2] != 0.f) atomicAdd(&cnt[pix + a.w], 1);
+        if (inx && iny && w4[3] != 0.f) atomicAdd(&cnt[pix + a.w + 1], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt -> off (each thread owns a contiguous run of pixels)
+    const int per = (HW + SCAT_THREADS - 1) / SCAT_THREADS;
+    const int b0 = min(tid * per, HW), b1 = min(b0 + per, HW);
+    int run = 0;
+    for (int i = b0; i < b1; ++i) run += cnt[i];
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
+    if ((tid & 63) == 63) wtot[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += wtot[wv];
+    int o2 = base + incl - run;
+    for (int i = b0; i < b1; ++i) { const int c = cnt[i]; off[i] = o2; o2 += c; }
+    if (tid == SCAT_THREADS - 1) off[HW] = o2;
+    __syncthreads();
+    for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;       // becomes the fill cursor
+    __syncthreads();
+    for (int pp = tid; pp < P; pp += SCAT_THREADS) {
+        const int i = pp / S, j = pp - i * S;
+        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        const int pix = y0 * a.w + x0;
+        auto put = [&](int q, float wgt) {
+            const int slot = off[q] + atomicAdd(&cnt[q], 1);
+            ewgt[slot] = wgt; eidx[slot] = (unsigned short)pp;
+        };
+        if (w4[0] != 0.f) put(pix, w4[0]);
+        if (inx && w4[1] != 0.f) put(pix + 1, w4[1]);
+        if (iny && w4[2] != 0.f) put(pix + a.w, w4[2]);
+        if (inx && iny && w4[3] != 0.f) put(pix + a.w + 1, w4[3]);
+    }
+    __syncthreads();
+    // sort every pixel's list by position (insertion sort, lists are short)
+    for (int q = tid; q < HW; q += SCAT_THREADS) {
+        const int e0 = off[q], e1 = off[q + 1];
+        for (int i = e0 + 1; i < e1; ++i) {
+            const unsigned short ki = eidx[i]; const float wi = ewgt[i];
+            int j = i - 1;
+            while (j >= e0 && eidx[j] > ki) { eidx[j + 1] = eidx[j]; ewgt[j + 1] = ewgt[j]; --j; }
+            eidx[j + 1] = ki; ewgt[j + 1] = wi;
+        }
+    }
+    __syncthreads();
+    // copy out: [off (HW+1 ints)][weights 4P floats][positions 4P ushorts], one record per (cs, image)
+    const size_t rec = dg_taps_record_bytes(HW, P);
+    char* dst = a.taps + ((size_t)cs * a.B + nimg) * rec;
+    int* g_off = reinterpret_cast<int*>(dst);
+    float* g_w = reinterpret_cast<float*>(g_off + HW + 1);
+    unsigned short* g_p = reinterpret_cast<unsigned short*>(g_w + 4 * P);
+    for (int i = tid; i <= HW; i += SCAT_THREADS) g_off[i] = off[i];
+    const int ne = off[HW];
+    for (int i = tid; i < ne; i += SCAT_THREADS) { g_w[i] = ewgt[i]; g_p[i] = eidx[i]; }
+}
+
+// Stage 2: adjoint of sample() as a GATHER (no floating-point atomics).  One block = one destination image and
+// SCAT_DC channels; for every source image that lands there it copies that image's tap lists into LDS and every thread
+// gathers its (pixel, channel) outputs into registers; rows of the fp32 gradient buffers are read, nothing is scattered.
+// grid (ceil(D / SCAT_DC), B, 2), block SCAT_THREADS, dynamic LDS = one tap record (>= the output staging tile).
+template <int NPASS>
+__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sg[];
+    const int tid = threadIdx.x, HW = a.h * a.w, P = a.P;
+    const int* off = reinterpret_cast<const int*>(sg);
+    const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
+    const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
     const int dc0 = blockIdx.x * SCAT_DC, bdst = blockIdx.y, dest = blockIdx.z;
     const int dl = tid & (SCAT_DC - 1), px = tid / SCAT_DC, d = dc0 + dl;
     const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
-    float acc[SCAT_MAXPASS];
+    const size_t rec = dg_taps_record_bytes(HW, P);
+    float acc[NPASS];
 #pragma unroll
-    for (int i = 0; i < SCAT_MAXPASS; ++i) acc[i] = 0.f;
+    for (int i = 0; i < NPASS; ++i) acc[i] = 0.f;
 
-    auto one_source = [&](const float* buf, float sc, const float* coords, int nimg) {
-        // ---- count taps per pixel
-        for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;
+    auto one_source = [&](const float* buf, float sc, int cs, int nimg) {
+        // tap lists of (cs, nimg) -> LDS (16-byte copies; the record is padded to 16 bytes)
+        const uint4* g = reinterpret_cast<const uint4*>(a.taps + ((size_t)cs * a.B + nimg) * rec);
+        for (int i = tid; i < (int)(rec / 16); i += SCAT_THREADS) reinterpret_cast<uint4*>(sg)[i] = g[i];
         __syncthreads();
-        int x0 = 0, y0 = 0; bool inx = false, iny = false; float w4[4] = {0.f, 0.f, 0.f, 0.f};
-        const int p = tid;                         // one position per thread per round (P <= 1024 per round)
-        for (int pb = 0; pb < P; pb += SCAT_THREADS) {
-            const int pp = pb + p;
-            if (pp < P) {
-                const int i = pp / S, j = pp - i * S;
-                dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
-                const int pix = y0 * a.w + x0;
-                if (w4[0] != 0.f) atomicAdd(&cnt[pix], 1);
-                if (inx && w4[1] != 0.f) atomicAdd(&cnt[pix + 1], 1);
-                if (iny && w4[2] != 0.f) atomicAdd(&cnt[pix + a.w], 1);
-                if (inx && iny && w4[3] != 0.f) atomicAdd(&cnt[pix + a.w + 1], 1);
-            }
-        }
-        __syncthreads();
-        // ---- exclusive scan of cnt -> off (each thread owns a contiguous run of pixels)
-        const int per = (HW + SCAT_THREADS - 1) / SCAT_THREADS;
-        const int b0 = min(tid * per, HW), b1 = min(b0 + per, HW);
-        int run = 0;
-        for (int i = b0; i < b1; ++i) run += cnt[i];
-        int incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += t; }
-        if ((tid & 63) == 63) wtot[tid >> 6] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int wv = 0; wv < (tid >> 6); ++wv) base += wtot[wv];
-        int o2 = base + incl - run;
-        for (int i = b0; i < b1; ++i) { const int c = cnt[i]; off[i] = o2; o2 += c; }
-        __syncthreads();
-        for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;       // becomes the fill cursor
-        __syncthreads();
-        // ---- fill the lists
-        for (int pb = 0; pb < P; pb += SCAT_THREADS) {
-            const int pp = pb + p;
-            if (pp < P) {
-                const int i = pp / S, j = pp - i * S;
-                dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
-                const int pix = y0 * a.w + x0;
-                auto put = [&](int q, float wgt) {
-                    const int slot = off[q] + atomicAdd(&cnt[q], 1);
-                    ewgt[slot] = wgt; eidx[slot] = (unsigned short)pp;
-                };
-                if (w4[0] != 0.f) put(pix, w4[0]);
-                if (inx && w4[1] != 0.f) put(pix + 1, w4[1]);
-                if (iny && w4[2] != 0.f) put(pix + a.w, w4[2]);
-                if (inx && iny && w4[3] != 0.f) put(pix + a.w + 1, w4[3]);
-            }
-        }
-        __syncthreads();
-        // ---- gather
         if (d < a.D) {
             const float* src = buf + (size_t)nimg * a.Ppad * a.DP + d;
+            // first tap of every pixel of this thread: independent loads, all in flight together
+            float first[NPASS];
+            int e0a[NPASS], e1a[NPASS];
 #pragma unroll
-            for (int ps = 0; ps < SCAT_MAXPASS; ++ps) {
+            for (int ps = 0; ps < NPASS; ++ps) {
                 const int pix = ps * SCAT_PX + px;
-                if (ps < npass && pix < HW) {
-                    const int e0 = off[pix], e1 = e0 + cnt[pix];
-                    float sum = 0.f;
-                    for (int e = e0; e < e1; ++e) sum = fmaf(ewgt[e], src[(size_t)eidx[e] * a.DP], sum);
-                    acc[ps] = fmaf(sc, sum, acc[ps]);
-                }
+                const bool ok = ps < npass && pix < HW;
+                e0a[ps] = ok ? off[pix] : 0;
+                e1a[ps] = ok ? off[pix + 1] : 0;
+                first[ps] = e1a[ps] > e0a[ps] ? ewgt[e0a[ps]] * src[(size_t)eidx[e0a[ps]] * a.DP] : 0.f;
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                float sum = first[ps];
+                for (int e = e0a[ps] + 1; e < e1a[ps]; ++e) sum = fmaf(ewgt[e], src[(size_t)eidx[e] * a.DP], sum);
+                acc[ps] = fmaf(sc, sum, acc[ps]);
             }
         }
         __syncthreads();
     };
 
     // direct sources (already combined): image bdst -> destination bdst; coords1 for grad_code, coords2 for grad_code_pos
-    one_source(a.comb[dest], 1.0f, dest == 0 ? a.coords1 : a.coords2, bdst);
+    one_source(a.comb[dest], 1.0f, dest == 0 ? 0 : 1, bdst);
     // routed sources (negatives): image n scatters into destination route[n] with n's coords
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
         const float sc = q.factor * a.gscal[q.gidx];
-        const float* coords = q.coords_sel == 0 ? a.coords1 : a.coords2;
         for (int n0 = 0; n0 < a.B; n0 += 64) {           // which images route here: one ballot per 64 images
             const int nn = n0 + (tid & 63);
             const bool hit = nn < a.B && (int)q.route[nn] == bdst;
@@ -151,14 +187,14 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
             while (m) {
                 const int n = n0 + __builtin_ctzll(m);
                 m &= m - 1;
-                one_source(q.buf, sc, coords, n);
+                one_source(q.buf, sc, q.coords_sel, n);
             }
         }
     }
     // ---- write (B,D,h,w): transpose through LDS so that the stores run along the pixels
     float* stage = reinterpret_cast<float*>(sg);     // [SCAT_DC][HW + 1]
 #pragma unroll
-    for (int ps = 0; ps < SCAT_MAXPASS; ++ps) {
+    for (int ps = 0; ps < NPASS; ++ps) {
         const int pix = ps * SCAT_PX + px;
         if (ps < npass && pix < HW) stage[dl * (HW + 1) + pix] = acc[ps];
     }
@@ -170,23 +206,32 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     }
 }
 
-size_t dg_scatter_lds_bytes(int HW, int P) {
-    const size_t lists = (size_t)(2 * HW + 1) * 4 + (size_t)4 * P * 6 + 16;
-    const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
-    return lists > stage ? lists : stage;
-}
-
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
     hipLaunchKernelGGL(k_grad_combine, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, s, a);
     const int HW = a.h * a.w;
     if (HW > SCAT_PX * SCAT_MAXPASS || a.P > 65535) return hipErrorInvalidValue;
-    const int smem = (int)dg_scatter_lds_bytes(HW, a.P);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_grad), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    const size_t rec = dg_taps_record_bytes(HW, a.P);
+    const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
+    const int smem = (int)(rec > stage ? rec : stage);
+    const int build_smem = (int)(rec + (size_t)HW * 4 + 16);     // the record plus the per-pixel counters
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_taps), hipFuncAttributeMaxDynamicSharedMemorySize, build_smem);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_build_taps, dim3(a.B, 2), dim3(SCAT_THREADS), build_smem, s, a);
     dim3 grid((a.D + SCAT_DC - 1) / SCAT_DC, a.B, 2);
-    hipLaunchKernelGGL(k_scatter_grad, grid, dim3(SCAT_THREADS), smem, s, a);
-    return hipGetLastError();
+    const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
+#define DG_SCAT(NP)                                                                                                      \
+    {                                                                                                                    \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_grad<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL(k_scatter_grad<NP>, grid, dim3(SCAT_THREADS), smem, s, a);                                    \
+        return hipGetLastError();                                                                                        \
+    }
+    if (npass <= 2) DG_SCAT(2)
+    if (npass <= 8) DG_SCAT(8)
+    if (npass <= 16) DG_SCAT(16)
+    DG_SCAT(32)
+#undef DG_SCAT
 }
 
 // ------------------------------------------------------------------------------------------
