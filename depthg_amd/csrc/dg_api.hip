@@ -29,7 +29,7 @@ static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, nchunk, blob;
-    bool shared, depth, grad, pointwise;
+    bool shared, depth, grad, pointwise, ident;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2], m0[DG_MAX_NEG + 2];
@@ -59,6 +59,9 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.depth = (d->flags & DG_DEPTH_TERM) != 0;
     p.grad = (d->flags & DG_NEED_GRAD) != 0;
     p.pointwise = (d->flags & DG_POINTWISE) != 0;
+    p.ident = (d->flags & DG_IDENTITY_GRID) != 0;
+    if (p.ident && (!p.shared || d->S != d->h || d->S != d->w || d->w > 32))
+        return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs DG_SHARED_COORDS and S == h == w <= 32");
     p.nops = p.shared ? 2 : p.T;
     p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
     p.nrb = (p.Ppad + p.rf * 32 - 1) / (p.rf * 32);
@@ -71,7 +74,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
-        p.colpart[i] = take(B * (p.Ppad / 32) * p.KF * 4);
+        p.colpart[i] = take(B * (size_t)(p.ident ? p.h : p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
     }
     for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * p.nchunk * 4); p.m0[t] = take(4); }
@@ -197,9 +200,15 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int HW = p.h * p.w;
 
-    // 1. channel-last copies of the four maps (the gather reads whole channel vectors per tap)
-    DG_HIP(dg_launch_transpose(orig_feats, F32(p.nhwc_f[0]), p.B, p.C, HW, p.C4, stream));
-    DG_HIP(dg_launch_transpose(orig_feats_pos, F32(p.nhwc_f[1]), p.B, p.C, HW, p.C4, stream));
+    // 1. channel-last copies of the maps (the gather reads whole channel vectors per tap); on the dense identity grid
+    //    the feats operands are built straight from NCHW instead
+    if (!p.ident) {
+        DG_HIP(dg_launch_transpose(orig_feats, F32(p.nhwc_f[0]), p.B, p.C, HW, p.C4, stream));
+        DG_HIP(dg_launch_transpose(orig_feats_pos, F32(p.nhwc_f[1]), p.B, p.C, HW, p.C4, stream));
+    } else {
+        DG_HIP(dg_launch_prep_dense_feats(orig_feats, orig_feats_pos, ws + p.op[0], ws + p.op[1], F32(p.colpart[0]),
+                                          F32(p.colpart[1]), p.B, p.C, p.KF, p.KD, p.h, p.w, p.P, p.Ppad, stream));
+    }
     DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
     DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
 
@@ -213,17 +222,19 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
             const float* coords = o == 0 ? coords1 : coords2;
             const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
-            DgGatherJob& f = g.jobs[nj++];
-            f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
-            f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
-            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
+            if (!p.ident) {
+                DgGatherJob& f = g.jobs[nj++];
+                f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
+                f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
+                f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
+            }
             DgGatherJob& c = g.jobs[nj++];
             c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
             c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
             c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
         }
         g.njobs = nj;
-        DG_HIP(dg_launch_gather(g, p.KF, stream));
+        DG_HIP(dg_launch_gather(g, p.ident ? p.KD : p.KF, stream));
     }
     if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
 
@@ -232,7 +243,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DgColmeanArgs c;
         memset(&c, 0, sizeof(c));
         c.nops = p.nops; c.B = p.B; c.P = p.P; c.Ppad = p.Ppad; c.KF = p.KF;
-        for (int o = 0; o < p.nops; ++o) { c.colpart[o] = F32(p.colpart[o]); c.bbar[o] = F32(p.bbar[o]); }
+        for (int o = 0; o < p.nops; ++o) { c.colpart[o] = F32(p.colpart[o]); c.bbar[o] = F32(p.bbar[o]); c.ngroups[o] = p.ident ? p.h : p.Ppad / 32; }
         DG_HIP(dg_launch_colmean(c, stream));
         DgRowmeanArgs r;
         memset(&r, 0, sizeof(r));

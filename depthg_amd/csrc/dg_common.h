@@ -131,6 +131,7 @@ struct DgGatherArgs {
 struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_tiles colpart[o][n][tile][k]
     const float* colpart[DG_MAX_NEG + 2];
     float* bbar[DG_MAX_NEG + 2];
+    int32_t ngroups[DG_MAX_NEG + 2];   // partial-sum groups per image (tiles, or source rows on the dense path)
     int32_t nops, B, P, Ppad, KF;
 };
 
@@ -183,6 +184,8 @@ hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int H
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
+hipError_t dg_launch_prep_dense_feats(const float* f0, const float* f1, char* blob0, char* blob1, float* cp0, float* cp1,
+                                      int B, int K, int KF, int KD, int h, int w, int P, int Ppad, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,

@@ -155,6 +155,113 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Dense identity grid (S == h == w, coords = the pixel centres): sample() is an exact spatial transpose
+// (out[b,:,i,j] = t[b,:,j,i], reference quirk Q3), so the feats operand is built straight from the NCHW map: no
+// channel-last copy, no bilinear taps.  One block per (source row y, image): reads the K x w slab of that row
+// (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
+// grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
+struct DgDenseFeatsArgs {
+    const float* src[2];     // NCHW fp32 (B,K,h,w)
+    char* blob[2];
+    float* colpart[2];       // [B][h][KF] per-source-row column sums
+    int32_t B, K, KF, KD, h, w, P, Ppad;
+};
+
+__global__ __launch_bounds__(256) void k_prep_dense_feats(const DgDenseFeatsArgs a) {
+    extern __shared__ float sl[];                  // [w][KF + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int y = blockIdx.x, n = blockIdx.y, o = blockIdx.z;
+    const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h, LD = KF + 1;
+    const DgBlob L(a.KF, a.KD);
+    const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w;
+    // load: channel k, pixel x  (x fastest: w contiguous floats per channel)
+    {
+        constexpr int UN = 12;                      // independent loads in flight per thread
+        const int x = tid & 31, k0 = tid >> 5;      // 8 channels per sweep of the block
+        for (int kb = k0; kb < KF; kb += 8 * UN) {
+            float t[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = kb + 8 * u;
+                t[u] = (x < w && k < K) ? src[(size_t)k * h * w + x] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = kb + 8 * u;
+                if (x < w && k < KF) sl[x * LD + k] = t[u];
+            }
+        }
+    }
+    __syncthreads();
+    // one wave per position x: normalise over channels, write the blob row, accumulate column sums
+    float colacc[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) colacc[m][0] = colacc[m][1] = colacc[m][2] = colacc[m][3] = 0.f;
+    for (int x = wid; x < w; x += 4) {
+        const float* row = sl + x * LD;
+        float v[3][4];
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * lane + 256 * m + e;
+                v[m][e] = k < KF ? row[k] : 0.f;
+                ss = fmaf(v[m][e], v[m][e], ss);
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
+        const int p = x * S + y;                        // sample() output position (i, j) = (x, y)
+        char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
+        const int q = p & 31;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int k = 4 * lane + 256 * m;
+            if (k < KF) {
+                bf16x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float u = v[m][e] * inv; colacc[m][e] += u; t[e] = (__bf16)u; }
+                *reinterpret_cast<uint2*>(blob + L.f(q, k >> 3) + (k & 7) * 2) = *reinterpret_cast<uint2*>(&t);
+            }
+        }
+    }
+    // zero rows of the ragged last tile (positions P .. Ppad-1), once per image
+    if (y == 0) {
+        for (int idx = tid; idx < (a.Ppad - a.P) * (KF / 4); idx += 256) {
+            const int p = a.P + idx / (KF / 4), k = (idx % (KF / 4)) * 4;
+            char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
+            *reinterpret_cast<uint2*>(blob + L.f(p & 31, k >> 3) + (k & 7) * 2) = make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    float* colred = sl;                              // reuse: [4][KF]
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * lane + 256 * m + e;
+            if (k < KF) colred[wid * KF + k] = colacc[m][e];
+        }
+    __syncthreads();
+    for (int k = tid; k < KF; k += 256)
+        a.colpart[o][((size_t)n * h + y) * KF + k] = colred[k] + colred[KF + k] + colred[2 * KF + k] + colred[3 * KF + k];
+}
+
+hipError_t dg_launch_prep_dense_feats(const float* f0, const float* f1, char* blob0, char* blob1, float* cp0, float* cp1,
+                                      int B, int K, int KF, int KD, int h, int w, int P, int Ppad, hipStream_t s) {
+    DgDenseFeatsArgs a;
+    a.src[0] = f0; a.src[1] = f1; a.blob[0] = blob0; a.blob[1] = blob1; a.colpart[0] = cp0; a.colpart[1] = cp1;
+    a.B = B; a.K = K; a.KF = KF; a.KD = KD; a.h = h; a.w = w; a.P = P; a.Ppad = Ppad;
+    if (w > 32 || KF > 768) return hipErrorInvalidValue;
+    const int smem = max(w * (KF + 1), 4 * KF) * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_dense_feats), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prep_dense_feats, dim3(h, B, 2), dim3(256), smem, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // depth (B,1,H,W) -> nz[n][p] over the S x S resize, p = i*S + j (row major)
 __global__ void k_depth_nz(const float* __restrict__ depth, float* __restrict__ nz, int B, int H, int W, int S, int Ppad) {
     const int n = blockIdx.y;
@@ -188,7 +295,7 @@ hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W
 
 // bbar[o][n][k] = (1/P) sum over tiles of the per-tile column sums.  grid (B, nops), block 256.
 __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
-    const int n = blockIdx.x, o = blockIdx.y, nt = a.Ppad / 32;
+    const int n = blockIdx.x, o = blockIdx.y, nt = a.ngroups[o];
     const float invP = 1.f / (float)a.P;
     for (int k = threadIdx.x; k < a.KF; k += 256) {
         float s = 0.f;

@@ -28,6 +28,16 @@ def super_perm(size: int, device) -> torch.Tensor:
     return perm % size
 
 
+def super_perms(count: int, size: int, device) -> torch.Tensor:
+    """`count` independent super_perm draws as one (count, size) tensor with ONE sort launch: argsort of iid uniforms
+    is a uniform random permutation, like randperm; then the same fixed-point bump (src/modules.py:1186-1188)."""
+    if count == 0:
+        return torch.zeros(0, size, dtype=torch.long, device=device)
+    perm = torch.argsort(torch.rand(count, size, device=device), dim=1)
+    ar = torch.arange(size, device=device).unsqueeze(0)
+    return torch.where(perm == ar, perm + 1, perm) % size
+
+
 def identity_coords(b: int, s: int, device) -> torch.Tensor:
     """coords such that sample() reads every pixel of an s x s map exactly once (transposed, quirk Q3)."""
     lin = torch.linspace(-1.0, 1.0, s, device=device)
@@ -95,13 +105,14 @@ class ContrastiveCorrelationLoss(nn.Module):
         coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
                                                      depth, depth_pos)
         B = orig_feats.shape[0]
-        perms = [super_perm(B, orig_feats.device) for _ in range(int(self.cfg.neg_samples))]
+        perms = super_perms(int(self.cfg.neg_samples), B, orig_feats.device)
+        # `shared` is only ever set together with the identity grid drawn above
         return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                                 shared_coords=shared)
+                                 shared_coords=shared, identity_grid=shared)
 
     # -- everything after the RNG draws (explicit coords / perms: parity tests, DP shards) ----------
     def forward_with(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                     shared_coords=False):
+                     shared_coords=False, identity_grid=False):
         cfg = self.cfg
         B, C, h, w = orig_feats.shape
         D = orig_code.shape[1]
@@ -128,7 +139,8 @@ class ContrastiveCorrelationLoss(nn.Module):
                              shared_coords=bool(shared_coords),
                              shifts=(cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift,
                                      cfg.depth_feat_shift if depth_term else 0.0),
-                             depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0))
+                             depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
+                             identity_grid=bool(identity_grid))
         holder = {}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()

@@ -25,7 +25,7 @@ def _f32c(t, name):
 
 
 def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
-              shifts, depth_hw=(0, 0)):
+              shifts, depth_hw=(0, 0), identity_grid=False):
     flags = 0
     flags |= _lib.DG_POINTWISE if pointwise else 0
     flags |= _lib.DG_ZERO_CLAMP if zero_clamp else 0
@@ -33,6 +33,7 @@ def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, dept
     flags |= _lib.DG_DEPTH_TERM if depth_term else 0
     flags |= _lib.DG_NEED_GRAD if need_grad else 0
     flags |= _lib.DG_SHARED_COORDS if shared_coords else 0
+    flags |= _lib.DG_IDENTITY_GRID if identity_grid else 0
     return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
                     float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]))
 

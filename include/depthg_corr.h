@@ -36,6 +36,10 @@ extern "C" {
 #define DG_SHARED_COORDS  (1u << 5)  /* coords1[n] == coords2[m] for all n, m (dense grid): negatives reuse
                                         the prepared operand of `feats`/`code` through the batch permutation */
 
+#define DG_IDENTITY_GRID  (1u << 6)  /* with DG_SHARED_COORDS and S == h == w: both coords are the pixel-centre grid
+                                        (coords[b,u,v] = (lin[v], lin[u]), lin = linspace(-1,1,S)): sample() is an exact
+                                        transpose and the feats operands are built without bilinear taps */
+
 #define DG_MAX_NEG 8
 
 /* error codes */

@@ -184,18 +184,21 @@ def test_headline_size_properties(dev):
     coords = identity_coords(B, hw, dev)
     cfg = O.default_cfg(feature_samples=hw, dg_outputs="reduced")
 
-    def run(cfg, shared, weights=(0.67, 0.25, 0.63, 0.19)):
+    def run(cfg, shared, weights=(0.67, 0.25, 0.63, 0.19), ident=False):
         cg, cpg = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
-        out = ContrastiveCorrelationLoss(cfg).forward_with(f, fp, cg, cpg, d, coords, coords, perms, shared_coords=shared)
+        out = ContrastiveCorrelationLoss(cfg).forward_with(f, fp, cg, cpg, d, coords, coords, perms, shared_coords=shared,
+                                                           identity_grid=ident)
         tot = weights[0] * out[0] + weights[1] * out[2] + weights[2] * out[4].mean() + weights[3] * out[6]
         tot.backward()
         return [float(out[i].mean()) for i in range(8)], cg.grad, cpg.grad
 
     s_shared, g_shared, gp_shared = run(cfg, True)
     s_gen, g_gen, gp_gen = run(cfg, False)
-    for a, b in zip(s_shared, s_gen):
-        assert a == pytest.approx(b, rel=1e-6, abs=1e-9)
-    assert (g_shared - g_gen).norm() <= 1e-5 * g_gen.norm()
+    s_id, g_id, gp_id = run(cfg, True, ident=True)          # feats operands built straight from NCHW (no taps)
+    for a, b, c_ in zip(s_shared, s_gen, s_id):
+        assert a == pytest.approx(b, rel=1e-6, abs=1e-9) and a == pytest.approx(c_, rel=1e-6, abs=1e-9)
+    assert (g_shared - g_gen).norm() <= 1e-5 * g_gen.norm() and (g_id - g_gen).norm() <= 1e-4 * g_gen.norm()
+    assert (gp_id - gp_gen).norm() <= 1e-4 * gp_gen.norm()
     # (b) zero-clamped cd >= 0: with shift -> 0 the loss changes by shift * mean(clamp(cd)) for each term
     cfg0 = O.default_cfg(feature_samples=hw, dg_outputs="reduced", pos_intra_shift=0.0, pos_inter_shift=0.0,
                          neg_inter_shift=0.0, depth_feat_shift=0.0)

@@ -109,6 +109,11 @@ def test_super_perm_properties():
             if n > 1:
                 assert not bool((p == torch.arange(n)).any())
     assert super_perm(1, "cpu").tolist() == [0]      # quirk Q6
+    from depthg_amd.loss import super_perms
+    ps = super_perms(5, 32, "cpu")
+    assert ps.shape == (5, 32) and not bool((ps == torch.arange(32)).any()) and int(ps.max()) < 32
+    assert all(len(set(row.tolist())) >= 30 for row in ps)          # near-permutations (duplicates possible, Q6)
+    assert super_perms(3, 1, "cpu").tolist() == [[0], [0], [0]] and super_perms(0, 4, "cpu").shape == (0, 4)
     g = load_golden("functions.npz")
     torch.manual_seed(3)
     assert np.array_equal(super_perm(8, "cpu").numpy(), g["superperm_8"])   # same RNG consumption as the reference
