@@ -82,7 +82,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
-    p.jobsum = take((DG_MAX_JOBS + 1) * 2 * 8);
+    p.jobsum = take((DG_MAX_JOBS + B) * 2 * 8);
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     p.total = off;
     return DG_OK;

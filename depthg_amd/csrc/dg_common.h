@@ -108,7 +108,7 @@ struct DgFinishArgs {
     int32_t njobs;
     const float* nz;                 // [B][Ppad] or null
     int32_t B, P, Ppad;
-    double* jobsum;                  // [DG_MAX_JOBS + 1][2] scratch (stage 1 -> stage 2)
+    double* jobsum;                  // [njobs + B][2] scratch (stage 1 -> stage 2)
     float* out;                      // [DG_OUT_COUNT]
 };
 

@@ -449,20 +449,18 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 }
 
 // ---- final reduction of the per-block partial sums into the 8 output scalars (two tiny launches)
-// stage 1: one block per job (+ one for mean(dd)); stage 2: one thread combines the job sums in a fixed order.
+// stage 1: one block per job (+ one per image for mean(dd)); stage 2: one thread combines the sums in a fixed order.
 __global__ __launch_bounds__(256) void k_corr_finish1(const DgFinishArgs a) {
     __shared__ double wred[4][2];
     const int tid = threadIdx.x, j = blockIdx.x;
     double l = 0.0, c = 0.0;
     if (j < a.njobs) {
         for (int i = tid; i < a.nblk[j]; i += 256) { l += a.part[j][2 * i]; c += a.part[j][2 * i + 1]; }
-    } else if (a.nz) {   // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2 ; one wave per image, summed below
-        for (int n = tid >> 6; n < a.B; n += 4) {
-            double s = 0.0;
-            for (int p = tid & 63; p < a.P; p += 64) s += a.nz[(size_t)n * a.Ppad + p];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if ((tid & 63) == 0) l += s * s;
-        }
+    } else if (a.nz) {   // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2: block njobs + n sums image n
+        const int n = j - a.njobs;
+        float s = 0.f;
+        for (int p = tid; p < a.P; p += 256) s += a.nz[(size_t)n * a.Ppad + p];
+        l = s;
     }
     for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); }
     if ((tid & 63) == 0) { wred[tid >> 6][0] = l; wred[tid >> 6][1] = c; }
@@ -481,7 +479,11 @@ __global__ void k_corr_finish2(const DgFinishArgs a) {
         if (a.slot_loss[j] >= 0) acc[a.slot_loss[j]] += -a.jobsum[2 * j] * (double)a.scale[j];
         if (a.slot_cd[j] >= 0) acc[a.slot_cd[j]] += a.jobsum[2 * j + 1] * (double)a.scale[j];
     }
-    if (a.nz) acc[DG_OUT_DD] = a.jobsum[2 * a.njobs] / ((double)a.B * a.P * a.P);
+    if (a.nz) {
+        double m = 0.0;
+        for (int n = 0; n < a.B; ++n) { const double s = a.jobsum[2 * (a.njobs + n)]; m += s * s; }
+        acc[DG_OUT_DD] = m / ((double)a.B * a.P * a.P);
+    }
     for (int i = 0; i < DG_OUT_COUNT; ++i) a.out[i] = (float)acc[i];
 }
 
@@ -524,7 +526,7 @@ hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, in
 }
 
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_corr_finish1, dim3(a.njobs + 1), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_corr_finish1, dim3(a.njobs + (a.nz ? a.B : 0)), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_corr_finish2, dim3(1), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
