@@ -36,7 +36,7 @@ struct Plan {
     size_t nz;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
-    size_t comb[2], jobsum, taps;
+    size_t comb[2], jobsum, taps, gbuf[DG_MAX_NEG + 2];
     size_t total;
 };
 
@@ -84,6 +84,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
     p.jobsum = take((DG_MAX_JOBS + B) * 2 * 8);
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
+    for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
     p.total = off;
     return DG_OK;
 }
@@ -152,6 +153,20 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 // Job table of the fused correlation launch: pass A (stationary = operand 1) for every pair-set, then (with
 // gradients) pass B (stationary = operand 2), the cheap depth job last.  Pass-A jobs come first: returns their count
 // (the depth job, when present, is the last job of the table and is also a pass-A job for the loss sums).
+// k_gs jobs: one per pair-set; the producing job is pass A of helper_job(t) (R = operand 1, S = operand 2 of t)
+static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArgs& g) {
+    memset(&g, 0, sizeof(g));
+    g.njobs = p.T; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
+    for (int t = 0; t < p.T; ++t) {
+        const int o2 = op_of(p, t);
+        g.jobs[t].G = reinterpret_cast<const uint16_t*>(ws + p.gbuf[t]);
+        g.jobs[t].Rop = ws + p.op[0]; g.jobs[t].ridx = nullptr;
+        g.jobs[t].Sop = ws + p.op[o2]; g.jobs[t].sidx = map_of(p, t, perms);
+        g.jobs[t].ScInv = reinterpret_cast<const float*>(ws + p.inv[o2]);
+        g.jobs[t].dS = reinterpret_cast<float*>(ws + p.dRB[t]);
+    }
+}
+
 static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a,
                            int* depth_index) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
@@ -161,15 +176,11 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         DgJob j = helper_job(p, desc, ws, t, false, perms);
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
+        j.Gout = p.grad ? reinterpret_cast<uint16_t*>(ws + p.gbuf[t]) : nullptr;
         a.jobs[nj++] = j;
     }
     const int njA = nj;
-    if (p.grad)
-        for (int t = 0; t < p.T; ++t) {
-            DgJob j = helper_job(p, desc, ws, t, true, perms);
-            j.dR = F32(p.dRB[t]);
-            a.jobs[nj++] = j;
-        }
+    // (the gradient of the streamed operand's code comes from k_gs, which consumes the G tiles these jobs store)
     *depth_index = -1;
     if (p.depth) {
         DgJob j = depth_job(p, desc, ws);
@@ -261,6 +272,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     int depth_index;
     const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream));
+    if (p.grad) {
+        DgGsArgs g;
+        build_gs_jobs(p, ws, perms, g);
+        DG_HIP(dg_launch_gs(g, stream));
+    }
 
     // 5. scalar outputs
     DgFinishArgs f;

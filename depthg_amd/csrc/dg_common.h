@@ -78,6 +78,7 @@ struct DgJob {
     float* part;          // fp32 [blocks of this job][2] partial sums (sum clamp(cd)*(fd-shift), sum cd); or null
     float* out_cd;        // fp32 [B][P][P] (op1 position major) or null    (materialise; needs center_on_lane == 0)
     float* out_loss;      // fp32 [B][P][P] or null
+    uint16_t* Gout;       // fp16 [B][nt][nt][64 lanes][16] = G tiles in accumulator order (input of k_gs) or null
     float shift;
     int32_t kind;
     int32_t center_on_lane;  // 1: R is operand 1 (rvec / nzR indexed by lane); 0: R is operand 2 (rvec by tile row)
@@ -172,6 +173,22 @@ struct DgScatterArgs {
     int32_t debug;         // developer ablation bits (0 in production)
 };
 
+// k_gs: gradient w.r.t. the STREAMED operand's code from the G tiles the fused kernel stored:
+//   dS[q][:] = sum_p G[q][p] * x_R[p][:], then normalisation backward with the S code.
+struct DgGsJob {
+    const uint16_t* G;     // fp16 tiles [B][nt(R tile)][nt(S tile)][64][16]
+    const char* Rop;       // operand blobs of the stationary operand of the producing job (P part is read)
+    const char* Sop;       // operand blobs of the streamed operand (C part: x_S for the normalisation backward)
+    const float* ScInv;    // [B][Ppad] 1/max(||c||,eps) of the S code operand
+    const int64_t* ridx;   // batch maps of the producing job (null = identity)
+    const int64_t* sidx;
+    float* dS;             // fp32 [B][Ppad][KD] out
+};
+struct DgGsArgs {
+    DgGsJob jobs[DG_MAX_NEG + 2];
+    int32_t njobs, B, P, Ppad, KF, KD;
+};
+
 // bytes of one inverse-tap record: off[HW+1] ints, 4P weights, 4P positions (ushort), padded to 16
 __host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
     return (((size_t)(HW + 1) * 4 + (size_t)4 * P * 6) + 15) / 16 * 16;
@@ -180,6 +197,7 @@ __host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
+hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W, int S, int Ppad, hipStream_t s);

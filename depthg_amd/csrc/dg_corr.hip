@@ -127,6 +127,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr int NSF = KIND == KIND_DEPTH ? 0 : NKF;     // feature k-steps per tile
     constexpr int NS = NKD + NSF;                         // MFMA steps of one Y chain
     static_assert(!RCREG || RF == 1, "register-resident code rows only with one fragment per wave");
+    constexpr bool GOUT = GRAD && KIND == KIND_LANE;     // pass-A helper jobs store their G tiles for k_gs
     constexpr bool STAG = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,6 +150,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         Rblob[f] = job.Rop + ((size_t)nR * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
     }
     const bool wave_active = act[0];
+    // global stores this wave issues per tile (G tiles; younger than the tile DMAs, counted by vmcnt like them)
+    const int nst = GOUT ? 2 * ((act[0] ? 1 : 0) + (RF == 2 && act[RF - 1] ? 1 : 0)) : 0;
 
     // ---- stationary operand: feats fragments -> registers, code rows -> LDS (DMA of the C part of its blob)
     const uint32_t smem_a = lds_addr(smem);
@@ -311,6 +314,17 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 ga[RF - 1][0] = f16x8{}; ga[RF - 1][1] = f16x8{};
             }
         }
+        if (GRAD && GOUT) {
+            // G tile (fp16, accumulator order) -> HBM, 2 KiB per wave and tile, fully coalesced: input of k_gs, which
+            // forms the gradient of the STREAMED operand's code without recomputing fd / cd
+#pragma unroll
+            for (int f = 0; f < RF; ++f)
+                if (act[f]) {
+                    uint4* g = reinterpret_cast<uint4*>(job.Gout + ((((size_t)n * ntiles + rtile0 + f) * ntiles + t) * 64 + lane) * 16);
+                    g[0] = __builtin_bit_cast(uint4, ga[f][0]);
+                    g[1] = __builtin_bit_cast(uint4, ga[f][1]);
+                }
+        }
         if (GRAD && !(args.debug & 4)) {
             // dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
 #pragma unroll
@@ -335,7 +349,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         const bool late = wid >= NWAVES / 2;
         issue(0, 0);
         auto top = [&](int t) {          // identical in both halves: same barriers, same DMA issue points
-            wait_vmcnt(0);
+            wait_vmcnt(nst);             // tile t landed; only the G stores of the previous tile may still be in flight
             __builtin_amdgcn_s_barrier();
             if (t + 1 < ntiles && !(args.debug & 1)) issue(t + 1, (t + 1) % 3);
         };
@@ -363,7 +377,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         int bcur = 0;
         for (int t = 0; t < ntiles; ++t) {
             // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
-            wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma : 0);
+            wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma + nst : nst);
             __builtin_amdgcn_s_barrier();
             if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
             const char* tile = smem + bcur * BUF;
@@ -446,6 +460,95 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
     if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH>(args, job, n, rb, smem);
     else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW>(args, job, n, rb, smem);
     else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE>(args, job, n, rb, smem);
+}
+
+// ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------
+// One block = one S tile (32 positions q) of one image and pair-set; 4 waves split the R tiles (K dimension).  A G tile
+// arrives as the producing wave's accumulator-order fp16 registers (lane = R position p, 16 S positions per lane); it is
+// transposed through a per-wave LDS scratch (p order permuted with dg_perm32 so that one 16-byte read is the A fragment
+// matching a granule of the R operand's P part, which is the B fragment), then 6 MFMAs:
+//     dS[q][:] += sum_p G[q][p] * x_R[p][:]
+// Finally the 4 partial sums are added in LDS, the normalisation backward is applied with the S code and the rows are
+// written as fp32 [B][Ppad][KD] (same format as the fused kernel's own gradient output).
+template <int NKF, int NKD>
+__global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
+    using BL = BlobT<NKF, NKD>;
+    constexpr int KD = BL::KD, NDF = KD / 32, TS = 80;      // TS: row stride (bytes) of the transposition scratch
+    __shared__ __attribute__((aligned(16))) char scratch[4][32 * TS];
+    __shared__ float part[4][32][KD + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int st = blockIdx.x, n = blockIdx.y;
+    const DgGsJob& J = a.jobs[blockIdx.z];
+    const int nt = a.Ppad >> 5;
+    const int nR = J.ridx ? (int)J.ridx[n] : n;
+    const int nS = J.sidx ? (int)J.sidx[n] : n;
+    f32x16 acc[NDF];
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) acc[f] = f32x16{};
+    char* T = scratch[wid];
+    const int pcol = dg_perm32(r) * 2;          // byte column of this lane's R position in the scratch rows
+    for (int rt = wid; rt < nt; rt += 4) {
+        const uint4* g = reinterpret_cast<const uint4*>(J.G + ((((size_t)n * nt + rt) * nt + st) * 64 + lane) * 16);
+        const uint4 g0 = g[0], g1 = g[1];
+        const char* Pp = J.Rop + ((size_t)nR * nt + rt) * BL::BYTES + BL::OFF_P;
+        f16x8 bfrag[NDF][2];
+#pragma unroll
+        for (int f = 0; f < NDF; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bfrag[f][ks] = *reinterpret_cast<const f16x8*>(Pp + ((2 * ks + h) * KD + 32 * f + r) * 16);
+        const uint32_t w[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {            // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
+            const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const uint16_t v = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+            *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = v;
+        }
+        // (same wave wrote and reads: program order + the compiler's lgkmcnt waits are enough)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
+#pragma unroll
+            for (int f = 0; f < NDF; ++f)
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag[f][ks], acc[f], 0, 0, 0);
+        }
+    }
+    // partial sums -> LDS: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r)
+#pragma unroll
+    for (int f = 0; f < NDF; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wid][(i & 3) + 8 * (i >> 2) + 4 * h][32 * f + r] = acc[f][i];
+    __syncthreads();
+    // normalisation backward per row q: 8 threads per row, each KD/8 channels
+    const int q = tid >> 3, sub = tid & 7;
+    constexpr int CH = KD / 8;
+    const char* Cp = J.Sop + ((size_t)nS * nt + st) * BL::BYTES + BL::OFF_C;
+    float v[CH], x[CH];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int d = sub * CH + c;
+        v[c] = part[0][q][d] + part[1][q][d] + part[2][q][d] + part[3][q][d];
+        x[c] = (float)*reinterpret_cast<const _Float16*>(Cp + ((d >> 3) * 32 + q) * 16 + (d & 7) * 2);
+        dot = fmaf(x[c], v[c], dot);
+    }
+    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+    const int pos = st * 32 + q;
+    if (pos < a.P) {
+        const float inv = J.ScInv[(size_t)nS * a.Ppad + pos];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            J.dS[((size_t)n * a.Ppad + pos) * KD + sub * CH + c] = (v[c] - x[c] * dot) * inv;
+    }
+}
+
+hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
+    dim3 grid(a.Ppad / 32, a.B, a.njobs), block(256);
+#define DG_GS(NKF_, NKD_) \
+    if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) { hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, 0, stream, a); return hipGetLastError(); }
+    DG_GS(8, 6) DG_GS(8, 8) DG_GS(24, 6) DG_GS(24, 8) DG_GS(48, 6) DG_GS(48, 8)
+#undef DG_GS
+    return hipErrorInvalidValue;
 }
 
 // ---- final reduction of the per-block partial sums into the 8 output scalars (two tiny launches)
