@@ -187,6 +187,7 @@ struct DgGsJob {
 struct DgGsArgs {
     DgGsJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
+    int32_t debug;         // developer ablation bits (0 in production)
 };
 
 // bytes of one inverse-tap record: off[HW+1] ints, 4P weights, 4P positions (ushort), padded to 16

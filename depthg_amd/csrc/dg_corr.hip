@@ -87,7 +87,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define DG_STAGGER 1
 #endif
 #ifndef PF
-#define PF 4       // LDS fragment reads kept in flight per wave
+#define PF 6       // LDS fragment reads kept in flight per wave
 #endif
 
 // One accumulator element of a 32x32 tile: (fd, cd) -> loss term, G = dLoss/dcd.  vv = per-tile-row value
@@ -130,11 +130,18 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr bool GOUT = GRAD && KIND == KIND_LANE;     // pass-A helper jobs store their G tiles for k_gs
     constexpr bool STAG = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT;
 
+    // kernarg fields used inside the tile loop are copied to locals: behind the asm memory clobbers hipcc would re-load
+    // them (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS read ring) in every iteration
+    const int dbg = args.debug;
+    uint16_t* const Gout = job.Gout;
+    float* const out_cd = job.out_cd;
+    float* const out_loss = job.out_loss;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int Ppad = args.Ppad, P = args.P;
-    const int ntiles = Ppad >> 5;
+    const int ntiles_all = Ppad >> 5;
+    const int ntiles = (dbg & 128) ? 1 : ntiles_all;     // developer ablation: one tile only (fixed per-block cost)
     const int nR = job.ridx ? (int)job.ridx[n] : n;
     const int nS = job.sidx ? (int)job.sidx[n] : n;
 
@@ -145,9 +152,9 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const char* Rblob[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-        act[f] = rtile0 + f < ntiles;                       // wave-uniform
+        act[f] = rtile0 + f < ntiles_all;                       // wave-uniform
         pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;         // stationary position of this lane (clamped when idle)
-        Rblob[f] = job.Rop + ((size_t)nR * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
+        Rblob[f] = job.Rop + ((size_t)nR * ntiles_all + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
     }
     const bool wave_active = act[0];
     // global stores this wave issues per tile (G tiles; younger than the tile DMAs, counted by vmcnt like them)
@@ -170,19 +177,24 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 dma16(Rblob[f] + BL::OFF_C + c * 1024 + lane * 16, smem_a + NBUF * BUF + (wid * RF + f) * RCB + c * 1024);
     }
     bf16x8 Rf[RF][NSF > 0 ? NSF : 1];
-    if (KIND != KIND_DEPTH) {
+    if (KIND != KIND_DEPTH && !(dbg & 2048)) {
 #pragma unroll
         for (int f = 0; f < RF; ++f)
 #pragma unroll
             for (int ks = 0; ks < NKF; ++ks)
                 Rf[f][ks] = *reinterpret_cast<const bf16x8*>(Rblob[f] + (r * GF + ((2 * ks + h) ^ (r & 15))) * 16);
-        // make hipcc wait for these loads HERE: its counted vmcnt waits at their first use inside the tile loop
-        // would also count (and drain) the tile DMAs it does not know about
-#pragma unroll
-        for (int f = 0; f < RF; ++f)
-#pragma unroll
-            for (int ks = 0; ks < NKF; ++ks) asm volatile("" : "+v"(Rf[f][ks]));
     }
+    // Make hipcc wait for the fragment loads at ONE place (right after the first tile DMAs are issued, so the two
+    // latencies overlap): its counted vmcnt waits at their first use inside the tile loop would otherwise also count
+    // (and drain) the tile DMAs it does not know about.
+    auto settle_R = [&]() {
+        if (KIND != KIND_DEPTH && !(dbg & 1024)) {
+#pragma unroll
+            for (int f = 0; f < RF; ++f)
+#pragma unroll
+                for (int ks = 0; ks < NKF; ++ks) asm volatile("" : "+v"(Rf[f][ks]));
+        }
+    };
 
     // ---- per-job scalars
     float c0 = -job.shift;    // fd'' - shift = Yf - rowmean + (m0 - shift)
@@ -198,7 +210,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const bool has_vec = KIND == KIND_DEPTH || (KIND == KIND_ROW && job.rvec != nullptr);
 
     // ---- tile staging by LDS-DMA (1 KiB per wave instruction, linear in HBM and in LDS)
-    const char* Sbase = job.Sop + (size_t)nS * ntiles * BL::BYTES + lane * 16;
+    const char* Sbase = job.Sop + (size_t)nS * ntiles_all * BL::BYTES + lane * 16;
     const float* vsrc = reinterpret_cast<const float*>(args.dummy);      // per-row vector of the tile (rvec or nz)
     if (KIND == KIND_ROW && job.rvec) vsrc = job.rvec + (size_t)n * Ppad;
     if (KIND == KIND_DEPTH) vsrc = job.nzS + (size_t)n * Ppad;
@@ -291,8 +303,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 const int p = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (act[f] && pr[f] < P && p < P) {
                     const size_t o = ((size_t)n * P + p) * P + pr[f];
-                    if (job.out_cd) job.out_cd[o] = KIND == KIND_DEPTH ? nz_lane[f] * vv[i] : Yc[f][i];
-                    if (job.out_loss) job.out_loss[o] = li;
+                    if (out_cd) out_cd[o] = KIND == KIND_DEPTH ? nz_lane[f] * vv[i] : Yc[f][i];
+                    if (out_loss) out_loss[o] = li;
                 }
             }
         };
@@ -304,7 +316,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             });
 #pragma unroll
             for (int i = 0; i < 16; ++i) epi(RF - 1, i);
-        } else if (args.debug & 16) {   // developer ablation: no epilogue VALU (results invalid)
+        } else if (dbg & 16) {   // developer ablation: no epilogue VALU (results invalid)
 #pragma unroll
             for (int f = 0; f < RF; ++f) { ga[f][0] = __builtin_bit_cast(f16x8, Yf[f][0] > 1e30f ? v4i{1, 1, 1, 1} : v4i{0, 0, 0, 0}); ga[f][1] = ga[f][0]; lsum += Yc[f][0]; }
         } else {
@@ -314,18 +326,18 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 ga[RF - 1][0] = f16x8{}; ga[RF - 1][1] = f16x8{};
             }
         }
-        if (GRAD && GOUT) {
+        if (GRAD && GOUT && !(dbg & 8)) {
             // G tile (fp16, accumulator order) -> HBM, 2 KiB per wave and tile, fully coalesced: input of k_gs, which
             // forms the gradient of the STREAMED operand's code without recomputing fd / cd
 #pragma unroll
             for (int f = 0; f < RF; ++f)
                 if (act[f]) {
-                    uint4* g = reinterpret_cast<uint4*>(job.Gout + ((((size_t)n * ntiles + rtile0 + f) * ntiles + t) * 64 + lane) * 16);
+                    uint4* g = reinterpret_cast<uint4*>(Gout + ((((size_t)n * ntiles_all + rtile0 + f) * ntiles_all + t) * 64 + lane) * 16);
                     g[0] = __builtin_bit_cast(uint4, ga[f][0]);
                     g[1] = __builtin_bit_cast(uint4, ga[f][1]);
                 }
         }
-        if (GRAD && !(args.debug & 4)) {
+        if (GRAD && !(dbg & 4)) {
             // dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
 #pragma unroll
             for (int d = 0; d < NDF; ++d) {
@@ -348,10 +360,11 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         // Tile t-1 must stay in LDS during iteration t, so tiles are fetched one (not two) ahead.
         const bool late = wid >= NWAVES / 2;
         issue(0, 0);
+        settle_R();
         auto top = [&](int t) {          // identical in both halves: same barriers, same DMA issue points
             wait_vmcnt(nst);             // tile t landed; only the G stores of the previous tile may still be in flight
-            __builtin_amdgcn_s_barrier();
-            if (t + 1 < ntiles && !(args.debug & 1)) issue(t + 1, (t + 1) % 3);
+            if (!(dbg & 256)) __builtin_amdgcn_s_barrier();
+            if (t + 1 < ntiles && !(dbg & 1)) issue(t + 1, (t + 1) % 3);
         };
         if (!late) {
             for (int t = 0; t < ntiles; ++t) {
@@ -374,12 +387,13 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     } else {
         issue(0, 0);
         if (NBUF == 3 && ntiles > 1) issue(1, 1);
+        settle_R();
         int bcur = 0;
         for (int t = 0; t < ntiles; ++t) {
             // tile t has landed (this wave's pieces: vmcnt; everybody's: barrier); the buffer of tile t-1 is free again
             wait_vmcnt((NBUF == 3 && t + 1 < ntiles) ? my_dma + nst : nst);
             __builtin_amdgcn_s_barrier();
-            if (t + NBUF - 1 < ntiles && !(args.debug & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
+            if (t + NBUF - 1 < ntiles && !(dbg & 1)) issue(t + NBUF - 1, bcur >= 1 ? bcur - 1 : NBUF - 1);
             const char* tile = smem + bcur * BUF;
             bcur = bcur == NBUF - 1 ? 0 : bcur + 1;
             if (!wave_active) continue;
@@ -403,7 +417,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     }
 
     // ---- normalisation backward and store:  dc = (dx - x <x,dx>) / max(||c||, eps)
-    if (GRAD && job.dR) {
+    if (GRAD && job.dR && !(dbg & 512)) {
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
             if (!act[f]) continue;
@@ -463,23 +477,28 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 }
 
 // ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------
-// One block = one S tile (32 positions q) of one image and pair-set; 4 waves split the R tiles (K dimension).  A G tile
-// arrives as the producing wave's accumulator-order fp16 registers (lane = R position p, 16 S positions per lane); it is
-// transposed through a per-wave LDS scratch (p order permuted with dg_perm32 so that one 16-byte read is the A fragment
-// matching a granule of the R operand's P part, which is the B fragment), then 6 MFMAs:
+// One block = 4 consecutive S tiles (one per wave, 32 positions q each) of one image and pair-set.  The block walks
+// over the R tiles (the K dimension): the P part of the R operand's blob (the B fragments, shared by the 4 waves) is
+// staged in LDS one tile ahead; each wave loads its own G tile - the producing wave's accumulator-order fp16 registers
+// (lane = R position p, 16 S positions per lane) - transposes it through a per-wave LDS scratch (p order permuted with
+// dg_perm32 so that one 16-byte read is the A fragment matching a granule of the P part) and issues 6 MFMAs:
 //     dS[q][:] += sum_p G[q][p] * x_R[p][:]
-// Finally the 4 partial sums are added in LDS, the normalisation backward is applied with the S code and the rows are
-// written as fp32 [B][Ppad][KD] (same format as the fused kernel's own gradient output).
+// Then the normalisation backward with the S code is applied in registers and the rows are written as fp32
+// [B][Ppad][KD] (same format as the fused kernel's own gradient output).  grid (ceil(nt/4), B, jobs), block 256.
 template <int NKF, int NKD>
 __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, NDF = KD / 32, TS = 80;      // TS: row stride (bytes) of the transposition scratch
+    constexpr int PB = BL::BYTES - BL::OFF_P;               // bytes of a P part
     __shared__ __attribute__((aligned(16))) char scratch[4][32 * TS];
-    __shared__ float part[4][32][KD + 1];
+    __shared__ __attribute__((aligned(16))) char pbuf[2][PB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int st = blockIdx.x, n = blockIdx.y;
+    const int n = blockIdx.y;
     const DgGsJob& J = a.jobs[blockIdx.z];
     const int nt = a.Ppad >> 5;
+    const int st = blockIdx.x * 4 + wid;                    // S tile of this wave
+    const bool active = st < nt;
+    const int stc = active ? st : nt - 1;
     const int nR = J.ridx ? (int)J.ridx[n] : n;
     const int nS = J.sidx ? (int)J.sidx[n] : n;
     f32x16 acc[NDF];
@@ -487,65 +506,92 @@ __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
     for (int f = 0; f < NDF; ++f) acc[f] = f32x16{};
     char* T = scratch[wid];
     const int pcol = dg_perm32(r) * 2;          // byte column of this lane's R position in the scratch rows
-    for (int rt = wid; rt < nt; rt += 4) {
-        const uint4* g = reinterpret_cast<const uint4*>(J.G + ((((size_t)n * nt + rt) * nt + st) * 64 + lane) * 16);
-        const uint4 g0 = g[0], g1 = g[1];
-        const char* Pp = J.Rop + ((size_t)nR * nt + rt) * BL::BYTES + BL::OFF_P;
-        f16x8 bfrag[NDF][2];
+    const char* Pbase = J.Rop + (size_t)nR * nt * BL::BYTES + BL::OFF_P;
+    const uint4* Gbase = reinterpret_cast<const uint4*>(J.G + (((size_t)n * nt * nt + stc) * 64 + lane) * 16);
+    constexpr int PG = PB / 16;                 // 16-byte granules of a P part
+    auto stage_load = [&](int rt, uint4 (&v)[2]) {
 #pragma unroll
-        for (int f = 0; f < NDF; ++f)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                bfrag[f][ks] = *reinterpret_cast<const f16x8*>(Pp + ((2 * ks + h) * KD + 32 * f + r) * 16);
-        const uint32_t w[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {            // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
-            const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const uint16_t v = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-            *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = v;
+        for (int k = 0; k < 2; ++k) {
+            const int g = tid + 256 * k;
+            v[k] = g < PG ? reinterpret_cast<const uint4*>(Pbase + (size_t)rt * BL::BYTES)[g] : make_uint4(0, 0, 0, 0);
         }
-        // (same wave wrote and reads: program order + the compiler's lgkmcnt waits are enough)
+    };
+    auto stage_store = [&](int b, const uint4 (&v)[2]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
-#pragma unroll
-            for (int f = 0; f < NDF; ++f)
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag[f][ks], acc[f], 0, 0, 0);
+        for (int k = 0; k < 2; ++k) {
+            const int g = tid + 256 * k;
+            if (g < PG) reinterpret_cast<uint4*>(pbuf[b])[g] = v[k];
         }
+    };
+    static_assert(PG <= 512, "P part larger than two granules per thread");
+    uint4 pv[2], gcur[2], gnext[2];
+    stage_load(0, pv);
+    stage_store(0, pv);
+    gcur[0] = Gbase[0]; gcur[1] = Gbase[1];
+    for (int rt = 0; rt < nt; ++rt) {
+        __syncthreads();                                     // pbuf[rt&1] is complete; pbuf[(rt+1)&1] is free again
+        if (rt + 1 < nt) {
+            stage_load(rt + 1, pv);
+            const uint4* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt + 1) * nt * 64 * 2;
+            gnext[0] = gp[0]; gnext[1] = gp[1];
+        }
+        if (active && !(a.debug & 32)) {
+            const uint32_t w[8] = {gcur[0].x, gcur[0].y, gcur[0].z, gcur[0].w, gcur[1].x, gcur[1].y, gcur[1].z, gcur[1].w};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {            // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
+                *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+            }
+            const char* P = pbuf[rt & 1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
+#pragma unroll
+                for (int f = 0; f < NDF; ++f) {
+                    const f16x8 bfrag = *reinterpret_cast<const f16x8*>(P + ((2 * ks + h) * KD + 32 * f + r) * 16);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[f], 0, 0, 0);
+                }
+            }
+        }
+        if (rt + 1 < nt) { stage_store((rt + 1) & 1, pv); gcur[0] = gnext[0]; gcur[1] = gnext[1]; }
     }
-    // partial sums -> LDS: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r)
+    if (!active) return;
+    // normalisation backward: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r);  dc = (dx - x <x,dx>) / ||c||
+    const char* Cp = J.Sop + ((size_t)nS * nt + st) * BL::BYTES + BL::OFF_C;
+    float dot[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dot[i] = 0.f;
 #pragma unroll
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) part[wid][(i & 3) + 8 * (i >> 2) + 4 * h][32 * f + r] = acc[f][i];
-    __syncthreads();
-    // normalisation backward per row q: 8 threads per row, each KD/8 channels
-    const int q = tid >> 3, sub = tid & 7;
-    constexpr int CH = KD / 8;
-    const char* Cp = J.Sop + ((size_t)nS * nt + st) * BL::BYTES + BL::OFF_C;
-    float v[CH], x[CH];
-    float dot = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * f + r;
+            const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+            dot[i] = fmaf(x, acc[f][i], dot[i]);
+        }
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int d = sub * CH + c;
-        v[c] = part[0][q][d] + part[1][q][d] + part[2][q][d] + part[3][q][d];
-        x[c] = (float)*reinterpret_cast<const _Float16*>(Cp + ((d >> 3) * 32 + q) * 16 + (d & 7) * 2);
-        dot = fmaf(x[c], v[c], dot);
-    }
-    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
-    const int pos = st * 32 + q;
-    if (pos < a.P) {
-        const float inv = J.ScInv[(size_t)nS * a.Ppad + pos];
+    for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-            J.dS[((size_t)n * a.Ppad + pos) * KD + sub * CH + c] = (v[c] - x[c] * dot) * inv;
+    for (int i = 0; i < 16; ++i) {
+        const int q = (i & 3) + 8 * (i >> 2) + 4 * h, pos = st * 32 + q;
+        if (pos < a.P) {
+            const float inv = J.ScInv[(size_t)nS * a.Ppad + pos];
+#pragma unroll
+            for (int f = 0; f < NDF; ++f) {
+                const int ch = 32 * f + r;
+                const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                J.dS[((size_t)n * a.Ppad + pos) * KD + ch] = (acc[f][i] - x * dot[i]) * inv;
+            }
+        }
     }
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
-    dim3 grid(a.Ppad / 32, a.B, a.njobs), block(256);
+    dim3 grid((a.Ppad / 32 + 3) / 4, a.B, a.njobs), block(256);
+    DgGsArgs a2 = a;
+    if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
 #define DG_GS(NKF_, NKD_) \
-    if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) { hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, 0, stream, a); return hipGetLastError(); }
+    if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) { hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, 0, stream, a2); return hipGetLastError(); }
     DG_GS(8, 6) DG_GS(8, 8) DG_GS(24, 6) DG_GS(24, 8) DG_GS(48, 6) DG_GS(48, 8)
 #undef DG_GS
     return hipErrorInvalidValue;
