@@ -322,27 +322,34 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     const float f = (float)(1.0 / ((double)p.B * p.P * p.P));
     const float fn = p.N > 0 ? f / (float)p.N : 0.f;
     int n = 0;
-    auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest) {
+    auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest, int raw) {
         s.src[n].buf = F32(buf); s.src[n].route = route; s.src[n].gidx = gidx; s.src[n].coords_sel = csel;
-        s.src[n].factor = factor; s.src[n].dest = dest; ++n;
+        s.src[n].factor = factor; s.src[n].dest = dest; s.src[n].raw = raw; ++n;
     };
-    add(p.dRA[0], nullptr, 0, 0, f, 0);
-    add(p.dRB[0], nullptr, 0, 0, f, 0);
-    add(p.dRA[1], nullptr, 1, 0, f, 0);
-    add(p.dRB[1], nullptr, 1, 1, f, 1);
+    // dRA[t]: the fused kernel's raw accumulator-order tiles (stationary operand = operand 1 for every pair-set);
+    // dRB[t]: k_gs output, row-major, normalisation backward already applied
+    add(p.dRA[0], nullptr, 0, 0, f, 0, 1);
+    add(p.dRB[0], nullptr, 0, 0, f, 0, 0);
+    add(p.dRA[1], nullptr, 1, 0, f, 0, 1);
+    add(p.dRB[1], nullptr, 1, 1, f, 1, 0);
     for (int k = 0; k < p.N; ++k) {
-        add(p.dRA[2 + k], nullptr, 2, 0, fn, 0);
-        add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0);
+        add(p.dRA[2 + k], nullptr, 2, 0, fn, 0, 1);
+        add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0, 0);
     }
-    if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
+    if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0, 1);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
     s.nsrc = n;
     s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
     s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
     s.taps = ws + p.taps;
+    {
+        const DgBlob bl(p.KF, p.KD);
+        s.xop = ws + p.op[0]; s.xinv = F32(p.inv[0]); s.blob_bytes = bl.bytes; s.blob_off_c = bl.off_c;
+    }
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
     s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
     if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);
     s.DC = 8;
+    s.dense = p.ident ? 1 : 0;
     DG_HIP(dg_launch_scatter(s, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }

@@ -7,6 +7,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
@@ -58,6 +59,16 @@ struct BlobT {
     static_assert(GF % 16 == 0, "swizzle needs 16-granule groups");
 };
 
+// Gradient buffers (w.r.t. sampled code rows) are kept in MFMA accumulator order ("gradient tiles"):
+//   [image][tile of 32 positions][channel group f = d/32][g = q/8][lane = (d%32) + 32*((q/4)%2)][e = q%4]   fp32
+// i.e. exactly the registers of a 32x32 accumulator tile (rows = positions, lanes = channels), so that the kernels that
+// produce them (k_corr_main, k_gs) and the combine kernel move 16 bytes per lane, 1 KiB per wave instruction.
+// Float index of (position p, channel d) inside one image:
+__host__ __device__ inline size_t dg_gtile_off(int p, int d, int DP) {
+    const int q = p & 31;
+    return ((size_t)(p >> 5) * (DP >> 5) + (d >> 5)) * 1024 + (q >> 3) * 256 + ((d & 31) + 32 * ((q >> 2) & 1)) * 4 + (q & 3);
+}
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 
@@ -74,7 +85,7 @@ struct DgJob {
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
     const int64_t* ridx;  // batch index map of R operands (null = identity)
     const int64_t* sidx;  // batch index map of S operands (null = identity)
-    float* dR;            // fp32 [B][Ppad][DP] gradient w.r.t. the sampled (unnormalised) R code, unit upstream; or null
+    float* dR;            // gradient tiles (dg_gtile_off): d/d(normalised R code), unit upstream, normalisation backward pending; or null
     float* part;          // fp32 [blocks of this job][2] partial sums (sum clamp(cd)*(fd-shift), sum cd); or null
     float* out_cd;        // fp32 [B][P][P] (op1 position major) or null    (materialise; needs center_on_lane == 0)
     float* out_loss;      // fp32 [B][P][P] or null
@@ -152,12 +163,14 @@ struct DgRowmeanArgs {
 };
 
 struct DgScatterSrc {
-    const float* buf;      // fp32 [B][Ppad][DP]
+    const float* buf;      // gradient tiles [B][Ppad/32][DP/32][4][64][4] (dg_gtile_off).  raw == 1: the fused kernel's
+                           // d/d(normalised operand-1 code), normalisation backward pending; raw == 0: k_gs output (final)
     const int64_t* route;  // null: image n scatters to destination n; else destination = route[n]
     int32_t gidx;          // upstream scalar index (0 intra, 1 inter, 2 neg, 3 depth)
     int32_t coords_sel;    // 0: coords1, 1: coords2
     float factor;          // constant factor (1/numel etc.)
     int32_t dest;          // 0: grad_code, 1: grad_code_pos
+    int32_t raw;           // see buf
 };
 #define DG_MAX_SCATTER 32
 struct DgScatterArgs {
@@ -166,11 +179,15 @@ struct DgScatterArgs {
     const float* coords1;
     const float* coords2;
     const float* gscal;    // [4] upstream gradients (device)
-    float* comb[2];        // [B][Ppad][DP] combined direct sources per destination (scratch)
+    float* comb[2];        // gradient tiles: combined direct sources per destination (scratch)
     char* taps;            // [2 coords sets][B] inverse tap records (dg_taps_record_bytes each)
+    const char* xop;       // operand-1 blobs (C part = normalised code rows the raw sources refer to)
+    const float* xinv;     // [B][Ppad] 1 / max(||code||, eps) of operand 1
+    int32_t blob_bytes, blob_off_c;
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
     int32_t B, D, DP, h, w, S, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
     int32_t debug;         // developer ablation bits (0 in production)
+    int32_t dense;         // 1: identity grid (DG_IDENTITY_GRID): the adjoint of sample() is a transposed copy
 };
 
 // k_gs: gradient w.r.t. the STREAMED operand's code from the G tiles the fused kernel stored:
@@ -182,7 +199,7 @@ struct DgGsJob {
     const float* ScInv;    // [B][Ppad] 1/max(||c||,eps) of the S code operand
     const int64_t* ridx;   // batch maps of the producing job (null = identity)
     const int64_t* sidx;
-    float* dS;             // fp32 [B][Ppad][KD] out
+    float* dS;             // gradient tiles (dg_gtile_off) out
 };
 struct DgGsArgs {
     DgGsJob jobs[DG_MAX_NEG + 2];

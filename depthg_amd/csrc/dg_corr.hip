@@ -416,40 +416,22 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
     }
 
-    // ---- normalisation backward and store:  dc = (dx - x <x,dx>) / max(||c||, eps)
+    // ---- store the RAW gradient w.r.t. the normalised stationary code in accumulator order
+    //      [image][R tile][channel group d][i>>2][lane][i&3] (16 bytes per lane and store, 1 KiB per wave instruction).
+    //      The normalisation backward is linear with the same x for every pair-set whose stationary operand is operand 1,
+    //      so k_grad_combine applies it once to the weighted sum of these buffers.
     if (GRAD && job.dR && !(dbg & 512)) {
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
             if (!act[f]) continue;
-            // dR[f][d][i] is (stationary row rr = row0 + (i&3)+8*(i>>2)+4*h, code channel 32 d + r)
-            const int row0 = (rtile0 + f) * 32;
-            const char* xb = RCREG ? Rblob[f] + BL::OFF_C : rc_lds + f * RCB;
-            float dot[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dot[i] = 0.f;
+            float* base = job.dR + ((size_t)n * (Ppad >> 5) + rtile0 + f) * (32 * DP) + lane * 4;
 #pragma unroll
             for (int d = 0; d < NDF; ++d)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
-                    const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                    dot[i] = fmaf(x, dR[f][d][i], dot[i]);
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {dR[f][d][4 * g], dR[f][d][4 * g + 1], dR[f][d][4 * g + 2], dR[f][d][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256) = v;
                 }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int q = (i & 3) + 8 * (i >> 2) + 4 * h, rr = row0 + q;
-                if (rr < P) {
-                    const float inv = job.RcInv[(size_t)nR * Ppad + rr];
-#pragma unroll
-                    for (int d = 0; d < NDF; ++d) {
-                        const int ch = 32 * d + r;
-                        const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                        job.dR[((size_t)n * Ppad + rr) * DP + ch] = (dR[f][d][i] - x * dot[i]) * inv;
-                    }
-                }
-            }
         }
     }
 }
@@ -477,28 +459,29 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 }
 
 // ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------
-// One block = 4 consecutive S tiles (one per wave, 32 positions q each) of one image and pair-set.  The block walks
-// over the R tiles (the K dimension): the P part of the R operand's blob (the B fragments, shared by the 4 waves) is
-// staged in LDS one tile ahead; each wave loads its own G tile - the producing wave's accumulator-order fp16 registers
-// (lane = R position p, 16 S positions per lane) - transposes it through a per-wave LDS scratch (p order permuted with
-// dg_perm32 so that one 16-byte read is the A fragment matching a granule of the P part) and issues 6 MFMAs:
-//     dS[q][:] += sum_p G[q][p] * x_R[p][:]
-// Then the normalisation backward with the S code is applied in registers and the rows are written as fp32
-// [B][Ppad][KD] (same format as the fused kernel's own gradient output).  grid (ceil(nt/4), B, jobs), block 256.
+// One WAVE = one S tile (32 positions q) of one image and pair-set; waves are independent (no block barrier).  The
+// wave walks over the R tiles (the K dimension).  Per R tile it needs
+//   * its own G tile - the producing wave's accumulator-order fp16 registers (lane = R position p, 16 S positions per
+//     lane), 2 KiB, streamed from HBM (non-temporal), prefetched GS_DG tiles ahead in a register ring;
+//   * the P part of the R operand's blob: in HBM it already is the B-fragment layout (granule c of channel d = 8
+//     positions in dg_perm32 order), so each lane loads its six 16-byte fragments straight from L2 (512 contiguous
+//     bytes per half wave; the 4 waves of a block walk the same R tiles and share them in the vector L1), one tile ahead.
+// The G tile is transposed through a per-wave LDS scratch (p order permuted with dg_perm32 so that one 16-byte read is
+// the A fragment matching a granule of the P part) and 6 MFMAs accumulate   dS[q][:] += sum_p G[q][p] * x_R[p][:].
+// Then the normalisation backward with the S code is applied in registers and the accumulator tile is written as a
+// gradient tile (dg_gtile_off; 16 bytes per lane and store).  grid (ceil(nt/4), B, jobs), block 256.
+#define GS_DG 3
 template <int NKF, int NKD>
 __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, NDF = KD / 32, TS = 80;      // TS: row stride (bytes) of the transposition scratch
-    constexpr int PB = BL::BYTES - BL::OFF_P;               // bytes of a P part
     __shared__ __attribute__((aligned(16))) char scratch[4][32 * TS];
-    __shared__ __attribute__((aligned(16))) char pbuf[2][PB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n = blockIdx.y;
     const DgGsJob& J = a.jobs[blockIdx.z];
     const int nt = a.Ppad >> 5;
     const int st = blockIdx.x * 4 + wid;                    // S tile of this wave
-    const bool active = st < nt;
-    const int stc = active ? st : nt - 1;
+    if (st >= nt) return;
     const int nR = J.ridx ? (int)J.ridx[n] : n;
     const int nS = J.sidx ? (int)J.sidx[n] : n;
     f32x16 acc[NDF];
@@ -506,56 +489,60 @@ __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
     for (int f = 0; f < NDF; ++f) acc[f] = f32x16{};
     char* T = scratch[wid];
     const int pcol = dg_perm32(r) * 2;          // byte column of this lane's R position in the scratch rows
-    const char* Pbase = J.Rop + (size_t)nR * nt * BL::BYTES + BL::OFF_P;
-    const uint4* Gbase = reinterpret_cast<const uint4*>(J.G + (((size_t)n * nt * nt + stc) * 64 + lane) * 16);
-    constexpr int PG = PB / 16;                 // 16-byte granules of a P part
-    auto stage_load = [&](int rt, uint4 (&v)[2]) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int g = tid + 256 * k;
-            v[k] = g < PG ? reinterpret_cast<const uint4*>(Pbase + (size_t)rt * BL::BYTES)[g] : make_uint4(0, 0, 0, 0);
-        }
+    // B fragment (ks, f) of R tile rt: 16 bytes at P part + ((2 ks + h) * KD + 32 f + r) * 16
+    const char* Pbase = J.Rop + (size_t)nR * nt * BL::BYTES + BL::OFF_P + (h * KD + r) * 16;
+    const v4i* Gbase = reinterpret_cast<const v4i*>(J.G + (((size_t)n * nt * nt + st) * 64 + lane) * 16);
+    const size_t gstride = (size_t)nt * 64 * 2;             // v4i per R tile step
+    auto load_g = [&](int rt, v4i (&g)[2]) {
+        const v4i* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt) * gstride;
+        g[0] = __builtin_nontemporal_load(gp);
+        g[1] = __builtin_nontemporal_load(gp + 1);
     };
-    auto stage_store = [&](int b, const uint4 (&v)[2]) {
+    auto load_p = [&](int rt, v4i (&b)[2][NDF]) {
+        const char* pp = Pbase + (size_t)rt * BL::BYTES;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int g = tid + 256 * k;
-            if (g < PG) reinterpret_cast<uint4*>(pbuf[b])[g] = v[k];
-        }
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int f = 0; f < NDF; ++f) b[ks][f] = *reinterpret_cast<const v4i*>(pp + (2 * ks * KD + 32 * f) * 16);
     };
-    static_assert(PG <= 512, "P part larger than two granules per thread");
-    uint4 pv[2], gcur[2], gnext[2];
-    stage_load(0, pv);
-    stage_store(0, pv);
-    gcur[0] = Gbase[0]; gcur[1] = Gbase[1];
-    for (int rt = 0; rt < nt; ++rt) {
-        __syncthreads();                                     // pbuf[rt&1] is complete; pbuf[(rt+1)&1] is free again
-        if (rt + 1 < nt) {
-            stage_load(rt + 1, pv);
-            const uint4* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt + 1) * nt * 64 * 2;
-            gnext[0] = gp[0]; gnext[1] = gp[1];
-        }
-        if (active && !(a.debug & 32)) {
-            const uint32_t w[8] = {gcur[0].x, gcur[0].y, gcur[0].z, gcur[0].w, gcur[1].x, gcur[1].y, gcur[1].z, gcur[1].w};
+    v4i gring[GS_DG][2], pcur[2][NDF], pnext[2][NDF];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {            // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
-                const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
-                *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-            }
-            const char* P = pbuf[rt & 1];
+    for (int k = 0; k < GS_DG; ++k)
+        if (k < nt) load_g(k, gring[k]);
+    load_p(0, pcur);
+    for (int rt0 = 0; rt0 < nt; rt0 += GS_DG) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
+        for (int k = 0; k < GS_DG; ++k) {
+            const int rt = rt0 + k;
+            if (rt < nt) {
+                if (rt + 1 < nt) load_p(rt + 1, pnext);
+                if (!(a.debug & 32)) {
+                    const v4i g0 = gring[k][0], g1 = gring[k][1];
+                    const uint32_t w[8] = {(uint32_t)g0[0], (uint32_t)g0[1], (uint32_t)g0[2], (uint32_t)g0[3],
+                                           (uint32_t)g1[0], (uint32_t)g1[1], (uint32_t)g1[2], (uint32_t)g1[3]};
 #pragma unroll
-                for (int f = 0; f < NDF; ++f) {
-                    const f16x8 bfrag = *reinterpret_cast<const f16x8*>(P + ((2 * ks + h) * KD + 32 * f + r) * 16);
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[f], 0, 0, 0);
+                    for (int i = 0; i < 16; ++i) {    // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
+                        const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
+                    }
                 }
+                if (rt + GS_DG < nt) load_g(rt + GS_DG, gring[k]);
+                if (!(a.debug & 32)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
+#pragma unroll
+                        for (int f = 0; f < NDF; ++f)
+                            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, __builtin_bit_cast(f16x8, pcur[ks][f]), acc[f], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int f = 0; f < NDF; ++f) pcur[ks][f] = pnext[ks][f];
             }
         }
-        if (rt + 1 < nt) { stage_store((rt + 1) & 1, pv); gcur[0] = gnext[0]; gcur[1] = gnext[1]; }
     }
-    if (!active) return;
     // normalisation backward: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r);  dc = (dx - x <x,dx>) / ||c||
     const char* Cp = J.Sop + ((size_t)nS * nt + st) * BL::BYTES + BL::OFF_C;
     float dot[16];
@@ -571,19 +558,26 @@ __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
         }
 #pragma unroll
     for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
+    float inv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int q = (i & 3) + 8 * (i >> 2) + 4 * h, pos = st * 32 + q;
-        if (pos < a.P) {
-            const float inv = J.ScInv[(size_t)nS * a.Ppad + pos];
-#pragma unroll
-            for (int f = 0; f < NDF; ++f) {
-                const int ch = 32 * f + r;
-                const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                J.dS[((size_t)n * a.Ppad + pos) * KD + ch] = (acc[f][i] - x * dot[i]) * inv;
-            }
-        }
+        const int pos = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        inv[i] = pos < a.P ? J.ScInv[(size_t)nS * a.Ppad + pos] : 0.f;
     }
+    float* out = J.dS + ((size_t)n * nt + st) * (32 * KD) + lane * 4;
+#pragma unroll
+    for (int f = 0; f < NDF; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * g + e, q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * f + r;
+                const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                v[e] = (acc[f][i] - x * dot[i]) * inv[i];
+            }
+            *reinterpret_cast<f32x4*>(out + (f * 4 + g) * 256) = v;
+        }
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {

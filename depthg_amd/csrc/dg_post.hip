@@ -22,22 +22,84 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
     w00 = wy0 * wx0; w01 = wy0 * wx1; w10 = wy1 * wx0; w11 = wy1 * wx1;
 }
 
-// Stage 1: comb[dest][b][p][:] = sum over the direct sources of `dest` of factor * upstream * buf[b][p][:]
-// (elementwise, float4).  grid (ceil(B*Ppad*DP/4 / 256), 2).
-__global__ __launch_bounds__(256) void k_grad_combine(const DgScatterArgs a) {
-    const int dest = blockIdx.y;
-    const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+// Stage 1: comb[dest] = weighted sum of the direct sources of `dest` (gradient tiles in, gradient tile out).
+// One wave = one tile of 32 sampled positions of one image and destination.  Raw sources (the fused kernel's
+// accumulator tiles) are summed with their weights first, then the normalisation backward
+//     dc = (dx - x <x, dx>) / max(||c||, eps)
+// is applied ONCE with the operand-1 code rows (all raw sources share them); final sources (k_gs output, already
+// through their own normalisation backward) are added.  grid (Ppad/32, B, 2), block 64.
+// Register layout of a tile: v[d][i] = (row (i&3) + 8 (i>>2) + 4 (lane>>5), channel 32 d + (lane&31)).
+template <int NDF>
+__global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
+    const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5, DP = NDF * 32;
+    float v[NDF][16];
+#pragma unroll
+    for (int d = 0; d < NDF; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[d][i] = 0.f;
+    bool any_raw = false;
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
-        if (q.dest != dest || q.route != nullptr) continue;
+        if (q.dest != dest || q.route != nullptr || !q.raw) continue;
+        any_raw = true;
         const float sc = q.factor * a.gscal[q.gidx];
-        const float4 v = reinterpret_cast<const float4*>(q.buf)[i];
-        acc.x = fmaf(sc, v.x, acc.x); acc.y = fmaf(sc, v.y, acc.y); acc.z = fmaf(sc, v.z, acc.z); acc.w = fmaf(sc, v.w, acc.w);
+        const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
+#pragma unroll
+        for (int d = 0; d < NDF; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (d * 4 + g) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, t[e], v[d][4 * g + e]);
+            }
     }
-    reinterpret_cast<float4*>(a.comb[dest])[i] = acc;
+    if (any_raw) {
+        const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c;
+        float x[NDF][16], dot[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dot[i] = 0.f;
+#pragma unroll
+        for (int d = 0; d < NDF; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
+                x[d][i] = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                dot[i] = fmaf(x[d][i], v[d][i], dot[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = dot[i];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
+            const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float inv = rr < a.P ? a.xinv[(size_t)n * a.Ppad + rr] : 0.f;
+#pragma unroll
+            for (int d = 0; d < NDF; ++d) v[d][i] = (v[d][i] - x[d][i] * t) * inv;
+        }
+    }
+    for (int s = 0; s < a.nsrc; ++s) {
+        const DgScatterSrc& q = a.src[s];
+        if (q.dest != dest || q.route != nullptr || q.raw) continue;
+        const float sc = q.factor * a.gscal[q.gidx];
+        const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
+#pragma unroll
+        for (int d = 0; d < NDF; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (d * 4 + g) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, t[e], v[d][4 * g + e]);
+            }
+    }
+    float* out = a.comb[dest] + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
+#pragma unroll
+    for (int d = 0; d < NDF; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = {v[d][4 * g], v[d][4 * g + 1], v[d][4 * g + 2], v[d][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(out + (d * 4 + g) * 256) = t;
+        }
 }
 
 #define SCAT_THREADS 1024
@@ -151,7 +213,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
         for (int i = tid; i < (int)(rec / 16); i += SCAT_THREADS) reinterpret_cast<uint4*>(sg)[i] = g[i];
         __syncthreads();
         if (d < a.D) {
-            const float* src = buf + (size_t)nimg * a.Ppad * a.DP + d;
+            const float* src = buf + (size_t)nimg * a.Ppad * a.DP;   // gradient tiles of image nimg
+            const int DPc = a.DP;
             // first tap of every pixel of this thread: independent loads, all in flight together
             float first[NPASS];
             int e0a[NPASS], e1a[NPASS];
@@ -161,12 +224,12 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
                 const bool ok = ps < npass && pix < HW;
                 e0a[ps] = ok ? off[pix] : 0;
                 e1a[ps] = ok ? off[pix + 1] : 0;
-                first[ps] = e1a[ps] > e0a[ps] ? ewgt[e0a[ps]] * src[(size_t)eidx[e0a[ps]] * a.DP] : 0.f;
+                first[ps] = e1a[ps] > e0a[ps] ? ewgt[e0a[ps]] * src[dg_gtile_off(eidx[e0a[ps]], d, DPc)] : 0.f;
             }
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 float sum = first[ps];
-                for (int e = e0a[ps] + 1; e < e1a[ps]; ++e) sum = fmaf(ewgt[e], src[(size_t)eidx[e] * a.DP], sum);
+                for (int e = e0a[ps] + 1; e < e1a[ps]; ++e) sum = fmaf(ewgt[e], src[dg_gtile_off(eidx[e], d, DPc)], sum);
                 acc[ps] = fmaf(sc, sum, acc[ps]);
             }
         }
@@ -206,10 +269,102 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     }
 }
 
+// Stage 2 on the identity grid (DG_IDENTITY_GRID): sample() reads pixel (y = j, x = i) for position p = i*S + j with
+// weight 1, so its adjoint is a transposed copy.  One block = one destination image, one group of 32 channels: every
+// wave sums, tile by tile, the combined direct gradient tile and the tiles of the images routed here (negatives,
+// in a fixed order: bit-reproducible), drops the rows into an LDS stage [channel][pixel] and the block writes (B,D,h,w)
+// rows of h*w contiguous floats.  grid (DP/32, B, 2), block 256, dynamic LDS 32*(HW+1) floats + the routed list.
+#define DENSE_MAXROUTE 1024
+__global__ __launch_bounds__(256) void k_scatter_dense(const DgScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sd[];
+    const int HW = a.h * a.w, S = a.S, nt = a.Ppad >> 5, NF = a.DP >> 5;
+    float* stage = reinterpret_cast<float*>(sd);                       // [32][HW + 1]
+    int* rl_n = reinterpret_cast<int*>(stage + 32 * (HW + 1));         // routed list: source image
+    int* rl_s = rl_n + DENSE_MAXROUTE;                                 //              source index
+    __shared__ int rl_cnt;
+    const int f = blockIdx.x, b = blockIdx.y, dest = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    // routed list in (source, image) order: every thread tests one pair per round, ballot + prefix compaction
+    __shared__ int wcnt[4];
+    if (tid == 0) rl_cnt = 0;
+    __syncthreads();
+    for (int s = 0; s < a.nsrc; ++s) {
+        const DgScatterSrc& q = a.src[s];
+        if (q.dest != dest || q.route == nullptr) continue;          // uniform
+        for (int n0 = 0; n0 < a.B; n0 += 256) {
+            const int n = n0 + tid;
+            const bool hit = n < a.B && (int)q.route[n] == b;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcnt[wid] = __popcll(m);
+            __syncthreads();
+            int base = rl_cnt;
+            for (int wv = 0; wv < wid; ++wv) base += wcnt[wv];
+            if (hit) {
+                const int o = base + __popcll(m & ((1ull << lane) - 1));
+                if (o < DENSE_MAXROUTE) { rl_n[o] = n; rl_s[o] = s; }
+            }
+            __syncthreads();
+            if (tid == 0) rl_cnt = min(rl_cnt + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3], DENSE_MAXROUTE);
+            __syncthreads();
+        }
+    }
+    const int cnt = rl_cnt;
+    for (int t = wid; t < nt; t += 4) {
+        const size_t toff = ((size_t)t * NF + f) * 1024 + lane * 4;
+        f32x4 v[4];
+        const float* cb = a.comb[dest] + (size_t)b * a.Ppad * a.DP + toff;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(cb + g * 256);
+        for (int e = 0; e < cnt; ++e) {
+            const DgScatterSrc& q = a.src[rl_s[e]];
+            const float sc = q.factor * a.gscal[q.gidx];
+            const float* sb = q.buf + (size_t)rl_n[e] * a.Ppad * a.DP + toff;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(sb + g * 256);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[g][k] = fmaf(sc, u[k], v[g][k]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = t * 32 + k + 8 * g + 4 * h;
+                if (p < a.P) {
+                    const int i = p / S, j = p - i * S;
+                    stage[r * (HW + 1) + j * a.w + i] = v[g][k];
+                }
+            }
+    }
+    __syncthreads();
+    float* out = a.out[dest];
+    for (int idx = tid; idx < 32 * HW; idx += 256) {
+        const int c = idx / HW, pix = idx - c * HW, d = 32 * f + c;
+        if (d < a.D) out[((size_t)b * a.D + d) * HW + pix] = stage[c * (HW + 1) + pix];
+    }
+}
+
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
-    const size_t n4 = (size_t)a.B * a.Ppad * a.DP / 4;
-    hipLaunchKernelGGL(k_grad_combine, dim3((unsigned)((n4 + 255) / 256), 2), dim3(256), 0, s, a);
+    {
+        const dim3 cgrid(a.Ppad / 32, a.B, 2);
+        if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid, dim3(64), 0, s, a);
+        else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid, dim3(64), 0, s, a);
+        else return hipErrorInvalidValue;
+    }
     const int HW = a.h * a.w;
+    {
+        // identity grid: transposed copy (needs the [32][HW+1] stage in LDS and a bounded routed list)
+        int nrouted = 0;
+        for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
+        const size_t dsm = (size_t)32 * (HW + 1) * 4 + (size_t)DENSE_MAXROUTE * 8;
+        if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_scatter_dense, dim3(a.DP / 32, a.B, 2), dim3(256), dsm, s, a);
+            return hipGetLastError();
+        }
+    }
     if (HW > SCAT_PX * SCAT_MAXPASS || a.P > 65535) return hipErrorInvalidValue;
     const size_t rec = dg_taps_record_bytes(HW, a.P);
     const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
