@@ -69,6 +69,37 @@ __host__ __device__ inline size_t dg_gtile_off(int p, int d, int DP) {
     return ((size_t)(p >> 5) * (DP >> 5) + (d >> 5)) * 1024 + (q >> 3) * 256 + ((d & 31) + 32 * ((q >> 2) & 1)) * 4 + (q & 3);
 }
 
+#ifdef __HIPCC__
+// Code rows of one tile for the normalisation backward, in accumulator order: x[f][i] = normalised code of position
+// q = (i&3) + 8 (i>>2) + 4 (lane>>5), channel 32 f + (lane&31).  `Cp` = C part of the tile's blob (K-major granules),
+// read with coalesced 16-byte loads and turned around through a per-wave LDS scratch of DG_XROWS_LDS bytes (granule rows
+// padded by one granule against bank conflicts).
+#define DG_XROWS_LDS (4 * 33 * 16)
+template <int NDF>
+__device__ __forceinline__ void dg_load_code_rows(const char* Cp, char* T, int lane, _Float16 (&x)[NDF][16]) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    const int r = lane & 31, h = lane >> 5;
+    v4i_ raw[NDF][2];
+#pragma unroll
+    for (int f = 0; f < NDF; ++f)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) raw[f][k] = *reinterpret_cast<const v4i_*>(Cp + f * 2048 + k * 1024 + lane * 16);
+#pragma unroll
+    for (int f = 0; f < NDF; ++f) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int L = k * 64 + lane;
+            *reinterpret_cast<v4i_*>(T + ((L >> 5) * 33 + (L & 31)) * 16) = raw[f][k];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
+            x[f][i] = *reinterpret_cast<const _Float16*>(T + ((r >> 3) * 33 + q) * 16 + (r & 7) * 2);
+        }
+    }
+}
+#endif
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 

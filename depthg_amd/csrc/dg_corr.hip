@@ -459,103 +459,130 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 }
 
 // ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------
-// One WAVE = one S tile (32 positions q) of one image and pair-set; waves are independent (no block barrier).  The
-// wave walks over the R tiles (the K dimension).  Per R tile it needs
+//     dS[q][:] = sum_p G[q][p] * x_R[p][:]     per image and pair-set: (P x P) fp16 G, read exactly once from HBM
+// One block = GS_CW consumer waves + 1 producer wave.  Consumer wave c owns S tile blockIdx.x*GS_CW + c (32 positions q)
+// and walks over the R tiles (the K dimension); per R tile it needs
 //   * its own G tile - the producing wave's accumulator-order fp16 registers (lane = R position p, 16 S positions per
-//     lane), 2 KiB, streamed from HBM (non-temporal), prefetched GS_DG tiles ahead in a register ring;
-//   * the P part of the R operand's blob: in HBM it already is the B-fragment layout (granule c of channel d = 8
-//     positions in dg_perm32 order), so each lane loads its six 16-byte fragments straight from L2 (512 contiguous
-//     bytes per half wave; the 4 waves of a block walk the same R tiles and share them in the vector L1), one tile ahead.
+//     lane), 2 KiB, streamed from HBM (non-temporal) three tiles ahead into a register ring;
+//   * the P part of the R operand's blob (the B fragments: granule c of channel d = 8 positions in dg_perm32 order),
+//     shared by all consumers: the producer wave moves it global -> LDS with the LDS-DMA into a ring of GS_NB buffers,
+//     GS_NB-1 tiles ahead, and is the only wave that waits on it (counted vmcnt), so the one barrier per R tile never
+//     exposes a load latency.
 // The G tile is transposed through a per-wave LDS scratch (p order permuted with dg_perm32 so that one 16-byte read is
-// the A fragment matching a granule of the P part) and 6 MFMAs accumulate   dS[q][:] += sum_p G[q][p] * x_R[p][:].
-// Then the normalisation backward with the S code is applied in registers and the accumulator tile is written as a
-// gradient tile (dg_gtile_off; 16 bytes per lane and store).  grid (ceil(nt/4), B, jobs), block 256.
-#define GS_DG 3
+// the A fragment matching a granule of the P part) and 6 MFMAs accumulate it.  Then the normalisation backward with the
+// S code is applied in registers and the accumulator tile is written as a gradient tile (dg_gtile_off).
+// grid (ceil(nt/GS_CW), B, jobs), block (GS_CW+1)*64, dynamic LDS GS_NB P parts + GS_CW scratch tiles.
+#define GS_CW 7
+#define GS_NB 6
+#define GS_TS 80            // row stride (bytes) of the transposition scratch
+template <int CH>
+__device__ __forceinline__ void gs_wait_tiles(int k) {   // at most k tiles (CH DMA instructions each) still in flight
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CH) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CH) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * CH) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * CH) : "memory"); break;
+    }
+}
 template <int NKF, int NKD>
-__global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
+__global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     using BL = BlobT<NKF, NKD>;
-    constexpr int KD = BL::KD, NDF = KD / 32, TS = 80;      // TS: row stride (bytes) of the transposition scratch
-    __shared__ __attribute__((aligned(16))) char scratch[4][32 * TS];
+    constexpr int KD = BL::KD, NDF = KD / 32, TS = GS_TS;
+    constexpr int PB = BL::BYTES - BL::OFF_P, CH = PB / 1024;     // bytes / DMA instructions of a P part
+    static_assert(GS_NB - 2 <= 4 && 4 * CH < 64, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char gs_smem[];   // [GS_NB][PB] ring, [GS_CW][32*TS] scratch
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     const int n = blockIdx.y;
     const DgGsJob& J = a.jobs[blockIdx.z];
-    const int nt = a.Ppad >> 5;
-    const int st = blockIdx.x * 4 + wid;                    // S tile of this wave
-    if (st >= nt) return;
+    const int ntS = a.Ppad >> 5;
+    const int nt = (a.debug & 4096) ? 1 : ntS;              // (ablation: one R tile only)
     const int nR = J.ridx ? (int)J.ridx[n] : n;
+    if (wid == GS_CW) {
+        // ---- producer: P parts of R tiles 0..nt-1 through the ring
+        const char* Pg = J.Rop + (size_t)nR * ntS * BL::BYTES + BL::OFF_P + lane * 16;
+        const uint32_t ring_a = lds_addr(gs_smem);
+        auto issue = [&](int t) {
+            const uint32_t dst = ring_a + (t % GS_NB) * PB;
+            const char* src = Pg + (size_t)t * BL::BYTES;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) dma16(src + c * 1024, dst + c * 1024);
+        };
+        for (int t = 0; t < GS_NB - 1 && t < nt; ++t) issue(t);
+        for (int rt = 0; rt < nt; ++rt) {
+            gs_wait_tiles<CH>(min(GS_NB - 2, nt - 1 - rt));      // tile rt has landed
+            __builtin_amdgcn_s_barrier();                          // ... and the consumers are done with tile rt-1
+            if (rt + GS_NB - 1 < nt) issue(rt + GS_NB - 1);        // into the buffer tile rt-1 occupied
+        }
+        return;
+    }
+    const int st = blockIdx.x * GS_CW + wid;                // S tile of this wave
+    if (st >= ntS) {                                        // nothing to do but keep the barrier count
+        for (int rt = 0; rt < nt; ++rt) __builtin_amdgcn_s_barrier();
+        return;
+    }
     const int nS = J.sidx ? (int)J.sidx[n] : n;
     f32x16 acc[NDF];
 #pragma unroll
     for (int f = 0; f < NDF; ++f) acc[f] = f32x16{};
-    char* T = scratch[wid];
+    char* T = gs_smem + GS_NB * PB + wid * (32 * TS);
     const int pcol = dg_perm32(r) * 2;          // byte column of this lane's R position in the scratch rows
-    // B fragment (ks, f) of R tile rt: 16 bytes at P part + ((2 ks + h) * KD + 32 f + r) * 16
-    const char* Pbase = J.Rop + (size_t)nR * nt * BL::BYTES + BL::OFF_P + (h * KD + r) * 16;
-    const v4i* Gbase = reinterpret_cast<const v4i*>(J.G + (((size_t)n * nt * nt + st) * 64 + lane) * 16);
-    const size_t gstride = (size_t)nt * 64 * 2;             // v4i per R tile step
+    const v4i* Gbase = reinterpret_cast<const v4i*>(J.G + (((size_t)n * ntS * ntS + st) * 64 + lane) * 16);
+    const size_t gstride = (size_t)ntS * 64 * 2;            // v4i per R tile step
     auto load_g = [&](int rt, v4i (&g)[2]) {
         const v4i* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt) * gstride;
         g[0] = __builtin_nontemporal_load(gp);
         g[1] = __builtin_nontemporal_load(gp + 1);
     };
-    auto load_p = [&](int rt, v4i (&b)[2][NDF]) {
-        const char* pp = Pbase + (size_t)rt * BL::BYTES;
+    v4i gring[3][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int f = 0; f < NDF; ++f) b[ks][f] = *reinterpret_cast<const v4i*>(pp + (2 * ks * KD + 32 * f) * 16);
-    };
-    v4i gring[GS_DG][2], pcur[2][NDF], pnext[2][NDF];
-#pragma unroll
-    for (int k = 0; k < GS_DG; ++k)
+    for (int k = 0; k < 3; ++k)
         if (k < nt) load_g(k, gring[k]);
-    load_p(0, pcur);
-    for (int rt0 = 0; rt0 < nt; rt0 += GS_DG) {
+    for (int rt0 = 0; rt0 < nt; rt0 += 3) {
 #pragma unroll
-        for (int k = 0; k < GS_DG; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const int rt = rt0 + k;
             if (rt < nt) {
-                if (rt + 1 < nt) load_p(rt + 1, pnext);
-                if (!(a.debug & 32)) {
-                    const v4i g0 = gring[k][0], g1 = gring[k][1];
-                    const uint32_t w[8] = {(uint32_t)g0[0], (uint32_t)g0[1], (uint32_t)g0[2], (uint32_t)g0[3],
-                                           (uint32_t)g1[0], (uint32_t)g1[1], (uint32_t)g1[2], (uint32_t)g1[3]};
+                // own scratch: no cross-wave hazard, so the transposition writes may start before the barrier
+                const v4i g0 = gring[k][0], g1 = gring[k][1];
+                const uint32_t w[8] = {(uint32_t)g0[0], (uint32_t)g0[1], (uint32_t)g0[2], (uint32_t)g0[3],
+                                       (uint32_t)g1[0], (uint32_t)g1[1], (uint32_t)g1[2], (uint32_t)g1[3]};
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {    // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
-                        const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
-                        *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-                    }
+                for (int i = 0; i < 16; ++i) {        // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
+                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
                 }
-                if (rt + GS_DG < nt) load_g(rt + GS_DG, gring[k]);
+                if (rt + 3 < nt) load_g(rt + 3, gring[k]);
+                __builtin_amdgcn_s_barrier();               // P part of tile rt is in the ring
+                asm volatile("" ::: "memory");
                 if (!(a.debug & 32)) {
+                    const char* P = gs_smem + (rt % GS_NB) * PB;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
                         const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
 #pragma unroll
-                        for (int f = 0; f < NDF; ++f)
-                            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, __builtin_bit_cast(f16x8, pcur[ks][f]), acc[f], 0, 0, 0);
+                        for (int f = 0; f < NDF; ++f) {
+                            const f16x8 bfrag = *reinterpret_cast<const f16x8*>(P + ((2 * ks + h) * KD + 32 * f + r) * 16);
+                            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag, bfrag, acc[f], 0, 0, 0);
+                        }
                     }
                 }
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int f = 0; f < NDF; ++f) pcur[ks][f] = pnext[ks][f];
             }
         }
     }
+    if (a.debug & 2048) { if (acc[0][0] == 1.2345f) J.dS[0] = acc[1][0] + acc[2][0]; return; }   // (ablation: no epilogue)
     // normalisation backward: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r);  dc = (dx - x <x,dx>) / ||c||
-    const char* Cp = J.Sop + ((size_t)nS * nt + st) * BL::BYTES + BL::OFF_C;
+    const char* Cp = J.Sop + ((size_t)nS * ntS + st) * BL::BYTES + BL::OFF_C;
+    static_assert(32 * GS_TS >= DG_XROWS_LDS, "scratch too small for the code rows");
+    _Float16 x[NDF][16];
+    dg_load_code_rows<NDF>(Cp, T, lane, x);
     float dot[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dot[i] = 0.f;
 #pragma unroll
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * f + r;
-            const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-            dot[i] = fmaf(x, acc[f][i], dot[i]);
-        }
+        for (int i = 0; i < 16; ++i) dot[i] = fmaf((float)x[f][i], acc[f][i], dot[i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
     float inv[16];
@@ -564,7 +591,7 @@ __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
         const int pos = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         inv[i] = pos < a.P ? J.ScInv[(size_t)nS * a.Ppad + pos] : 0.f;
     }
-    float* out = J.dS + ((size_t)n * nt + st) * (32 * KD) + lane * 4;
+    float* out = J.dS + ((size_t)n * ntS + st) * (32 * KD) + lane * 4;
 #pragma unroll
     for (int f = 0; f < NDF; ++f)
 #pragma unroll
@@ -572,20 +599,25 @@ __global__ __launch_bounds__(256) void k_gs(const DgGsArgs a) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = 4 * g + e, q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * f + r;
-                const float x = (float)*reinterpret_cast<const _Float16*>(Cp + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                v[e] = (acc[f][i] - x * dot[i]) * inv[i];
+                const int i = 4 * g + e;
+                v[e] = (acc[f][i] - (float)x[f][i] * dot[i]) * inv[i];
             }
             *reinterpret_cast<f32x4*>(out + (f * 4 + g) * 256) = v;
         }
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
-    dim3 grid((a.Ppad / 32 + 3) / 4, a.B, a.njobs), block(256);
+    dim3 grid((a.Ppad / 32 + GS_CW - 1) / GS_CW, a.B, a.njobs), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
-#define DG_GS(NKF_, NKD_) \
-    if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) { hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, 0, stream, a2); return hipGetLastError(); }
+    const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;
+#define DG_GS(NKF_, NKD_)                                                                                               \
+    if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) {                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gs<NKF_, NKD_>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+        if (e != hipSuccess) return e;                                                                                   \
+        hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, smem, stream, a2);                                           \
+        return hipGetLastError();                                                                                        \
+    }
     DG_GS(8, 6) DG_GS(8, 8) DG_GS(24, 6) DG_GS(24, 8) DG_GS(48, 6) DG_GS(48, 8)
 #undef DG_GS
     return hipErrorInvalidValue;

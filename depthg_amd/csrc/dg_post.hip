@@ -32,7 +32,7 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
 template <int NDF>
 __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5, DP = NDF * 32;
+    const int lane = threadIdx.x, h = lane >> 5, DP = NDF * 32;
     float v[NDF][16];
 #pragma unroll
     for (int d = 0; d < NDF; ++d)
@@ -56,17 +56,16 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     }
     if (any_raw) {
         const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c;
-        float x[NDF][16], dot[16];
+        __shared__ __attribute__((aligned(16))) char xs[DG_XROWS_LDS];
+        _Float16 x[NDF][16];
+        dg_load_code_rows<NDF>(xb, xs, lane, x);
+        float dot[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) dot[i] = 0.f;
 #pragma unroll
         for (int d = 0; d < NDF; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
-                x[d][i] = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                dot[i] = fmaf(x[d][i], v[d][i], dot[i]);
-            }
+            for (int i = 0; i < 16; ++i) dot[i] = fmaf((float)x[d][i], v[d][i], dot[i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float t = dot[i];
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
             const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             const float inv = rr < a.P ? a.xinv[(size_t)n * a.Ppad + rr] : 0.f;
 #pragma unroll
-            for (int d = 0; d < NDF; ++d) v[d][i] = (v[d][i] - x[d][i] * t) * inv;
+            for (int d = 0; d < NDF; ++d) v[d][i] = (v[d][i] - (float)x[d][i] * t) * inv;
         }
     }
     for (int s = 0; s < a.nsrc; ++s) {
@@ -273,25 +272,28 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
 // weight 1, so its adjoint is a transposed copy.  One block = one destination image, one group of 32 channels: every
 // wave sums, tile by tile, the combined direct gradient tile and the tiles of the images routed here (negatives,
 // in a fixed order: bit-reproducible), drops the rows into an LDS stage [channel][pixel] and the block writes (B,D,h,w)
-// rows of h*w contiguous floats.  grid (DP/32, B, 2), block 256, dynamic LDS 32*(HW+1) floats + the routed list.
+// rows of h*w contiguous floats.  grid (DP/32, B, 2), block 1024, dynamic LDS 32*(HW+1) floats + the routed list.
 #define DENSE_MAXROUTE 1024
-__global__ __launch_bounds__(256) void k_scatter_dense(const DgScatterArgs a) {
+#define DENSE_THREADS 1024
+__global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sd[];
     const int HW = a.h * a.w, S = a.S, nt = a.Ppad >> 5, NF = a.DP >> 5;
     float* stage = reinterpret_cast<float*>(sd);                       // [32][HW + 1]
-    int* rl_n = reinterpret_cast<int*>(stage + 32 * (HW + 1));         // routed list: source image
-    int* rl_s = rl_n + DENSE_MAXROUTE;                                 //              source index
+    const float** rl_p = reinterpret_cast<const float**>(stage + 32 * (HW + 2));   // routed list: image base (8-byte aligned)
+    float* rl_w = reinterpret_cast<float*>(rl_p + DENSE_MAXROUTE);                  //              weight
     __shared__ int rl_cnt;
     const int f = blockIdx.x, b = blockIdx.y, dest = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     // routed list in (source, image) order: every thread tests one pair per round, ballot + prefix compaction
-    __shared__ int wcnt[4];
+    constexpr int NW = DENSE_THREADS / 64;
+    __shared__ int wcnt[NW];
     if (tid == 0) rl_cnt = 0;
     __syncthreads();
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;          // uniform
-        for (int n0 = 0; n0 < a.B; n0 += 256) {
+        const float sc = q.factor * a.gscal[q.gidx];
+        for (int n0 = 0; n0 < a.B; n0 += DENSE_THREADS) {
             const int n = n0 + tid;
             const bool hit = n < a.B && (int)q.route[n] == b;
             const unsigned long long m = __ballot(hit);
@@ -301,30 +303,41 @@ __global__ __launch_bounds__(256) void k_scatter_dense(const DgScatterArgs a) {
             for (int wv = 0; wv < wid; ++wv) base += wcnt[wv];
             if (hit) {
                 const int o = base + __popcll(m & ((1ull << lane) - 1));
-                if (o < DENSE_MAXROUTE) { rl_n[o] = n; rl_s[o] = s; }
+                if (o < DENSE_MAXROUTE) { rl_p[o] = q.buf + (size_t)n * a.Ppad * a.DP; rl_w[o] = sc; }
             }
             __syncthreads();
-            if (tid == 0) rl_cnt = min(rl_cnt + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3], DENSE_MAXROUTE);
+            if (tid == 0) {
+                int c = rl_cnt;
+                for (int wv = 0; wv < NW; ++wv) c += wcnt[wv];
+                rl_cnt = min(c, DENSE_MAXROUTE);
+            }
             __syncthreads();
         }
     }
     const int cnt = rl_cnt;
-    for (int t = wid; t < nt; t += 4) {
+    for (int t = wid; t < nt; t += NW) {
         const size_t toff = ((size_t)t * NF + f) * 1024 + lane * 4;
         f32x4 v[4];
         const float* cb = a.comb[dest] + (size_t)b * a.Ppad * a.DP + toff;
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(cb + g * 256);
-        for (int e = 0; e < cnt; ++e) {
-            const DgScatterSrc& q = a.src[rl_s[e]];
-            const float sc = q.factor * a.gscal[q.gidx];
-            const float* sb = q.buf + (size_t)rl_n[e] * a.Ppad * a.DP + toff;
+        for (int e0 = 0; e0 < cnt; e0 += 4) {                 // 4 routed images per round: 16 loads in flight
+            f32x4 u[4][4];
+            float sc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(sb + g * 256);
+            for (int k = 0; k < 4; ++k) {
+                const int e = min(e0 + k, cnt - 1);
+                sc[k] = e0 + k < cnt ? rl_w[e] : 0.f;
+                const float* sb = rl_p[e] + toff;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[g][k] = fmaf(sc, u[k], v[g][k]);
+                for (int g = 0; g < 4; ++g) u[k][g] = *reinterpret_cast<const f32x4*>(sb + g * 256);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[g][c] = fmaf(sc[k], u[k][g][c], v[g][c]);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(256) void k_scatter_dense(const DgScatterArgs a) {
     }
     __syncthreads();
     float* out = a.out[dest];
-    for (int idx = tid; idx < 32 * HW; idx += 256) {
+    for (int idx = tid; idx < 32 * HW; idx += DENSE_THREADS) {
         const int c = idx / HW, pix = idx - c * HW, d = 32 * f + c;
         if (d < a.D) out[((size_t)b * a.D + d) * HW + pix] = stage[c * (HW + 1) + pix];
     }
@@ -357,11 +370,11 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
         // identity grid: transposed copy (needs the [32][HW+1] stage in LDS and a bounded routed list)
         int nrouted = 0;
         for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
-        const size_t dsm = (size_t)32 * (HW + 1) * 4 + (size_t)DENSE_MAXROUTE * 8;
+        const size_t dsm = (size_t)32 * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
         if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_scatter_dense, dim3(a.DP / 32, a.B, 2), dim3(256), dsm, s, a);
+            hipLaunchKernelGGL(k_scatter_dense, dim3(a.DP / 32, a.B, 2), dim3(DENSE_THREADS), dsm, s, a);
             return hipGetLastError();
         }
     }
