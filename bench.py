@@ -63,9 +63,12 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     return fwd, bwd
 
 
-def total_of(cfg, out):
-    return (cfg.pos_inter_weight * out[2] + cfg.pos_intra_weight * out[0] + cfg.neg_inter_weight * out[4].mean() +
-            cfg.depth_feat_weight * out[6]) * cfg.correspondence_weight
+def total_weights(cfg, device):
+    """Weights of the four loss means in the training total (reference src/train_segmentation.py:303-312), in the
+    order of the fused output vector: intra, inter, neg, depth."""
+    w = torch.tensor([cfg.pos_intra_weight, cfg.pos_inter_weight, cfg.neg_inter_weight, cfg.depth_feat_weight],
+                     dtype=torch.float32)
+    return (w * cfg.correspondence_weight).to(device)
 
 
 def cpu_baseline(seconds_budget=15.0):
@@ -136,12 +139,13 @@ def main():
     c.requires_grad_(True)
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
+    wvec = total_weights(cfg, dev)
 
     def step():
         c.grad = None
         cp.grad = None
-        out = loss_fn(f, fp, None, None, c, cp, d, dp)
-        total = total_of(cfg, out)
+        loss_fn(f, fp, None, None, c, cp, d, dp)
+        total = torch.dot(loss_fn.scalars[:4], wvec)      # the weighted total of the four loss means, one op
         total.backward()
         if world > 1:
             # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size

@@ -11,7 +11,7 @@ DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARE
     (1 << i for i in range(7))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
-           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords"]
+           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -52,6 +52,8 @@ def load():
     lib.dg_fps_workspace_bytes.argtypes = [ctypes.c_int32] * 3
     lib.dg_fps_coords.restype = ctypes.c_int
     lib.dg_fps_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_super_perms.restype = ctypes.c_int
+    lib.dg_super_perms.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
     _lib = lib
     return lib
 

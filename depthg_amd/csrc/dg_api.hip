@@ -28,15 +28,15 @@ extern "C" const char* dg_last_error(void) { return g_err; }
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
-    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, nchunk, blob;
+    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;
     bool shared, depth, grad, pointwise, ident;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
-    size_t rvec[DG_MAX_NEG + 2], rsum[DG_MAX_NEG + 2], m0[DG_MAX_NEG + 2];
-    size_t nz;
+    size_t rvec[DG_MAX_NEG + 2], rtile[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
+    size_t nz, nzsum, tickets;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
-    size_t comb[2], jobsum, taps, gbuf[DG_MAX_NEG + 2];
+    size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
     size_t total;
 };
 
@@ -65,7 +65,6 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.nops = p.shared ? 2 : p.T;
     p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
     p.nrb = (p.Ppad + p.rf * 32 - 1) / (p.rf * 32);
-    p.nchunk = (p.Ppad + DG_RM_ROWS - 1) / DG_RM_ROWS;
     p.blob = DgBlob(p.KF, p.KD).bytes;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
@@ -77,12 +76,14 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.colpart[i] = take(B * (size_t)(p.ident ? p.h : p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
     }
-    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rsum[t] = take(B * p.nchunk * 4); p.m0[t] = take(4); }
+    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rtile[t] = take(B * (p.Ppad / 32) * 4); p.rimg[t] = take(B * 4); }
     p.nz = take(B * p.Ppad * 4);
+    p.nzsum = take(B * 4);
+    p.tickets = take((B + 1) * 4);
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
-    p.jobsum = take((DG_MAX_JOBS + B) * 2 * 8);
+    p.scratch_out = take(DG_OUT_COUNT * 4);
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
     p.total = off;
@@ -124,7 +125,7 @@ static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, b
         j.Sop = ws + p.op[0]; j.sidx = nullptr;
         j.center_on_lane = 0;
     }
-    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.m0 = F32(p.m0[t]); }
+    if (p.pointwise) { j.rvec = F32(p.rvec[t]); j.rimg = F32(p.rimg[t]); }
     j.shift = shift_of(d, t);
     j.kind = DG_JOB_HELPER;
     return j;
@@ -171,12 +172,19 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
                            int* depth_index) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     corr_args_base(p, desc, ws, a);
+    const double numel = (double)p.B * p.P * p.P;
+    a.ticket = reinterpret_cast<int32_t*>(ws + p.tickets) + p.B;
+    a.nzsum = p.depth ? F32(p.nzsum) : nullptr;
+    a.out_scalars = F32(p.scratch_out);        // the caller points this at its output
     int nj = 0;
     for (int t = 0; t < p.T; ++t) {
         DgJob j = helper_job(p, desc, ws, t, false, perms);
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
         j.Gout = p.grad ? reinterpret_cast<uint16_t*>(ws + p.gbuf[t]) : nullptr;
+        j.slot_loss = t < 2 ? t : DG_OUT_LOSS_NEG;
+        j.slot_cd = t < 2 ? DG_OUT_CD_INTRA + t : DG_OUT_CD_NEG;
+        j.fin_scale = (float)(1.0 / (t < 2 ? numel : numel * p.N));
         a.jobs[nj++] = j;
     }
     const int njA = nj;
@@ -186,6 +194,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         DgJob j = depth_job(p, desc, ws);
         j.part = F32(p.part[p.T]);
         j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
+        j.slot_loss = DG_OUT_LOSS_DEPTH; j.slot_cd = -1; j.fin_scale = (float)(1.0 / numel);
         *depth_index = nj;
         a.jobs[nj++] = j;
     }
@@ -211,43 +220,46 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int HW = p.h * p.w;
 
-    // 1. channel-last copies of the maps (the gather reads whole channel vectors per tap); on the dense identity grid
-    //    the feats operands are built straight from NCHW instead
-    if (!p.ident) {
+    // 1.+2. operands.  Identity grid: one launch builds both feats and both code operands straight from NCHW (+ the
+    //       depth indicators).  General coords: channel-last copies (the gather reads whole channel vectors per tap), then
+    //       sample + normalise + operand blobs.
+    if (p.ident) {
+        DgDenseArgs g;
+        memset(&g, 0, sizeof(g));
+        g.src[0] = orig_feats; g.src[1] = orig_feats_pos; g.code[0] = orig_code; g.code[1] = orig_code_pos;
+        for (int o = 0; o < 2; ++o) { g.blob[o] = ws + p.op[o]; g.colpart[o] = F32(p.colpart[o]); g.inv_norm[o] = F32(p.inv[o]); }
+        g.depth = p.depth ? depth : nullptr; g.nz = F32(p.nz); g.nzsum = F32(p.nzsum);
+        g.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
+        g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
+        g.dH = desc->depth_h; g.dW = desc->depth_w;
+        DG_HIP(dg_launch_prep_dense(g, stream));
+    } else {
         DG_HIP(dg_launch_transpose(orig_feats, F32(p.nhwc_f[0]), p.B, p.C, HW, p.C4, stream));
         DG_HIP(dg_launch_transpose(orig_feats_pos, F32(p.nhwc_f[1]), p.B, p.C, HW, p.C4, stream));
-    } else {
-        DG_HIP(dg_launch_prep_dense_feats(orig_feats, orig_feats_pos, ws + p.op[0], ws + p.op[1], F32(p.colpart[0]),
-                                          F32(p.colpart[1]), p.B, p.C, p.KF, p.KD, p.h, p.w, p.P, p.Ppad, stream));
-    }
-    DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
-    DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
-
-    // 2. sample + normalise + operand blobs
-    {
+        DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
+        DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
         g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
+        g.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
         int nj = 0;
         for (int o = 0; o < p.nops; ++o) {
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
             const float* coords = o == 0 ? coords1 : coords2;
             const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
-            if (!p.ident) {
-                DgGatherJob& f = g.jobs[nj++];
-                f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
-                f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
-                f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
-            }
+            DgGatherJob& f = g.jobs[nj++];
+            f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
+            f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
+            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
             DgGatherJob& c = g.jobs[nj++];
             c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
             c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
             c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
         }
         g.njobs = nj;
-        DG_HIP(dg_launch_gather(g, p.ident ? p.KD : p.KF, stream));
+        DG_HIP(dg_launch_gather(g, p.KF, stream));
+        if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
     }
-    if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
 
     // 3. row means of fd (pointwise centering as a rank-1 correction)
     if (p.pointwise) {
@@ -258,11 +270,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DG_HIP(dg_launch_colmean(c, stream));
         DgRowmeanArgs r;
         memset(&r, 0, sizeof(r));
-        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.nchunk = p.nchunk;
+        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
         for (int t = 0; t < p.T; ++t) {
             r.jobs[t].A = ws + p.op[0]; r.jobs[t].aidx = nullptr;
             r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
-            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rsum = F32(p.rsum[t]); r.m0[t] = F32(p.m0[t]);
+            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rtile = F32(p.rtile[t]); r.jobs[t].rimg = F32(p.rimg[t]);
         }
         DG_HIP(dg_launch_rowmean(r, stream));
     }
@@ -270,7 +282,8 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     // 4. fused correlation passes
     DgCorrArgs a;
     int depth_index;
-    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    a.out_scalars = out_scalars;               // written by the last block of the fused kernel
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream));
     if (p.grad) {
         DgGsArgs g;
@@ -278,30 +291,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DG_HIP(dg_launch_gs(g, stream));
     }
 
-    // 5. scalar outputs
-    DgFinishArgs f;
-    memset(&f, 0, sizeof(f));
-    const double numel = (double)p.B * p.P * p.P;
-    int nf = 0;
-    for (int j = 0; j < njA; ++j, ++nf) {
-        f.part[nf] = a.jobs[j].part;
-        f.nblk[nf] = p.B * p.nrb;
-        f.slot_loss[nf] = j < 2 ? j : DG_OUT_LOSS_NEG;
-        f.slot_cd[nf] = j < 2 ? DG_OUT_CD_INTRA + j : DG_OUT_CD_NEG;
-        f.scale[nf] = (float)(1.0 / (j < 2 ? numel : numel * p.N));
-    }
-    if (depth_index >= 0) {
-        f.part[nf] = a.jobs[depth_index].part;
-        f.nblk[nf] = p.B * p.nrb;
-        f.slot_loss[nf] = DG_OUT_LOSS_DEPTH; f.slot_cd[nf] = -1; f.scale[nf] = (float)(1.0 / numel);
-        ++nf;
-    }
-    f.njobs = nf;
-    f.nz = p.depth ? F32(p.nz) : nullptr;
-    f.B = p.B; f.P = p.P; f.Ppad = p.Ppad;
-    f.jobsum = reinterpret_cast<double*>(ws + p.jobsum);
-    f.out = out_scalars;
-    DG_HIP(dg_launch_finish(f, stream));
     return DG_OK;
 }
 
@@ -390,6 +379,14 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     int depth_index;
     build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_super_perms(const float* keys, int32_t count, int32_t B, int64_t* out, dg_stream_t stream_) {
+    if (count < 0 || B < 1 || B > 8192) return fail(DG_ERR_INVALID, "dg_super_perms: count=%d B=%d outside the supported range", count, B);
+    if (count == 0) return DG_OK;
+    if (!keys || !out) return fail(DG_ERR_INVALID, "null pointer");
+    DG_HIP(dg_launch_super_perms(keys, count, B, out, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

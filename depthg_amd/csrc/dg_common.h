@@ -110,7 +110,7 @@ struct DgJob {
     const char* Rop;      // operand blobs [B][Ppad/32][blob bytes] of the stationary operand
     const char* Sop;      // ... of the streamed operand
     const float* rvec;    // fp32 [B][Ppad] row means a_p . bbar (indexed by operand-1 position) or null
-    const float* m0;      // fp32 [1] mean of rvec over all valid (n, p) = old_mean of the reference (modules.py:1237) or null
+    const float* rimg;    // fp32 [B] per-image sums of rvec: m0 = sum / (B*P) = old_mean of the reference (modules.py:1237) or null
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
     const float* nzS;
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
@@ -124,10 +124,12 @@ struct DgJob {
     float shift;
     int32_t kind;
     int32_t center_on_lane;  // 1: R is operand 1 (rvec / nzR indexed by lane); 0: R is operand 2 (rvec by tile row)
-    int32_t pad_;
+    int32_t slot_loss;       // output scalar the loss sum of this job adds to (DG_OUT_*; -1 none)   } used by the
+    int32_t slot_cd;         // ... the cd sum                                                        } last block
+    float fin_scale;         // 1/numel of the tensor the job contributes to                         } (finish)
 };
 
-#define DG_MAX_JOBS 24
+#define DG_MAX_JOBS 12      // pair-sets (<= DG_MAX_NEG + 2) + the depth job
 
 struct DgCorrArgs {
     DgJob jobs[DG_MAX_JOBS];
@@ -139,21 +141,25 @@ struct DgCorrArgs {
     float inv_BP;         // 1 / (B*P)
     const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
     int32_t debug;        // developer ablation bits (0 in production)
+    // finish (done by the last block to retire, found with a ticket counter): partial sums -> the 8 output scalars
+    int32_t* ticket;      // zero on entry (set by the operand-preparation kernel), reset by the last block; null: no finish
+    const float* nzsum;   // [B] per-image sums of the depth indicators (mean(dd)) or null
+    float* out_scalars;   // [DG_OUT_COUNT]
 };
 
+// Cross-block hand-over without cache-wide fences (each XCD has its own L2): values are published with a returning
+// device-scope atomic (complete at the coherence point before the ticket is taken) and read back with agent-scope loads.
+#ifdef __HIPCC__
+__device__ __forceinline__ void dg_publish(float* p, float v) {
+    const float old = atomicExch(p, v);
+    asm volatile("" :: "v"(old) : "memory");
+}
+__device__ __forceinline__ float dg_read_published(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // ---- argument blocks of the helper kernels (one definition shared by kernels and host API)
-struct DgFinishArgs {
-    const float* part[DG_MAX_JOBS];  // per job: [nblk][2] partial (loss, cd) sums
-    int32_t nblk[DG_MAX_JOBS];
-    int32_t slot_loss[DG_MAX_JOBS];  // which output scalar the loss sum of job j adds to (-1 none)
-    int32_t slot_cd[DG_MAX_JOBS];
-    float scale[DG_MAX_JOBS];        // 1/numel of the tensor the job contributes to
-    int32_t njobs;
-    const float* nz;                 // [B][Ppad] or null
-    int32_t B, P, Ppad;
-    double* jobsum;                  // [njobs + B][2] scratch (stage 1 -> stage 2)
-    float* out;                      // [DG_OUT_COUNT]
-};
 
 struct DgGatherJob {
     const float* src;        // NHWC fp32 [B][h*w][K4]
@@ -167,8 +173,22 @@ struct DgGatherJob {
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
+    int32_t* tickets;        // [B + 1] completion counters of k_rowmean (per image) / k_corr_main, zeroed here
     DgGatherJob jobs[DG_MAX_GATHER];
     int32_t njobs, B, h, w, S, P, Ppad, KF, KD;
+};
+
+struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
+    const float* src[2];     // feats NCHW fp32 (B,K,h,w): orig_feats, orig_feats_pos
+    const float* code[2];    // code NCHW fp32 (B,D,h,w): orig_code, orig_code_pos
+    char* blob[2];           // operand blobs 0, 1
+    float* colpart[2];       // [B][h][KF] per-source-row column sums of the normalised feats
+    float* inv_norm[2];      // [B][Ppad] 1/max(||code||, eps)
+    const float* depth;      // (B,1,dH,dW) or null
+    float* nz;               // [B][Ppad] depth indicators
+    float* nzsum;            // [B] their per-image sums
+    int32_t* tickets;        // [B + 1] completion counters of k_rowmean (per image) / k_corr_main, zeroed here
+    int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
 };
 
 struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_tiles colpart[o][n][tile][k]
@@ -178,19 +198,19 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_tiles colpart[o][n][til
     int32_t nops, B, P, Ppad, KF;
 };
 
-#define DG_RM_ROWS 64       // rows per block of k_rowmean
 struct DgRowmeanJob {
     const char* A;            // operand-1 blobs
     const float* bbar;        // [B][KF] mean normalised feats of operand 2
     const int64_t* aidx;      // batch maps (null = identity)
     const int64_t* bidx;
     float* rvec;              // [B][Ppad]
-    float* rsum;              // [B][nchunk]
+    float* rtile;             // [B][Ppad/32] per-tile sums of rvec (scratch)
+    float* rimg;              // [B] per-image sums of rvec
 };
 struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
-    float* m0[DG_MAX_NEG + 2];   // [1] per job: sum(rsum) / (B*P), filled by k_m0 after k_rowmean
-    int32_t njobs, B, P, Ppad, KF, KD, nchunk;
+    int32_t njobs, B, P, Ppad, KF, KD;
+    int32_t* tickets;            // [B] completion counters per image (zero on entry, reset by the last wave)
 };
 
 struct DgScatterSrc {
@@ -245,15 +265,14 @@ __host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
 
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
-hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W, int S, int Ppad, hipStream_t s);
+hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
-hipError_t dg_launch_prep_dense_feats(const float* f0, const float* f1, char* blob0, char* blob1, float* cp0, float* cp1,
-                                      int B, int K, int KF, int KD, int h, int w, int P, int Ppad, hipStream_t s);
+hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
+hipError_t dg_launch_super_perms(const float* keys, int count, int B, int64_t* out, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

@@ -114,6 +114,39 @@ __device__ __forceinline__ float epi_elem(float yf, float cdv, float vv, float c
     return gi;
 }
 
+// Final reduction of the per-block partial sums into the 8 output scalars, by one wave of the last block to retire:
+// per job the partials are summed in double in a fixed (lane-strided, then butterfly) order, so the result does not
+// depend on which block happens to be last.
+__device__ __forceinline__ void finish_scalars(const DgCorrArgs& args, int lane) {
+    double acc[DG_OUT_COUNT];
+#pragma unroll
+    for (int i = 0; i < DG_OUT_COUNT; ++i) acc[i] = 0.0;
+    const int nblk = args.B * args.nrb;
+    for (int j = 0; j < args.njobs; ++j) {
+        const DgJob& J = args.jobs[j];
+        if (!J.part) continue;
+        double l = 0.0, c = 0.0;
+        for (int i = lane; i < nblk; i += 64) { l += dg_read_published(J.part + 2 * i); c += dg_read_published(J.part + 2 * i + 1); }
+        for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); }
+#pragma unroll
+        for (int i = 0; i < DG_OUT_COUNT; ++i) {
+            if (J.slot_loss == i) acc[i] += -l * (double)J.fin_scale;
+            if (J.slot_cd == i) acc[i] += c * (double)J.fin_scale;
+        }
+    }
+    if (args.nzsum) {        // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
+        double m = 0.0;
+        for (int n = lane; n < args.B; n += 64) { const double s = args.nzsum[n]; m += s * s; }
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+        acc[DG_OUT_DD] = m / ((double)args.B * args.P * args.P);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < DG_OUT_COUNT; ++i) args.out_scalars[i] = (float)acc[i];
+        atomicExch(args.ticket, 0);
+    }
+}
+
 template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND>
 __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
@@ -198,7 +231,11 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 
     // ---- per-job scalars
     float c0 = -job.shift;    // fd'' - shift = Yf - rowmean + (m0 - shift)
-    if (KIND != KIND_DEPTH && job.rvec) c0 += job.m0[0];
+    if (KIND != KIND_DEPTH && job.rvec) {       // m0: B per-image sums, added in a fixed order by every wave
+        float m = 0.f;
+        for (int i = lane; i < args.B; i += 64) m += job.rimg[i];
+        c0 += wave_sum(m) * args.inv_BP;
+    }
     float c0_lane[RF], nz_lane[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
@@ -409,11 +446,22 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     csum = wave_sum(csum);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
     __syncthreads();
-    if (tid == 0 && job.part) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < NWAVES; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
-        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
-        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
+    if (wid == 0 && job.part) {
+        int last = 0;
+        if (lane == 0) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < NWAVES; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+            if (args.ticket) {
+                dg_publish(job.part + (size_t)(n * args.nrb + rb) * 2, a);
+                dg_publish(job.part + (size_t)(n * args.nrb + rb) * 2 + 1, b);
+                last = atomicAdd(args.ticket, 1) == (int)gridDim.x - 1;
+            } else {
+                job.part[(size_t)(n * args.nrb + rb) * 2] = a;
+                job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
+            }
+        }
+        last = __shfl(last, 0, 64);
+        if (last) finish_scalars(args, lane);     // every block has published its partial sums: reduce them (wave 0)
     }
 
     // ---- store the RAW gradient w.r.t. the normalised stationary code in accumulator order
@@ -623,45 +671,6 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
-// ---- final reduction of the per-block partial sums into the 8 output scalars (two tiny launches)
-// stage 1: one block per job (+ one per image for mean(dd)); stage 2: one thread combines the sums in a fixed order.
-__global__ __launch_bounds__(256) void k_corr_finish1(const DgFinishArgs a) {
-    __shared__ double wred[4][2];
-    const int tid = threadIdx.x, j = blockIdx.x;
-    double l = 0.0, c = 0.0;
-    if (j < a.njobs) {
-        for (int i = tid; i < a.nblk[j]; i += 256) { l += a.part[j][2 * i]; c += a.part[j][2 * i + 1]; }
-    } else if (a.nz) {   // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2: block njobs + n sums image n
-        const int n = j - a.njobs;
-        float s = 0.f;
-        for (int p = tid; p < a.P; p += 256) s += a.nz[(size_t)n * a.Ppad + p];
-        l = s;
-    }
-    for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); }
-    if ((tid & 63) == 0) { wred[tid >> 6][0] = l; wred[tid >> 6][1] = c; }
-    __syncthreads();
-    if (tid == 0) {
-        a.jobsum[2 * j] = wred[0][0] + wred[1][0] + wred[2][0] + wred[3][0];
-        a.jobsum[2 * j + 1] = wred[0][1] + wred[1][1] + wred[2][1] + wred[3][1];
-    }
-}
-
-__global__ void k_corr_finish2(const DgFinishArgs a) {
-    if (threadIdx.x != 0) return;
-    double acc[DG_OUT_COUNT];
-    for (int i = 0; i < DG_OUT_COUNT; ++i) acc[i] = 0.0;
-    for (int j = 0; j < a.njobs; ++j) {
-        if (a.slot_loss[j] >= 0) acc[a.slot_loss[j]] += -a.jobsum[2 * j] * (double)a.scale[j];
-        if (a.slot_cd[j] >= 0) acc[a.slot_cd[j]] += a.jobsum[2 * j + 1] * (double)a.scale[j];
-    }
-    if (a.nz) {
-        double m = 0.0;
-        for (int n = 0; n < a.B; ++n) { const double s = a.jobsum[2 * (a.njobs + n)]; m += s * s; }
-        acc[DG_OUT_DD] = m / ((double)a.B * a.P * a.P);
-    }
-    for (int i = 0; i < DG_OUT_COUNT; ++i) a.out[i] = (float)acc[i];
-}
-
 // ---- launch helpers (host) ------------------------------------------------------------------
 template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE>
 static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
@@ -700,8 +709,3 @@ hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, in
     return hipErrorInvalidValue;
 }
 
-hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_corr_finish1, dim3(a.njobs + (a.nz ? a.B : 0)), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(k_corr_finish2, dim3(1), dim3(64), 0, stream, a);
-    return hipGetLastError();
-}

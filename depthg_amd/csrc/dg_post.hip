@@ -486,3 +486,24 @@ hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, 
     hipLaunchKernelGGL(k_fps_coords, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------
+// super_perm (src/modules.py:1184-1188) for `count` rows at once: rank of every key inside its row (ties by index) =
+// position of that index in the argsort, then the fixed-point bump modulo B.  grid (count), block 256, LDS B floats.
+__global__ __launch_bounds__(256) void k_super_perms(const float* __restrict__ keys, int B, int64_t* __restrict__ out) {
+    extern __shared__ float sk[];
+    const float* kr = keys + (size_t)blockIdx.x * B;
+    for (int i = threadIdx.x; i < B; i += 256) sk[i] = kr[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float ki = sk[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (sk[j] < ki) || (sk[j] == ki && j < i);
+        out[(size_t)blockIdx.x * B + rank] = (int64_t)((i == rank ? i + 1 : i) % B);
+    }
+}
+
+hipError_t dg_launch_super_perms(const float* keys, int count, int B, int64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_super_perms, dim3(count), dim3(256), B * sizeof(float), s, keys, B, out);
+    return hipGetLastError();
+}

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
     const DgGatherJob& J = a.jobs[blockIdx.z];
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const float* img = J.src + (size_t)ns * a.h * a.w * K4;
@@ -160,17 +161,8 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 // channel-last copy, no bilinear taps.  One block per (source row y, image): reads the K x w slab of that row
 // (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
 // grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
-struct DgDenseFeatsArgs {
-    const float* src[2];     // NCHW fp32 (B,K,h,w)
-    char* blob[2];
-    float* colpart[2];       // [B][h][KF] per-source-row column sums
-    int32_t B, K, KF, KD, h, w, P, Ppad;
-};
-
-__global__ __launch_bounds__(256) void k_prep_dense_feats(const DgDenseFeatsArgs a) {
-    extern __shared__ float sl[];                  // [w][KF + 1]
+__device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int n, int o) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int y = blockIdx.x, n = blockIdx.y, o = blockIdx.z;
     const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h, LD = KF + 1;
     const DgBlob L(a.KF, a.KD);
     const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w;
@@ -248,25 +240,91 @@ __global__ __launch_bounds__(256) void k_prep_dense_feats(const DgDenseFeatsArgs
         a.colpart[o][((size_t)n * h + y) * KF + k] = colred[k] + colred[KF + k] + colred[2 * KF + k] + colred[3 * KF + k];
 }
 
-hipError_t dg_launch_prep_dense_feats(const float* f0, const float* f1, char* blob0, char* blob1, float* cp0, float* cp1,
-                                      int B, int K, int KF, int KD, int h, int w, int P, int Ppad, hipStream_t s) {
-    DgDenseFeatsArgs a;
-    a.src[0] = f0; a.src[1] = f1; a.blob[0] = blob0; a.blob[1] = blob1; a.colpart[0] = cp0; a.colpart[1] = cp1;
-    a.B = B; a.K = K; a.KF = KF; a.KD = KD; a.h = h; a.w = w; a.P = P; a.Ppad = Ppad;
-    if (w > 32 || KF > 768) return hipErrorInvalidValue;
-    const int smem = max(w * (KF + 1), 4 * KF) * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_dense_feats), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+// Code operand on the identity grid: one block per tile of 32 positions p = i*S + j <- pixel (y = j, x = i) of the NCHW
+// code map; L2-normalise over the D channels (norm(), src/modules.py:789-790), write the C part (K-major granules), the
+// P part (position-major granules in dg_perm32 order) and 1/max(||c||, eps).  Same roundings as k_gather_norm.
+__device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int pt, int n, int o) {
+    const int tid = threadIdx.x, q = tid & 31, kk = tid >> 5;
+    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, LD = KD + 1;
+    float* xs = sl;                      // [32][KD + 1]
+    float* red = sl + 32 * LD;           // [8][32] partial sums of squares, then [32] 1/norm at red[256..]
+    const DgBlob L(a.KF, a.KD);
+    const int p = pt * 32 + q;
+    const bool valid = p < a.P;
+    const int i = p / S, j = p - i * S;
+    const float* src = a.code[o] + (size_t)n * D * HW + (valid ? j * a.w + i : 0);
+    {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = kk + 8 * u; t[u] = (valid && k < D) ? src[(size_t)k * HW] : 0.f; }
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int k = kk + 8 * u; if (k < KD) { xs[q * LD + k] = t[u]; ss = fmaf(t[u], t[u], ss); } }
+        red[kk * 32 + q] = ss;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ss += red[u * 32 + tid];
+        const float inv = (pt * 32 + tid) < a.P ? 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM) : 0.f;
+        red[256 + tid] = inv;
+        a.inv_norm[o][(size_t)n * a.Ppad + pt * 32 + tid] = inv;
+    }
+    __syncthreads();
+    char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
+    for (int id = tid; id < (KD / 8) * 32; id += 256) {       // C part: granule g of position qq
+        const int g = id >> 5, qq = id & 31;
+        const float inv = red[256 + qq];
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)(xs[qq * LD + 8 * g + e] * inv);
+        *reinterpret_cast<f16x8*>(blob + L.c(qq, g)) = v;
+    }
+    for (int id = tid; id < 4 * KD; id += 256) {              // P part: granule cc of channel d = slots 8cc .. 8cc+7
+        const int cc = id / KD, d = id - cc * KD;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pl = 16 * (cc >> 1) + 8 * ((e >> 2) & 1) + 4 * (cc & 1) + (e & 3);   // dg_perm32(pl) == 8 cc + e
+            v[e] = (_Float16)(xs[pl * LD + d] * red[256 + pl]);
+        }
+        *reinterpret_cast<f16x8*>(blob + L.p(d, cc)) = v;
+    }
+}
+
+__device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
+                                               int n, int H, int W, int S, int Ppad);
+
+// One launch prepares everything the fused kernel needs on the identity grid:
+//   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
+// grid (max(h, Ppad/32), B, 4 or 5), block 256, dynamic LDS max(w*(KF+1), 4*KF, 32*(KD+1) + 288) floats.
+__global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
+    extern __shared__ float sl[];
+    const int z = blockIdx.z, n = blockIdx.y;
+    if (z < 2) {
+        if ((int)blockIdx.x < a.h) prep_dense_feats(a, sl, blockIdx.x, n, z);
+    } else if (z < 4) {
+        if ((int)blockIdx.x < a.Ppad / 32) prep_dense_code(a, sl, blockIdx.x, n, z - 2);
+    } else if (blockIdx.x == 0) {
+        depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
+    }
+    if (blockIdx.x == 0 && z == 0 && threadIdx.x == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
+}
+
+hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
+    if (a.w > 32 || a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
+    const int nt = a.Ppad / 32, gx = max(a.h, nt);
+    const int smem = max(max(a.w * (a.KF + 1), 4 * a.KF), 32 * (a.KD + 1) + 288) * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_dense), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prep_dense_feats, dim3(h, B, 2), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(k_prep_dense, dim3(gx, a.B, a.depth ? 5 : 4), dim3(256), smem, s, a);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
 // depth (B,1,H,W) -> nz[n][p] over the S x S resize, p = i*S + j (row major)
-__global__ void k_depth_nz(const float* __restrict__ depth, float* __restrict__ nz, int B, int H, int W, int S, int Ppad) {
-    const int n = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Ppad) return;
+__device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, int n, int p, int H, int W, int S) {
     float out = 0.f;
     if (p < S * S) {
         const int i = p / S, j = p - i * S;
@@ -282,12 +340,33 @@ __global__ void k_depth_nz(const float* __restrict__ depth, float* __restrict__ 
         const float v = top * ly0 + bot * ly1;
         out = v / fmaxf(fabsf(v), DG_EPS_NORM);
     }
-    nz[(size_t)n * Ppad + p] = out;
+    return out;
 }
 
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, int B, int H, int W, int S, int Ppad, hipStream_t s) {
-    dim3 grid((Ppad + 127) / 128, B), block(128);
-    hipLaunchKernelGGL(k_depth_nz, grid, block, 0, s, depth, nz, B, H, W, S, Ppad);
+// all positions of image n by one block of 256 threads, plus their sum (mean(dd) = mean_n (sum_p nz)^2 / P^2)
+__device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
+                                               int n, int H, int W, int S, int Ppad) {
+    __shared__ float wred[4];
+    float s = 0.f;
+    for (int p = threadIdx.x; p < Ppad; p += 256) {
+        const float v = depth_nz_at(depth, n, p, H, W, S);
+        nz[(size_t)n * Ppad + p] = v;
+        s += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) nzsum[n] = wred[0] + wred[1] + wred[2] + wred[3];
+}
+
+__global__ __launch_bounds__(256) void k_depth_nz(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
+                                                  int H, int W, int S, int Ppad) {
+    depth_nz_image(depth, nz, nzsum, blockIdx.x, H, W, S, Ppad);
+}
+
+hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s) {
+    hipLaunchKernelGGL(k_depth_nz, dim3(B), dim3(256), 0, s, depth, nz, nzsum, H, W, S, Ppad);
     return hipGetLastError();
 }
 
@@ -298,8 +377,17 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
     const int n = blockIdx.x, o = blockIdx.y, nt = a.ngroups[o];
     const float invP = 1.f / (float)a.P;
     for (int k = threadIdx.x; k < a.KF; k += 256) {
+        const float* cp = a.colpart[o] + (size_t)n * nt * a.KF + k;
         float s = 0.f;
-        for (int t = 0; t < nt; ++t) s += a.colpart[o][((size_t)n * nt + t) * a.KF + k];
+        int t = 0;
+        for (; t + 8 <= nt; t += 8) {                // 8 independent loads in flight, summed in tile order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(t + u) * a.KF];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; t < nt; ++t) s += cp[(size_t)t * a.KF];
         a.bbar[o][(size_t)n * a.KF + k] = s * invP;
     }
 }
@@ -309,63 +397,72 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// r[n][p] = a[n][p] . bbar[n]; grid (nchunk, B, njobs), block 256: DG_RM_ROWS rows per block, one row per
-// wave step; lanes walk the 16-byte granule slots of the swizzled F rows.
-__global__ __launch_bounds__(256) void k_rowmean(const DgRowmeanArgs a) {
-    __shared__ float bbar[768];
-    __shared__ float wsum[4];
-    const int ch = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const DgRowmeanJob& J = a.jobs[blockIdx.z];
+// r[t][n][p] = a[n][p] . bbar_t[n] for all pair-sets t at once: one wave per operand-1 tile (32 positions) runs a
+// 32x32 MFMA chain over K with the tile's swizzled bf16 rows as A (read once for all pair-sets) and, as B, one column
+// per pair-set holding bbar split into two bf16 halves (columns t and 16 + t: hi + lo keeps ~16 mantissa bits, the
+// products with the bf16 rows are exact in the fp32 accumulator).  grid (Ppad/32, B), block 64.
+__global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
+    const int tile = blockIdx.x, n = blockIdx.y, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const int KF = a.KF, GF = KF / 8, nt = a.Ppad / 32;
     const DgBlob L(a.KF, a.KD);
-    const int na = J.aidx ? (int)J.aidx[n] : n;
+    const int jb = c & 15, lo = c >> 4;
+    const bool has = jb < a.njobs;
+    const DgRowmeanJob& J = a.jobs[has ? jb : 0];
     const int nb = J.bidx ? (int)J.bidx[n] : n;
-    for (int k = tid; k < KF; k += 256) bbar[k] = J.bbar[(size_t)nb * KF + k];
-    __syncthreads();
-    float tot = 0.f;
-    for (int pi = wid; pi < DG_RM_ROWS; pi += 4) {
-        const int p = ch * DG_RM_ROWS + pi;
-        if (p >= a.Ppad) break;
-        float d = 0.f;
-        if (p < a.P) {
-            const int q = p & 31;
-            const char* row = J.A + ((size_t)na * nt + (p >> 5)) * L.bytes + (size_t)q * GF * 16;
-            for (int slot = lane; slot < GF; slot += 64) {
-                const int g = slot ^ (q & 15);            // slot holds granule g (involution)
-                uint4 raw = *reinterpret_cast<const uint4*>(row + slot * 16);
-                const uint32_t wds[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float* bb = J.bbar + (size_t)nb * KF + 8 * h;
+    const char* row = a.jobs[0].A + ((size_t)n * nt + tile) * L.bytes + (size_t)c * GF * 16;   // A row q = c
+    f32x16 acc = {};
+    for (int ks0 = 0; ks0 < KF / 16; ks0 += 8) {     // KF / 16 is a multiple of 8 (KF in {128, 384, 768}); 24 loads in flight
+        bf16x8 af[8];
+        float4 b0[8], b1[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    d = fmaf(__uint_as_float(wds[e] << 16), bbar[8 * g + 2 * e], d);
-                    d = fmaf(__uint_as_float(wds[e] & 0xffff0000u), bbar[8 * g + 2 * e + 1], d);
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        for (int u = 0; u < 8; ++u) {
+            const int ks = ks0 + u;
+            af[u] = *reinterpret_cast<const bf16x8*>(row + (((2 * ks + h) ^ (c & 15)) * 16));
+            b0[u] = *reinterpret_cast<const float4*>(bb + 16 * ks);
+            b1[u] = *reinterpret_cast<const float4*>(bb + 16 * ks + 4);
         }
-        if (lane == 0) { J.rvec[(size_t)n * a.Ppad + p] = d; tot += d; }
-    }
-    if (lane == 0) wsum[wid] = tot;
-    __syncthreads();
-    if (tid == 0) J.rsum[(size_t)n * a.nchunk + ch] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// m0[t] = mean over valid (n, p) of rvec = the reference's fd.mean() before centering (fixed summation order)
-__global__ __launch_bounds__(256) void k_m0(const DgRowmeanArgs a) {
-    __shared__ float wsum[4];
-    const DgRowmeanJob& J = a.jobs[blockIdx.x];
-    const int tid = threadIdx.x, n = a.B * a.nchunk;
-    float s = 0.f;
-    for (int i = tid; i < n; i += 256) s += J.rsum[i];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((tid & 63) == 0) wsum[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) a.m0[blockIdx.x][0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / ((float)a.B * (float)a.P);
+        for (int u = 0; u < 8; ++u) {
+            const float bv[8] = {b0[u].x, b0[u].y, b0[u].z, b0[u].w, b1[u].x, b1[u].y, b1[u].z, b1[u].w};
+            bf16x8 bf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hi = (__bf16)bv[e];
+                bf[e] = !has ? (__bf16)0.f : (lo ? (__bf16)(bv[e] - (float)hi) : hi);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u], bf, acc, 0, 0, 0);
+        }
+    }
+    // lane (c, h) holds rows (i&3) + 8 (i>>2) + 4 h of column c; hi + lo columns are 16 lanes apart
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = acc[i] + __shfl(acc[i], (lane + 16) & 63, 64);
+        const int p = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float d = p < a.P ? v : 0.f;
+        if (has && !lo) J.rvec[(size_t)n * a.Ppad + p] = d;
+        tot += d;
+    }
+    tot += __shfl_xor(tot, 32, 64);
+    // per-image sums of the row means (the fused kernel adds the B of them up to m0 = the reference's fd.mean() before
+    // centering, src/modules.py:1237): per-tile sums are published, the last wave of the image (ticket zeroed by the
+    // operand-preparation kernel; nt waves per ticket) adds them in tile order
+    if (has && !lo && h == 0) dg_publish(J.rtile + (size_t)n * nt + tile, tot);
+    int last = 0;
+    if (lane == 0) last = atomicAdd(a.tickets + n, 1) == nt - 1;
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    if (has && !lo && h == 0) {
+        float s = 0.f;
+        for (int t = 0; t < nt; ++t) s += dg_read_published(J.rtile + (size_t)n * nt + t);
+        J.rimg[n] = s;
+    }
+    if (lane == 0) atomicExch(a.tickets + n, 0);
 }
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_rowmean, dim3(a.nchunk, a.B, a.njobs), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_m0, dim3(a.njobs), dim3(256), 0, s, a);
+    if (a.njobs > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32, a.B), dim3(64), 0, s, a);
     return hipGetLastError();
 }

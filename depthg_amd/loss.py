@@ -14,6 +14,8 @@ Extra, build-side cfg keys (all optional, read with getattr):
                     `.mean()` / logging keeps working) and nothing of size (B,P,P) ever reaches HBM.
     dg_dense_grid   True: with feature_samples == h == w use the identity grid for coords1 and
                     coords2 (SURVEY.md section 8(d) dense runs) instead of torch.rand.
+After a call, `.scalars` is the fused fp32 [8] output (DG_OUT_* order: the four loss means, then the four cd means)
+with its grad_fn, for callers that want the weighted total in one op instead of through the tuple elements.
 """
 import torch
 import torch.nn as nn
@@ -74,6 +76,7 @@ class ContrastiveCorrelationLoss(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
+        self._ident_cache = (None, None)
 
     # -- coordinate selection, src/modules.py:1287-1321 -------------------------------------------
     def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos):
@@ -94,7 +97,10 @@ class ContrastiveCorrelationLoss(nn.Module):
             assert tuple(c1.shape) == tuple(c2.shape) == tuple(coord_shape), f"{c1.shape} != {c2.shape} != {coord_shape}"
             return c1, c2, False
         if getattr(cfg, "dg_dense_grid", False) and S == orig_feats.shape[-2] == orig_feats.shape[-1]:
-            c = identity_coords(B, S, dev)
+            key = (B, S, str(dev))
+            if self._ident_cache[0] != key:          # constant tensor: built once per (B, S, device)
+                self._ident_cache = (key, identity_coords(B, S, dev))
+            c = self._ident_cache[1]
             return c, c, True
         c1 = torch.rand(coord_shape, device=dev) * 2 - 1
         c2 = torch.rand(coord_shape, device=dev) * 2 - 1
@@ -105,7 +111,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
                                                      depth, depth_pos)
         B = orig_feats.shape[0]
-        perms = super_perms(int(self.cfg.neg_samples), B, orig_feats.device)
+        perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device)   # dg_super_perms: rand + one kernel
         # `shared` is only ever set together with the identity grid drawn above
         return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
                                  shared_coords=shared, identity_grid=shared)
@@ -148,6 +154,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                                       coords1, coords2, perms_t, desc, holder)
         ws = holder["workspace"]
         self.last_scalars = out.detach()
+        self.scalars = out                     # the fused 8-vector with its grad_fn (DG_OUT_* order)
         self.last_call = (desc, perms_t, ws)   # measurement aid (bench.py re-launches the fused kernel alone)
 
         mode = getattr(cfg, "dg_outputs", "full")

@@ -100,6 +100,18 @@ def fps_coords(depth, feat_hw, n_samples, return_inds=False):
     return (coords, inds) if return_inds else coords
 
 
+def super_perms(count, size, device):
+    """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
+    lib = _lib.load()
+    out = torch.empty(count, size, dtype=torch.long, device=device)
+    if count == 0:
+        return out
+    keys = torch.rand(count, size, device=device)
+    rc = lib.dg_super_perms(_ptr(keys), int(count), int(size), _ptr(out), _stream(out.device))
+    _lib.check(rc, "dg_super_perms")
+    return out
+
+
 def corr_relaunch_main(desc, perms, workspace):
     """Measurement aid: launch only the fused correlation kernel again (operands already in `workspace`)."""
     lib = _lib.load()

@@ -147,6 +147,16 @@ int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_
                   void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
+ * Negative-pair batch permutations (replaces super_perm, src/modules.py:1184-1188, called n_neg times per step at
+ * :1336-1339): `count` independent uniform random permutations of 0..B-1 with fixed points bumped by one modulo B
+ * (quirk Q6: B == 1 gives [0]).  The randomness comes from the caller: `keys` holds count*B iid uniforms (torch.rand);
+ * row r of the result is the argsort of row r of the keys (ties by index), which is a uniform random permutation
+ * like torch.randperm.
+ *  keys : fp32 (count, B)      out : int64 (count, B)      B <= 8192
+ */
+int dg_super_perms(const float* keys, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+
+/*
  * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a
  * previous dg_corr_forward with the same desc / perms / workspace prepared.  Idempotent.
  */
