@@ -56,11 +56,18 @@ def synth_inputs(B, seed, device):
 
 
 def algorithmic_gflop(B, P, C, D, n_neg):
-    """one correlation = 2*B*P^2*K flop; recompute is not counted."""
+    """one correlation = 2*B*P^2*K flop (real K, no padding; nothing recomputed is counted).
+    Returns (step total, share done by the fused kernel k_corr_main, share done by k_gs):
+      forward   (2+n) feature correlations (K=C), (3+n) code correlations (K=D: the pair-sets + the depth term's cd),
+                1 rank-1 depth product (K=1)                                                   -> k_corr_main
+      backward  d/d(stationary code) for the (2+n) pair-sets + the depth term: (3+n) * K=D     -> k_corr_main
+                d/d(streamed code) for the (2+n) pair-sets: (2+n) * K=D                        -> k_gs
+                (the depth term is symmetric: its streamed side is the stationary side, counted once, doubled as a factor)"""
     corr = lambda k: 2.0 * B * P * P * k / 1e9
     fwd = (2 + n_neg) * corr(C) + (3 + n_neg) * corr(D) + corr(1)
-    bwd = 2 * (3 + n_neg) * corr(D)
-    return fwd, bwd
+    main = fwd + (3 + n_neg) * corr(D)
+    gs = (2 + n_neg) * corr(D)
+    return main + gs, main, gs
 
 
 def total_weights(cfg, device):
@@ -188,12 +195,22 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / reps
-    fwd_gf, bwd_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
-    achieved = (fwd_gf + bwd_gf) / 1e3 / (kern_ms / 1e3)   # TFLOP/s
+    step_gf, main_gf, gs_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
+    achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
+    # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 correction on gfx950, WRITE_SIZE),
+    # collected by scripts/profile_round.sh and committed under profiles/ (counters cannot be read from inside a run)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
+        for name, vals in pmc.items():
+            if "k_corr_main" in name and "hbm_traffic_bytes_per_launch" in vals:
+                traffic = float(vals["hbm_traffic_bytes_per_launch"])
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "kernel": "k_corr_main", "kernel_ms": round(kern_ms, 4),
-                "algorithmic_gflop_per_launch": round(fwd_gf + bwd_gf, 2)}
+                "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2)}
 
     if rank == 0:
         line = {

@@ -32,6 +32,7 @@ struct Plan {
     bool shared, depth, grad, pointwise, ident;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
+    size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rtile[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
     size_t nz, nzsum, tickets;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
@@ -75,6 +76,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.inv[i] = take(B * p.Ppad * 4);
         p.colpart[i] = take(B * (size_t)(p.ident ? p.h : p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
+        p.ccolpart[i] = take(B * (size_t)(p.Ppad / 32) * p.KD * 4);
+        p.csum[i] = take(B * p.KD * 4);
     }
     for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rtile[t] = take(B * (p.Ppad / 32) * 4); p.rimg[t] = take(B * 4); }
     p.nz = take(B * p.Ppad * 4);
@@ -119,6 +122,7 @@ static DgJob helper_job(const Plan& p, const dg_corr_desc* d, char* ws, int t, b
     if (!passB) {
         j.Rop = ws + p.op[0]; j.RcInv = F32(p.inv[0]); j.ridx = nullptr;
         j.Sop = ws + p.op[o2]; j.sidx = m2;
+        j.Scsum = F32(p.csum[o2]);
         j.center_on_lane = 1;
     } else {
         j.Rop = ws + p.op[o2]; j.RcInv = F32(p.inv[o2]); j.ridx = m2;
@@ -227,7 +231,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DgDenseArgs g;
         memset(&g, 0, sizeof(g));
         g.src[0] = orig_feats; g.src[1] = orig_feats_pos; g.code[0] = orig_code; g.code[1] = orig_code_pos;
-        for (int o = 0; o < 2; ++o) { g.blob[o] = ws + p.op[o]; g.colpart[o] = F32(p.colpart[o]); g.inv_norm[o] = F32(p.inv[o]); }
+        for (int o = 0; o < 2; ++o) { g.blob[o] = ws + p.op[o]; g.colpart[o] = F32(p.colpart[o]); g.inv_norm[o] = F32(p.inv[o]); g.ccolpart[o] = F32(p.ccolpart[o]); }
         g.depth = p.depth ? depth : nullptr; g.nz = F32(p.nz); g.nzsum = F32(p.nzsum);
         g.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
@@ -253,7 +257,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
             DgGatherJob& c = g.jobs[nj++];
             c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
-            c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = nullptr;
+            c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = F32(p.ccolpart[o]);
             c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
         }
         g.njobs = nj;
@@ -261,13 +265,20 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
     }
 
-    // 3. row means of fd (pointwise centering as a rank-1 correction)
-    if (p.pointwise) {
+    // 3. column sums of the operands (mean feats for the centering, code sums for the cd means), then the row means of
+    //    fd (pointwise centering as a rank-1 correction)
+    {
         DgColmeanArgs c;
         memset(&c, 0, sizeof(c));
-        c.nops = p.nops; c.B = p.B; c.P = p.P; c.Ppad = p.Ppad; c.KF = p.KF;
-        for (int o = 0; o < p.nops; ++o) { c.colpart[o] = F32(p.colpart[o]); c.bbar[o] = F32(p.bbar[o]); c.ngroups[o] = p.ident ? p.h : p.Ppad / 32; }
+        c.nops = p.nops; c.B = p.B; c.P = p.P; c.Ppad = p.Ppad; c.KF = p.KF; c.KD = p.KD;
+        for (int o = 0; o < p.nops; ++o) {
+            c.colpart[o] = p.pointwise ? F32(p.colpart[o]) : nullptr; c.bbar[o] = F32(p.bbar[o]);
+            c.ngroups[o] = p.ident ? p.h : p.Ppad / 32;
+            c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
+        }
         DG_HIP(dg_launch_colmean(c, stream));
+    }
+    if (p.pointwise) {
         DgRowmeanArgs r;
         memset(&r, 0, sizeof(r));
         r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
@@ -308,7 +319,8 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     DgScatterArgs s;
     memset(&s, 0, sizeof(s));
-    const float f = (float)(1.0 / ((double)p.B * p.P * p.P));
+    // the kernels keep -G (mask * (fd'' - shift)) and its products: the sign lives here
+    const float f = (float)(-1.0 / ((double)p.B * p.P * p.P));
     const float fn = p.N > 0 ? f / (float)p.N : 0.f;
     int n = 0;
     auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest, int raw) {

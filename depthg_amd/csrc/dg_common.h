@@ -114,6 +114,7 @@ struct DgJob {
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
     const float* nzS;
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
+    const float* Scsum;   // fp32 [B][KD] column sums (over positions) of the S operand's normalised code, or null
     const int64_t* ridx;  // batch index map of R operands (null = identity)
     const int64_t* sidx;  // batch index map of S operands (null = identity)
     float* dR;            // gradient tiles (dg_gtile_off): d/d(normalised R code), unit upstream, normalisation backward pending; or null
@@ -145,6 +146,7 @@ struct DgCorrArgs {
     int32_t* ticket;      // zero on entry (set by the operand-preparation kernel), reset by the last block; null: no finish
     const float* nzsum;   // [B] per-image sums of the depth indicators (mean(dd)) or null
     float* out_scalars;   // [DG_OUT_COUNT]
+    uint32_t* stamps;     // developer timing stamps (null in production)
 };
 
 // Cross-block hand-over without cache-wide fences (each XCD has its own L2): values are published with a returning
@@ -184,6 +186,7 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     char* blob[2];           // operand blobs 0, 1
     float* colpart[2];       // [B][h][KF] per-source-row column sums of the normalised feats
     float* inv_norm[2];      // [B][Ppad] 1/max(||code||, eps)
+    float* ccolpart[2];      // [B][Ppad/32][KD] per-tile column sums of the normalised code
     const float* depth;      // (B,1,dH,dW) or null
     float* nz;               // [B][Ppad] depth indicators
     float* nzsum;            // [B] their per-image sums
@@ -191,11 +194,13 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
 };
 
-struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_tiles colpart[o][n][tile][k]
-    const float* colpart[DG_MAX_NEG + 2];
+struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][group][k];  csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]
+    const float* colpart[DG_MAX_NEG + 2];   // feats partial column sums (null: skip)
     float* bbar[DG_MAX_NEG + 2];
-    int32_t ngroups[DG_MAX_NEG + 2];   // partial-sum groups per image (tiles, or source rows on the dense path)
-    int32_t nops, B, P, Ppad, KF;
+    const float* ccolpart[DG_MAX_NEG + 2];  // code partial column sums [B][Ppad/32][KD]
+    float* csum[DG_MAX_NEG + 2];            // [B][KD]
+    int32_t ngroups[DG_MAX_NEG + 2];   // feats partial-sum groups per image (tiles, or source rows on the dense path)
+    int32_t nops, B, P, Ppad, KF, KD;
 };
 
 struct DgRowmeanJob {

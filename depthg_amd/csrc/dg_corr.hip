@@ -18,6 +18,7 @@
 // depth_feature_correlation() :1256-1278 (job kind DG_JOB_DEPTH), norm() :789-790 (backward part).
 #include "dg_common.h"
 #include <cstdlib>
+#include <cstdio>
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -86,32 +87,43 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef DG_STAGGER
 #define DG_STAGGER 1
 #endif
+#ifndef DG_PRIO
+#define DG_PRIO 1  // static issue priority: 1 = the half that runs half a tile behind (waves 4-7), 2 = waves 0-3, 0 = none
+#endif
+#ifndef DG_TWOACC
+#define DG_TWOACC 0
+#endif
 #ifndef PF
 #define PF 6       // LDS fragment reads kept in flight per wave
 #endif
 
-// One accumulator element of a 32x32 tile: (fd, cd) -> loss term, G = dLoss/dcd.  vv = per-tile-row value
-// (row mean for KIND_ROW, depth indicator for KIND_DEPTH).
-template <int KIND, bool SIMPLE>
-__device__ __forceinline__ float epi_elem(float yf, float cdv, float vv, float c0, float c0_lane, float nz_lane,
+// One accumulator element of a 32x32 tile: (fd, cd) -> loss term and -G = -dLoss/dcd (the sign is folded into the
+// constant factors of the backward tail).  vv = per-tile-row value (row mean for KIND_ROW, depth indicator for
+// KIND_DEPTH).  KIND_LANE: the accumulator was started at c0_lane, so yf already is fd'' - shift.
+// FOLD (gradient pass of the zero_clamp / no stabalize case): the loss and cd sums are not accumulated per element -
+// with clamp(cd) = cd * mask they follow from the block's gradient accumulators (corr_body, "partial sums").
+template <int KIND, bool SIMPLE, bool FOLD>
+__device__ __forceinline__ float epi_elem(float yf, float cdv, float vv, float c0, float nz_lane,
                                           float lo, float hi, float& lsum, float& csum, float& li) {
     float fdv;
     if (KIND == KIND_DEPTH)     fdv = fmaf(nz_lane, vv, c0);
     else if (KIND == KIND_ROW)  fdv = yf + (c0 - vv);
-    else                        fdv = yf + c0_lane;
-    csum += cdv;
-    float gi;
+    else                        fdv = yf;
+    if (!FOLD) csum += cdv;
+    float gneg;
     if (SIMPLE) {                    // zero_clamp, no stabalize: clamp(cd) = cd * mask
-        gi = cdv >= 0.f ? -fdv : 0.f;
-        li = gi * cdv;               // = -clamp(cd) * (fd - shift)
-        lsum -= li;
+        gneg = cdv >= 0.f ? fdv : 0.f;
+        if (!FOLD) {
+            li = -gneg * cdv;        // = -clamp(cd) * (fd - shift)
+            lsum -= li;
+        }
     } else {
         const float cl = fminf(fmaxf(cdv, lo), hi);
         lsum = fmaf(cl, fdv, lsum);
-        gi = (cdv >= lo && cdv <= hi) ? -fdv : 0.f;
+        gneg = (cdv >= lo && cdv <= hi) ? fdv : 0.f;
         li = -cl * fdv;
     }
-    return gi;
+    return gneg;
 }
 
 // Final reduction of the per-block partial sums into the 8 output scalars, by one wave of the last block to retire:
@@ -162,6 +174,9 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     static_assert(!RCREG || RF == 1, "register-resident code rows only with one fragment per wave");
     constexpr bool GOUT = GRAD && KIND == KIND_LANE;     // pass-A helper jobs store their G tiles for k_gs
     constexpr bool STAG = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT;
+    // loss / cd sums from the gradient accumulators (see epi_elem).  Not for the depth term: its G takes two or three
+    // distinct values, so their fp16 rounding would be a bias (2e-4 relative) instead of noise.
+    constexpr bool FOLD = GRAD && SIMPLE && !MAT && KIND != KIND_DEPTH;
 
     // kernarg fields used inside the tile loop are copied to locals: behind the asm memory clobbers hipcc would re-load
     // them (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS read ring) in every iteration
@@ -174,6 +189,18 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const int r = lane & 31, h = lane >> 5;
     const int Ppad = args.Ppad, P = args.P;
     const int ntiles_all = Ppad >> 5;
+    // developer timing stamps (DG_STAMPS=<file>): phase times of one block, kept in LDS until the end
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RF * RCB) + NWAVES * 2 * 4);
+#ifdef DG_STAMP_BUILD      // make EXTRA=-DDG_STAMP_BUILD: instrumented build (perturbs the schedule slightly)
+    const bool stamping = args.stamps != nullptr && n == 0 && rb == 0 && KIND == KIND_LANE;
+    auto STAMP = [&](int t, int ph) {
+        if (stamping && lane == 0 && t < 25) st_lds[(wid * 25 + t) * 4 + ph] = (uint32_t)__builtin_readcyclecounter();
+    };
+#else
+    constexpr bool stamping = false;
+    auto STAMP = [&](int, int) {};
+    (void)st_lds;
+#endif
     const int ntiles = (dbg & 128) ? 1 : ntiles_all;     // developer ablation: one tile only (fixed per-block cost)
     const int nR = job.ridx ? (int)job.ridx[n] : n;
     const int nS = job.sidx ? (int)job.sidx[n] : n;
@@ -291,7 +318,14 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
                             : reinterpret_cast<const v4i*>(tile + BL::OFF_C + crow + (st - NSF) * 1024);
         };
-        Yf[f] = f32x16{}; Yc[f] = f32x16{};
+        Yc[f] = f32x16{};
+        if (KIND == KIND_LANE) {          // start the feature accumulator at c0_lane: fd'' - shift comes out of the chain
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Yf[f][i] = c0_lane[f];
+        } else {
+            Yf[f] = f32x16{};
+        }
+        f32x16 Yf2 = f32x16{};      // second feature accumulator: consecutive MFMAs do not wait for each other's result
         v4i ra[PF], rb[2];
 #pragma unroll
         for (int i = 0; i < PF; ++i) if (i < NS) ra[i] = *a_ptr(i);
@@ -304,7 +338,10 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         for (int st = 0; st < NS; ++st) {
             const v4i cur = ra[st % PF];
             if (st < NSF) {
-                Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
+                if (DG_TWOACC && (st & 1))
+                    Yf2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf2, 0, 0, 0);
+                else
+                    Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
             } else {
                 const int k = st - NSF;
                 const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
@@ -315,6 +352,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             between(st);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (DG_TWOACC && NSF > 1) Yf[f] += Yf2;
     };
 
     // ---- everything after the Y chains of tile t: epilogue (VALU) and the gradient MFMAs.  For RF == 2 the epilogue of
@@ -335,7 +373,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         f16x8 ga[RF][2];                   // G as the A operand of the gradient product: k-step sp holds elements 8sp..8sp+7
         auto epi = [&](int f, int i) {     // accumulator element i = (tile row (i&3)+8*(i>>2)+4*h, lane column r)
             float li;
-            ga[f][i >> 3][i & 7] = (_Float16)epi_elem<KIND, SIMPLE>(Yf[f][i], Yc[f][i], vv[i], c0, c0_lane[f], nz_lane[f], lo, hi, lsum, csum, li);
+            ga[f][i >> 3][i & 7] = (_Float16)epi_elem<KIND, SIMPLE, FOLD>(Yf[f][i], Yc[f][i], vv[i], c0, nz_lane[f], lo, hi, lsum, csum, li);
             if (MAT) {   // R = operand 2 on lanes -> stores contiguous along q
                 const int p = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (act[f] && pr[f] < P && p < P) {
@@ -396,18 +434,26 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         // epilogue runs under the other's MFMA chain instead of both alternating in lockstep behind the tile barrier.
         // Tile t-1 must stay in LDS during iteration t, so tiles are fetched one (not two) ahead.
         const bool late = wid >= NWAVES / 2;
+        {   // static priority (experiment bits: 32768 = none, 65536 = waves 0-3 instead)
+            const int prio_mode = (dbg & 32768) ? 0 : ((dbg & 65536) ? 2 : DG_PRIO);
+            if (prio_mode == 1 && late) __builtin_amdgcn_s_setprio(1);
+            if (prio_mode == 2 && !late) __builtin_amdgcn_s_setprio(1);
+        }
         issue(0, 0);
         settle_R();
         auto top = [&](int t) {          // identical in both halves: same barriers, same DMA issue points
+            STAMP(t, 0);
             wait_vmcnt(nst);             // tile t landed; only the G stores of the previous tile may still be in flight
             if (!(dbg & 256)) __builtin_amdgcn_s_barrier();
+            STAMP(t, 1);
             if (t + 1 < ntiles && !(dbg & 1)) issue(t + 1, (t + 1) % 3);
+            STAMP(t, 2);
         };
         if (!late) {
             for (int t = 0; t < ntiles; ++t) {
                 top(t);
                 const char* tile = smem + (t % 3) * BUF;
-                if (wave_active) { chain(tile, 0, [](int) {}); post(tile, t, false); }
+                if (wave_active) { chain(tile, 0, [](int) {}); STAMP(t, 3); post(tile, t, false); }
             }
         } else {
             top(0);
@@ -416,6 +462,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 top(t);
                 if (wave_active) {
                     post(smem + ((t - 1) % 3) * BUF, t - 1, false);
+                    STAMP(t, 3);
                     chain(smem + (t % 3) * BUF, 0, [](int) {});
                 }
             }
@@ -442,6 +489,30 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     // ---- partial sums of this block (deterministic two-level reduction; finished by k_corr_finish)
     // (rows of an inactive second fragment are all-zero operands? no: they are clamped copies -> excluded here)
     float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RF * RCB));
+    if (FOLD) {
+        // clamp(cd) = cd * mask, so with G' = mask * (fd'' - shift):
+        //   sum_pq clamp(cd) (fd'' - shift) = sum_pq G'_pq <x_p, y_q> = sum_p <x_p, dR'_p>      (dR' = the gradient accumulators)
+        //   sum_pq cd_pq                    = sum_p <x_p, sum_q y_q>                              (column sums of the streamed code)
+        // x_p = this wave's stationary code rows (LDS or registers), dR[f][d][i] = (row (i&3)+8*(i>>2)+4*h, channel 32 d + r)
+        lsum = 0.f; csum = 0.f;
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            if (!act[f]) continue;
+            const char* xb = RCREG ? Rblob[f] + BL::OFF_C : rc_lds + f * RCB;
+            float cs[NDF];
+#pragma unroll
+            for (int d = 0; d < NDF; ++d) cs[d] = (KIND != KIND_DEPTH && job.Scsum) ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
+#pragma unroll
+            for (int d = 0; d < NDF; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
+                    const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
+                    lsum = fmaf(x, dR[f][d][i], lsum);
+                    csum = fmaf(x, cs[d], csum);
+                }
+        }
+    }
     lsum = wave_sum(lsum);
     csum = wave_sum(csum);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
@@ -464,6 +535,10 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         if (last) finish_scalars(args, lane);     // every block has published its partial sums: reduce them (wave 0)
     }
 
+    if (stamping) {
+        __syncthreads();
+        for (int i = tid; i < NWAVES * 100; i += NWAVES * 64) args.stamps[i] = st_lds[i];
+    }
     // ---- store the RAW gradient w.r.t. the normalised stationary code in accumulator order
     //      [image][R tile][channel group d][i>>2][lane][i&3] (16 bytes per lane and store, 1 KiB per wave instruction).
     //      The normalisation backward is linear with the same x for every pair-set whose stationary operand is operand 1,
@@ -683,7 +758,23 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     const int grid = args.njobs * args.B * args.nrb;
     DgCorrArgs a2 = args;
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only, results invalid)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem, stream, a2);
+    const char* stamp_file = getenv("DG_STAMPS");                     // developer aid: phase time stamps of one block
+    static uint32_t* stamp_buf = nullptr;
+    int smem2 = smem;
+    if (stamp_file && smem + NWAVES * 400 <= 160 * 1024) {
+        if (!stamp_buf && hipMalloc(&stamp_buf, NWAVES * 400) != hipSuccess) stamp_buf = nullptr;
+        if (stamp_buf) {
+            a2.stamps = stamp_buf; smem2 = smem + NWAVES * 400;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem2, stream, a2);
+    if (a2.stamps) {
+        uint32_t host[8 * 100];
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, NWAVES * 400, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, NWAVES * 100, fp); fclose(fp); }
+        }
+    }
     return hipGetLastError();
 }
 

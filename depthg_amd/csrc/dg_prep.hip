@@ -281,6 +281,12 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
         for (int e = 0; e < 8; ++e) v[e] = (_Float16)(xs[qq * LD + 8 * g + e] * inv);
         *reinterpret_cast<f16x8*>(blob + L.c(qq, g)) = v;
     }
+    for (int d = tid; d < KD; d += 256) {                     // per-tile column sums (for the cd means)
+        float cs = 0.f;
+#pragma unroll 8
+        for (int qq = 0; qq < 32; ++qq) cs += xs[qq * LD + d] * red[256 + qq];
+        a.ccolpart[o][((size_t)n * (a.Ppad / 32) + pt) * KD + d] = cs;
+    }
     for (int id = tid; id < 4 * KD; id += 256) {              // P part: granule cc of channel d = slots 8cc .. 8cc+7
         const int cc = id / KD, d = id - cc * KD;
         f16x8 v;
@@ -374,22 +380,25 @@ hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B
 
 // bbar[o][n][k] = (1/P) sum over tiles of the per-tile column sums.  grid (B, nops), block 256.
 __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
-    const int n = blockIdx.x, o = blockIdx.y, nt = a.ngroups[o];
-    const float invP = 1.f / (float)a.P;
-    for (int k = threadIdx.x; k < a.KF; k += 256) {
-        const float* cp = a.colpart[o] + (size_t)n * nt * a.KF + k;
-        float s = 0.f;
-        int t = 0;
-        for (; t + 8 <= nt; t += 8) {                // 8 independent loads in flight, summed in tile order
-            float v[8];
+    const int n = blockIdx.x, o = blockIdx.y;
+    auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) {
+        for (int k = threadIdx.x; k < K; k += 256) {
+            const float* cp = part + (size_t)n * ngroups * K + k;
+            float s = 0.f;
+            int t = 0;
+            for (; t + 8 <= ngroups; t += 8) {            // 8 independent loads in flight, summed in group order
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(t + u) * a.KF];
+                for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(t + u) * K];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; t < ngroups; ++t) s += cp[(size_t)t * K];
+            out[(size_t)n * K + k] = s * scale;
         }
-        for (; t < nt; ++t) s += cp[(size_t)t * a.KF];
-        a.bbar[o][(size_t)n * a.KF + k] = s * invP;
-    }
+    };
+    if (a.colpart[o]) reduce(a.colpart[o], a.ngroups[o], a.KF, 1.f / (float)a.P, a.bbar[o]);
+    if (a.ccolpart[o]) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
 }
 
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {

@@ -86,7 +86,10 @@ def test_reduced_outputs_match_full(dev):
     fx = load_golden("forward_c1_none.npz")
     _, out_f, total_f, g_f, gp_f = _run_fixture(fx, dev)
     _, out_r, total_r, g_r, gp_r = _run_fixture(fx, dev, dg_outputs="reduced")
-    assert float(total_f) == pytest.approx(float(total_r), rel=1e-6)
+    # "full" takes the negative term from the materialised fp32 tensor, "reduced" from the fused sums (which, on the
+    # gradient pass, come out of the fp16-rounded G accumulators): same quantity along two routes, O(1e-2) terms that
+    # nearly cancel in this fixture's total
+    assert float(total_f) == pytest.approx(float(total_r), rel=2e-4, abs=1e-7)
     # LDS float atomics in the scatter make the last bits order-dependent
     assert torch.allclose(g_f, g_r, rtol=1e-4, atol=1e-9) and torch.allclose(gp_f, gp_r, rtol=1e-4, atol=1e-9)
     assert out_r[4].numel() == 1 and float(out_r[1]) == pytest.approx(float(out_f[1].mean()), rel=1e-4)
