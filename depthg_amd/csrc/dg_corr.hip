@@ -134,6 +134,7 @@ __device__ __forceinline__ void finish_scalars(const DgCorrArgs& args, int lane)
 #pragma unroll
     for (int i = 0; i < DG_OUT_COUNT; ++i) acc[i] = 0.0;
     const int nblk = args.B * args.nrb;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // nothing stale from this CU's L1 (the loads below are sc1 as well)
     for (int j = 0; j < args.njobs; ++j) {
         const DgJob& J = args.jobs[j];
         if (!J.part) continue;

@@ -462,6 +462,7 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
     if (lane == 0) last = atomicAdd(a.tickets + n, 1) == nt - 1;
     last = __shfl(last, 0, 64);
     if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (has && !lo && h == 0) {
         float s = 0.f;
         for (int t = 0; t < nt; ++t) s += dg_read_published(J.rtile + (size_t)n * nt + t);
