@@ -192,6 +192,7 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     float* nzsum;            // [B] their per-image sums
     int32_t* tickets;        // [B + 1] completion counters of k_rowmean (per image) / k_corr_main, zeroed here
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
+    int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
 };
 
 struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][group][k];  csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]

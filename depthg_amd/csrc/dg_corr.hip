@@ -617,8 +617,10 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     static_assert(GS_NB - 2 <= 4 && 4 * CH < 64, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char gs_smem[];   // [GS_NB][PB] ring, [GS_CW][32*TS] scratch
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    const int n = blockIdx.y;
-    const DgGsJob& J = a.jobs[blockIdx.z];
+    // the fused kernel wrote the G tiles image-major in ascending image order: walk the images in descending order (and all
+    // pair-sets of an image together) so that the most recently written tiles are read first, while the Infinity Cache has them
+    const int n = a.B - 1 - (int)blockIdx.z;
+    const DgGsJob& J = a.jobs[blockIdx.y];
     const int ntS = a.Ppad >> 5;
     const int nt = (a.debug & 4096) ? 1 : ntS;              // (ablation: one R tile only)
     const int nR = J.ridx ? (int)J.ridx[n] : n;
@@ -731,7 +733,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
-    dim3 grid((a.Ppad / 32 + GS_CW - 1) / GS_CW, a.B, a.njobs), block((GS_CW + 1) * 64);
+    dim3 grid((a.Ppad / 32 + GS_CW - 1) / GS_CW, a.njobs, a.B), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;

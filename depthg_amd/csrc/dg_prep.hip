@@ -8,6 +8,7 @@
 //   k_rowmean        r[n][p] = a[n][p] . mean_q b[n][q]   (row means of fd for `pointwise`,
 //                    src/modules.py:1236-1239 restated as a rank-1 term)
 #include "dg_common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
 __global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int K, int HW, int K4) {
@@ -162,61 +163,53 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 // (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
 // grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
 __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int n, int o) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h, LD = KF + 1;
+    // thread (x = tid & 31, k0 = tid >> 5) owns pixel x of the row and the channels k0 + 8u: all of them are loaded in one
+    // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a pixel through LDS,
+    // and only the NORMALISED bf16 row tile goes to LDS (half the bytes of an fp32 stage -> twice the blocks per CU).
+    const int tid = threadIdx.x, x = tid & 31, k0 = tid >> 5;
+    const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h;
+    const int RS = KF * 2 + 8;                      // LDS row stride in bytes: 8-byte aligned rows, 2-way writes at worst
     const DgBlob L(a.KF, a.KD);
-    const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w;
-    // load: channel k, pixel x  (x fastest: w contiguous floats per channel)
-    {
-        constexpr int UN = 12;                      // independent loads in flight per thread
-        const int x = tid & 31, k0 = tid >> 5;      // 8 channels per sweep of the block
-        for (int kb = k0; kb < KF; kb += 8 * UN) {
-            float t[UN];
+    const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w + x;
+    char* tb = reinterpret_cast<char*>(sl);         // [w][RS] bf16 rows
+    float* red = reinterpret_cast<float*>(tb + 32 * RS);   // [8][32] partial squared norms
+    constexpr int MAXU = 96;                        // KF <= 768
+    const int nu = KF >> 3;
+    float t[MAXU];
+    float ss = 0.f;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = kb + 8 * u;
-                t[u] = (x < w && k < K) ? src[(size_t)k * h * w + x] : 0.f;
-            }
+    for (int u = 0; u < MAXU; ++u) {
+        const int k = k0 + 8 * u;
+        t[u] = (u < nu && x < w && k < K) ? src[(size_t)k * h * w] : 0.f;
+    }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = kb + 8 * u;
-                if (x < w && k < KF) sl[x * LD + k] = t[u];
-            }
-        }
+    for (int u = 0; u < MAXU; ++u) ss = fmaf(t[u], t[u], ss);
+    red[k0 * 32 + x] = ss;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += red[j * 32 + x];
+    const float inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
+    if (x < w) {
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u)
+            if (u < nu) *reinterpret_cast<__bf16*>(tb + x * RS + (k0 + 8 * u) * 2) = (__bf16)(t[u] * inv);
     }
     __syncthreads();
-    // one wave per position x: normalise over channels, write the blob row, accumulate column sums
-    float colacc[3][4];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) colacc[m][0] = colacc[m][1] = colacc[m][2] = colacc[m][3] = 0.f;
-    for (int x = wid; x < w; x += 4) {
-        const float* row = sl + x * LD;
-        float v[3][4];
-        float ss = 0.f;
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = 4 * lane + 256 * m + e;
-                v[m][e] = k < KF ? row[k] : 0.f;
-                ss = fmaf(v[m][e], v[m][e], ss);
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        const float inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
-        const int p = x * S + y;                        // sample() output position (i, j) = (x, y)
+    // blob rows: position p = x*S + y (sample() output (i, j) = (x, y)); 8-byte pieces, the lanes of a row run along K
+    const int pieces = KF / 4;                      // 8-byte pieces per row
+    for (int id = tid; id < w * pieces; id += 256) {
+        const int xx = id / pieces, pc = id - xx * pieces, k = 4 * pc;
+        const uint2 v = *reinterpret_cast<const uint2*>(tb + xx * RS + k * 2);
+        const int p = xx * S + y;
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
-        const int q = p & 31;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const int k = 4 * lane + 256 * m;
-            if (k < KF) {
-                bf16x4 t;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float u = v[m][e] * inv; colacc[m][e] += u; t[e] = (__bf16)u; }
-                *reinterpret_cast<uint2*>(blob + L.f(q, k >> 3) + (k & 7) * 2) = *reinterpret_cast<uint2*>(&t);
-            }
-        }
+        *reinterpret_cast<uint2*>(blob + L.f(p & 31, k >> 3) + (k & 7) * 2) = v;
+    }
+    // per-source-row column sums of the normalised (bf16-rounded, i.e. exactly what the MFMA sees) rows
+    for (int k = tid; k < KF; k += 256) {
+        float cs = 0.f;
+        for (int xx = 0; xx < w; ++xx) cs += (float)*reinterpret_cast<const __bf16*>(tb + xx * RS + k * 2);
+        a.colpart[o][((size_t)n * h + y) * KF + k] = cs;
     }
     // zero rows of the ragged last tile (positions P .. Ppad-1), once per image
     if (y == 0) {
@@ -226,76 +219,80 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
             *reinterpret_cast<uint2*>(blob + L.f(p & 31, k >> 3) + (k & 7) * 2) = make_uint2(0u, 0u);
         }
     }
-    __syncthreads();
-    float* colred = sl;                              // reuse: [4][KF]
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 4 * lane + 256 * m + e;
-            if (k < KF) colred[wid * KF + k] = colacc[m][e];
-        }
-    __syncthreads();
-    for (int k = tid; k < KF; k += 256)
-        a.colpart[o][((size_t)n * h + y) * KF + k] = colred[k] + colred[KF + k] + colred[2 * KF + k] + colred[3 * KF + k];
 }
 
-// Code operand on the identity grid: one block per tile of 32 positions p = i*S + j <- pixel (y = j, x = i) of the NCHW
-// code map; L2-normalise over the D channels (norm(), src/modules.py:789-790), write the C part (K-major granules), the
-// P part (position-major granules in dg_perm32 order) and 1/max(||c||, eps).  Same roundings as k_gather_norm.
-__device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int pt, int n, int o) {
-    const int tid = threadIdx.x, q = tid & 31, kk = tid >> 5;
-    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, LD = KD + 1;
-    float* xs = sl;                      // [32][KD + 1]
-    float* red = sl + 32 * LD;           // [8][32] partial sums of squares, then [32] 1/norm at red[256..]
+// Code operand on the identity grid: one block per DENSE_TPB consecutive tiles (position p = i*S + j <- pixel (y = j, x = i)
+// of the NCHW code map, so a run of positions is a run of source COLUMNS: the block reads, per channel and source row, the
+// few-pixel run of its columns).  L2-normalise over the D channels (norm(), src/modules.py:789-790), write the C part
+// (K-major granules), the P part (position-major granules in dg_perm32 order), 1/max(||c||, eps) and the per-tile column
+// sums.  Same roundings as k_gather_norm.
+#define DENSE_TPB 3
+__device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int tb, int n, int o) {
+    const int tid = threadIdx.x;
+    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, LD = KD + 1, nt = a.Ppad / 32;
+    const int t0 = tb * DENSE_TPB, ntile = min(DENSE_TPB, nt - t0);
+    const int p0 = t0 * 32, np = ntile * 32, pend = min(p0 + np, a.P);
+    const int xa = p0 / S, NC = (pend - 1) / S - xa + 1;
+    float* xs = sl;                      // [np][KD + 1]
+    float* inv = sl + DENSE_TPB * 32 * LD;
     const DgBlob L(a.KF, a.KD);
-    const int p = pt * 32 + q;
-    const bool valid = p < a.P;
-    const int i = p / S, j = p - i * S;
-    const float* src = a.code[o] + (size_t)n * D * HW + (valid ? j * a.w + i : 0);
-    {
-        float t[16];
+    // zero what the loads below do not write: channels D..KD-1 and the positions P..Ppad-1 of the ragged last tile
+    for (int id = tid; id < np * (KD - D); id += 256) { const int pos = id / (KD - D), c = id - pos * (KD - D); xs[pos * LD + D + c] = 0.f; }
+    for (int id = tid; id < (p0 + np - pend) * D; id += 256) { const int pos = pend - p0 + id / D, c = id % D; xs[pos * LD + c] = 0.f; }
+    const float* src = a.code[o] + (size_t)n * D * HW;
+    // one (source row y, column xl) pair per thread (one integer division per thread, none per load), channels in batches
+    constexpr int UN = 14;
+    for (int pair = tid; pair < S * NC; pair += 256) {
+        const int y = pair / NC, xl = pair - y * NC;
+        const int pp = (xa + xl) * S + y;
+        if (pp < p0 || pp >= pend) continue;
+        const float* sp = src + y * a.w + xa + xl;
+        float* dp = xs + (pp - p0) * LD;
+        for (int kb = 0; kb < D; kb += UN) {
+            float t[UN];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int k = kk + 8 * u; t[u] = (valid && k < D) ? src[(size_t)k * HW] : 0.f; }
-        float ss = 0.f;
+            for (int u = 0; u < UN; ++u) t[u] = kb + u < D ? sp[(size_t)(kb + u) * HW] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int k = kk + 8 * u; if (k < KD) { xs[q * LD + k] = t[u]; ss = fmaf(t[u], t[u], ss); } }
-        red[kk * 32 + q] = ss;
+            for (int u = 0; u < UN; ++u) if (kb + u < D) dp[kb + u] = t[u];
+        }
     }
     __syncthreads();
-    if (tid < 32) {
+    for (int pos = tid; pos < np; pos += 256) {
         float ss = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ss += red[u * 32 + tid];
-        const float inv = (pt * 32 + tid) < a.P ? 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM) : 0.f;
-        red[256 + tid] = inv;
-        a.inv_norm[o][(size_t)n * a.Ppad + pt * 32 + tid] = inv;
+#pragma unroll 10
+        for (int k = 0; k < D; ++k) ss = fmaf(xs[pos * LD + k], xs[pos * LD + k], ss);
+        const float iv = (p0 + pos) < a.P ? 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM) : 0.f;
+        inv[pos] = iv;
+        a.inv_norm[o][(size_t)n * a.Ppad + p0 + pos] = iv;
     }
     __syncthreads();
-    char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
-    for (int id = tid; id < (KD / 8) * 32; id += 256) {       // C part: granule g of position qq
-        const int g = id >> 5, qq = id & 31;
-        const float inv = red[256 + qq];
+    char* blob0 = a.blob[o] + ((size_t)n * nt + t0) * L.bytes;
+    const int GD = KD / 8;
+    for (int id = tid; id < ntile * GD * 32; id += 256) {     // C part: granule g of position qq of tile tl
+        const int tl = id / (GD * 32), rem = id - tl * (GD * 32), g = rem >> 5, qq = rem & 31;
+        const float* row = xs + (tl * 32 + qq) * LD + 8 * g;
+        const float iv = inv[tl * 32 + qq];
         f16x8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (_Float16)(xs[qq * LD + 8 * g + e] * inv);
-        *reinterpret_cast<f16x8*>(blob + L.c(qq, g)) = v;
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)(row[e] * iv);
+        *reinterpret_cast<f16x8*>(blob0 + (size_t)tl * L.bytes + L.c(qq, g)) = v;
     }
-    for (int d = tid; d < KD; d += 256) {                     // per-tile column sums (for the cd means)
-        float cs = 0.f;
-#pragma unroll 8
-        for (int qq = 0; qq < 32; ++qq) cs += xs[qq * LD + d] * red[256 + qq];
-        a.ccolpart[o][((size_t)n * (a.Ppad / 32) + pt) * KD + d] = cs;
-    }
-    for (int id = tid; id < 4 * KD; id += 256) {              // P part: granule cc of channel d = slots 8cc .. 8cc+7
-        const int cc = id / KD, d = id - cc * KD;
+    for (int id = tid; id < ntile * 4 * KD; id += 256) {      // P part: granule cc of channel d = slots 8cc .. 8cc+7
+        const int tl = id / (4 * KD), rem = id - tl * (4 * KD), cc = rem / KD, d = rem - cc * KD;
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int pl = 16 * (cc >> 1) + 8 * ((e >> 2) & 1) + 4 * (cc & 1) + (e & 3);   // dg_perm32(pl) == 8 cc + e
-            v[e] = (_Float16)(xs[pl * LD + d] * red[256 + pl]);
+            v[e] = (_Float16)(xs[(tl * 32 + pl) * LD + d] * inv[tl * 32 + pl]);
         }
-        *reinterpret_cast<f16x8*>(blob + L.p(d, cc)) = v;
+        *reinterpret_cast<f16x8*>(blob0 + (size_t)tl * L.bytes + L.p(d, cc)) = v;
+    }
+    for (int id = tid; id < ntile * KD; id += 256) {          // per-tile column sums (for the cd means)
+        const int tl = id / KD, d = id - tl * KD;
+        float cs = 0.f;
+#pragma unroll 8
+        for (int qq = 0; qq < 32; ++qq) cs += xs[(tl * 32 + qq) * LD + d] * inv[tl * 32 + qq];
+        a.ccolpart[o][((size_t)n * nt + t0 + tl) * KD + d] = cs;
     }
 }
 
@@ -304,27 +301,40 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
-// grid (max(h, Ppad/32), B, 4 or 5), block 256, dynamic LDS max(w*(KF+1), 4*KF, 32*(KD+1) + 288) floats.
+// grid h * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
 __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     extern __shared__ float sl[];
-    const int z = blockIdx.z, n = blockIdx.y;
+    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): consecutive logical ids - the source rows of one
+    // image, which share 128-byte lines of the NCHW map - get one XCD, so a line is fetched into one L2 once
+    int bid;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    }
+    const int gx = a.h;                                  // (>= the code role's ceil(tiles / DENSE_TPB) blocks: launcher)
+    const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
+    const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
     if (z < 2) {
-        if ((int)blockIdx.x < a.h) prep_dense_feats(a, sl, blockIdx.x, n, z);
+        if (x < a.h && !(a.debug & 1)) prep_dense_feats(a, sl, x, n, z);
     } else if (z < 4) {
-        if ((int)blockIdx.x < a.Ppad / 32) prep_dense_code(a, sl, blockIdx.x, n, z - 2);
-    } else if (blockIdx.x == 0) {
+        if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code(a, sl, x, n, z - 2);
+    } else if (x == 0 && !(a.debug & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
     }
-    if (blockIdx.x == 0 && z == 0 && threadIdx.x == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
+    if (x == 0 && z == 0 && threadIdx.x == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
 }
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.w > 32 || a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
-    const int nt = a.Ppad / 32, gx = max(a.h, nt);
-    const int smem = max(max(a.w * (a.KF + 1), 4 * a.KF), 32 * (a.KD + 1) + 288) * 4;
+    const int nt = a.Ppad / 32, gx = a.h;
+    if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
+    const int smem = max(32 * (a.KF * 2 + 8) + 8 * 32 * 4, DENSE_TPB * 32 * (a.KD + 2) * 4);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_dense), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prep_dense, dim3(gx, a.B, a.depth ? 5 : 4), dim3(256), smem, s, a);
+    DgDenseArgs a2 = a;
+    if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
+    hipLaunchKernelGGL(k_prep_dense, dim3(gx * a.B * (a.depth ? 5 : 4)), dim3(256), smem, s, a2);
     return hipGetLastError();
 }
 
