@@ -285,17 +285,17 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     auto issue = [&](int t, int b) {
         const char* src = Sbase + (size_t)t * BL::BYTES;
         const uint32_t dst = smem_a + b * BUF;
-        // every wave issues the same number of pieces (a ragged tail re-fetches the last piece: same bytes, same
-        // place), so the counted wait below is a compile-time constant
+        // chunk c goes to wave NWAVES-1 - c % NWAVES (a ragged remainder lands on the waves that run half a tile behind);
+        // the counted waits below use this wave's own number of pieces (my_dma)
 #pragma unroll
         for (int k = 0; k < PIECES; ++k) {
-            const int c = min(C_BEGIN + wid + k * NWAVES, C_END - 1);
-            dma16(src + c * 1024, dst + c * 1024);
+            const int c = C_BEGIN + (NWAVES - 1 - wid) + k * NWAVES;
+            if (c < C_END) dma16(src + c * 1024, dst + c * 1024);
         }
         if (KIND != KIND_LANE)     // 32 floats of the tile rows; all waves write the same bytes (lanes 32-63: a copy behind)
             dma4(vsrc + t * 32 + (lane & 31), dst + BL::BYTES);
     };
-    constexpr int my_dma = PIECES + (KIND != KIND_LANE ? 1 : 0);   // DMA instructions per wave and tile
+    const int my_dma = (C_END - C_BEGIN - (NWAVES - 1 - wid) + NWAVES - 1) / NWAVES + (KIND != KIND_LANE ? 1 : 0);   // DMA instructions of this wave per tile
 
     f32x16 dR[RF][NDF];
 #pragma unroll
@@ -314,6 +314,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     // ---- one Y chain = NSF feature k-steps then NKD code k-steps.  The A operands (S fragments) run through an
     //      explicit ring of PF registers that is refilled right after each MFMA, so that PF LDS reads are always in
     //      flight; scheduling fences pin that order (left alone hipcc serialises read -> wait -> MFMA here).
+    const int late_prio = (STAG && DG_PRIO == 1 && wid >= NWAVES / 2 && !(dbg & 32768)) ? 1 : 0;   // priority outside the chain
     auto chain = [&](const char* tile, const int f, auto&& between) {
         auto a_ptr = [&](int st) -> const v4i* {
             return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
@@ -335,6 +336,9 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             for (int k = 0; k < 2; ++k) rb[k] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + k * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // the wave in its MFMA chain wins the issue port: an MFMA needs it 8 cycles in 32, the partner's epilogue VALU
+        // stream would otherwise starve the matrix pipe (stamps: iteration 4410 -> 4070 cycles)
+        if (STAG && !(dbg & 131072)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             const v4i cur = ra[st % PF];
@@ -353,6 +357,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             between(st);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (STAG && !(dbg & 131072)) { if (late_prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if (DG_TWOACC && NSF > 1) Yf[f] += Yf2;
     };
 
