@@ -290,3 +290,41 @@ def test_super_perms_kernel(dev):
     assert p.shape == (5, 32) and int(p.min()) >= 0 and int(p.max()) < 32
     assert not bool((p == torch.arange(32, device=dev)).any())          # no image is its own negative
     assert ops.super_perms(0, 4, dev).shape == (0, 4)
+
+
+@pytest.mark.parametrize("B,C,D,hw,N,ident", [(1, 64, 16, 8, 2, True),      # B=1: super_perm(1) == [0], the image is its own negative (quirk Q6)
+                                              (3, 64, 24, 7, 1, True),      # one negative
+                                              (2, 128, 70, 9, 1, True),     # odd map size, P = 81 (ragged last tile)
+                                              (3, 64, 24, 7, 1, False),     # same through the general gather path
+                                              (5, 96, 33, 6, 3, True)])     # P = 36: one full + one ragged tile, odd batch
+def test_edge_shapes_dense_and_general(B, C, D, hw, N, ident, dev):
+    """Small / degenerate shapes against the CPU oracle on the identity grid (S == h == w): dense NCHW path
+    (DG_IDENTITY_GRID) and the general gather path must both reproduce the reference's arithmetic."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(7 + 13 * B + hw)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 5 * hw, 5 * hw), generator=g).float()
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    coords = O.identity_coords(B, hw)
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dg_outputs="reduced")
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=coords, coords2=coords, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    pt = torch.stack(perms).to(dev) if N > 0 else torch.zeros(0, B, dtype=torch.long, device=dev)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), coords.to(dev), coords.to(dev),
+                                                       pt, shared_coords=ident, identity_grid=ident)
+    O.total_loss(cfg, out).backward()
+    # (neg_samples == 0 is not a case: the reference itself raises on the empty torch.cat, src/modules.py:1341)
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 2e-3, 1e-5, f"tuple[{i}]")
+    for i in (1, 3, 5, 7):
+        _relclose(out[i].mean(), ref[i].mean(), 2e-3, 1e-5, f"tuple[{i}] mean")
+    for got, want in ((cg.grad, cr.grad), (cpg.grad, cpr.grad)):
+        if float(want.norm()) == 0.0:
+            assert float(got.norm()) == 0.0
+            continue
+        rel = (got.cpu() - want).norm() / want.norm()
+        assert rel < 3e-2, float(rel)
