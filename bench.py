@@ -70,14 +70,6 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     return main + gs, main, gs
 
 
-def total_weights(cfg, device):
-    """Weights of the four loss means in the training total (reference src/train_segmentation.py:303-312), in the
-    order of the fused output vector: intra, inter, neg, depth."""
-    w = torch.tensor([cfg.pos_intra_weight, cfg.pos_inter_weight, cfg.neg_inter_weight, cfg.depth_feat_weight],
-                     dtype=torch.float32)
-    return (w * cfg.correspondence_weight).to(device)
-
-
 def cpu_baseline(seconds_budget=15.0):
     """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the headline
     workload: same C, D, S, pair-sets and backward, smaller batch; scaled to steps/s of the full batch."""
@@ -137,6 +129,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from depthg_amd import ContrastiveCorrelationLoss, ops
+    from depthg_amd.training import correspondence_weights
     from depthg_amd.parallel import GradBucket
 
     H = HEADLINE
@@ -146,7 +139,8 @@ def main():
     c.requires_grad_(True)
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
-    wvec = total_weights(cfg, dev)
+    # weights of the four loss means in the training total (depthg_amd.training, reference src/train_segmentation.py:330-333)
+    wvec = correspondence_weights(cfg, True, dev)
 
     def step():
         c.grad = None

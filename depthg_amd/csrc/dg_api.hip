@@ -33,7 +33,7 @@ struct Plan {
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
     size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2];
-    size_t rvec[DG_MAX_NEG + 2], rtile[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
+    size_t rvec[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
     size_t nz, nzsum, tickets;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
@@ -79,10 +79,10 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.ccolpart[i] = take(B * (size_t)(p.Ppad / 32) * p.KD * 4);
         p.csum[i] = take(B * p.KD * 4);
     }
-    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rtile[t] = take(B * (p.Ppad / 32) * 4); p.rimg[t] = take(B * 4); }
+    for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rimg[t] = take(B * 4); }
     p.nz = take(B * p.Ppad * 4);
     p.nzsum = take(B * 4);
-    p.tickets = take((B + 1) * 4);
+    p.tickets = take(4);
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
@@ -177,7 +177,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     corr_args_base(p, desc, ws, a);
     const double numel = (double)p.B * p.P * p.P;
-    a.ticket = reinterpret_cast<int32_t*>(ws + p.tickets) + p.B;
+    a.ticket = reinterpret_cast<int32_t*>(ws + p.tickets);
     a.nzsum = p.depth ? F32(p.nzsum) : nullptr;
     a.out_scalars = F32(p.scratch_out);        // the caller points this at its output
     int nj = 0;
@@ -281,11 +281,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     if (p.pointwise) {
         DgRowmeanArgs r;
         memset(&r, 0, sizeof(r));
-        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
+        r.B = p.B; r.P = p.P; r.Ppad = p.Ppad; r.KF = p.KF; r.KD = p.KD; r.njobs = p.T; r.abar = F32(p.bbar[0]);
         for (int t = 0; t < p.T; ++t) {
             r.jobs[t].A = ws + p.op[0]; r.jobs[t].aidx = nullptr;
             r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
-            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rtile = F32(p.rtile[t]); r.jobs[t].rimg = F32(p.rimg[t]);
+            r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rimg = F32(p.rimg[t]);
         }
         DG_HIP(dg_launch_rowmean(r, stream));
     }

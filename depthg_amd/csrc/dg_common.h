@@ -175,7 +175,7 @@ struct DgGatherJob {
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
-    int32_t* tickets;        // [B + 1] completion counters of k_rowmean (per image) / k_corr_main, zeroed here
+    int32_t* tickets;        // [1] completion counter of k_corr_main, zeroed here
     DgGatherJob jobs[DG_MAX_GATHER];
     int32_t njobs, B, h, w, S, P, Ppad, KF, KD;
 };
@@ -190,7 +190,7 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     const float* depth;      // (B,1,dH,dW) or null
     float* nz;               // [B][Ppad] depth indicators
     float* nzsum;            // [B] their per-image sums
-    int32_t* tickets;        // [B + 1] completion counters of k_rowmean (per image) / k_corr_main, zeroed here
+    int32_t* tickets;        // [1] completion counter of k_corr_main, zeroed here
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
     int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
 };
@@ -210,13 +210,12 @@ struct DgRowmeanJob {
     const int64_t* aidx;      // batch maps (null = identity)
     const int64_t* bidx;
     float* rvec;              // [B][Ppad]
-    float* rtile;             // [B][Ppad/32] per-tile sums of rvec (scratch)
     float* rimg;              // [B] per-image sums of rvec
 };
 struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
-    int32_t* tickets;            // [B] completion counters per image (zero on entry, reset by the last wave)
+    const float* abar;           // [B][KF] mean normalised feats of operand 1
 };
 
 struct DgScatterSrc {

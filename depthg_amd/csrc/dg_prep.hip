@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
     const DgGatherJob& J = a.jobs[blockIdx.z];
-    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) a.tickets[0] = 0;
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const float* img = J.src + (size_t)ns * a.h * a.w * K4;
@@ -105,10 +105,11 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             const int k = 4 * lane + 256 * m;
             if (k < Kpad) {
                 float4 u = make_float4(v[m].x * inv, v[m].y * inv, v[m].z * inv, v[m].w * inv);
-                colacc[m][0] += u.x; colacc[m][1] += u.y; colacc[m][2] += u.z; colacc[m][3] += u.w;
                 uint2 o;
+                // column sums of the ROUNDED values: exactly what the MFMAs see (row means, cd means stay consistent)
                 if (J.is_code) {
                     f16x4 t; t[0] = (_Float16)u.x; t[1] = (_Float16)u.y; t[2] = (_Float16)u.z; t[3] = (_Float16)u.w;
+                    colacc[m][0] += (float)t[0]; colacc[m][1] += (float)t[1]; colacc[m][2] += (float)t[2]; colacc[m][3] += (float)t[3];
                     o = *reinterpret_cast<uint2*>(&t);
                     *reinterpret_cast<uint2*>(blob + L.c(pi, k >> 3) + (k & 7) * 2) = o;
                     const int pp = dg_perm32(pi);
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
                     for (int e = 0; e < 4; ++e) ptile[(k + e) * 32 + pp] = ob[e];
                 } else {
                     bf16x4 t; t[0] = (__bf16)u.x; t[1] = (__bf16)u.y; t[2] = (__bf16)u.z; t[3] = (__bf16)u.w;
+                    colacc[m][0] += (float)t[0]; colacc[m][1] += (float)t[1]; colacc[m][2] += (float)t[2]; colacc[m][3] += (float)t[3];
                     o = *reinterpret_cast<uint2*>(&t);
                     *reinterpret_cast<uint2*>(blob + L.f(pi, k >> 3) + (k & 7) * 2) = o;
                 }
@@ -291,7 +293,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
         const int tl = id / KD, d = id - tl * KD;
         float cs = 0.f;
 #pragma unroll 8
-        for (int qq = 0; qq < 32; ++qq) cs += xs[(tl * 32 + qq) * LD + d] * inv[tl * 32 + qq];
+        for (int qq = 0; qq < 32; ++qq) cs += (float)(_Float16)(xs[(tl * 32 + qq) * LD + d] * inv[tl * 32 + qq]);
         a.ccolpart[o][((size_t)n * nt + t0 + tl) * KD + d] = cs;
     }
 }
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     } else if (x == 0 && !(a.debug & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
     }
-    if (x == 0 && z == 0 && threadIdx.x == 0) { a.tickets[n] = 0; if (n == 0) a.tickets[a.B] = 0; }
+    if (x == 0 && z == 0 && n == 0 && threadIdx.x == 0) a.tickets[0] = 0;
 }
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
@@ -454,31 +456,28 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
         }
     }
     // lane (c, h) holds rows (i&3) + 8 (i>>2) + 4 h of column c; hi + lo columns are 16 lanes apart
-    float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const float v = acc[i] + __shfl(acc[i], (lane + 16) & 63, 64);
         const int p = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const float d = p < a.P ? v : 0.f;
-        if (has && !lo) J.rvec[(size_t)n * a.Ppad + p] = d;
-        tot += d;
+        if (has && !lo) J.rvec[(size_t)n * a.Ppad + p] = p < a.P ? v : 0.f;
     }
-    tot += __shfl_xor(tot, 32, 64);
     // per-image sums of the row means (the fused kernel adds the B of them up to m0 = the reference's fd.mean() before
-    // centering, src/modules.py:1237): per-tile sums are published, the last wave of the image (ticket zeroed by the
-    // operand-preparation kernel; nt waves per ticket) adds them in tile order
-    if (has && !lo && h == 0) dg_publish(J.rtile + (size_t)n * nt + tile, tot);
-    int last = 0;
-    if (lane == 0) last = atomicAdd(a.tickets + n, 1) == nt - 1;
-    last = __shfl(last, 0, 64);
-    if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (has && !lo && h == 0) {
+    // centering, src/modules.py:1237): sum_p a_p . bbar = P * abar . bbar, one K-long dot per pair-set, by the image's first wave
+    if (tile != 0) return;
+    float av[12];                                   // KF <= 768: 12 values per lane
+#pragma unroll
+    for (int j = 0; j < 12; ++j) av[j] = lane + 64 * j < KF ? a.abar[(size_t)n * KF + lane + 64 * j] : 0.f;
+    for (int t = 0; t < a.njobs; ++t) {
+        const DgRowmeanJob& Jt = a.jobs[t];
+        const float* bt = Jt.bbar + (size_t)(Jt.bidx ? (int)Jt.bidx[n] : n) * KF;
         float s = 0.f;
-        for (int t = 0; t < nt; ++t) s += dg_read_published(J.rtile + (size_t)n * nt + t);
-        J.rimg[n] = s;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) s = fmaf(av[j], lane + 64 * j < KF ? bt[lane + 64 * j] : 0.f, s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) Jt.rimg[n] = s * (float)a.P;
     }
-    if (lane == 0) atomicExch(a.tickets + n, 0);
 }
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {

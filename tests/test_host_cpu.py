@@ -125,3 +125,50 @@ def test_shard_range_covers_batch():
         spans = [shard_range(gb, world, r) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == gb
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_correspondence_total_matches_fixture_totals():
+    """depthg_amd.training.correspondence_total (row A13, src/train_segmentation.py:303-350) on the golden tuples:
+    the fixture's `total` was computed by the fixture generator from the reference's own tuple."""
+    import torch
+    from conftest import FORWARD_CASES, cfg_from_fixture, load_golden
+    from depthg_amd.training import correspondence_total, correspondence_weights
+    from oracle import depthg_oracle as O
+    T = torch.from_numpy
+    for case in FORWARD_CASES[:6]:
+        fx = load_golden(f"forward_{case}.npz")
+        cfg = cfg_from_fixture(fx)
+        out = O.forward(cfg, T(fx["feats"]), T(fx["feats_pos"]), T(fx["code"]), T(fx["code_pos"]), T(fx["depth"]),
+                        T(fx["depth"]), coords1=T(fx["coords1"]), coords2=T(fx["coords2"]), perms=list(T(fx["perms"])))
+        total, logs = correspondence_total(cfg, out)
+        assert float(total) == pytest.approx(float(fx["total"]), rel=1e-5, abs=1e-8)
+        want_keys = {"loss/pos_intra", "loss/pos_inter", "loss/neg_inter", "cd/pos_intra", "cd/pos_inter", "cd/neg_inter"}
+        if cfg.depth_feat_correlation_loss:
+            want_keys |= {"loss/depth_feat", "cd/depth_feat"}
+        assert set(logs) == want_keys
+        assert float(logs["loss/pos_intra"]) == pytest.approx(float(fx["pos_intra_loss"]), rel=1e-5, abs=1e-8)
+        # the fused-vector weights give the same total
+        depth = bool(cfg.depth_feat_correlation_loss)
+        vec = torch.stack([out[0].mean(), out[2].mean(), out[4].mean(), out[6].mean() if depth else torch.zeros(())])
+        assert float(torch.dot(vec, correspondence_weights(cfg, depth, "cpu"))) == pytest.approx(float(total), rel=1e-6, abs=1e-9)
+
+
+def test_correspondence_total_lhp_and_balance():
+    import torch
+    from types import SimpleNamespace
+    from depthg_amd.training import correspondence_total
+    cfg = SimpleNamespace(pos_intra_weight=0.5, pos_inter_weight=0.25, neg_inter_weight=0.75, depth_feat_weight=0.2,
+                          correspondence_weight=1.0, depth_feat_correlation_loss=True, lhp=True, lhp_weight=0.3,
+                          lhp_weight_balance=True, lhp_depth_weight=0.5)
+    s = lambda v: torch.tensor(float(v))
+    out = (s(1), s(0), s(2), s(0), torch.tensor([3.0, 5.0]), s(0), s(6), s(0))
+    lhp = (s(10), s(0), s(20), s(0), torch.tensor([30.0, 50.0]), s(0), s(60), s(0))
+    total, _ = correspondence_total(cfg, out, lhp)
+    base = (0.25 * 2 + 0.5 * 1 + 0.75 * 4 + 0.2 * 6) * (1.0 - 0.3)
+    extra = (0.25 * 20 + 0.5 * 10 + 0.75 * 40 + 0.2 * 0.5 * 60) * 0.3
+    assert float(total) == pytest.approx(base + extra, rel=1e-6)
+    with pytest.raises(ValueError):
+        correspondence_total(cfg, out)                     # lhp set, second tuple missing
+    cfg.depth_feat_correlation_loss = False
+    with pytest.raises(ValueError):
+        correspondence_total(cfg, out)                     # 8-tuple without the depth term configured
