@@ -414,7 +414,7 @@ extern "C" int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int
     if (!depth || !out_coords) return fail(DG_ERR_INVALID, "null pointer");
     if (B < 1 || h < 1 || w < 1 || S < 1 || depth_h < h || depth_w < w) return fail(DG_ERR_INVALID, "bad FPS dimensions");
     if (S * S > h * w) return fail(DG_ERR_INVALID, "cannot sample %d points from a %dx%d map", S * S, h, w);
-    if ((size_t)h * w * 20 > 150 * 1024) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the LDS sampler", h, w);
+    if ((size_t)h * w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the sampler (max 4096 pixels)", h, w);
     // 2*tan(fov/2) with fov = 90 taken in radians (reference quirk, src/modules.py:989,1016), float32 bits
     const uint32_t bits = 0x404f54cbu;
     float factor;

@@ -411,11 +411,10 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
                                                             int32_t* __restrict__ out_inds) {
     extern __shared__ float sm[];
     const int HW = h * w, nsel = S * S;
-    float* px = sm; float* py = px + HW; float* pz = py + HW; float* dist = pz + HW;
-    int* sel = reinterpret_cast<int*>(dist + HW);          // 1 when selected
-    __shared__ float rv[FPS_THREADS / 64];
-    __shared__ int ri[FPS_THREADS / 64];
-    __shared__ int s_last;
+    float* px = sm; float* py = px + HW; float* pz = py + HW;
+    int* sel = reinterpret_cast<int*>(pz + HW);            // 1 when selected
+    __shared__ float rv[2 * FPS_THREADS / 64];
+    __shared__ int ri[2 * FPS_THREADS / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const float* d = depth + (size_t)n * H * W;
     // adaptive_avg_pool2d + depth2points
@@ -423,49 +422,74 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
         const int i = idx / w, j = idx - i * w;
         const int ys = (i * H) / h, ye = ((i + 1) * H + h - 1) / h;
         const int xs = (j * W) / w, xe = ((j + 1) * W + w - 1) / w;
-        float s = 0.f;
-        for (int y = ys; y < ye; ++y)
-            for (int x = xs; x < xe; ++x) s = __fadd_rn(s, d[(size_t)y * W + x]);
+        float s = 0.f;                                   // row-major sequential sum (the reference's CPU order), loads batched
+        for (int y = ys; y < ye; ++y) {
+            const float* row = d + (size_t)y * W;
+            for (int x = xs; x < xe; x += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = x + u < xe ? row[x + u] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (x + u < xe) s = __fadd_rn(s, t[u]);
+            }
+        }
         const float dv = __fdiv_rn(s, (float)((ye - ys) * (xe - xs)));
         const float fd = __fmul_rn(factor, dv);
         py[idx] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)i, (float)h / 2.0f)), (float)h);
         px[idx] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)j, (float)w / 2.0f)), (float)w);
         pz[idx] = __fmul_rn(-dv, 5.0f);
-        dist[idx] = __builtin_inff();
         sel[idx] = 0;
     }
-    if (tid == 0) { s_last = 0; if (out_inds) out_inds[(size_t)n * nsel] = 0; }
+    if (tid == 0 && out_inds) out_inds[(size_t)n * nsel] = 0;
     __syncthreads();
+    // Rounds: every thread keeps its points (idx = tid + FPS_THREADS*k), their running distances and a "taken" mask in
+    // registers; one barrier per round: the waves publish their arg-max in slots that alternate with the round parity, every
+    // thread combines the four results itself (lowest index wins ties, as numpy's first-max over the ascending remainder).
+    constexpr int NPT = 16;                              // points per thread: h*w <= 4096
+    float qx[NPT], qy[NPT], qz[NPT], qd[NPT];
+    uint32_t taken = 0;
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const int idx = tid + FPS_THREADS * k;
+        const bool in = idx < HW;
+        qx[k] = in ? px[idx] : 0.f; qy[k] = in ? py[idx] : 0.f; qz[k] = in ? pz[idx] : 0.f;
+        qd[k] = __builtin_inff();
+        if (!in) taken |= 1u << k;
+    }
+    if (tid == 0) taken |= 1u;                           // point 0 starts the selection
     if (tid == 0) sel[0] = 1;
-    __syncthreads();
+    int last = 0;
     for (int it = 1; it < nsel; ++it) {
-        const int last = s_last;
         const float lx = px[last], ly = py[last], lz = pz[last];
         float bv = -1.f; int bi = 0x7fffffff;
-        for (int idx = tid; idx < HW; idx += FPS_THREADS) {
-            if (sel[idx]) continue;
-            const float dx = __fsub_rn(lx, px[idx]), dy = __fsub_rn(ly, py[idx]), dz = __fsub_rn(lz, pz[idx]);
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            if (FPS_THREADS * k >= HW) break;            // uniform
+            const float dx = __fsub_rn(lx, qx[k]), dy = __fsub_rn(ly, qy[k]), dz = __fsub_rn(lz, qz[k]);
             const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            const float nd = fminf(dd, dist[idx]);
-            dist[idx] = nd;
-            if (nd > bv) { bv = nd; bi = idx; }      // ascending idx per thread -> first max kept
+            const bool live = !((taken >> k) & 1u);
+            const float nd = fminf(dd, qd[k]);
+            if (live) qd[k] = nd;
+            if (live && nd > bv) { bv = nd; bi = tid + FPS_THREADS * k; }      // ascending idx per thread -> first max kept
         }
-        // block argmax with lowest-index tie-break
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        if ((tid & 63) == 0) { rv[tid >> 6] = bv; ri[tid >> 6] = bi; }
+        const int par = (it & 1) * (FPS_THREADS / 64);
+        if ((tid & 63) == 0) { rv[par + (tid >> 6)] = bv; ri[par + (tid >> 6)] = bi; }
         __syncthreads();
-        if (tid == 0) {
-            float v = rv[0]; int i0 = ri[0];
-            for (int k = 1; k < FPS_THREADS / 64; ++k)
-                if (rv[k] > v || (rv[k] == v && ri[k] < i0)) { v = rv[k]; i0 = ri[k]; }
-            s_last = i0; sel[i0] = 1;
-            if (out_inds) out_inds[(size_t)n * nsel + it] = i0;
+        float v = rv[par]; int i0 = ri[par];
+#pragma unroll
+        for (int k = 1; k < FPS_THREADS / 64; ++k) {
+            const float ov = rv[par + k]; const int oi = ri[par + k];
+            if (ov > v || (ov == v && oi < i0)) { v = ov; i0 = oi; }
         }
-        __syncthreads();
+        last = i0;
+        if ((i0 & (FPS_THREADS - 1)) == tid) { taken |= 1u << (i0 / FPS_THREADS); sel[i0] = 1; }
+        if (tid == 0 && out_inds) out_inds[(size_t)n * nsel + it] = i0;
     }
+    __syncthreads();
     // selected set in row-major order -> coords (row/h, col/w)*2-1
     for (int idx = tid; idx < HW; idx += FPS_THREADS) {
         if (!sel[idx]) continue;
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
 
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s) {
-    const int smem = h * w * 5 * 4;
+    const int smem = h * w * 4 * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fps_coords), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_fps_coords, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
