@@ -140,13 +140,13 @@ def main():
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
     # weights of the four loss means in the training total (depthg_amd.training, reference src/train_segmentation.py:330-333)
-    wvec = correspondence_weights(cfg, True, dev)
+    wvec = correspondence_weights(cfg, True, dev, full=True)
 
     def step():
         c.grad = None
         cp.grad = None
         loss_fn(f, fp, None, None, c, cp, d, dp)
-        total = torch.dot(loss_fn.scalars[:4], wvec)      # the weighted total of the four loss means, one op
+        total = torch.dot(loss_fn.scalars, wvec)          # the weighted total of the four loss means, one op
         total.backward()
         if world > 1:
             # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size

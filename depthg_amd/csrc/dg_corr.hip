@@ -624,8 +624,18 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     // the fused kernel wrote the G tiles image-major in ascending image order: walk the images in descending order (and all
     // pair-sets of an image together) so that the most recently written tiles are read first, while the Infinity Cache has them
-    const int n = a.B - 1 - (int)blockIdx.z;
-    const DgGsJob& J = a.jobs[blockIdx.y];
+    // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): the blocks of one image - they all read the same R
+    // operand - get consecutive logical ids on one XCD, so its P parts are fetched into one L2 once
+    int bid;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    }
+    const int nbx = (a.Ppad / 32 + GS_CW - 1) / GS_CW;
+    const int bx = bid % nbx, by = (bid / nbx) % a.njobs, bz = bid / (nbx * a.njobs);
+    const int n = a.B - 1 - bz;
+    const DgGsJob& J = a.jobs[by];
     const int ntS = a.Ppad >> 5;
     const int nt = (a.debug & 4096) ? 1 : ntS;              // (ablation: one R tile only)
     const int nR = J.ridx ? (int)J.ridx[n] : n;
@@ -647,7 +657,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
         }
         return;
     }
-    const int st = blockIdx.x * GS_CW + wid;                // S tile of this wave
+    const int st = bx * GS_CW + wid;                        // S tile of this wave
     if (st >= ntS) {                                        // nothing to do but keep the barrier count
         for (int rt = 0; rt < nt; ++rt) __builtin_amdgcn_s_barrier();
         return;
@@ -738,7 +748,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
-    dim3 grid((a.Ppad / 32 + GS_CW - 1) / GS_CW, a.njobs, a.B), block((GS_CW + 1) * 64);
+    dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;

@@ -53,11 +53,13 @@ def correspondence_total(cfg, out: Sequence[torch.Tensor], lhp_out: Optional[Seq
     return total, logs
 
 
-def correspondence_weights(cfg, depth: bool, device) -> torch.Tensor:
-    """fp32 [4] weights of (intra, inter, neg, depth) loss means in the total, in the order of the fused output vector."""
+def correspondence_weights(cfg, depth: bool, device, full: bool = False) -> torch.Tensor:
+    """fp32 [4] weights of (intra, inter, neg, depth) loss means in the total, in the order of the fused output vector;
+    `full`: [8], zero-padded over the four cd means, so that `dot(loss_fn.scalars, w)` needs no slice (and its backward
+    no zero-fill + copy)."""
     scale = (cfg.correspondence_weight - _balance(cfg)) if depth else cfg.correspondence_weight
     w = torch.tensor([cfg.pos_intra_weight, cfg.pos_inter_weight, cfg.neg_inter_weight,
-                      cfg.depth_feat_weight if depth else 0.0], dtype=torch.float32)
+                      cfg.depth_feat_weight if depth else 0.0] + ([0.0] * 4 if full else []), dtype=torch.float32)
     return (w * scale).to(device)
 
 
