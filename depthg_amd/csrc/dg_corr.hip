@@ -447,19 +447,23 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         }
         issue(0, 0);
         settle_R();
-        auto top = [&](int t) {          // identical in both halves: same barriers, same DMA issue points
+        auto top = [&](int t) {          // same barrier sequence in both halves
             STAMP(t, 0);
             wait_vmcnt(nst);             // tile t landed; only the G stores of the previous tile may still be in flight
             if (!(dbg & 256)) __builtin_amdgcn_s_barrier();
             STAMP(t, 1);
-            if (t + 1 < ntiles && !(dbg & 1)) issue(t + 1, (t + 1) % 3);
+            // waves 4-7 fetch the next tile here; waves 0-3 do it after their chain (the issue of 4-5 LDS-DMA pieces costs
+            // 400-600 cycles in front of the chain, but hides beside the partner's chain) - bit 524288 switches that off
+            if (t + 1 < ntiles && !(dbg & 1) && (late || (dbg & 524288))) issue(t + 1, (t + 1) % 3);
             STAMP(t, 2);
         };
         if (!late) {
             for (int t = 0; t < ntiles; ++t) {
                 top(t);
                 const char* tile = smem + (t % 3) * BUF;
-                if (wave_active) { chain(tile, 0, [](int) {}); STAMP(t, 3); post(tile, t, false); }
+                if (wave_active) { chain(tile, 0, [](int) {}); STAMP(t, 3); }
+                if (t + 1 < ntiles && !(dbg & 1) && !(dbg & 524288)) issue(t + 1, (t + 1) % 3);
+                if (wave_active) post(tile, t, false);
             }
         } else {
             top(0);
