@@ -228,7 +228,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
 // few-pixel run of its columns).  L2-normalise over the D channels (norm(), src/modules.py:789-790), write the C part
 // (K-major granules), the P part (position-major granules in dg_perm32 order), 1/max(||c||, eps) and the per-tile column
 // sums.  Same roundings as k_gather_norm.
-#define DENSE_TPB 3
+#define DENSE_TPB 1
 __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int tb, int n, int o) {
     const int tid = threadIdx.x;
     const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, LD = KD + 1, nt = a.Ppad / 32;
@@ -242,20 +242,22 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
     for (int id = tid; id < np * (KD - D); id += 256) { const int pos = id / (KD - D), c = id - pos * (KD - D); xs[pos * LD + D + c] = 0.f; }
     for (int id = tid; id < (p0 + np - pend) * D; id += 256) { const int pos = pend - p0 + id / D, c = id % D; xs[pos * LD + c] = 0.f; }
     const float* src = a.code[o] + (size_t)n * D * HW;
-    // one (source row y, column xl) pair per thread (one integer division per thread, none per load), channels in batches
-    constexpr int UN = 14;
-    for (int pair = tid; pair < S * NC; pair += 256) {
+    // lanes walk the (source row y, column xl) pairs, the four waves split the channels (k = wave + 4u): one integer
+    // division per pair, none per load, and all loads of a thread in flight at once
+    constexpr int UN = 18;                               // one batch for D <= 72
+    const int kg = tid >> 6;
+    for (int pair = tid & 63; pair < S * NC; pair += 64) {
         const int y = pair / NC, xl = pair - y * NC;
         const int pp = (xa + xl) * S + y;
         if (pp < p0 || pp >= pend) continue;
         const float* sp = src + y * a.w + xa + xl;
         float* dp = xs + (pp - p0) * LD;
-        for (int kb = 0; kb < D; kb += UN) {
+        for (int kb = kg; kb < D; kb += 4 * UN) {
             float t[UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) t[u] = kb + u < D ? sp[(size_t)(kb + u) * HW] : 0.f;
+            for (int u = 0; u < UN; ++u) t[u] = kb + 4 * u < D ? sp[(size_t)(kb + 4 * u) * HW] : 0.f;
 #pragma unroll
-            for (int u = 0; u < UN; ++u) if (kb + u < D) dp[kb + u] = t[u];
+            for (int u = 0; u < UN; ++u) if (kb + 4 * u < D) dp[kb + 4 * u] = t[u];
         }
     }
     __syncthreads();
