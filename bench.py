@@ -129,7 +129,6 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from depthg_amd import ContrastiveCorrelationLoss, ops
-    from depthg_amd.training import correspondence_weights
     from depthg_amd.parallel import GradBucket
 
     H = HEADLINE
@@ -139,14 +138,12 @@ def main():
     c.requires_grad_(True)
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
-    # weights of the four loss means in the training total (depthg_amd.training, reference src/train_segmentation.py:330-333)
-    wvec = correspondence_weights(cfg, True, dev, full=True)
 
     def step():
         c.grad = None
         cp.grad = None
         loss_fn(f, fp, None, None, c, cp, d, dp)
-        total = torch.dot(loss_fn.scalars, wvec)          # the weighted total of the four loss means, one op
+        total = loss_fn.total          # weighted total of the four loss means (training_step's term), formed by the library
         total.backward()
         if world > 1:
             # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size

@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdepthg_hip.so")
 
-DG_OUT_COUNT = 8
+DG_OUT_COUNT = 9
+DG_OUT_TOTAL = 8
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID = \
     (1 << i for i in range(7))
 
@@ -20,7 +21,9 @@ class CorrDesc(ctypes.Structure):
                 ("w", ctypes.c_int32), ("S", ctypes.c_int32), ("n_neg", ctypes.c_int32),
                 ("depth_h", ctypes.c_int32), ("depth_w", ctypes.c_int32), ("flags", ctypes.c_uint32),
                 ("shift_intra", ctypes.c_float), ("shift_inter", ctypes.c_float), ("shift_neg", ctypes.c_float),
-                ("shift_depth", ctypes.c_float)]
+                ("shift_depth", ctypes.c_float),
+                ("w_intra", ctypes.c_float), ("w_inter", ctypes.c_float), ("w_neg", ctypes.c_float),
+                ("w_depth", ctypes.c_float)]
 
 
 _lib = None

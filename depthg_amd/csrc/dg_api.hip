@@ -180,6 +180,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     a.ticket = reinterpret_cast<int32_t*>(ws + p.tickets);
     a.nzsum = p.depth ? F32(p.nzsum) : nullptr;
     a.out_scalars = F32(p.scratch_out);        // the caller points this at its output
+    a.wtot[0] = desc->w_intra; a.wtot[1] = desc->w_inter; a.wtot[2] = desc->w_neg; a.wtot[3] = desc->w_depth;
     int nj = 0;
     for (int t = 0; t < p.T; ++t) {
         DgJob j = helper_job(p, desc, ws, t, false, perms);
@@ -340,6 +341,7 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0, 1);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
     s.nsrc = n;
     s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
+    s.wtot[0] = desc->w_intra; s.wtot[1] = desc->w_inter; s.wtot[2] = desc->w_neg; s.wtot[3] = desc->w_depth;
     s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
     s.taps = ws + p.taps;
     {

@@ -146,6 +146,7 @@ struct DgCorrArgs {
     int32_t* ticket;      // zero on entry (set by the operand-preparation kernel), reset by the last block; null: no finish
     const float* nzsum;   // [B] per-image sums of the depth indicators (mean(dd)) or null
     float* out_scalars;   // [DG_OUT_COUNT]
+    float wtot[4];        // weights of the four loss means in out_scalars[DG_OUT_TOTAL]
     uint32_t* stamps;     // developer timing stamps (null in production)
 };
 
@@ -234,7 +235,8 @@ struct DgScatterArgs {
     int32_t nsrc;
     const float* coords1;
     const float* coords2;
-    const float* gscal;    // [4] upstream gradients (device)
+    const float* gscal;    // [DG_OUT_COUNT] upstream gradient of the output vector (device); see dg_gscal
+    float wtot[4];         // weights of the four loss means in the total
     float* comb[2];        // gradient tiles: combined direct sources per destination (scratch)
     char* taps;            // [2 coords sets][B] inverse tap records (dg_taps_record_bytes each)
     const char* xop;       // operand-1 blobs (C part = normalised code rows the raw sources refer to)
@@ -245,6 +247,11 @@ struct DgScatterArgs {
     int32_t debug;         // developer ablation bits (0 in production)
     int32_t dense;         // 1: identity grid (DG_IDENTITY_GRID): the adjoint of sample() is a transposed copy
 };
+
+#ifdef __HIPCC__
+// effective upstream gradient of loss mean i: direct + through the weighted total
+__device__ __forceinline__ float dg_gscal(const DgScatterArgs& a, int i) { return a.gscal[i] + a.gscal[DG_OUT_TOTAL] * a.wtot[i]; }
+#endif
 
 // k_gs: gradient w.r.t. the STREAMED operand's code from the G tiles the fused kernel stored:
 //   dS[q][:] = sum_p G[q][p] * x_R[p][:], then normalisation backward with the S code.

@@ -154,6 +154,9 @@ __device__ __forceinline__ void finish_scalars(const DgCorrArgs& args, int lane)
         acc[DG_OUT_DD] = m / ((double)args.B * args.P * args.P);
     }
     if (lane == 0) {
+        acc[DG_OUT_TOTAL] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[DG_OUT_TOTAL] += (double)args.wtot[i] * (double)(float)acc[i];
 #pragma unroll
         for (int i = 0; i < DG_OUT_COUNT; ++i) args.out_scalars[i] = (float)acc[i];
         atomicExch(args.ticket, 0);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route != nullptr || !q.raw) continue;
         any_raw = true;
-        const float sc = q.factor * a.gscal[q.gidx];
+        const float sc = q.factor * dg_gscal(a, q.gidx);
         const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
 #pragma unroll
         for (int d = 0; d < NDF; ++d)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route != nullptr || q.raw) continue;
-        const float sc = q.factor * a.gscal[q.gidx];
+        const float sc = q.factor * dg_gscal(a, q.gidx);
         const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
 #pragma unroll
         for (int d = 0; d < NDF; ++d)
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
-        const float sc = q.factor * a.gscal[q.gidx];
+        const float sc = q.factor * dg_gscal(a, q.gidx);
         for (int n0 = 0; n0 < a.B; n0 += 64) {           // which images route here: one ballot per 64 images
             const int nn = n0 + (tid & 63);
             const bool hit = nn < a.B && (int)q.route[nn] == bdst;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;          // uniform
-        const float sc = q.factor * a.gscal[q.gidx];
+        const float sc = q.factor * dg_gscal(a, q.gidx);
         for (int n0 = 0; n0 < a.B; n0 += DENSE_THREADS) {
             const int n = n0 + tid;
             const bool hit = n < a.B && (int)q.route[n] == b;

@@ -14,8 +14,9 @@ Extra, build-side cfg keys (all optional, read with getattr):
                     `.mean()` / logging keeps working) and nothing of size (B,P,P) ever reaches HBM.
     dg_dense_grid   True: with feature_samples == h == w use the identity grid for coords1 and
                     coords2 (SURVEY.md section 8(d) dense runs) instead of torch.rand.
-After a call, `.scalars` is the fused fp32 [8] output (DG_OUT_* order: the four loss means, then the four cd means)
-with its grad_fn, for callers that want the weighted total in one op instead of through the tuple elements.
+After a call, `.scalars` is the fused fp32 output vector (DG_OUT_* order: the four loss means, the four cd means, the
+weighted total) with its grad_fn and `.total` its last element = the term `training_step` adds to its loss
+(src/train_segmentation.py:330-349, weights read from cfg), so `loss_fn.total.backward()` needs no further torch ops.
 """
 import torch
 import torch.nn as nn
@@ -67,7 +68,7 @@ class _CorrLossFunction(torch.autograd.Function):
         coords1, coords2, perms = ctx.saved_tensors
         if not (ctx.desc.flags & ops._lib.DG_NEED_GRAD):
             raise RuntimeError("depthg_amd: backward called on a forward that ran without gradient pieces")
-        gs = gout[:4].to(torch.float32).contiguous()
+        gs = gout.to(torch.float32).contiguous()      # [DG_OUT_COUNT]: entries 0..3 and DG_OUT_TOTAL are used
         g_code, g_code_pos = ops.corr_backward(ctx.desc, gs, coords1, coords2, perms, ctx.ws, ctx.shape)
         return g_code, g_code_pos, None, None, None, None, None, None, None, None
 
@@ -77,6 +78,15 @@ class ContrastiveCorrelationLoss(nn.Module):
         super().__init__()
         self.cfg = cfg
         self._ident_cache = (None, None)
+
+    def _total_weights(self, depth_term):
+        """Weights of (intra, inter, neg, depth) loss means in the caller's total, src/train_segmentation.py:325-349."""
+        cfg = self.cfg
+        g = lambda k: float(getattr(cfg, k, 0.0))
+        balance = g("lhp_weight") if (depth_term and getattr(cfg, "lhp", False) and getattr(cfg, "lhp_weight_balance", False)) else 0.0
+        scale = g("correspondence_weight") - balance
+        return (g("pos_intra_weight") * scale, g("pos_inter_weight") * scale, g("neg_inter_weight") * scale,
+                g("depth_feat_weight") * scale if depth_term else 0.0)
 
     # -- coordinate selection, src/modules.py:1287-1321 -------------------------------------------
     def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos):
@@ -146,7 +156,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                              shifts=(cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift,
                                      cfg.depth_feat_shift if depth_term else 0.0),
                              depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
-                             identity_grid=bool(identity_grid))
+                             identity_grid=bool(identity_grid), weights=self._total_weights(depth_term))
         holder = {}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
@@ -154,7 +164,8 @@ class ContrastiveCorrelationLoss(nn.Module):
                                       coords1, coords2, perms_t, desc, holder)
         ws = holder["workspace"]
         self.last_scalars = out.detach()
-        self.scalars = out                     # the fused 8-vector with its grad_fn (DG_OUT_* order)
+        self.scalars = out                     # the fused output vector with its grad_fn (DG_OUT_* order)
+        self.total = out[ops._lib.DG_OUT_TOTAL]  # weighted total of the loss means (src/train_segmentation.py:330-349)
         self.last_call = (desc, perms_t, ws)   # measurement aid (bench.py re-launches the fused kernel alone)
 
         mode = getattr(cfg, "dg_outputs", "full")

@@ -25,7 +25,7 @@ def _f32c(t, name):
 
 
 def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
-              shifts, depth_hw=(0, 0), identity_grid=False):
+              shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0)):
     flags = 0
     flags |= _lib.DG_POINTWISE if pointwise else 0
     flags |= _lib.DG_ZERO_CLAMP if zero_clamp else 0
@@ -35,7 +35,8 @@ def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, dept
     flags |= _lib.DG_SHARED_COORDS if shared_coords else 0
     flags |= _lib.DG_IDENTITY_GRID if identity_grid else 0
     return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
-                    float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]))
+                    float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]),
+                    float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]))
 
 
 def workspace_bytes(desc):
@@ -50,7 +51,7 @@ def alloc_workspace(desc, device):
 
 
 def corr_forward(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, perms, workspace):
-    """Returns fp32 [8] device tensor (order: DG_OUT_* of include/depthg_corr.h)."""
+    """Returns fp32 [DG_OUT_COUNT] device tensor (order: DG_OUT_* of include/depthg_corr.h)."""
     lib = _lib.load()
     dev = feats.device
     out = torch.empty(_lib.DG_OUT_COUNT, dtype=torch.float32, device=dev)

@@ -8,8 +8,8 @@ nothing here touches the HIP library, so it runs on any device the tuple lives o
     total, logs = correspondence_total(cfg, out)                 # what `loss += ...` adds at :335-350
     total.backward()
 
-`fused_correspondence_total(cfg, loss_fn)` is the same number taken from the module's fused 8-vector (`loss_fn.scalars`)
-with one dot product instead of one op per tuple element (what bench.py times).
+`fused_correspondence_total(cfg, loss_fn)` is the same number as formed inside the library (`loss_fn.total`, no torch op at
+all; what bench.py times).
 """
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -55,20 +55,20 @@ def correspondence_total(cfg, out: Sequence[torch.Tensor], lhp_out: Optional[Seq
 
 def correspondence_weights(cfg, depth: bool, device, full: bool = False) -> torch.Tensor:
     """fp32 [4] weights of (intra, inter, neg, depth) loss means in the total, in the order of the fused output vector;
-    `full`: [8], zero-padded over the four cd means, so that `dot(loss_fn.scalars, w)` needs no slice (and its backward
+    `full`: zero-padded to the length of the fused output vector, so that `dot(loss_fn.scalars, w)` needs no slice (and its backward
     no zero-fill + copy)."""
     scale = (cfg.correspondence_weight - _balance(cfg)) if depth else cfg.correspondence_weight
     w = torch.tensor([cfg.pos_intra_weight, cfg.pos_inter_weight, cfg.neg_inter_weight,
-                      cfg.depth_feat_weight if depth else 0.0] + ([0.0] * 4 if full else []), dtype=torch.float32)
+                      cfg.depth_feat_weight if depth else 0.0] + ([0.0] * 5 if full else []), dtype=torch.float32)
     return (w * scale).to(device)
 
 
 def fused_correspondence_total(cfg, loss_fn) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """Same value as correspondence_total(cfg, out) for the last call of `loss_fn` (without LHP), from its fused output
-    vector: one dot product forward, one scaled copy backward."""
+    """Same value as correspondence_total(cfg, out) for the last call of `loss_fn` (without LHP): the library's own
+    weighted total."""
     s = loss_fn.scalars
     depth = bool(getattr(cfg, "depth_feat_correlation_loss", False))
-    total = torch.dot(s[:4], correspondence_weights(cfg, depth, s.device))
+    total = loss_fn.total                      # formed by the library with the weights of cfg (DG_OUT_TOTAL)
     d = s.detach()
     logs = {k: d[i] for i, k in enumerate(LOG_KEYS_LOSS[:4 if depth else 3])}
     logs.update({k: d[4 + i] for i, k in enumerate(LOG_KEYS_CD[:4 if depth else 3])})

@@ -62,6 +62,10 @@ typedef struct dg_corr_desc {
     int32_t depth_h, depth_w; /* size of the depth map (image resolution); 0 if no depth */
     uint32_t flags;
     float shift_intra, shift_inter, shift_neg, shift_depth; /* cfg.pos_intra_shift ... cfg.depth_feat_shift */
+    /* weights of the four loss means in the caller's total (src/train_segmentation.py:330-349: cfg.pos_intra_weight,
+       pos_inter_weight, neg_inter_weight, depth_feat_weight, each times correspondence_weight - balance);
+       out_scalars[DG_OUT_TOTAL] = their weighted sum.  All zero: no total wanted. */
+    float w_intra, w_inter, w_neg, w_depth;
 } dg_corr_desc;
 
 /* indices into out_scalars[] of dg_corr_forward */
@@ -74,7 +78,8 @@ enum {
     DG_OUT_CD_INTER   = 5, /* pos_inter_cd.mean()             (mean of element 3) */
     DG_OUT_CD_NEG     = 6, /* neg_inter_cd.mean()             (mean of element 5) */
     DG_OUT_DD         = 7, /* depth_feat_cd.mean() (= mean of dd, element 7) */
-    DG_OUT_COUNT      = 8
+    DG_OUT_TOTAL      = 8, /* w_intra*[0] + w_inter*[1] + w_neg*[2] + w_depth*[3]: the term training_step adds to its loss */
+    DG_OUT_COUNT      = 9
 };
 
 int dg_version(void);
@@ -110,7 +115,9 @@ int dg_corr_forward(const dg_corr_desc* desc,
 
 /*
  * Backward (replaces autograd through helper()/sample(), SURVEY.md section 9 "Gradient"):
- *  grad_scalars : fp32 [4] device = upstream gradients of the four loss means
+ *  grad_scalars : fp32 [DG_OUT_COUNT] device = upstream gradient of the out_scalars vector: entries 0..3 (the four
+ *                 loss means) and DG_OUT_TOTAL are used, effective d/d(loss mean i) = g[i] + g[DG_OUT_TOTAL] * w_i;
+ *                 the cd means carry no gradient
  *                 (DG_OUT_LOSS_INTRA..DG_OUT_LOSS_DEPTH order)
  *  grad_code, grad_code_pos : fp32 (B,D,h,w), overwritten.
  */

@@ -5,7 +5,6 @@ import sys, time, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from depthg_amd import ContrastiveCorrelationLoss
-from depthg_amd.training import correspondence_weights
 from oracle.depthg_oracle import default_cfg   # cfg container only (no oracle arithmetic is run here)
 
 CONFIGS = {
@@ -28,11 +27,10 @@ for name, (B, C, D, hw, S, samp, pw, dense) in CONFIGS.items():
     d, dp = (torch.randint(0, 256, (B, 1, 8 * hw, 8 * hw), generator=g).float().to(dev) for _ in range(2))
     cfg = default_cfg(feature_samples=S, depth_sampling=samp, pointwise=pw, dg_outputs="reduced", dg_dense_grid=dense)
     loss = ContrastiveCorrelationLoss(cfg)
-    w = correspondence_weights(cfg, True, dev)
     def step():
         c.grad = None; cp.grad = None
         loss(f, fp, None, None, c, cp, d, dp)
-        torch.dot(loss.scalars[:4], w).backward()
+        loss.total.backward()
     try:
         for _ in range(3): step()
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -328,3 +328,27 @@ def test_edge_shapes_dense_and_general(B, C, D, hw, N, ident, dev):
             continue
         rel = (got.cpu() - want).norm() / want.norm()
         assert rel < 3e-2, float(rel)
+
+
+def test_fused_total_matches_tuple_route(dev):
+    """out_scalars[DG_OUT_TOTAL] (formed in the kernel with the weights of cfg) == training.correspondence_total on the
+    tuple, and backward through it == backward through the tuple elements."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.training import correspondence_total, fused_correspondence_total
+    fx = load_golden("forward_c1_none.npz")
+    cfg = cfg_from_fixture(fx, dg_outputs="reduced")
+    T = lambda a: torch.from_numpy(a).to(dev)
+    grads = []
+    for route in ("tuple", "fused"):
+        loss = ContrastiveCorrelationLoss(cfg)
+        code, code_pos = T(fx["code"]).requires_grad_(True), T(fx["code_pos"]).requires_grad_(True)
+        out = loss.forward_with(T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), T(fx["coords1"]),
+                                T(fx["coords2"]), T(fx["perms"]))
+        total, logs = correspondence_total(cfg, out) if route == "tuple" else fused_correspondence_total(cfg, loss)
+        total.backward()
+        grads.append((float(total), code.grad.clone(), code_pos.grad.clone(), logs))
+    assert grads[0][0] == pytest.approx(grads[1][0], rel=1e-5, abs=1e-9)
+    assert torch.allclose(grads[0][1], grads[1][1], rtol=1e-4, atol=1e-10) and torch.allclose(grads[0][2], grads[1][2], rtol=1e-4, atol=1e-10)
+    assert set(grads[0][3]) == set(grads[1][3])
+    for k in grads[0][3]:
+        assert float(grads[0][3][k]) == pytest.approx(float(grads[1][3][k]), rel=1e-6, abs=1e-9)

@@ -41,7 +41,7 @@ def test_descriptor_validation_and_workspace():
 
 def test_struct_layout_matches_header():
     from depthg_amd._lib import CorrDesc
-    assert ctypes.sizeof(CorrDesc) == 14 * 4
+    assert ctypes.sizeof(CorrDesc) == 18 * 4
     assert [f[0] for f in CorrDesc._fields_][:10] == ["B", "C", "D", "h", "w", "S", "n_neg", "depth_h", "depth_w", "flags"]
 
 
