@@ -34,7 +34,7 @@ struct Plan {
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
     size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
-    size_t nz, nzsum, tickets;
+    size_t nz, nzsum;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
@@ -82,7 +82,6 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int t = 0; t < p.T; ++t) { p.rvec[t] = take(B * p.Ppad * 4); p.rimg[t] = take(B * 4); }
     p.nz = take(B * p.Ppad * 4);
     p.nzsum = take(B * 4);
-    p.tickets = take(4);
     for (int t = 0; t <= p.T; ++t) { p.dRA[t] = take(B * p.Ppad * p.KD * 4); p.part[t] = take(B * p.nrb * 2 * 4); }
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
@@ -177,10 +176,6 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     corr_args_base(p, desc, ws, a);
     const double numel = (double)p.B * p.P * p.P;
-    a.ticket = reinterpret_cast<int32_t*>(ws + p.tickets);
-    a.nzsum = p.depth ? F32(p.nzsum) : nullptr;
-    a.out_scalars = F32(p.scratch_out);        // the caller points this at its output
-    a.wtot[0] = desc->w_intra; a.wtot[1] = desc->w_inter; a.wtot[2] = desc->w_neg; a.wtot[3] = desc->w_depth;
     int nj = 0;
     for (int t = 0; t < p.T; ++t) {
         DgJob j = helper_job(p, desc, ws, t, false, perms);
@@ -234,7 +229,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         g.src[0] = orig_feats; g.src[1] = orig_feats_pos; g.code[0] = orig_code; g.code[1] = orig_code_pos;
         for (int o = 0; o < 2; ++o) { g.blob[o] = ws + p.op[o]; g.colpart[o] = F32(p.colpart[o]); g.inv_norm[o] = F32(p.inv[o]); g.ccolpart[o] = F32(p.ccolpart[o]); }
         g.depth = p.depth ? depth : nullptr; g.nz = F32(p.nz); g.nzsum = F32(p.nzsum);
-        g.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         DG_HIP(dg_launch_prep_dense(g, stream));
@@ -246,7 +240,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
         g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
-        g.tickets = reinterpret_cast<int32_t*>(ws + p.tickets);
         int nj = 0;
         for (int o = 0; o < p.nops; ++o) {
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
@@ -295,12 +288,26 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     DgCorrArgs a;
     int depth_index;
     build_corr_jobs(p, desc, ws, perms, a, &depth_index);
-    a.out_scalars = out_scalars;               // written by the last block of the fused kernel
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream));
+
+    // 5. scalar outputs: the partial sums are reduced by the next launch (k_gs on a gradient pass)
+    DgFinishArgs f;
+    memset(&f, 0, sizeof(f));
+    for (int j = 0; j < a.njobs; ++j) {
+        f.part[j] = a.jobs[j].part; f.slot_loss[j] = a.jobs[j].slot_loss; f.slot_cd[j] = a.jobs[j].slot_cd;
+        f.scale[j] = a.jobs[j].fin_scale;
+    }
+    f.njobs = a.njobs; f.nblk = p.B * p.nrb; f.B = p.B; f.P = p.P;
+    f.nzsum = p.depth ? F32(p.nzsum) : nullptr;
+    f.out = out_scalars;
+    f.wtot[0] = desc->w_intra; f.wtot[1] = desc->w_inter; f.wtot[2] = desc->w_neg; f.wtot[3] = desc->w_depth;
     if (p.grad) {
         DgGsArgs g;
         build_gs_jobs(p, ws, perms, g);
+        g.fin = f;
         DG_HIP(dg_launch_gs(g, stream));
+    } else {
+        DG_HIP(dg_launch_finish(f, stream));
     }
 
     return DG_OK;

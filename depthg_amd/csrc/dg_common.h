@@ -125,9 +125,9 @@ struct DgJob {
     float shift;
     int32_t kind;
     int32_t center_on_lane;  // 1: R is operand 1 (rvec / nzR indexed by lane); 0: R is operand 2 (rvec by tile row)
-    int32_t slot_loss;       // output scalar the loss sum of this job adds to (DG_OUT_*; -1 none)   } used by the
-    int32_t slot_cd;         // ... the cd sum                                                        } last block
-    float fin_scale;         // 1/numel of the tensor the job contributes to                         } (finish)
+    int32_t slot_loss;       // output scalar the loss sum of this job adds to (DG_OUT_*; -1 none)   } copied into
+    int32_t slot_cd;         // ... the cd sum                                                        } DgFinishArgs
+    float fin_scale;         // 1/numel of the tensor the job contributes to                         } by the host
 };
 
 #define DG_MAX_JOBS 12      // pair-sets (<= DG_MAX_NEG + 2) + the depth job
@@ -142,25 +142,22 @@ struct DgCorrArgs {
     float inv_BP;         // 1 / (B*P)
     const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
     int32_t debug;        // developer ablation bits (0 in production)
-    // finish (done by the last block to retire, found with a ticket counter): partial sums -> the 8 output scalars
-    int32_t* ticket;      // zero on entry (set by the operand-preparation kernel), reset by the last block; null: no finish
-    const float* nzsum;   // [B] per-image sums of the depth indicators (mean(dd)) or null
-    float* out_scalars;   // [DG_OUT_COUNT]
-    float wtot[4];        // weights of the four loss means in out_scalars[DG_OUT_TOTAL]
     uint32_t* stamps;     // developer timing stamps (null in production)
 };
 
-// Cross-block hand-over without cache-wide fences (each XCD has its own L2): values are published with a returning
-// device-scope atomic (complete at the coherence point before the ticket is taken) and read back with agent-scope loads.
-#ifdef __HIPCC__
-__device__ __forceinline__ void dg_publish(float* p, float v) {
-    const float old = atomicExch(p, v);
-    asm volatile("" :: "v"(old) : "memory");
-}
-__device__ __forceinline__ float dg_read_published(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#endif
+// Final reduction of the per-block partial sums of k_corr_main into the output scalars.  It runs in the NEXT launch on the
+// stream (the first block of k_gs on a gradient pass, the one-wave k_finish otherwise), so the fused kernel needs neither
+// atomics nor fences for it.
+struct DgFinishArgs {
+    const float* part[DG_MAX_JOBS];   // per job: [nblk][2] partial (loss, cd) sums; null: job contributes nothing
+    int32_t slot_loss[DG_MAX_JOBS];   // output scalar the loss sum of job j adds to (DG_OUT_*; -1 none)
+    int32_t slot_cd[DG_MAX_JOBS];
+    float scale[DG_MAX_JOBS];         // 1/numel of the tensor the job contributes to
+    int32_t njobs, nblk, B, P;
+    const float* nzsum;               // [B] per-image sums of the depth indicators (mean(dd)) or null
+    float* out;                       // [DG_OUT_COUNT]; null: nothing to do
+    float wtot[4];                    // weights of the four loss means in out[DG_OUT_TOTAL]
+};
 
 // ---- argument blocks of the helper kernels (one definition shared by kernels and host API)
 
@@ -176,7 +173,6 @@ struct DgGatherJob {
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
-    int32_t* tickets;        // [1] completion counter of k_corr_main, zeroed here
     DgGatherJob jobs[DG_MAX_GATHER];
     int32_t njobs, B, h, w, S, P, Ppad, KF, KD;
 };
@@ -191,7 +187,6 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     const float* depth;      // (B,1,dH,dW) or null
     float* nz;               // [B][Ppad] depth indicators
     float* nzsum;            // [B] their per-image sums
-    int32_t* tickets;        // [1] completion counter of k_corr_main, zeroed here
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
     int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
 };
@@ -268,6 +263,7 @@ struct DgGsArgs {
     DgGsJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
     int32_t debug;         // developer ablation bits (0 in production)
+    DgFinishArgs fin;      // the first block also reduces k_corr_main's partial sums (fin.out == null: nothing to do)
 };
 
 // bytes of one inverse-tap record: off[HW+1] ints, 4P weights, 4P positions (ushort), padded to 16
@@ -278,6 +274,7 @@ __host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
+hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s);

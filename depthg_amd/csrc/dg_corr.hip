@@ -126,41 +126,43 @@ __device__ __forceinline__ float epi_elem(float yf, float cdv, float vv, float c
     return gneg;
 }
 
-// Final reduction of the per-block partial sums into the 8 output scalars, by one wave of the last block to retire:
-// per job the partials are summed in double in a fixed (lane-strided, then butterfly) order, so the result does not
-// depend on which block happens to be last.
-__device__ __forceinline__ void finish_scalars(const DgCorrArgs& args, int lane) {
+// Final reduction of the per-block partial sums of k_corr_main into the output scalars, by one wave of the next launch
+// (DgFinishArgs): per job the partials are summed in double in a fixed (lane-strided, then butterfly) order.
+__device__ __forceinline__ void finish_scalars(const DgFinishArgs& f, int lane) {
     double acc[DG_OUT_COUNT];
 #pragma unroll
     for (int i = 0; i < DG_OUT_COUNT; ++i) acc[i] = 0.0;
-    const int nblk = args.B * args.nrb;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // nothing stale from this CU's L1 (the loads below are sc1 as well)
-    for (int j = 0; j < args.njobs; ++j) {
-        const DgJob& J = args.jobs[j];
-        if (!J.part) continue;
+    for (int j = 0; j < f.njobs; ++j) {
+        if (!f.part[j]) continue;
         double l = 0.0, c = 0.0;
-        for (int i = lane; i < nblk; i += 64) { l += dg_read_published(J.part + 2 * i); c += dg_read_published(J.part + 2 * i + 1); }
+        for (int i = lane; i < f.nblk; i += 64) { l += f.part[j][2 * i]; c += f.part[j][2 * i + 1]; }
         for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); }
 #pragma unroll
         for (int i = 0; i < DG_OUT_COUNT; ++i) {
-            if (J.slot_loss == i) acc[i] += -l * (double)J.fin_scale;
-            if (J.slot_cd == i) acc[i] += c * (double)J.fin_scale;
+            if (f.slot_loss[j] == i) acc[i] += -l * (double)f.scale[j];
+            if (f.slot_cd[j] == i) acc[i] += c * (double)f.scale[j];
         }
     }
-    if (args.nzsum) {        // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
+    if (f.nzsum) {        // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
         double m = 0.0;
-        for (int n = lane; n < args.B; n += 64) { const double s = args.nzsum[n]; m += s * s; }
+        for (int n = lane; n < f.B; n += 64) { const double s = f.nzsum[n]; m += s * s; }
         for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
-        acc[DG_OUT_DD] = m / ((double)args.B * args.P * args.P);
+        acc[DG_OUT_DD] = m / ((double)f.B * f.P * f.P);
     }
     if (lane == 0) {
         acc[DG_OUT_TOTAL] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[DG_OUT_TOTAL] += (double)args.wtot[i] * (double)(float)acc[i];
+        for (int i = 0; i < 4; ++i) acc[DG_OUT_TOTAL] += (double)f.wtot[i] * (double)(float)acc[i];
 #pragma unroll
-        for (int i = 0; i < DG_OUT_COUNT; ++i) args.out_scalars[i] = (float)acc[i];
-        atomicExch(args.ticket, 0);
+        for (int i = 0; i < DG_OUT_COUNT; ++i) f.out[i] = (float)acc[i];
     }
+}
+
+__global__ __launch_bounds__(64) void k_finish(const DgFinishArgs f) { finish_scalars(f, threadIdx.x); }
+
+hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, stream, a);
+    return hipGetLastError();
 }
 
 template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND>
@@ -499,60 +501,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         }
     }
 
-    // ---- partial sums of this block (deterministic two-level reduction; finished by k_corr_finish)
-    // (rows of an inactive second fragment are all-zero operands? no: they are clamped copies -> excluded here)
-    float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RF * RCB));
-    if (FOLD) {
-        // clamp(cd) = cd * mask, so with G' = mask * (fd'' - shift):
-        //   sum_pq clamp(cd) (fd'' - shift) = sum_pq G'_pq <x_p, y_q> = sum_p <x_p, dR'_p>      (dR' = the gradient accumulators)
-        //   sum_pq cd_pq                    = sum_p <x_p, sum_q y_q>                              (column sums of the streamed code)
-        // x_p = this wave's stationary code rows (LDS or registers), dR[f][d][i] = (row (i&3)+8*(i>>2)+4*h, channel 32 d + r)
-        lsum = 0.f; csum = 0.f;
-#pragma unroll
-        for (int f = 0; f < RF; ++f) {
-            if (!act[f]) continue;
-            const char* xb = RCREG ? Rblob[f] + BL::OFF_C : rc_lds + f * RCB;
-            float cs[NDF];
-#pragma unroll
-            for (int d = 0; d < NDF; ++d) cs[d] = (KIND != KIND_DEPTH && job.Scsum) ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
-#pragma unroll
-            for (int d = 0; d < NDF; ++d)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h, ch = 32 * d + r;
-                    const float x = (float)*reinterpret_cast<const _Float16*>(xb + ((ch >> 3) * 32 + q) * 16 + (ch & 7) * 2);
-                    lsum = fmaf(x, dR[f][d][i], lsum);
-                    csum = fmaf(x, cs[d], csum);
-                }
-        }
-    }
-    lsum = wave_sum(lsum);
-    csum = wave_sum(csum);
-    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
-    __syncthreads();
-    if (wid == 0 && job.part) {
-        int last = 0;
-        if (lane == 0) {
-            float a = 0.f, b = 0.f;
-            for (int w = 0; w < NWAVES; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
-            if (args.ticket) {
-                dg_publish(job.part + (size_t)(n * args.nrb + rb) * 2, a);
-                dg_publish(job.part + (size_t)(n * args.nrb + rb) * 2 + 1, b);
-                last = atomicAdd(args.ticket, 1) == (int)gridDim.x - 1;
-            } else {
-                job.part[(size_t)(n * args.nrb + rb) * 2] = a;
-                job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
-            }
-        }
-        last = __shfl(last, 0, 64);
-        if (last) finish_scalars(args, lane);     // every block has published its partial sums: reduce them (wave 0)
-    }
-
-    if (stamping) {
-        __syncthreads();
-        for (int i = tid; i < NWAVES * 100; i += NWAVES * 64) args.stamps[i] = st_lds[i];
-    }
-    // ---- store the RAW gradient w.r.t. the normalised stationary code in accumulator order
+    // ---- store the RAW gradient w.r.t. the normalised stationary code in accumulator order (first: the stores drain
+    //      while the block sums are formed and published)
     //      [image][R tile][channel group d][i>>2][lane][i&3] (16 bytes per lane and store, 1 KiB per wave instruction).
     //      The normalisation backward is linear with the same x for every pair-set whose stationary operand is operand 1,
     //      so k_grad_combine applies it once to the weighted sum of these buffers.
@@ -569,6 +519,61 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                     *reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256) = v;
                 }
         }
+    }
+
+    // ---- partial sums of this block (deterministic two-level reduction; finished by the last block to retire)
+    // (rows of an inactive second fragment are all-zero operands? no: they are clamped copies -> excluded here)
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF + (RCREG ? 0 : NWAVES * RF * RCB));
+    if (FOLD) {
+        // clamp(cd) = cd * mask, so with G' = mask * (fd'' - shift):
+        //   sum_pq clamp(cd) (fd'' - shift) = sum_pq G'_pq <x_p, y_q> = sum_p <x_p, dR'_p>      (dR' = the gradient accumulators)
+        //   sum_pq cd_pq                    = sum_p <x_p, sum_q y_q>                              (column sums of the streamed code)
+        // x_p = this wave's stationary code rows (LDS or registers), dR[f][d][i] = (row (i&3)+8*(i>>2)+4*h, channel 32 d + r)
+        lsum = 0.f; csum = 0.f;
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            if (!act[f]) continue;
+            float cs[NDF];
+#pragma unroll
+            for (int d = 0; d < NDF; ++d) cs[d] = (KIND != KIND_DEPTH && job.Scsum) ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
+            // x in the layout of dR (rows in registers, channel on the lane) = X * I: the stationary code fragments (the
+            // B operands of the cd chain, same register layout as an A fragment) times 0/1 selector fragments
+            f16x8 sel[2];
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sel[sI][j] = (8 * h + j + 16 * sI == r) ? (_Float16)1.f : (_Float16)0.f;
+#pragma unroll
+            for (int d = 0; d < NDF; ++d) {
+                f32x16 X = f32x16{};
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    const int k = 2 * d + sI;
+                    const f16x8 xa = RCREG ? Rc[k] : *reinterpret_cast<const f16x8*>(rc_lds + f * RCB + crow + k * 1024);
+                    X = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, sel[sI], X, 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    lsum = fmaf(X[i], dR[f][d][i], lsum);
+                    csum = fmaf(X[i], cs[d], csum);
+                }
+            }
+        }
+    }
+    lsum = wave_sum(lsum);
+    csum = wave_sum(csum);
+    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
+    __syncthreads();
+    if (tid == 0 && job.part) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < NWAVES; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
+        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
+    }
+
+    if (stamping) {
+        __syncthreads();
+        for (int i = tid; i < NWAVES * 100; i += NWAVES * 64) args.stamps[i] = st_lds[i];
     }
 }
 
@@ -664,6 +669,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
         }
         return;
     }
+    if (bid == 0 && wid == 0 && a.fin.out) finish_scalars(a.fin, lane);     // k_corr_main's partial sums -> output scalars
     const int st = bx * GS_CW + wid;                        // S tile of this wave
     if (st >= ntS) {                                        // nothing to do but keep the barrier count
         for (int rt = 0; rt < nt; ++rt) __builtin_amdgcn_s_barrier();

@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
     const DgGatherJob& J = a.jobs[blockIdx.z];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) a.tickets[0] = 0;
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const float* img = J.src + (size_t)ns * a.h * a.w * K4;
@@ -326,7 +325,6 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     } else if (x == 0 && !(a.debug & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
     }
-    if (x == 0 && z == 0 && n == 0 && threadIdx.x == 0) a.tickets[0] = 0;
 }
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
