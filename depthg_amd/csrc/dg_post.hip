@@ -29,10 +29,22 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
 // is applied ONCE with the operand-1 code rows (all raw sources share them); final sources (k_gs output, already
 // through their own normalisation backward) are added.  grid (Ppad/32, B, 2), block 64.
 // Register layout of a tile: v[d][i] = (row (i&3) + 8 (i>>2) + 4 (lane>>5), channel 32 d + (lane&31)).
+// the four effective upstream gradients, loaded once (five independent loads) instead of per source
+#define DG_LOAD_GS(a, gs)                                                                                   \
+    float gs[4];                                                                                            \
+    {                                                                                                       \
+        const float gt_ = (a).gscal[DG_OUT_TOTAL];                                                          \
+        const float g0_ = (a).gscal[0], g1_ = (a).gscal[1], g2_ = (a).gscal[2], g3_ = (a).gscal[3];        \
+        gs[0] = g0_ + gt_ * (a).wtot[0]; gs[1] = g1_ + gt_ * (a).wtot[1];                                  \
+        gs[2] = g2_ + gt_ * (a).wtot[2]; gs[3] = g3_ + gt_ * (a).wtot[3];                                  \
+    }
+__device__ __forceinline__ float dg_pick(const float (&gs)[4], int i) { return i == 0 ? gs[0] : (i == 1 ? gs[1] : (i == 2 ? gs[2] : gs[3])); }
+
 template <int NDF>
 __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
     const int lane = threadIdx.x, h = lane >> 5, DP = NDF * 32;
+    DG_LOAD_GS(a, gs)
     float v[NDF][16];
 #pragma unroll
     for (int d = 0; d < NDF; ++d)
@@ -43,7 +55,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route != nullptr || !q.raw) continue;
         any_raw = true;
-        const float sc = q.factor * dg_gscal(a, q.gidx);
+        const float sc = q.factor * dg_pick(gs, q.gidx);
         const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
 #pragma unroll
         for (int d = 0; d < NDF; ++d)
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route != nullptr || q.raw) continue;
-        const float sc = q.factor * dg_gscal(a, q.gidx);
+        const float sc = q.factor * dg_pick(gs, q.gidx);
         const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
 #pragma unroll
         for (int d = 0; d < NDF; ++d)
@@ -195,6 +207,7 @@ template <int NPASS>
 __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sg[];
     const int tid = threadIdx.x, HW = a.h * a.w, P = a.P;
+    DG_LOAD_GS(a, gs)
     const int* off = reinterpret_cast<const int*>(sg);
     const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
     const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
-        const float sc = q.factor * dg_gscal(a, q.gidx);
+        const float sc = q.factor * dg_pick(gs, q.gidx);
         for (int n0 = 0; n0 < a.B; n0 += 64) {           // which images route here: one ballot per 64 images
             const int nn = n0 + (tid & 63);
             const bool hit = nn < a.B && (int)q.route[nn] == bdst;
@@ -278,43 +291,52 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
 __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sd[];
     const int HW = a.h * a.w, S = a.S, nt = a.Ppad >> 5, NF = a.DP >> 5;
+    DG_LOAD_GS(a, gs)
     float* stage = reinterpret_cast<float*>(sd);                       // [32][HW + 1]
     const float** rl_p = reinterpret_cast<const float**>(stage + 32 * (HW + 2));   // routed list: image base (8-byte aligned)
     float* rl_w = reinterpret_cast<float*>(rl_p + DENSE_MAXROUTE);                  //              weight
     __shared__ int rl_cnt;
     const int f = blockIdx.x, b = blockIdx.y, dest = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
-    // routed list in (source, image) order: every thread tests one pair per round, ballot + prefix compaction
+    // routed list in (source, image) order: the (routed source, image) pairs are numbered source-major, every thread tests
+    // one pair per round (all sources at once), ballot + prefix compaction keeps the order
     constexpr int NW = DENSE_THREADS / 64;
     __shared__ int wcnt[NW];
+    __shared__ int rsrc[DG_MAX_SCATTER];
+    int nr = 0;
+    for (int s = 0; s < a.nsrc; ++s)                                   // uniform: which sources are routed here
+        if (a.src[s].dest == dest && a.src[s].route != nullptr) { if (tid == 0) rsrc[nr] = s; ++nr; }
     if (tid == 0) rl_cnt = 0;
     __syncthreads();
-    for (int s = 0; s < a.nsrc; ++s) {
-        const DgScatterSrc& q = a.src[s];
-        if (q.dest != dest || q.route == nullptr) continue;          // uniform
-        const float sc = q.factor * dg_gscal(a, q.gidx);
-        for (int n0 = 0; n0 < a.B; n0 += DENSE_THREADS) {
-            const int n = n0 + tid;
-            const bool hit = n < a.B && (int)q.route[n] == b;
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) wcnt[wid] = __popcll(m);
-            __syncthreads();
-            int base = rl_cnt;
-            for (int wv = 0; wv < wid; ++wv) base += wcnt[wv];
-            if (hit) {
-                const int o = base + __popcll(m & ((1ull << lane) - 1));
-                if (o < DENSE_MAXROUTE) { rl_p[o] = q.buf + (size_t)n * a.Ppad * a.DP; rl_w[o] = sc; }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int c = rl_cnt;
-                for (int wv = 0; wv < NW; ++wv) c += wcnt[wv];
-                rl_cnt = min(c, DENSE_MAXROUTE);
-            }
-            __syncthreads();
+    for (int i0 = 0; i0 < nr * a.B; i0 += DENSE_THREADS) {
+        const int i = i0 + tid;
+        bool hit = false;
+        int n = 0, s = 0;
+        if (i < nr * a.B) {
+            const int rs = i / a.B;
+            n = i - rs * a.B; s = rsrc[rs];
+            hit = (int)a.src[s].route[n] == b;
         }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) wcnt[wid] = __popcll(m);
+        __syncthreads();
+        int base = rl_cnt;
+        for (int wv = 0; wv < wid; ++wv) base += wcnt[wv];
+        if (hit) {
+            const int o = base + __popcll(m & ((1ull << lane) - 1));
+            const DgScatterSrc& q = a.src[s];
+            if (o < DENSE_MAXROUTE) { rl_p[o] = q.buf + (size_t)n * a.Ppad * a.DP; rl_w[o] = q.factor * dg_pick(gs, q.gidx); }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int c = rl_cnt;
+            for (int wv = 0; wv < NW; ++wv) c += wcnt[wv];
+            rl_cnt = min(c, DENSE_MAXROUTE);
+        }
+        __syncthreads();
     }
     const int cnt = rl_cnt;
+    const float invS = 1.f / (float)S;
     for (int t = wid; t < nt; t += NW) {
         const size_t toff = ((size_t)t * NF + f) * 1024 + lane * 4;
         f32x4 v[4];
@@ -345,16 +367,17 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
             for (int k = 0; k < 4; ++k) {
                 const int p = t * 32 + k + 8 * g + 4 * h;
                 if (p < a.P) {
-                    const int i = p / S, j = p - i * S;
+                    const int i = (int)(((float)p + 0.5f) * invS), j = p - i * S;    // p / S without an integer division
                     stage[r * (HW + 1) + j * a.w + i] = v[g][k];
                 }
             }
     }
     __syncthreads();
     float* out = a.out[dest];
-    for (int idx = tid; idx < 32 * HW; idx += DENSE_THREADS) {
-        const int c = idx / HW, pix = idx - c * HW, d = 32 * f + c;
-        if (d < a.D) out[((size_t)b * a.D + d) * HW + pix] = stage[c * (HW + 1) + pix];
+    for (int c = 0; c < 32; ++c) {
+        const int d = 32 * f + c;
+        if (d >= a.D) break;
+        for (int pix = tid; pix < HW; pix += DENSE_THREADS) out[((size_t)b * a.D + d) * HW + pix] = stage[c * (HW + 1) + pix];
     }
 }
 
