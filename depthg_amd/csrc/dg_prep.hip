@@ -163,6 +163,7 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 // channel-last copy, no bilinear taps.  One block per (source row y, image): reads the K x w slab of that row
 // (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
 // grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
+template <int MAXU>      // channels per thread = KF / 8 <= MAXU
 __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int n, int o) {
     // thread (x = tid & 31, k0 = tid >> 5) owns pixel x of the row and the channels k0 + 8u: all of them are loaded in one
     // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a pixel through LDS,
@@ -174,7 +175,6 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w + x;
     char* tb = reinterpret_cast<char*>(sl);         // [w][RS] bf16 rows
     float* red = reinterpret_cast<float*>(tb + 32 * RS);   // [8][32] partial squared norms
-    constexpr int MAXU = 96;                        // KF <= 768
     const int nu = KF >> 3;
     float t[MAXU];
     float ss = 0.f;
@@ -305,6 +305,7 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
 // grid h * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
+template <int MAXU>
 __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     extern __shared__ float sl[];
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): consecutive logical ids - the source rows of one
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
     if (z < 2) {
-        if (x < a.h && !(a.debug & 1)) prep_dense_feats(a, sl, x, n, z);
+        if (x < a.h && !(a.debug & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
     } else if (z < 4) {
         if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code(a, sl, x, n, z - 2);
     } else if (x == 0 && !(a.debug & 4)) {
@@ -332,12 +333,16 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     const int nt = a.Ppad / 32, gx = a.h;
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
     const int smem = max(32 * (a.KF * 2 + 8) + 8 * 32 * 4, DENSE_TPB * 32 * (a.KD + 2) * 4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_prep_dense), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return e;
     DgDenseArgs a2 = a;
     if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
-    hipLaunchKernelGGL(k_prep_dense, dim3(gx * a.B * (a.depth ? 5 : 4)), dim3(256), smem, s, a2);
-    return hipGetLastError();
+    const dim3 grid(gx * a.B * (a.depth ? 5 : 4));
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a2);
+        return hipGetLastError();
+    };
+    return a.KF <= 384 ? launch(k_prep_dense<48>) : launch(k_prep_dense<96>);   // registers per thread follow the width
 }
 
 // ------------------------------------------------------------------------------------------
