@@ -669,12 +669,16 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
         }
         return;
     }
-    if (bid == 0 && wid == 0 && a.fin.out) finish_scalars(a.fin, lane);     // k_corr_main's partial sums -> output scalars
     const int st = bx * GS_CW + wid;                        // S tile of this wave
+    // k_corr_main's partial sums -> output scalars: by a consumer wave that has no S tile (after its barriers, beside the
+    // other waves' work), or by wave 0 of the first block when every consumer is busy
+    const bool spare = (a.Ppad / 32) % GS_CW != 0;
     if (st >= ntS) {                                        // nothing to do but keep the barrier count
         for (int rt = 0; rt < nt; ++rt) __builtin_amdgcn_s_barrier();
+        if (a.fin.out && bid == nbx - 1 && wid == GS_CW - 1) finish_scalars(a.fin, lane);
         return;
     }
+    if (a.fin.out && !spare && bid == 0 && wid == 0) finish_scalars(a.fin, lane);
     const int nS = J.sidx ? (int)J.sidx[n] : n;
     f32x16 acc[NDF];
 #pragma unroll
