@@ -110,15 +110,22 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="give each step's all-reduce one step of slack (it then overlaps the next step's kernels, as it would "
+                         "overlap the frozen ViT forward in training); default: the compute stream waits for it right away")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
@@ -137,7 +144,7 @@ def main():
     f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev)
     c.requires_grad_(True)
     cp.requires_grad_(True)
-    bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if world > 1 else None)
+    bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None)
 
     def step():
         c.grad = None
@@ -145,15 +152,17 @@ def main():
         loss_fn(f, fp, None, None, c, cp, d, dp)
         total = loss_fn.total          # weighted total of the four loss means (training_step's term), formed by the library
         total.backward()
-        if world > 1:
+        if use_dist:
             # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size
             # filled from this step's d/d code, all-reduced (sum) over xGMI and scaled by 1/world
+            bucket.wait()                  # the previous step's exchange must be done before its buffer is refilled
             bucket.fill_from(c.grad)
-            bucket.allreduce_mean_()
+            bucket.allreduce_mean_(even_if_alone=args.force_dist, async_op=args.overlap_allreduce)
         return total
 
     def sync():
-        if world > 1:
+        if use_dist:
+            bucket.wait()                  # every all-reduce of the timed steps completes inside the timed region
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +174,7 @@ def main():
         total = step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -219,7 +228,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

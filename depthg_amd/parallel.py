@@ -60,11 +60,24 @@ class GradBucket:
         n = min(src.numel(), self.flat.numel())
         self.flat[:n].copy_(src[:n])
 
-    def allreduce_mean_(self):
+    def allreduce_mean_(self, even_if_alone: bool = False, async_op: bool = False):
+        """Average the flat buffer over the group.  async_op (RCCL only): the collective is enqueued on the communication
+        stream and the compute stream does NOT wait for it here; call `wait()` before the buffer is read or refilled - the
+        exchange then overlaps whatever is launched in between (in training: the frozen ViT forward of the next step)."""
         if self.dist is None:
             return self.flat
         world = self.dist.get_world_size(self.group)
-        if world > 1:
-            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / world)
+        if world > 1 or even_if_alone:
+            if self.dist.get_backend(self.group) == "nccl":        # RCCL averages inside the collective: no extra kernel
+                self._work = self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            else:                                                   # gloo (CPU tests) has no AVG
+                self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.flat.mul_(1.0 / world)
         return self.flat
+
+    def wait(self):
+        """Make the current stream wait for an outstanding async all-reduce (no host block)."""
+        w = getattr(self, "_work", None)
+        if w is not None:
+            w.wait()
+            self._work = None
