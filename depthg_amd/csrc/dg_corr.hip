@@ -418,9 +418,11 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 #pragma unroll
             for (int f = 0; f < RF; ++f)
                 if (act[f]) {
-                    uint4* g = reinterpret_cast<uint4*>(Gout + ((((size_t)n * ntiles_all + rtile0 + f) * ntiles_all + t) * 64 + lane) * 16);
-                    g[0] = __builtin_bit_cast(uint4, ga[f][0]);
-                    g[1] = __builtin_bit_cast(uint4, ga[f][1]);
+                    // non-temporal: the tiles are read by the NEXT kernel only; keeping them out of the way leaves the L2 to
+                    // the operand blobs this kernel streams over and over
+                    v4i* g = reinterpret_cast<v4i*>(Gout + ((((size_t)n * ntiles_all + rtile0 + f) * ntiles_all + t) * 64 + lane) * 16);
+                    __builtin_nontemporal_store(__builtin_bit_cast(v4i, ga[f][0]), g);
+                    __builtin_nontemporal_store(__builtin_bit_cast(v4i, ga[f][1]), g + 1);
                 }
         }
         if (GRAD && !(dbg & 4)) {
@@ -516,7 +518,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {dR[f][d][4 * g], dR[f][d][4 * g + 1], dR[f][d][4 * g + 2], dR[f][d][4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
                 }
         }
     }
