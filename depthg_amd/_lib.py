@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdepthg_hip.so")
+LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg_hip.so")   # DEPTHG_LIB: developer A/B builds
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8

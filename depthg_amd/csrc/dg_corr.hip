@@ -94,7 +94,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define DG_TWOACC 0
 #endif
 #ifndef PF
-#define PF 6       // LDS fragment reads kept in flight per wave
+#define PF 4       // LDS fragment reads kept in flight per wave (4 vs 6 vs 8: 4 is 1-2 % ahead, fewer registers)
 #endif
 
 // One accumulator element of a 32x32 tile: (fd, cd) -> loss term and -G = -dLoss/dcd (the sign is folded into the
