@@ -271,6 +271,25 @@ __host__ __device__ inline size_t dg_taps_record_bytes(int HW, int P) {
     return (((size_t)(HW + 1) * 4 + (size_t)4 * P * 6) + 15) / 16 * 16;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a host round trip of a few microseconds: do it once per kernel (and
+// again only if a larger size is ever needed).  Host threads of different devices may race benignly (same value).
+#include <map>
+#include <mutex>
+#include <utility>
+inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> bytes granted
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(kern, dev);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[key] = bytes;
+    return e;
+}
+
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);

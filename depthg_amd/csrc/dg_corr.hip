@@ -773,7 +773,7 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;
 #define DG_GS(NKF_, NKD_)                                                                                               \
     if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) {                                                                        \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gs<NKF_, NKD_>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_gs<NKF_, NKD_>), smem); \
         if (e != hipSuccess) return e;                                                                                   \
         hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, smem, stream, a2);                                           \
         return hipGetLastError();                                                                                        \
@@ -790,7 +790,7 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     const bool big = BL::BYTES > 48 * 1024;
     const int smem = (big ? 2 : 3) * (BL::BYTES + 256) + (big ? 0 : NWAVES * RF * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
     auto kern = k_corr_main<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
     const int grid = args.njobs * args.B * args.nrb;
     DgCorrArgs a2 = args;
@@ -802,7 +802,7 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
         if (!stamp_buf && hipMalloc(&stamp_buf, NWAVES * 400) != hipSuccess) stamp_buf = nullptr;
         if (stamp_buf) {
             a2.stamps = stamp_buf; smem2 = smem + NWAVES * 400;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+            (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem2);
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem2, stream, a2);

@@ -395,7 +395,7 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
         for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
         const size_t dsm = (size_t)32 * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
         if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
+            hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_dense), (int)dsm);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_scatter_dense, dim3(a.DP / 32, a.B, 2), dim3(DENSE_THREADS), dsm, s, a);
             return hipGetLastError();
@@ -406,14 +406,14 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
     const int smem = (int)(rec > stage ? rec : stage);
     const int build_smem = (int)(rec + (size_t)HW * 4 + 16);     // the record plus the per-pixel counters
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_taps), hipFuncAttributeMaxDynamicSharedMemorySize, build_smem);
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_build_taps), build_smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_build_taps, dim3(a.B, 2), dim3(SCAT_THREADS), build_smem, s, a);
     dim3 grid((a.D + SCAT_DC - 1) / SCAT_DC, a.B, 2);
     const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
 #define DG_SCAT(NP)                                                                                                      \
     {                                                                                                                    \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter_grad<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+        e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_grad<NP>), smem); \
         if (e != hipSuccess) return e;                                                                                   \
         hipLaunchKernelGGL(k_scatter_grad<NP>, grid, dim3(SCAT_THREADS), smem, s, a);                                    \
         return hipGetLastError();                                                                                        \
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s) {
     const int smem = h * w * 4 * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fps_coords), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_fps_coords), smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_fps_coords, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
     return hipGetLastError();

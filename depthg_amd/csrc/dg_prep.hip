@@ -337,7 +337,7 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
     const dim3 grid(gx * a.B * (a.depth ? 5 : 4));
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a2);
         return hipGetLastError();
