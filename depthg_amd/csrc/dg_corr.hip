@@ -427,17 +427,16 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         }
         if (GRAD && !(dbg & 4)) {
             // dR[f][r][:] += sum_s G[f][s][r] * ScP[s][:]   (accumulator tile as the A operand; B shared by the fragments)
+            // k-step outer, channel group inner: consecutive MFMAs go to different accumulators
 #pragma unroll
-            for (int d = 0; d < NDF; ++d) {
-                const char* base = tile + BL::OFF_P + (h * KD + 32 * d + r) * 16;
+            for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(base + sp * (2 * KD * 16));
+                for (int d = 0; d < NDF; ++d) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(tile + BL::OFF_P + (h * KD + 32 * d + r) * 16 + sp * (2 * KD * 16));
 #pragma unroll
                     for (int f = 0; f < RF; ++f)
                         dR[f][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[f][sp], b, dR[f][d], 0, 0, 0);
                 }
-            }
         }
     };
 
