@@ -352,3 +352,34 @@ def test_fused_total_matches_tuple_route(dev):
     assert set(grads[0][3]) == set(grads[1][3])
     for k in grads[0][3]:
         assert float(grads[0][3][k]) == pytest.approx(float(grads[1][3][k]), rel=1e-6, abs=1e-9)
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_bitwise_reproducible(dense, dev):
+    """Same inputs -> bit-identical scalars and gradients on every run (no floating-point atomics on the path; a mismatch
+    would mean a missing wait or barrier in the DMA / producer-consumer pipelines)."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.loss import identity_coords
+    from oracle import depthg_oracle as O
+    B, C, D, hw = 8, 384, 70, 28
+    g = torch.Generator().manual_seed(77)
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+    d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float().to(dev)
+    perms = torch.stack([O.super_perm(B, g) for _ in range(5)]).to(dev)
+    if dense:
+        c1 = c2 = identity_coords(B, hw, dev)
+    else:
+        c1 = (torch.rand(B, hw, hw, 2, generator=g) * 2 - 1).to(dev)
+        c2 = (torch.rand(B, hw, hw, 2, generator=g) * 2 - 1).to(dev)
+    loss = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=hw, dg_outputs="reduced"))
+    ref = None
+    for _ in range(6):
+        cg, cpg = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+        loss.forward_with(f, fp, cg, cpg, d, c1, c2, perms, shared_coords=dense, identity_grid=dense)
+        loss.total.backward()
+        cur = (loss.scalars.detach().clone(), cg.grad.clone(), cpg.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
