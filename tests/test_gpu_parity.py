@@ -90,7 +90,7 @@ def test_reduced_outputs_match_full(dev):
     # gradient pass, come out of the fp16-rounded G accumulators): same quantity along two routes, O(1e-2) terms that
     # nearly cancel in this fixture's total
     assert float(total_f) == pytest.approx(float(total_r), rel=2e-4, abs=1e-7)
-    # LDS float atomics in the scatter make the last bits order-dependent
+    # "full" also launches the materialise passes; the gradients come from the same kernels either way
     assert torch.allclose(g_f, g_r, rtol=1e-4, atol=1e-9) and torch.allclose(gp_f, gp_r, rtol=1e-4, atol=1e-9)
     assert out_r[4].numel() == 1 and float(out_r[1]) == pytest.approx(float(out_f[1].mean()), rel=1e-4)
 
