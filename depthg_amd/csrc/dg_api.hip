@@ -32,7 +32,7 @@ struct Plan {
     bool shared, depth, grad, pointwise, ident;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
-    size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2];
+    size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2], bsplit[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
     size_t nz, nzsum;
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
@@ -76,6 +76,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.inv[i] = take(B * p.Ppad * 4);
         p.colpart[i] = take(B * (size_t)(p.ident ? p.h : p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
+        p.bsplit[i] = take(B * 2 * p.KF * 2);
         p.ccolpart[i] = take(B * (size_t)(p.Ppad / 32) * p.KD * 4);
         p.csum[i] = take(B * p.KD * 4);
     }
@@ -267,6 +268,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         c.nops = p.nops; c.B = p.B; c.P = p.P; c.Ppad = p.Ppad; c.KF = p.KF; c.KD = p.KD;
         for (int o = 0; o < p.nops; ++o) {
             c.colpart[o] = p.pointwise ? F32(p.colpart[o]) : nullptr; c.bbar[o] = F32(p.bbar[o]);
+            c.bsplit[o] = reinterpret_cast<__bf16*>(ws + p.bsplit[o]);
             c.ngroups[o] = p.ident ? p.h : p.Ppad / 32;
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
@@ -279,6 +281,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         for (int t = 0; t < p.T; ++t) {
             r.jobs[t].A = ws + p.op[0]; r.jobs[t].aidx = nullptr;
             r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
+            r.jobs[t].bsplit = reinterpret_cast<const __bf16*>(ws + p.bsplit[op_of(p, t)]);
             r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rimg = F32(p.rimg[t]);
         }
         DG_HIP(dg_launch_rowmean(r, stream));

@@ -100,6 +100,30 @@ __device__ __forceinline__ void dg_load_code_rows(const char* Cp, char* T, int l
 }
 #endif
 
+#ifdef __HIPCC__
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS byte address (wave-uniform) of a pointer into the dynamic shared segment
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)p);
+}
+
+// LDS-DMA: every lane gives its own global source address; the wave writes 64 x 16 (or 64 x 4) contiguous
+// bytes at the wave-uniform LDS address.  Issued through inline asm so that hipcc neither drains it with
+// vmcnt(0) before unrelated LDS reads nor counts it; completion is enforced by the explicit counted
+// "s_waitcnt vmcnt" + s_barrier at the top of the tile loop (cdna guide 5.7: M0 written in the same statement).
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#endif
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 
@@ -194,6 +218,7 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
 struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][group][k];  csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]
     const float* colpart[DG_MAX_NEG + 2];   // feats partial column sums (null: skip)
     float* bbar[DG_MAX_NEG + 2];
+    __bf16* bsplit[DG_MAX_NEG + 2];         // [B][2][KF] bbar split into bf16 hi / lo
     const float* ccolpart[DG_MAX_NEG + 2];  // code partial column sums [B][Ppad/32][KD]
     float* csum[DG_MAX_NEG + 2];            // [B][KD]
     int32_t ngroups[DG_MAX_NEG + 2];   // feats partial-sum groups per image (tiles, or source rows on the dense path)
@@ -203,6 +228,7 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
 struct DgRowmeanJob {
     const char* A;            // operand-1 blobs
     const float* bbar;        // [B][KF] mean normalised feats of operand 2
+    const __bf16* bsplit;     // [B][2][KF] the same as bf16 hi / lo halves (B fragments of the row-mean MFMAs)
     const int64_t* aidx;      // batch maps (null = identity)
     const int64_t* bidx;
     float* rvec;              // [B][Ppad]

@@ -20,28 +20,6 @@
 #include <cstdlib>
 #include <cstdio>
 
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// LDS byte address (wave-uniform) of a pointer into the dynamic shared segment
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)p);
-}
-
-// LDS-DMA: every lane gives its own global source address; the wave writes 64 x 16 (or 64 x 4) contiguous
-// bytes at the wave-uniform LDS address.  Issued through inline asm so that hipcc neither drains it with
-// vmcnt(0) before unrelated LDS reads nor counts it; completion is enforced by the explicit counted
-// "s_waitcnt vmcnt" + s_barrier at the top of the tile loop (cdna guide 5.7: M0 written in the same statement).
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 __device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;

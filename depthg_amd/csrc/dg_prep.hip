@@ -414,7 +414,17 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
             out[(size_t)n * K + k] = s * scale;
         }
     };
-    if (a.colpart[o]) reduce(a.colpart[o], a.ngroups[o], a.KF, 1.f / (float)a.P, a.bbar[o]);
+    if (a.colpart[o]) {
+        reduce(a.colpart[o], a.ngroups[o], a.KF, 1.f / (float)a.P, a.bbar[o]);
+        // bbar as two bf16 halves (hi + lo keeps ~16 mantissa bits): the B fragments of k_rowmean, [n][2][KF]
+        __syncthreads();
+        for (int k = threadIdx.x; k < a.KF; k += 256) {
+            const float v = a.bbar[o][(size_t)n * a.KF + k];
+            const __bf16 hi = (__bf16)v;
+            a.bsplit[o][((size_t)n * 2) * a.KF + k] = hi;
+            a.bsplit[o][((size_t)n * 2 + 1) * a.KF + k] = (__bf16)(v - (float)hi);
+        }
+    }
     if (a.ccolpart[o]) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
 }
 
@@ -428,6 +438,7 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
 // per pair-set holding bbar split into two bf16 halves (columns t and 16 + t: hi + lo keeps ~16 mantissa bits, the
 // products with the bf16 rows are exact in the fp32 accumulator).  grid (Ppad/32, B), block 64.
 __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char rm_smem[];     // the tile's F part (32 swizzled bf16 rows)
     const int tile = blockIdx.x, n = blockIdx.y, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     const int KF = a.KF, GF = KF / 8, nt = a.Ppad / 32;
     const DgBlob L(a.KF, a.KD);
@@ -435,29 +446,32 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
     const bool has = jb < a.njobs;
     const DgRowmeanJob& J = a.jobs[has ? jb : 0];
     const int nb = J.bidx ? (int)J.bidx[n] : n;
-    const float* bb = J.bbar + (size_t)nb * KF + 8 * h;
-    const char* row = a.jobs[0].A + ((size_t)n * nt + tile) * L.bytes + (size_t)c * GF * 16;   // A row q = c
+    // the F part comes in linearly by LDS-DMA (1 KiB per instruction, fully coalesced); the B fragments (pre-split bbar)
+    // are plain 16-byte loads
+    const char* fp = a.jobs[0].A + ((size_t)n * nt + tile) * L.bytes + lane * 16;
+    const uint32_t dst = lds_addr(rm_smem);
+    const int pieces = L.off_c / 1024;
+    for (int pc = 0; pc < pieces; ++pc) dma16(fp + pc * 1024, dst + pc * 1024);
+    const __bf16* bb = J.bsplit + ((size_t)nb * 2 + lo) * KF + 8 * h;
     f32x16 acc = {};
-    for (int ks0 = 0; ks0 < KF / 16; ks0 += 8) {     // KF / 16 is a multiple of 8 (KF in {128, 384, 768}); 24 loads in flight
-        bf16x8 af[8];
-        float4 b0[8], b1[8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* row = rm_smem + (size_t)c * GF * 16;                    // A row q = c
+    for (int ks0 = 0; ks0 < KF / 16; ks0 += 8) {     // KF / 16 is a multiple of 8 (KF in {128, 384, 768})
+        bf16x8 af[8], bf[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int ks = ks0 + u;
             af[u] = *reinterpret_cast<const bf16x8*>(row + (((2 * ks + h) ^ (c & 15)) * 16));
-            b0[u] = *reinterpret_cast<const float4*>(bb + 16 * ks);
-            b1[u] = *reinterpret_cast<const float4*>(bb + 16 * ks + 4);
+            bf[u] = *reinterpret_cast<const bf16x8*>(bb + 16 * ks);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float bv[8] = {b0[u].x, b0[u].y, b0[u].z, b0[u].w, b1[u].x, b1[u].y, b1[u].z, b1[u].w};
-            bf16x8 bf;
+            bf16x8 b = bf[u];
+            if (!has) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const __bf16 hi = (__bf16)bv[e];
-                bf[e] = !has ? (__bf16)0.f : (lo ? (__bf16)(bv[e] - (float)hi) : hi);
+                for (int e = 0; e < 8; ++e) b[e] = (__bf16)0.f;
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u], bf, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u], b, acc, 0, 0, 0);
         }
     }
     // lane (c, h) holds rows (i&3) + 8 (i>>2) + 4 h of column c; hi + lo columns are 16 lanes apart
@@ -487,6 +501,9 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
     if (a.njobs > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32, a.B), dim3(64), 0, s, a);
+    const int smem = 32 * (a.KF / 8) * 16;
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_rowmean), smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32, a.B), dim3(64), smem, s, a);
     return hipGetLastError();
 }
