@@ -429,6 +429,25 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
 // FPS.  One block per image.  All arithmetic is IEEE fp32 with the reference's operation order and
 // no fused multiply-add, so that the selected set is bit-identical to numpy's for the same depth.
 #define FPS_THREADS 256
+// Wave-wide max / min through DPP: inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then the row totals are
+// carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lane 63 holds the result.
+__device__ __forceinline__ float dpp_wave_max(float v) {
+    const int ninf = 0xff800000;     // -inf
+#define DG_DPP_MAX(ctrl, rmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), ctrl, rmask, 0xf, false)))
+    DG_DPP_MAX(0x111, 0xf); DG_DPP_MAX(0x112, 0xf); DG_DPP_MAX(0x114, 0xf); DG_DPP_MAX(0x118, 0xf);
+    DG_DPP_MAX(0x142, 0xa); DG_DPP_MAX(0x143, 0xc);
+#undef DG_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int dpp_wave_min(int v) {
+    const int big = 0x7fffffff;
+#define DG_DPP_MIN(ctrl, rmask) v = min(v, __builtin_amdgcn_update_dpp(big, v, ctrl, rmask, 0xf, false))
+    DG_DPP_MIN(0x111, 0xf); DG_DPP_MIN(0x112, 0xf); DG_DPP_MIN(0x114, 0xf); DG_DPP_MIN(0x118, 0xf);
+    DG_DPP_MIN(0x142, 0xa); DG_DPP_MIN(0x143, 0xc);
+#undef DG_DPP_MIN
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int NPT>       // points per thread: h*w <= NPT * FPS_THREADS
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restrict__ depth, int H, int W, int h, int w,
                                                             int S, float factor, float* __restrict__ out_coords,
                                                             int32_t* __restrict__ out_inds) {
@@ -436,6 +455,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
     const int HW = h * w, nsel = S * S;
     float* px = sm; float* py = px + HW; float* pz = py + HW;
     int* sel = reinterpret_cast<int*>(pz + HW);            // 1 when selected
+    int* order = sel + HW;                                 // [nsel] selection order
     __shared__ float rv[2 * FPS_THREADS / 64];
     __shared__ int ri[2 * FPS_THREADS / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -463,12 +483,11 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
         pz[idx] = __fmul_rn(-dv, 5.0f);
         sel[idx] = 0;
     }
-    if (tid == 0 && out_inds) out_inds[(size_t)n * nsel] = 0;
+    if (tid == 0) order[0] = 0;
     __syncthreads();
     // Rounds: every thread keeps its points (idx = tid + FPS_THREADS*k), their running distances and a "taken" mask in
     // registers; one barrier per round: the waves publish their arg-max in slots that alternate with the round parity, every
     // thread combines the four results itself (lowest index wins ties, as numpy's first-max over the ascending remainder).
-    constexpr int NPT = 16;                              // points per thread: h*w <= 4096
     float qx[NPT], qy[NPT], qz[NPT], qd[NPT];
     uint32_t taken = 0;
 #pragma unroll
@@ -487,7 +506,6 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
         float bv = -1.f; int bi = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
-            if (FPS_THREADS * k >= HW) break;            // uniform
             const float dx = __fsub_rn(lx, qx[k]), dy = __fsub_rn(ly, qy[k]), dz = __fsub_rn(lz, qz[k]);
             const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
             const bool live = !((taken >> k) & 1u);
@@ -495,9 +513,11 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
             if (live) qd[k] = nd;
             if (live && nd > bv) { bv = nd; bi = tid + FPS_THREADS * k; }      // ascending idx per thread -> first max kept
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        // wave arg-max with DPP row operations (no LDS crossbar): max of the values, then min of the indices that attain it
+        {
+            const float wmax = dpp_wave_max(bv);
+            bi = dpp_wave_min(bv == wmax ? bi : 0x7fffffff);
+            bv = wmax;
         }
         const int par = (it & 1) * (FPS_THREADS / 64);
         if ((tid & 63) == 0) { rv[par + (tid >> 6)] = bv; ri[par + (tid >> 6)] = bi; }
@@ -510,9 +530,11 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
         }
         last = i0;
         if ((i0 & (FPS_THREADS - 1)) == tid) { taken |= 1u << (i0 / FPS_THREADS); sel[i0] = 1; }
-        if (tid == 0 && out_inds) out_inds[(size_t)n * nsel + it] = i0;
+        if (tid == 0) order[it] = i0;          // (kept in LDS: a global store per round would be waited for at every barrier)
     }
     __syncthreads();
+    if (out_inds)
+        for (int k = tid; k < nsel; k += FPS_THREADS) out_inds[(size_t)n * nsel + k] = order[k];
     // selected set in row-major order -> coords (row/h, col/w)*2-1
     for (int idx = tid; idx < HW; idx += FPS_THREADS) {
         if (!sel[idx]) continue;
@@ -527,11 +549,16 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
 
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s) {
-    const int smem = h * w * 4 * 4;
-    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_fps_coords), smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fps_coords, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
-    return hipGetLastError();
+    const int smem = h * w * 4 * 4 + S * S * 4;
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
+        return hipGetLastError();
+    };
+    if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);
+    if (h * w <= 8 * FPS_THREADS) return launch(k_fps_coords<8>);
+    return launch(k_fps_coords<16>);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -102,8 +102,14 @@ class ContrastiveCorrelationLoss(nn.Module):
         if mode in ("fps", "fps_depth_feat"):   # 'fps_depth_feat' == 'fps' in the reference (quirk Q13)
             if depth is None or depth_pos is None:
                 raise AttributeError("depth_sampling='fps' needs depth and depth_pos (the reference fails on None too, quirk Q8)")
-            c1 = ops.fps_coords(depth, orig_feats.shape[-2:], S)
-            c2 = ops.fps_coords(depth_pos, orig_feats_pos.shape[-2:], S)
+            if depth.shape == depth_pos.shape and orig_feats.shape[-2:] == orig_feats_pos.shape[-2:]:
+                # one launch for both maps: the sampler is a sequential per-image loop (one block per image), so the two
+                # calls of the reference (src/modules.py:1304-1308) simply run side by side on twice as many CUs
+                both = ops.fps_coords(torch.cat([depth, depth_pos], dim=0), orig_feats.shape[-2:], S)
+                c1, c2 = both[:B], both[B:]
+            else:
+                c1 = ops.fps_coords(depth, orig_feats.shape[-2:], S)
+                c2 = ops.fps_coords(depth_pos, orig_feats_pos.shape[-2:], S)
             assert tuple(c1.shape) == tuple(c2.shape) == tuple(coord_shape), f"{c1.shape} != {c2.shape} != {coord_shape}"
             return c1, c2, False
         if getattr(cfg, "dg_dense_grid", False) and S == orig_feats.shape[-2] == orig_feats.shape[-1]:
