@@ -143,7 +143,8 @@ hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND>
+// NKC: code k-steps of the Y chain actually run (<= NKD): with D <= 16*NKC the remaining fragments are zero padding
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND, int NKC = NKD>
 __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, GF = BL::GF;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr int NBUF = BL::BYTES > 48 * 1024 ? 2 : 3;   // LDS buffers; tiles are fetched NBUF-1 ahead
     constexpr bool RCREG = BL::BYTES > 48 * 1024;         // LDS full (ViT-B): stationary code rows live in registers
     constexpr int NSF = KIND == KIND_DEPTH ? 0 : NKF;     // feature k-steps per tile
-    constexpr int NS = NKD + NSF;                         // MFMA steps of one Y chain
+    constexpr int NS = NKC + NSF;                         // MFMA steps of one Y chain
     static_assert(!RCREG || RF == 1, "register-resident code rows only with one fragment per wave");
     constexpr bool GOUT = GRAD && KIND == KIND_LANE;     // pass-A helper jobs store their G tiles for k_gs
     constexpr bool STAG = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT;
@@ -334,7 +335,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                 const int k = st - NSF;
                 const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
                 Yc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur), b, Yc[f], 0, 0, 0);
-                if (!RCREG && k + 2 < NKD) rb[k & 1] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + (k + 2) * 1024);
+                if (!RCREG && k + 2 < NKC) rb[k & 1] = *reinterpret_cast<const v4i*>(rc_lds + f * RCB + crow + (k + 2) * 1024);
             }
             if (st + PF < NS) ra[st % PF] = *a_ptr(st + PF);
             between(st);
@@ -556,7 +557,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     }
 }
 
-template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE>
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int NKC = NKD>
 __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] + Rc[NWAVES][RF][C part] + red[NWAVES][2]
     // ---- XCD-aware block order: blocks that share an XCD (orig % 8) get a contiguous range of logical ids,
@@ -573,9 +574,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
     const int jid = bid / args.nrb;
     const int rb = bid - jid * args.nrb;
     const DgJob& job = args.jobs[jid];
-    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH>(args, job, n, rb, smem);
-    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW>(args, job, n, rb, smem);
-    else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE>(args, job, n, rb, smem);
+    if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH, NKC>(args, job, n, rb, smem);
+    else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW, NKC>(args, job, n, rb, smem);
+    else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE, NKC>(args, job, n, rb, smem);
 }
 
 // ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------
@@ -761,12 +762,12 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
 }
 
 // ---- launch helpers (host) ------------------------------------------------------------------
-template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE>
+template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int NKC = NKD>
 static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     using BL = BlobT<NKF, NKD>;
     const bool big = BL::BYTES > 48 * 1024;
     const int smem = (big ? 2 : 3) * (BL::BYTES + 256) + (big ? 0 : NWAVES * RF * (BL::OFF_P - BL::OFF_C)) + NWAVES * 2 * 4;
-    auto kern = k_corr_main<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE>;
+    auto kern = k_corr_main<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, NKC>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
     const int grid = args.njobs * args.B * args.nrb;
@@ -807,6 +808,9 @@ hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, in
         if (mode == 2) return launch_corr_t<NKF_, NKD_, NW_, 1, false, true, false>(args, stream);      \
         return launch_corr_t<NKF_, NKD_, NW_, 1, false, false, false>(args, stream);                    \
     }
+    // ViT-S recipe (D = 70 <= 80): the sixth code k-step of the Y chain would multiply zero padding
+    if (KF == 384 && KD == 96 && nwaves == 8 && mode == 1 && simple && args.D <= 80)
+        return launch_corr_t<24, 6, 8, 1, true, false, true, 5>(args, stream);
     DG_CASE(8, 6, 4) DG_CASE(8, 8, 4)
     DG_CASE(24, 6, 4) DG_CASE(24, 6, 8) DG_CASE(24, 8, 4)
     DG_CASE(48, 6, 4) DG_CASE(48, 8, 4)
