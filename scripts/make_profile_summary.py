@@ -34,7 +34,7 @@ o += ["\n(`k_corr_main` has extra calls: `bench.py`'s roofline leg re-launches i
       f"* HBM traffic per launch (PMC): FETCH_SIZE {m['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction) = {m['hbm_read_bytes_corrected']/1e6:.0f} MB read, "
       f"WRITE_SIZE {m['WRITE_SIZE']:.0f} KiB = {m['hbm_write_bytes']/1e6:.0f} MB written (287 MB fp16 G tiles for k_gs + 77 MB raw gradient tiles), "
       f"total {m['hbm_traffic_bytes_per_launch']/1e6:.0f} MB = {m['hbm_traffic_bytes_per_launch']/(avg*1e-6)/1e12:.2f} TB/s during the kernel.",
-      f"* SQ counters per launch: SQ_VALU_MFMA_BUSY_CYCLES {m['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} (= 5.28 M MFMAs x 32 cycles), "
+      f"* SQ counters per launch: SQ_VALU_MFMA_BUSY_CYCLES {m['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} (= MFMA instructions x 32 cycles), "
       f"SQ_INSTS_VALU {m['SQ_INSTS_VALU']:.3g}, SQ_INSTS_LDS {m['SQ_INSTS_LDS']:.3g}, SQ_LDS_BANK_CONFLICT {m['SQ_LDS_BANK_CONFLICT']:.0f}, "
       f"SQ_WAVE_CYCLES {m['SQ_WAVE_CYCLES']:.3g}, SQ_WAIT_INST_ANY {m['SQ_WAIT_INST_ANY']:.3g}.",
       f"\n## Step\n\n{b['value']} steps/s ({b['ms_per_step']} ms per step) on one GPU; CPU restatement on {b['cpu_baseline']['cores']} host threads: "
