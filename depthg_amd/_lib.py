@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
+DG_VERSION = 101                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID = \
     (1 << i for i in range(7))
 
@@ -40,6 +41,9 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, cp = ctypes.c_void_p, ctypes.POINTER(CorrDesc)
     lib.dg_version.restype = ctypes.c_int
+    if lib.dg_version() != DG_VERSION:
+        raise RuntimeError(f"depthg_amd: {LIB_PATH} is version {lib.dg_version()}, the Python layer expects {DG_VERSION}; "
+                           "rebuild it with `make -C depthg_amd/csrc`")
     lib.dg_last_error.restype = ctypes.c_char_p
     lib.dg_corr_workspace_bytes.restype = ctypes.c_size_t
     lib.dg_corr_workspace_bytes.argtypes = [cp]

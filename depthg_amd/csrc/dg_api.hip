@@ -155,10 +155,8 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
     a.dummy = ws + p.op[0];
 }
 
-// Job table of the fused correlation launch: pass A (stationary = operand 1) for every pair-set, then (with
-// gradients) pass B (stationary = operand 2), the cheap depth job last.  Pass-A jobs come first: returns their count
-// (the depth job, when present, is the last job of the table and is also a pass-A job for the loss sums).
-// k_gs jobs: one per pair-set; the producing job is pass A of helper_job(t) (R = operand 1, S = operand 2 of t)
+// k_gs jobs: one per pair-set; the producing job of the G tiles is helper_job(t) of the fused launch (R = operand 1,
+// S = operand 2 of pair-set t)
 static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArgs& g) {
     memset(&g, 0, sizeof(g));
     g.njobs = p.T; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
@@ -172,6 +170,9 @@ static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArg
     }
 }
 
+// Job table of the fused correlation launch: one job per pair-set (stationary = operand 1), the cheap depth job last.
+// Returns the number of pair-set jobs; *depth_index = position of the depth job or -1.  (Stationary = operand 2 is only
+// used by dg_corr_materialize, whose stores then run along the second position index.)
 static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a,
                            int* depth_index) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 100
+#define DG_VERSION 101   /* 101: descriptor carries the total weights, out_scalars has DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
