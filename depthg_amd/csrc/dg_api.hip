@@ -159,7 +159,7 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 // S = operand 2 of pair-set t)
 static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArgs& g) {
     memset(&g, 0, sizeof(g));
-    g.njobs = p.T; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
+    g.njobs = p.T; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD; g.D = p.D;
     for (int t = 0; t < p.T; ++t) {
         const int o2 = op_of(p, t);
         g.jobs[t].G = reinterpret_cast<const uint16_t*>(ws + p.gbuf[t]);

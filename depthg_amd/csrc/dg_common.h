@@ -288,6 +288,7 @@ struct DgGsJob {
 struct DgGsArgs {
     DgGsJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
+    int32_t D;             // real code channels (<= KD)
     int32_t debug;         // developer ablation bits (0 in production)
     DgFinishArgs fin;      // the first block also reduces k_corr_main's partial sums (fin.out == null: nothing to do)
 };

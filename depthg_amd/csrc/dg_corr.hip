@@ -496,7 +496,8 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {dR[f][d][4 * g], dR[f][d][4 * g + 1], dR[f][d][4 * g + 2], dR[f][d][4 * g + 3]};
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
+                    if (32 * d + r < args.D)      // padding channels (D..KD-1) are never read: do not spend HBM writes on them
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
                 }
         }
     }
@@ -740,7 +741,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
                 const int i = 4 * g + e;
                 v[e] = (acc[f][i] - (float)x[f][i] * dot[i]) * inv[i];
             }
-            *reinterpret_cast<f32x4*>(out + (f * 4 + g) * 256) = v;
+            if (32 * f + r < a.D) *reinterpret_cast<f32x4*>(out + (f * 4 + g) * 256) = v;      // padding channels are never read
         }
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ float dg_pick(const float (&gs)[4], int i) { return i
 template <int NDF>
 __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
-    const int lane = threadIdx.x, h = lane >> 5, DP = NDF * 32;
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5, DP = NDF * 32;
     DG_LOAD_GS(a, gs)
     float v[NDF][16];
 #pragma unroll
@@ -61,9 +61,13 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         for (int d = 0; d < NDF; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (d * 4 + g) * 256);
+                // padding channels are not stored by the producers: those lanes re-read a valid address (cache hit, no
+                // branch around the batched loads) and contribute zero
+                const bool ok = 32 * d + r < a.D;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
+                const float scm = ok ? sc : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, t[e], v[d][4 * g + e]);
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(scm, t[e], v[d][4 * g + e]);
             }
     }
     if (any_raw) {
@@ -98,9 +102,13 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         for (int d = 0; d < NDF; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (d * 4 + g) * 256);
+                // padding channels are not stored by the producers: those lanes re-read a valid address (cache hit, no
+                // branch around the batched loads) and contribute zero
+                const bool ok = 32 * d + r < a.D;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
+                const float scm = ok ? sc : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, t[e], v[d][4 * g + e]);
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(scm, t[e], v[d][4 * g + e]);
             }
     }
     float* out = a.comb[dest] + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 t = {v[d][4 * g], v[d][4 * g + 1], v[d][4 * g + 2], v[d][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(out + (d * 4 + g) * 256) = t;
+            if (32 * d + r < a.D) *reinterpret_cast<f32x4*>(out + (d * 4 + g) * 256) = t;
         }
 }
 
@@ -341,8 +349,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
         const size_t toff = ((size_t)t * NF + f) * 1024 + lane * 4;
         f32x4 v[4];
         const float* cb = a.comb[dest] + (size_t)b * a.Ppad * a.DP + toff;
+        const bool chan = 32 * f + r < a.D;                   // padding channels are not stored by the producers
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(cb + g * 256);
+        for (int g = 0; g < 4; ++g) v[g] = chan ? *reinterpret_cast<const f32x4*>(cb + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         for (int e0 = 0; e0 < cnt; e0 += 4) {                 // 4 routed images per round: 16 loads in flight
             f32x4 u[4][4];
             float sc[4];
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
                 sc[k] = e0 + k < cnt ? rl_w[e] : 0.f;
                 const float* sb = rl_p[e] + toff;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) u[k][g] = *reinterpret_cast<const f32x4*>(sb + g * 256);
+                for (int g = 0; g < 4; ++g) u[k][g] = chan ? *reinterpret_cast<const f32x4*>(sb + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
