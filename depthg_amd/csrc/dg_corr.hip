@@ -590,8 +590,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 //     shared by all consumers: the producer wave moves it global -> LDS with the LDS-DMA into a ring of GS_NB buffers,
 //     GS_NB-1 tiles ahead, and is the only wave that waits on it (counted vmcnt), so the one barrier per R tile never
 //     exposes a load latency.
-// The G tile is transposed through a per-wave LDS scratch (p order permuted with dg_perm32 so that one 16-byte read is
-// the A fragment matching a granule of the P part) and 6 MFMAs accumulate it.  Then the normalisation backward with the
+// The G tile is transposed through a per-wave LDS scratch: four 8-byte stores per lane into a swizzled [p][q] image, read
+// back with the transposing ds_read_b64_tr_b16 (rows picked in the position order of the P part's granules); 6 MFMAs
+// accumulate it.  Then the normalisation backward with the
 // S code is applied in registers and the accumulator tile is written as a gradient tile (dg_gtile_off).
 // grid (ceil(nt/GS_CW), B, jobs), block (GS_CW+1)*64, dynamic LDS GS_NB P parts + GS_CW scratch tiles.
 #define GS_CW 7
@@ -665,7 +666,9 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
 #pragma unroll
     for (int f = 0; f < NDF; ++f) acc[f] = f32x16{};
     char* T = gs_smem + GS_NB * PB + wid * (32 * TS);
-    const int pcol = dg_perm32(r) * 2;          // byte column of this lane's R position in the scratch rows
+    // ds_read_b64_tr_b16 addressing: lane l of a 16-lane group supplies row (l>>2)&3 and chunk 4*((l>>4)&1) + (l&3) of the block
+    const int tr_a = (lane >> 2) & 3, tr_c = 4 * ((lane >> 4) & 1) + (lane & 3);
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
     const v4i* Gbase = reinterpret_cast<const v4i*>(J.G + (((size_t)n * ntS * ntS + st) * 64 + lane) * 16);
     const size_t gstride = (size_t)ntS * 64 * 2;            // v4i per R tile step
     auto load_g = [&](int rt, v4i (&g)[2]) {
@@ -686,11 +689,11 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
                 const v4i g0 = gring[k][0], g1 = gring[k][1];
                 const uint32_t w[8] = {(uint32_t)g0[0], (uint32_t)g0[1], (uint32_t)g0[2], (uint32_t)g0[3],
                                        (uint32_t)g1[0], (uint32_t)g1[1], (uint32_t)g1[2], (uint32_t)g1[3]};
+                // [p][q] image, 64-byte rows of 8 chunks (4 q each), chunk index XOR-ed with p&7: the lane (p = r, h) owns
+                // the chunks 2g + h of its row: elements 4g..4g+3 = q 8g+4h .. +3, packed in w[2g], w[2g+1]
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {        // element i of the producing lane: S row q = (i&3)+8*(i>>2)+4*h
-                    const int q = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    *reinterpret_cast<uint16_t*>(T + q * TS + pcol) = (uint16_t)(w[i >> 1] >> (16 * (i & 1)));
-                }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(T + r * 64 + (((2 * g + h) ^ (r & 7)) * 8)) = make_uint2(w[2 * g], w[2 * g + 1]);
                 if (rt + 3 < nt) load_g(rt + 3, gring[k]);
                 __builtin_amdgcn_s_barrier();               // P part of tile rt is in the ring
                 asm volatile("" ::: "memory");
@@ -698,7 +701,19 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
                     const char* P = gs_smem + (rt % GS_NB) * PB;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        const f16x8 afrag = *reinterpret_cast<const f16x8*>(T + r * TS + (2 * ks + h) * 16);
+                        // A fragment of dS = G^T x: element e of lane (q, h) is G[q][p], p = 16 ks + 8 (e>>2) + 4 h + (e&3) (the
+                        // position order of the P part's granule 2 ks + h); two transposing reads of 4 image rows each
+                        f16x8 afrag;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int prow = 16 * ks + 8 * u + 4 * h + tr_a;
+                            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_p;
+                            const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (lds_s16x4_p)(T + prow * 64 + ((tr_c ^ (prow & 7)) * 8)));
+                            const f16x4 tf = __builtin_bit_cast(f16x4, t);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) afrag[4 * u + e] = tf[e];
+                        }
 #pragma unroll
                         for (int f = 0; f < NDF; ++f) {
                             const f16x8 bfrag = *reinterpret_cast<const f16x8*>(P + ((2 * ks + h) * KD + 32 * f + r) * 16);
