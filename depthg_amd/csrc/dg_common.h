@@ -124,6 +124,21 @@ __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
 }
 #endif
 
+#ifdef __HIPCC__
+// Sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 separately), result in every lane of the half.  DPP row
+// operations instead of the LDS crossbar: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), row totals carried
+// into the odd rows (row_bcast15), then lanes 31 / 63 are broadcast.
+__device__ __forceinline__ float half_sum(float v) {
+#define DG_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    DG_DPP_ADD(0x111, 0xf); DG_DPP_ADD(0x112, 0xf); DG_DPP_ADD(0x114, 0xf); DG_DPP_ADD(0x118, 0xf);
+    DG_DPP_ADD(0x142, 0xa);
+#undef DG_DPP_ADD
+    const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (threadIdx.x & 32) ? s1 : s0;
+}
+#endif
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 

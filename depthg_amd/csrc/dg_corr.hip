@@ -53,13 +53,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 separately)
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 enum { KIND_LANE = 0, KIND_ROW = 1, KIND_DEPTH = 2 };   // centering vector on lanes (R = operand 1) / on tile rows / depth term
 typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef DG_STAGGER

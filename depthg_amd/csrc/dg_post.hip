@@ -84,9 +84,7 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
             for (int i = 0; i < 16; ++i) dot[i] = fmaf((float)x[d][i], v[d][i], dot[i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float t = dot[i];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
+            const float t = half_sum(dot[i]);
             const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             const float inv = rr < a.P ? a.xinv[(size_t)n * a.Ppad + rr] : 0.f;
 #pragma unroll
