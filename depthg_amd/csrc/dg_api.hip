@@ -235,10 +235,16 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
-        DG_HIP(dg_launch_transpose(orig_feats, F32(p.nhwc_f[0]), p.B, p.C, HW, p.C4, stream));
-        DG_HIP(dg_launch_transpose(orig_feats_pos, F32(p.nhwc_f[1]), p.B, p.C, HW, p.C4, stream));
-        DG_HIP(dg_launch_transpose(orig_code, F32(p.nhwc_c[0]), p.B, p.D, HW, p.D4, stream));
-        DG_HIP(dg_launch_transpose(orig_code_pos, F32(p.nhwc_c[1]), p.B, p.D, HW, p.D4, stream));
+        {
+            DgTransposeArgs t;
+            memset(&t, 0, sizeof(t));
+            t.nmaps = 4; t.HW = HW;
+            t.src[0] = orig_feats; t.dst[0] = F32(p.nhwc_f[0]); t.K[0] = p.C; t.K4[0] = p.C4;
+            t.src[1] = orig_feats_pos; t.dst[1] = F32(p.nhwc_f[1]); t.K[1] = p.C; t.K4[1] = p.C4;
+            t.src[2] = orig_code; t.dst[2] = F32(p.nhwc_c[0]); t.K[2] = p.D; t.K4[2] = p.D4;
+            t.src[3] = orig_code_pos; t.dst[3] = F32(p.nhwc_c[1]); t.K[3] = p.D; t.K4[3] = p.D4;
+            DG_HIP(dg_launch_transpose(t, p.B, stream));
+        }
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
         g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;

@@ -200,6 +200,13 @@ struct DgFinishArgs {
 
 // ---- argument blocks of the helper kernels (one definition shared by kernels and host API)
 
+struct DgTransposeArgs {    // NCHW (B,K,h,w) fp32 -> NHWC (B,h*w,K4) fp32 for up to four maps in one launch
+    const float* src[4];
+    float* dst[4];
+    int32_t K[4], K4[4];
+    int32_t nmaps, HW;
+};
+
 struct DgGatherJob {
     const float* src;        // NHWC fp32 [B][h*w][K4]
     const float* coords;     // [B][S][S][2]
@@ -336,7 +343,7 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
-hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s);
+hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);

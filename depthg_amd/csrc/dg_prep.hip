@@ -11,10 +11,17 @@
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
-__global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict__ dst, int K, int HW, int K4) {
+// all four maps of a step (feats, feats_pos, code, code_pos) in one launch: blockIdx.y walks the 32-channel groups of the
+// maps one after the other
+__global__ void k_nchw_to_nhwc(const DgTransposeArgs a) {
     __shared__ float t[32][33];
     const int b = blockIdx.z;
-    const int k0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    int m = 0, gy = blockIdx.y;
+    while (m < a.nmaps - 1 && gy >= (a.K4[m] + 31) / 32) { gy -= (a.K4[m] + 31) / 32; ++m; }
+    const float* __restrict__ src = a.src[m];
+    float* __restrict__ dst = a.dst[m];
+    const int K = a.K[m], K4 = a.K4[m], HW = a.HW;
+    const int k0 = gy * 32, p0 = blockIdx.x * 32;
     const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         int k = k0 + i, p = p0 + tx;
@@ -27,9 +34,11 @@ __global__ void k_nchw_to_nhwc(const float* __restrict__ src, float* __restrict_
     }
 }
 
-hipError_t dg_launch_transpose(const float* src, float* dst, int B, int K, int HW, int K4, hipStream_t s) {
-    dim3 grid((HW + 31) / 32, (K4 + 31) / 32, B), block(32, 8);
-    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, block, 0, s, src, dst, K, HW, K4);
+hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s) {
+    int gy = 0;
+    for (int m = 0; m < a.nmaps; ++m) gy += (a.K4[m] + 31) / 32;
+    dim3 grid((a.HW + 31) / 32, gy, B), block(32, 8);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, block, 0, s, a);
     return hipGetLastError();
 }
 
