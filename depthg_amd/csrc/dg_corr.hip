@@ -563,10 +563,32 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
     const int per_img = args.njobs * args.nrb;
-    const int n = bid / per_img;
-    bid -= n * per_img;
-    const int jid = bid / args.nrb;
-    const int rb = bid - jid * args.nrb;
+    int n, jid, rb;
+    const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
+    if ((gridDim.x & 7) == 0 && (args.B & 7) == 0 && nh > 0 && !(args.debug & 8388608)) {
+        // every XCD owns B/8 whole images; inside that chunk the long blocks go first (longest-processing-time order):
+        // pair-set jobs with a full row block, then their ragged last row block, then the cheap depth job
+        const int imgs = args.B >> 3, per_chunk = imgs * per_img;
+        const int xcd = bid / per_chunk;
+        int i = bid - xcd * per_chunk;
+        const bool ragged = args.nrb > 1 && ((args.Ppad >> 5) % (NWAVES * RF)) != 0;
+        const int nfull = args.nrb - (ragged ? 1 : 0);
+        const int cA = imgs * nh * nfull, cB = ragged ? imgs * nh : 0;
+        int nl;
+        if (i < cA) {
+            nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull;
+        } else if (i < cA + cB) {
+            i -= cA; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1;
+        } else {
+            i -= cA + cB; nl = i / args.nrb; jid = nh; rb = i - nl * args.nrb;
+        }
+        n = xcd * imgs + nl;
+    } else {
+        n = bid / per_img;
+        bid -= n * per_img;
+        jid = bid / args.nrb;
+        rb = bid - jid * args.nrb;
+    }
     const DgJob& job = args.jobs[jid];
     if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH, NKC>(args, job, n, rb, smem);
     else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW, NKC>(args, job, n, rb, smem);
