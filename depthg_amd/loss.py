@@ -51,7 +51,7 @@ def identity_coords(b: int, s: int, device) -> torch.Tensor:
 
 
 class _CorrLossFunction(torch.autograd.Function):
-    """out[8] = fused loss scalars; backward = dg_corr_backward with the upstream of out[0:4]."""
+    """out[DG_OUT_COUNT] = fused loss scalars (+ weighted total); backward = dg_corr_backward with the upstream of that vector."""
 
     @staticmethod
     def forward(ctx, orig_code, orig_code_pos, orig_feats, orig_feats_pos, depth, coords1, coords2, perms, desc, holder):
