@@ -183,8 +183,15 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const int nR = job.ridx ? (int)job.ridx[n] : n;
     const int nS = job.sidx ? (int)job.sidx[n] : n;
 
+    // ---- ragged last row block with ONE row tile (e.g. P = 784: 24.5 tiles): waves 0 and 1 both take that tile and share
+    //      the S tiles (even / odd), the other waves fetch; four tile buffers (the unused code-row slots hold the fourth).
+    //      Without this the block runs one wave for as long as a full block runs eight.
+    const int nact = min(NWAVES, (ntiles_all - rb * NWAVES * RF + RF - 1) / RF);
+    const bool pair = DG_STAGGER && NWAVES == 8 && RF == 1 && NBUF == 3 && !MAT && !RCREG && nact == 1 && ntiles > 1 &&
+                      !(dbg & 67108864);
+    const bool owner = !(pair && wid == 1);               // wave 1 hands its gradient accumulators to wave 0 at the end
     // ---- the RF 32-row tiles of R owned by this wave
-    const int rtile0 = (rb * NWAVES + wid) * RF;
+    const int rtile0 = (rb * NWAVES + ((pair && wid == 1) ? 0 : wid)) * RF;
     bool act[RF];
     int pr[RF];
     const char* Rblob[RF];
@@ -200,7 +207,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 
     // ---- stationary operand: feats fragments -> registers, code rows -> LDS (DMA of the C part of its blob)
     const uint32_t smem_a = lds_addr(smem);
-    char* rc_lds = smem + NBUF * BUF + wid * (RF * RCB);
+    char* rc_lds = smem + NBUF * BUF + (pair ? 0 : wid) * (RF * RCB);
     f16x8 Rc[RCREG ? NKD : 1];
     if (RCREG) {
 #pragma unroll
@@ -208,7 +215,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             Rc[ks] = *reinterpret_cast<const f16x8*>(Rblob[0] + BL::OFF_C + ((2 * ks + h) * 32 + r) * 16);
             asm volatile("" : "+v"(Rc[ks]));
         }
-    } else {
+    } else if (!pair || wid == 0) {
 #pragma unroll
         for (int f = 0; f < RF; ++f)
             for (int c = 0; c < RCB / 1024; ++c)
@@ -259,20 +266,33 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     constexpr int C_BEGIN = KIND == KIND_DEPTH ? BL::CHUNK_C0 : 0;
     constexpr int C_END = GRAD ? BL::CHUNKS : BL::CHUNK_P0;
     constexpr int PIECES = (C_END - C_BEGIN + NWAVES - 1) / NWAVES;
+    // which 1-KiB chunks of a tile this wave fetches: normally chunk c belongs to wave NWAVES-1 - c % NWAVES; in a ragged
+    // last row block (fewer than half of the waves own rows) the idle waves share all chunks
+    const int ncomp = pair ? 2 : nact;                      // waves that compute in this block
+    const bool idle_fetch = RF == 1 && nact > 0 && nact < NWAVES / 2 && !(dbg & 33554432);
+    const int dma_stride = idle_fetch ? NWAVES - ncomp : NWAVES;
+    const int dma_first = idle_fetch ? (wid >= ncomp ? wid - ncomp : -1) : 0;
     auto issue = [&](int t, int b) {
         const char* src = Sbase + (size_t)t * BL::BYTES;
-        const uint32_t dst = smem_a + b * BUF;
+        // (buffer 3: pair mode only, behind wave 0's code rows)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_a + b * BUF + (b == 3 ? RCB : 0));
         // chunk c goes to wave NWAVES-1 - c % NWAVES (a ragged remainder lands on the waves that run half a tile behind);
         // the counted waits below use this wave's own number of pieces (my_dma)
+        if (dma_stride == NWAVES) {
 #pragma unroll
-        for (int k = 0; k < PIECES; ++k) {
-            const int c = C_BEGIN + (NWAVES - 1 - wid) + k * NWAVES;
-            if (c < C_END) dma16(src + c * 1024, dst + c * 1024);
+            for (int k = 0; k < PIECES; ++k) {
+                const int c = C_BEGIN + (NWAVES - 1 - wid) + k * NWAVES;
+                if (c < C_END) dma16(src + c * 1024, dst + c * 1024);
+            }
+        } else if (dma_first >= 0) {     // ragged last row block: the waves without rows fetch the tiles for the few that have
+            for (int c = C_BEGIN + dma_first; c < C_END; c += dma_stride) dma16(src + c * 1024, dst + c * 1024);
         }
         if (KIND != KIND_LANE)     // 32 floats of the tile rows; all waves write the same bytes (lanes 32-63: a copy behind)
             dma4(vsrc + t * 32 + (lane & 31), dst + BL::BYTES);
     };
-    const int my_dma = (C_END - C_BEGIN - (NWAVES - 1 - wid) + NWAVES - 1) / NWAVES + (KIND != KIND_LANE ? 1 : 0);   // DMA instructions of this wave per tile
+    const int my_dma = (idle_fetch ? (dma_first >= 0 ? (C_END - C_BEGIN - dma_first + dma_stride - 1) / dma_stride : 0)
+                                   : (C_END - C_BEGIN - (NWAVES - 1 - wid) + NWAVES - 1) / NWAVES) +
+                       (KIND != KIND_LANE ? 1 : 0);   // DMA instructions of this wave per tile
 
     f32x16 dR[RF][NDF];
 #pragma unroll
@@ -423,25 +443,44 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             if (prio_mode == 1 && late) __builtin_amdgcn_s_setprio(1);
             if (prio_mode == 2 && !late) __builtin_amdgcn_s_setprio(1);
         }
+        // pair mode (ragged last row block): every wave takes the "early" schedule; waves 0 and 1 compute the even / odd tiles
+        // of a pair per barrier, waves 2-7 fetch the next pair into the other two of four buffers
+        const bool late2 = late && !pair;
+        auto tilep = [&](int t) -> const char* {
+            const int b = pair ? (t & 3) : t % 3;
+            return smem + b * BUF + (b == 3 ? RCB : 0);
+        };
         issue(0, 0);
+        if (pair) issue(1, 1);
         settle_R();
         auto top = [&](int t) {          // same barrier sequence in both halves
             STAMP(t, 0);
-            wait_vmcnt(nst);             // tile t landed; only the G stores of the previous tile may still be in flight
+            // tile t landed; only the G stores of the previous tile may still be in flight (fetch-only waves: nothing may)
+            wait_vmcnt((pair && dma_first >= 0) ? 0 : nst);
             if (!(dbg & 256)) __builtin_amdgcn_s_barrier();
             STAMP(t, 1);
-            // waves 4-7 fetch the next tile here; waves 0-3 do it after their chain (the issue of 4-5 LDS-DMA pieces costs
-            // 400-600 cycles in front of the chain, but hides beside the partner's chain) - bit 524288 switches that off
-            if (t + 1 < ntiles && !(dbg & 1) && (late || (dbg & 524288))) issue(t + 1, (t + 1) % 3);
+            if (pair) {
+                if (!(dbg & 1)) {
+                    if (t + 2 < ntiles) issue(t + 2, (t + 2) & 3);
+                    if (t + 3 < ntiles) issue(t + 3, (t + 3) & 3);
+                }
+            } else {
+                // waves 4-7 fetch the next tile here; waves 0-3 do it after their chain (the issue of 4-5 LDS-DMA pieces costs
+                // 400-600 cycles in front of the chain, but hides beside the partner's chain) - bit 524288 switches that off
+                if (t + 1 < ntiles && !(dbg & 1) && (late2 || (dbg & 524288))) issue(t + 1, (t + 1) % 3);
+            }
             STAMP(t, 2);
         };
-        if (!late) {
-            for (int t = 0; t < ntiles; ++t) {
-                top(t);
-                const char* tile = smem + (t % 3) * BUF;
-                if (wave_active) { chain(tile, 0, [](int) {}); STAMP(t, 3); }
-                if (t + 1 < ntiles && !(dbg & 1) && !(dbg & 524288)) issue(t + 1, (t + 1) % 3);
-                if (wave_active) post(tile, t, false);
+        if (!late2) {
+            const int tstep = pair ? 2 : 1, tfirst = pair ? wid : 0;
+            for (int t0 = 0; t0 < ntiles; t0 += tstep) {
+                top(t0);
+                const int t = t0 + tfirst;
+                const char* tile = tilep(t);
+                const bool work = wave_active && t < ntiles;
+                if (work) { chain(tile, 0, [](int) {}); STAMP(t0, 3); }
+                if (!pair && t0 + 1 < ntiles && !(dbg & 1) && !(dbg & 524288)) issue(t0 + 1, (t0 + 1) % 3);
+                if (work) post(tile, t, false);
             }
         } else {
             top(0);
@@ -479,7 +518,24 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     //      [image][R tile][channel group d][i>>2][lane][i&3] (16 bytes per lane and store, 1 KiB per wave instruction).
     //      The normalisation backward is linear with the same x for every pair-set whose stationary operand is operand 1,
     //      so k_grad_combine applies it once to the weighted sum of these buffers.
-    if (GRAD && job.dR && !(dbg & 512)) {
+    if (pair && GRAD) {          // wave 1's share of the gradient accumulators -> wave 0 (through the free tile buffers)
+        __syncthreads();
+        float* xch = reinterpret_cast<float*>(smem);
+        if (wid == 1) {
+#pragma unroll
+            for (int d = 0; d < NDF; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xch[(d * 16 + i) * 64 + lane] = dR[0][d][i];
+        }
+        __syncthreads();
+        if (wid == 0) {
+#pragma unroll
+            for (int d = 0; d < NDF; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dR[0][d][i] += xch[(d * 16 + i) * 64 + lane];
+        }
+    }
+    if (GRAD && job.dR && owner && !(dbg & 512)) {
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
             if (!act[f]) continue;
@@ -506,7 +562,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         lsum = 0.f; csum = 0.f;
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
-            if (!act[f]) continue;
+            if (!act[f] || !owner) continue;
             float cs[NDF];
 #pragma unroll
             for (int d = 0; d < NDF; ++d) cs[d] = (KIND != KIND_DEPTH && job.Scsum) ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
@@ -590,6 +646,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
         rb = bid - jid * args.nrb;
     }
     const DgJob& job = args.jobs[jid];
+    if ((args.debug & 16777216) && rb == args.nrb - 1 && args.nrb > 1) return;     // (ablation: skip the last row block)
     if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH, NKC>(args, job, n, rb, smem);
     else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW, NKC>(args, job, n, rb, smem);
     else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE, NKC>(args, job, n, rb, smem);
