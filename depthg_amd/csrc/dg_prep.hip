@@ -233,61 +233,76 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
 
 // Code operand on the identity grid: one block per DENSE_TPB consecutive tiles (position p = i*S + j <- pixel (y = j, x = i)
 // of the NCHW code map, so a run of positions is a run of source COLUMNS: the block reads, per channel and source row, the
-// few-pixel run of its columns).  L2-normalise over the D channels (norm(), src/modules.py:789-790), write the C part
-// (K-major granules), the P part (position-major granules in dg_perm32 order), 1/max(||c||, eps) and the per-tile column
-// sums.  Same roundings as k_gather_norm.
-#define DENSE_TPB 1
+// run of its 5-6 columns - the more tiles per block, the longer those runs and the fewer line requests of this gather).
+// L2-normalise over the D channels (norm(), src/modules.py:789-790; squared norms reduced from registers), keep the
+// NORMALISED fp16 tile in LDS and write from it the C part (K-major granules), the P part (position-major granules in
+// dg_perm32 order), 1/max(||c||, eps) and the per-tile column sums.  Same roundings as k_gather_norm.
+#define DENSE_TPB 2
+#define DENSE_CODE_PAIRS 192      // (source row, column) pairs of one block: S * (columns touched) <= 192
+template <int UN>        // channels per thread: D <= 4 * UN
 __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int tb, int n, int o) {
-    const int tid = threadIdx.x;
-    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, LD = KD + 1, nt = a.Ppad / 32;
+    const int tid = threadIdx.x, ps = tid & 63, kg = tid >> 6;
+    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, nt = a.Ppad / 32;
+    const int RS = (KD + 4) * 2;                       // LDS row stride (bytes): 8-byte aligned rows, odd multiple of 8
     const int t0 = tb * DENSE_TPB, ntile = min(DENSE_TPB, nt - t0);
     const int p0 = t0 * 32, np = ntile * 32, pend = min(p0 + np, a.P);
-    const int xa = p0 / S, NC = (pend - 1) / S - xa + 1;
-    float* xs = sl;                      // [np][KD + 1]
-    float* inv = sl + DENSE_TPB * 32 * LD;
+    const int xa = p0 / S, NC = (pend - 1) / S - xa + 1, npairs = S * NC;
+    char* xt = reinterpret_cast<char*>(sl);            // [np][RS] normalised fp16 rows
+    float* red = reinterpret_cast<float*>(xt + DENSE_TPB * 32 * RS);      // [4][DENSE_CODE_PAIRS] partial squared norms
+    float* inv = red + 4 * DENSE_CODE_PAIRS;                               // [np]
     const DgBlob L(a.KF, a.KD);
-    // zero what the loads below do not write: channels D..KD-1 and the positions P..Ppad-1 of the ragged last tile
-    for (int id = tid; id < np * (KD - D); id += 256) { const int pos = id / (KD - D), c = id - pos * (KD - D); xs[pos * LD + D + c] = 0.f; }
-    for (int id = tid; id < (p0 + np - pend) * D; id += 256) { const int pos = pend - p0 + id / D, c = id % D; xs[pos * LD + c] = 0.f; }
+    // zero tile (padding channels D..KD-1, positions P..Ppad-1 of the ragged last tile), 8 bytes per store
+    for (int id = tid; id < np * (RS / 8); id += 256) reinterpret_cast<uint2*>(xt)[id] = make_uint2(0u, 0u);
+    for (int pos = tid; pos < np; pos += 256) inv[pos] = 0.f;
     const float* src = a.code[o] + (size_t)n * D * HW;
-    // lanes walk the (source row y, column xl) pairs, the four waves split the channels (k = wave + 4u): one integer
-    // division per pair, none per load, and all loads of a thread in flight at once
-    constexpr int UN = 18;                               // one batch for D <= 72
-    const int kg = tid >> 6;
-    for (int pair = tid & 63; pair < S * NC; pair += 64) {
+    // lanes walk the (source row y, column xl) pairs (xl fastest: runs of NC contiguous pixels), the four waves split the
+    // channels (k = wave + 4u): one integer division per pair, none per load, all loads of a thread in flight at once
+    constexpr int NJ = DENSE_CODE_PAIRS / 64;            // <= 3 pairs per lane, all their channels in one batch
+    float t[NJ][UN];
+    int pos[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int pair = ps + 64 * j;
         const int y = pair / NC, xl = pair - y * NC;
         const int pp = (xa + xl) * S + y;
-        if (pp < p0 || pp >= pend) continue;
-        const float* sp = src + y * a.w + xa + xl;
-        float* dp = xs + (pp - p0) * LD;
-        for (int kb = kg; kb < D; kb += 4 * UN) {
-            float t[UN];
+        const bool ok = pair < npairs && pp >= p0 && pp < pend;
+        pos[j] = ok ? pp - p0 : -1;
+        const float* sp = src + (ok ? y * a.w + xa + xl : 0);
 #pragma unroll
-            for (int u = 0; u < UN; ++u) t[u] = kb + 4 * u < D ? sp[(size_t)(kb + 4 * u) * HW] : 0.f;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) if (kb + 4 * u < D) dp[kb + 4 * u] = t[u];
-        }
+        for (int u = 0; u < UN; ++u) t[j][u] = (ok && kg + 4 * u < D) ? sp[(size_t)(kg + 4 * u) * HW] : 0.f;
     }
-    __syncthreads();
-    for (int pos = tid; pos < np; pos += 256) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         float ss = 0.f;
-#pragma unroll 10
-        for (int k = 0; k < D; ++k) ss = fmaf(xs[pos * LD + k], xs[pos * LD + k], ss);
-        const float iv = (p0 + pos) < a.P ? 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM) : 0.f;
-        inv[pos] = iv;
-        a.inv_norm[o][(size_t)n * a.Ppad + p0 + pos] = iv;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) ss = fmaf(t[j][u], t[j][u], ss);
+        red[kg * DENSE_CODE_PAIRS + ps + 64 * j] = ss;
     }
     __syncthreads();
+    if (a.debug & 8) return;                                  // (ablation: loads only)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (pos[j] < 0) continue;
+        const int pair = ps + 64 * j;
+        const float ss = red[pair] + red[DENSE_CODE_PAIRS + pair] + red[2 * DENSE_CODE_PAIRS + pair] + red[3 * DENSE_CODE_PAIRS + pair];
+        const float iv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
+        if (kg == 0) { inv[pos[j]] = iv; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (kg + 4 * u < D) *reinterpret_cast<_Float16*>(xt + pos[j] * RS + (kg + 4 * u) * 2) = (_Float16)(t[j][u] * iv);
+    }
+    __syncthreads();
+    for (int pos2 = tid; pos2 < np; pos2 += 256) a.inv_norm[o][(size_t)n * a.Ppad + p0 + pos2] = inv[pos2];
+    if (a.debug & 16) return;                                 // (ablation: no output phases)
     char* blob0 = a.blob[o] + ((size_t)n * nt + t0) * L.bytes;
     const int GD = KD / 8;
     for (int id = tid; id < ntile * GD * 32; id += 256) {     // C part: granule g of position qq of tile tl
         const int tl = id / (GD * 32), rem = id - tl * (GD * 32), g = rem >> 5, qq = rem & 31;
-        const float* row = xs + (tl * 32 + qq) * LD + 8 * g;
-        const float iv = inv[tl * 32 + qq];
-        f16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (_Float16)(row[e] * iv);
-        *reinterpret_cast<f16x8*>(blob0 + (size_t)tl * L.bytes + L.c(qq, g)) = v;
+        const char* row = xt + (tl * 32 + qq) * RS + 16 * g;
+        uint4 v;
+        const uint2 lo = *reinterpret_cast<const uint2*>(row), hi = *reinterpret_cast<const uint2*>(row + 8);
+        v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+        *reinterpret_cast<uint4*>(blob0 + (size_t)tl * L.bytes + L.c(qq, g)) = v;
     }
     for (int id = tid; id < ntile * 4 * KD; id += 256) {      // P part: granule cc of channel d = slots 8cc .. 8cc+7
         const int tl = id / (4 * KD), rem = id - tl * (4 * KD), cc = rem / KD, d = rem - cc * KD;
@@ -295,7 +310,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int pl = 16 * (cc >> 1) + 8 * ((e >> 2) & 1) + 4 * (cc & 1) + (e & 3);   // dg_perm32(pl) == 8 cc + e
-            v[e] = (_Float16)(xs[(tl * 32 + pl) * LD + d] * inv[tl * 32 + pl]);
+            v[e] = *reinterpret_cast<const _Float16*>(xt + (tl * 32 + pl) * RS + d * 2);
         }
         *reinterpret_cast<f16x8*>(blob0 + (size_t)tl * L.bytes + L.p(d, cc)) = v;
     }
@@ -303,7 +318,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
         const int tl = id / KD, d = id - tl * KD;
         float cs = 0.f;
 #pragma unroll 8
-        for (int qq = 0; qq < 32; ++qq) cs += (float)(_Float16)(xs[(tl * 32 + qq) * LD + d] * inv[tl * 32 + qq]);
+        for (int qq = 0; qq < 32; ++qq) cs += (float)*reinterpret_cast<const _Float16*>(xt + (tl * 32 + qq) * RS + d * 2);
         a.ccolpart[o][((size_t)n * nt + t0 + tl) * KD + d] = cs;
     }
 }
@@ -314,7 +329,7 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
 // grid h * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
-template <int MAXU>
+template <int MAXU, int UNC>
 __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     extern __shared__ float sl[];
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): consecutive logical ids - the source rows of one
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     if (z < 2) {
         if (x < a.h && !(a.debug & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
     } else if (z < 4) {
-        if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code(a, sl, x, n, z - 2);
+        if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
     } else if (x == 0 && !(a.debug & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
     }
@@ -341,7 +356,9 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.w > 32 || a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
     const int nt = a.Ppad / 32, gx = a.h;
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
-    const int smem = max(32 * (a.KF * 2 + 8) + 8 * 32 * 4, DENSE_TPB * 32 * (a.KD + 2) * 4);
+    const int smem = max(32 * (a.KF * 2 + 8) + 8 * 32 * 4,
+                         DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);
+    if (a.h * ((DENSE_TPB * 32 + a.h - 1) / a.h + 1) > DENSE_CODE_PAIRS) return hipErrorInvalidValue;   // pairs per block
     DgDenseArgs a2 = a;
     if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
     const dim3 grid(gx * a.B * (a.depth ? 5 : 4));
@@ -351,7 +368,9 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a2);
         return hipGetLastError();
     };
-    return a.KF <= 384 ? launch(k_prep_dense<48>) : launch(k_prep_dense<96>);   // registers per thread follow the width
+    // registers per thread follow the widths
+    if (a.D <= 72) return a.KF <= 384 ? launch(k_prep_dense<48, 18>) : launch(k_prep_dense<96, 18>);
+    return a.KF <= 384 ? launch(k_prep_dense<48, 32>) : launch(k_prep_dense<96, 32>);
 }
 
 // ------------------------------------------------------------------------------------------
