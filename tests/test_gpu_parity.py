@@ -296,7 +296,9 @@ def test_super_perms_kernel(dev):
                                               (3, 64, 24, 7, 1, True),      # one negative
                                               (2, 128, 70, 9, 1, True),     # odd map size, P = 81 (ragged last tile)
                                               (3, 64, 24, 7, 1, False),     # same through the general gather path
-                                              (5, 96, 33, 6, 3, True)])     # P = 36: one full + one ragged tile, odd batch
+                                              (5, 96, 33, 6, 3, True),      # P = 36: one full + one ragged tile, odd batch
+                                              (2, 768, 100, 8, 2, True),    # ViT-B widths on the dense path (KF = 768, KD = 128)
+                                              (8, 384, 70, 28, 5, True)])   # headline width, B = 8: LPT block order, row-tile pair
 def test_edge_shapes_dense_and_general(B, C, D, hw, N, ident, dev):
     """Small / degenerate shapes against the CPU oracle on the identity grid (S == h == w): dense NCHW path
     (DG_IDENTITY_GRID) and the general gather path must both reproduce the reference's arithmetic."""
