@@ -298,7 +298,8 @@ def test_super_perms_kernel(dev):
                                               (3, 64, 24, 7, 1, False),     # same through the general gather path
                                               (5, 96, 33, 6, 3, True),      # P = 36: one full + one ragged tile, odd batch
                                               (2, 768, 100, 8, 2, True),    # ViT-B widths on the dense path (KF = 768, KD = 128)
-                                              (8, 384, 70, 28, 5, True)])   # headline width, B = 8: LPT block order, row-tile pair
+                                              (8, 384, 70, 28, 5, True),    # headline width, B = 8: LPT block order, row-tile pair
+                                              (2, 768, 100, 28, 2, True)])  # ViT-B at 28x28: 4-wave blocks, code rows in registers
 def test_edge_shapes_dense_and_general(B, C, D, hw, N, ident, dev):
     """Small / degenerate shapes against the CPU oracle on the identity grid (S == h == w): dense NCHW path
     (DG_IDENTITY_GRID) and the general gather path must both reproduce the reference's arithmetic."""
