@@ -15,6 +15,7 @@ CONFIGS = {
     "headline general path B=32 C=384 D=70 S=28 rand":  (32, 384, 70, 28, 28, "none", True, False),
     "headline dense path   B=32 C=384 D=70 S=28 ident": (32, 384, 70, 28, 28, "none", True, True),
     "C5 hi-res B=8 C=384 D=70 56x56 S=56 rand":         (8, 384, 70, 56, 56, "none", True, False),
+    "ViT-B dense path  B=32 C=768 D=100 S=28 ident":    (32, 768, 100, 28, 28, "none", True, True),
 }
 dev = torch.device("cuda:0")
 flt = os.environ.get("DG_CFG_FILTER", "")
