@@ -8,12 +8,13 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 101                     # must match include/depthg_corr.h: a stale library is refused
-DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID = \
-    (1 << i for i in range(7))
+DG_VERSION = 102                     # must match include/depthg_corr.h: a stale library is refused
+DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID = \
+    (1 << i for i in range(8))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
-           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms"]
+           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
+           "dg_salience_coords", "dg_simple_depth_coords"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -61,6 +62,10 @@ def load():
     lib.dg_fps_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_super_perms.restype = ctypes.c_int
     lib.dg_super_perms.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
+    lib.dg_salience_coords.restype = ctypes.c_int
+    lib.dg_salience_coords.argtypes = [vp] + [ctypes.c_int32] * 4 + [vp, vp, vp, vp]
+    lib.dg_simple_depth_coords.restype = ctypes.c_int
+    lib.dg_simple_depth_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -28,7 +28,7 @@ extern "C" const char* dg_last_error(void) { return g_err; }
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
-    int B, C, D, h, w, S, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;
+    int B, C, D, h, w, S, Sh, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;
     bool shared, depth, grad, pointwise, ident;
     size_t nhwc_f[2], nhwc_c[2];
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
@@ -50,7 +50,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (d->D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", d->D);
     if ((size_t)d->h * d->w > 16384) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large", d->h, d->w);
     p.B = d->B; p.C = d->C; p.D = d->D; p.h = d->h; p.w = d->w; p.S = d->S; p.N = d->n_neg;
-    p.P = d->S * d->S;
+    p.Sh = (d->flags & DG_LINE_GRID) ? 1 : d->S;      // sample grid: Sh rows x S columns
+    p.P = p.Sh * d->S;
     p.Ppad = (int)up(p.P, 32);
     p.KF = d->C <= 128 ? 128 : (d->C <= 384 ? 384 : 768);
     p.KD = d->D <= 96 ? 96 : 128;
@@ -61,7 +62,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.grad = (d->flags & DG_NEED_GRAD) != 0;
     p.pointwise = (d->flags & DG_POINTWISE) != 0;
     p.ident = (d->flags & DG_IDENTITY_GRID) != 0;
-    if (p.ident && (!p.shared || d->S != d->h || d->S != d->w || d->w > 32))
+    if (p.ident && (p.Sh != p.S || !p.shared || d->S != d->h || d->S != d->w || d->w > 32))
         return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs DG_SHARED_COORDS and S == h == w <= 32");
     p.nops = p.shared ? 2 : p.T;
     p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
@@ -247,7 +248,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         }
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
-        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
+        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.Sh = p.Sh; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
         int nj = 0;
         for (int o = 0; o < p.nops; ++o) {
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
@@ -264,7 +265,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         }
         g.njobs = nj;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
-        if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.S, p.Ppad, stream));
+        if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }
 
     // 3. column sums of the operands (mean feats for the centering, code sums for the cd means), then the row means of
@@ -366,7 +367,7 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
         s.xop = ws + p.op[0]; s.xinv = F32(p.inv[0]); s.blob_bytes = bl.bytes; s.blob_off_c = bl.off_c;
     }
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
-    s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.P = p.P; s.Ppad = p.Ppad;
+    s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.Sh = p.Sh; s.P = p.P; s.Ppad = p.Ppad;
     if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);
     s.DC = 8;
     s.dense = p.ident ? 1 : 0;
@@ -418,6 +419,26 @@ extern "C" int dg_super_perms(const float* keys, int32_t count, int32_t B, int64
     if (count == 0) return DG_OK;
     if (!keys || !out) return fail(DG_ERR_INVALID, "null pointer");
     DG_HIP(dg_launch_super_perms(keys, count, B, out, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_salience_coords(const float* salience, int32_t B, int32_t H, int32_t W, int32_t n, const float* u_sel,
+                                  const float* u_fallback, float* out_coords, dg_stream_t stream_) {
+    if (!salience || !u_sel || !u_fallback || !out_coords) return fail(DG_ERR_INVALID, "null pointer");
+    if (B < 1 || H < 1 || W < 1 || n < 1) return fail(DG_ERR_INVALID, "bad salience sampler dimensions");
+    if ((size_t)H * W > (1u << 24)) return fail(DG_ERR_UNSUPPORTED, "salience map %dx%d too large", H, W);
+    DG_HIP(dg_launch_salience_coords(salience, B, H, W, n, u_sel, u_fallback, out_coords, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_simple_depth_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_w, int32_t h, int32_t w,
+                                      int32_t n, const float* u_value, const float* u_pick, float* out_coords,
+                                      dg_stream_t stream_) {
+    if (!depth || !u_value || !u_pick || !out_coords) return fail(DG_ERR_INVALID, "null pointer");
+    if (B < 1 || h < 1 || w < 1 || n < 1 || depth_h < 1 || depth_w < 1) return fail(DG_ERR_INVALID, "bad sampler dimensions");
+    if ((size_t)h * w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the sampler (max 4096 pixels)", h, w);
+    DG_HIP(dg_launch_simple_coords(depth, B, depth_h, depth_w, h, w, n, u_value, u_pick, out_coords,
+                                   static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -220,7 +220,7 @@ struct DgGatherJob {
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
     DgGatherJob jobs[DG_MAX_GATHER];
-    int32_t njobs, B, h, w, S, P, Ppad, KF, KD;
+    int32_t njobs, B, h, w, S, Sh, P, Ppad, KF, KD;   // sample grid: Sh rows x S columns (Sh == S, or 1 with DG_LINE_GRID)
 };
 
 struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
@@ -286,7 +286,7 @@ struct DgScatterArgs {
     const float* xinv;     // [B][Ppad] 1 / max(||code||, eps) of operand 1
     int32_t blob_bytes, blob_off_c;
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
-    int32_t B, D, DP, h, w, S, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
+    int32_t B, D, DP, h, w, S, Sh, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
     int32_t debug;         // developer ablation bits (0 in production)
     int32_t dense;         // 1: identity grid (DG_IDENTITY_GRID): the adjoint of sample() is a transposed copy
 };
@@ -345,11 +345,15 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s);
+hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
 hipError_t dg_launch_super_perms(const float* keys, int count, int B, int64_t* out, hipStream_t s);
+hipError_t dg_launch_salience_coords(const float* sal, int B, int H, int W, int n, const float* u_sel, const float* u_fb,
+                                     float* out, hipStream_t s);
+hipError_t dg_launch_simple_coords(const float* depth, int B, int H, int W, int h, int w, int n, const float* u_val,
+                                   const float* u_pick, float* out, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

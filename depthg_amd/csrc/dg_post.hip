@@ -143,7 +143,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
     int x0 = 0, y0 = 0; bool inx = false, iny = false; float w4[4] = {0.f, 0.f, 0.f, 0.f};
     for (int pp = tid; pp < P; pp += SCAT_THREADS) {
         const int i = pp / S, j = pp - i * S;
-        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        dg_taps(coords + (((size_t)nimg * S + j) * a.Sh + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
         const int pix = y0 * a.w + x0;
         if (w4[0] != 0.f) atomicAdd(&cnt[pix], 1);
         if (inx && w4[1] != 0.f) atomicAdd(&cnt[pix + 1], 1);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
     __syncthreads();
     for (int pp = tid; pp < P; pp += SCAT_THREADS) {
         const int i = pp / S, j = pp - i * S;
-        dg_taps(coords + (((size_t)nimg * S + j) * S + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        dg_taps(coords + (((size_t)nimg * S + j) * a.Sh + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
         const int pix = y0 * a.w + x0;
         auto put = [&](int q, float wgt) {
             const int slot = off[q] + atomicAdd(&cnt[q], 1);

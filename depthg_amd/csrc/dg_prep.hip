@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const float* img = J.src + (size_t)ns * a.h * a.w * K4;
-    const int S = a.S;
+    const int S = a.S, Sh = a.Sh;
     const DgBlob L(a.KF, a.KD);
     char* blob = J.blob + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
 
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
         if (p < a.P) {
             // output position (i, j) = (p / S, p % S) reads x = coords[n][j][i][0], y = coords[n][j][i][1]
             const int i = p / S, j = p - i * S;
-            const float* c = J.coords + (((size_t)n * S + j) * S + i) * 2;
+            const float* c = J.coords + (((size_t)n * S + j) * Sh + i) * 2;
             float x = ((c[0] + 1.f) / 2.f) * (float)(a.w - 1);
             float y = ((c[1] + 1.f) / 2.f) * (float)(a.h - 1);
             x = fminf(fmaxf(x, 0.f), (float)(a.w - 1));
@@ -324,7 +324,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
 }
 
 __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                               int n, int H, int W, int S, int Ppad);
+                                               int n, int H, int W, int Sh, int S, int Ppad);
 
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     } else if (z < 4) {
         if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
     } else if (x == 0 && !(a.debug & 4)) {
-        depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.Ppad);
+        depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad);
     }
 }
 
@@ -375,11 +375,11 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // depth (B,1,H,W) -> nz[n][p] over the S x S resize, p = i*S + j (row major)
-__device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, int n, int p, int H, int W, int S) {
+__device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, int n, int p, int H, int W, int Sh, int S) {
     float out = 0.f;
-    if (p < S * S) {
+    if (p < Sh * S) {
         const int i = p / S, j = p - i * S;
-        const float sy = S > 1 ? (float)(H - 1) / (float)(S - 1) : 0.f;
+        const float sy = Sh > 1 ? (float)(H - 1) / (float)(Sh - 1) : 0.f;
         const float sx = S > 1 ? (float)(W - 1) / (float)(S - 1) : 0.f;
         const float fy = sy * (float)i, fx = sx * (float)j;
         int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
@@ -396,11 +396,11 @@ __device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, in
 
 // all positions of image n by one block of 256 threads, plus their sum (mean(dd) = mean_n (sum_p nz)^2 / P^2)
 __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                               int n, int H, int W, int S, int Ppad) {
+                                               int n, int H, int W, int Sh, int S, int Ppad) {
     __shared__ float wred[4];
     float s = 0.f;
     for (int p = threadIdx.x; p < Ppad; p += 256) {
-        const float v = depth_nz_at(depth, n, p, H, W, S);
+        const float v = depth_nz_at(depth, n, p, H, W, Sh, S);
         nz[(size_t)n * Ppad + p] = v;
         s += v;
     }
@@ -412,12 +412,12 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 }
 
 __global__ __launch_bounds__(256) void k_depth_nz(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                                  int H, int W, int S, int Ppad) {
-    depth_nz_image(depth, nz, nzsum, blockIdx.x, H, W, S, Ppad);
+                                                  int H, int W, int Sh, int S, int Ppad) {
+    depth_nz_image(depth, nz, nzsum, blockIdx.x, H, W, Sh, S, Ppad);
 }
 
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int S, int Ppad, hipStream_t s) {
-    hipLaunchKernelGGL(k_depth_nz, dim3(B), dim3(256), 0, s, depth, nz, nzsum, H, W, S, Ppad);
+hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s) {
+    hipLaunchKernelGGL(k_depth_nz, dim3(B), dim3(256), 0, s, depth, nz, nzsum, H, W, Sh, S, Ppad);
     return hipGetLastError();
 }
 

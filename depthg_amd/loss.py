@@ -94,11 +94,20 @@ class ContrastiveCorrelationLoss(nn.Module):
         B, S = orig_feats.shape[0], int(cfg.feature_samples)
         dev = orig_feats.device
         coord_shape = [B, S, S, 2]
-        if getattr(cfg, "use_salience", False):
-            raise NotImplementedError("depthg_amd: use_salience sampling is outside the hot path (SURVEY.md 8(f) N4)")
+        if getattr(cfg, "use_salience", False):          # src/modules.py:1290-1297
+            c1_nonzero = ops.salience_coords(orig_salience, S)
+            c2_nonzero = ops.salience_coords(orig_salience_pos, S)
+            c1_reg = torch.rand(coord_shape, device=dev) * 2 - 1
+            c2_reg = torch.rand(coord_shape, device=dev) * 2 - 1
+            mask = (torch.rand(coord_shape[:-1], device=dev) > .1).unsqueeze(-1).to(torch.float32)
+            return c1_nonzero * mask + c1_reg * (1 - mask), c2_nonzero * mask + c2_reg * (1 - mask), False
         mode = cfg.depth_sampling
-        if mode == "simple":
-            raise NotImplementedError("depthg_amd: depth_sampling='simple' is outside the hot path (SURVEY.md 8(f) N4)")
+        if mode == "simple":                             # src/modules.py:1299-1302: S x 1 grids, (B,S,1,2)
+            if depth is None or depth_pos is None:
+                raise AttributeError("depth_sampling='simple' needs depth and depth_pos")
+            c1 = ops.simple_depth_coords(depth, orig_feats.shape[-2:], S)
+            c2 = ops.simple_depth_coords(depth_pos, orig_feats_pos.shape[-2:], S)
+            return c1, c2, False
         if mode in ("fps", "fps_depth_feat"):   # 'fps_depth_feat' == 'fps' in the reference (quirk Q13)
             if depth is None or depth_pos is None:
                 raise AttributeError("depth_sampling='fps' needs depth and depth_pos (the reference fails on None too, quirk Q8)")
@@ -148,6 +157,10 @@ class ContrastiveCorrelationLoss(nn.Module):
         depth_c = ops._f32c(depth, "depth") if depth_term else None
         coords1 = ops._f32c(coords1, "coords1")
         coords2 = ops._f32c(coords2, "coords2")
+        if tuple(coords1.shape) != tuple(coords2.shape) or tuple(coords1.shape) not in ((B, S, S, 2), (B, S, 1, 2)):
+            raise ValueError(f"depthg_amd: coords must both be (B,S,S,2) or (B,S,1,2) with B={B}, S={S}; got "
+                             f"{tuple(coords1.shape)} and {tuple(coords2.shape)}")
+        line_grid = coords1.shape[2] == 1 and S != 1       # S x 1 grid of depth_sampling='simple'
         if isinstance(perms, (list, tuple)):
             perms_t = torch.stack([p.to(device=dev, dtype=torch.long) for p in perms]) if N > 0 else \
                 torch.zeros(0, B, dtype=torch.long, device=dev)
@@ -162,7 +175,8 @@ class ContrastiveCorrelationLoss(nn.Module):
                              shifts=(cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift,
                                      cfg.depth_feat_shift if depth_term else 0.0),
                              depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
-                             identity_grid=bool(identity_grid), weights=self._total_weights(depth_term))
+                             identity_grid=bool(identity_grid), weights=self._total_weights(depth_term),
+                             line_grid=line_grid)
         holder = {}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
@@ -200,7 +214,8 @@ class ContrastiveCorrelationLoss(nn.Module):
             # src/train_segmentation.py:303)
             neg_loss_t = torch.cat(neg_loss, dim=0) + (out[2] - out[2].detach())
         else:
-            neg_cd_t = torch.zeros(0, S, S, S, S, device=dev)
+            sh = 1 if line_grid else S
+            neg_cd_t = torch.zeros(0, sh, S, sh, S, device=dev)
             neg_loss_t = neg_cd_t.clone()
         res = (out[0], intra_cd, out[1], inter_cd, neg_loss_t, neg_cd_t)
         if depth_term:

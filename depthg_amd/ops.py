@@ -25,7 +25,7 @@ def _f32c(t, name):
 
 
 def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
-              shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0)):
+              shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0), line_grid=False):
     flags = 0
     flags |= _lib.DG_POINTWISE if pointwise else 0
     flags |= _lib.DG_ZERO_CLAMP if zero_clamp else 0
@@ -34,6 +34,7 @@ def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, dept
     flags |= _lib.DG_NEED_GRAD if need_grad else 0
     flags |= _lib.DG_SHARED_COORDS if shared_coords else 0
     flags |= _lib.DG_IDENTITY_GRID if identity_grid else 0
+    flags |= _lib.DG_LINE_GRID if line_grid else 0
     return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
                     float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]),
                     float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]))
@@ -76,7 +77,8 @@ def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_
 def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False):
     lib = _lib.load()
     dev = workspace.device
-    shape = (desc.B, desc.S, desc.S, desc.S, desc.S)
+    sh = 1 if (desc.flags & _lib.DG_LINE_GRID) else desc.S
+    shape = (desc.B, sh, desc.S, sh, desc.S)
     cd = torch.empty(shape, dtype=torch.float32, device=dev) if want_cd else None
     loss = torch.empty(shape, dtype=torch.float32, device=dev) if want_loss else None
     rc = lib.dg_corr_materialize(ctypes.byref(desc), int(which), _ptr(cd), _ptr(loss), _ptr(workspace),
@@ -99,6 +101,44 @@ def fps_coords(depth, feat_hw, n_samples, return_inds=False):
                            _stream(depth.device))
     _lib.check(rc, "dg_fps_coords")
     return (coords, inds) if return_inds else coords
+
+
+def salience_coords(salience, n_side, u_sel=None, u_fallback=None):
+    """sample_nonzero_locations (src/modules.py:1191-1204) on the GPU: salience (B,H,W) -> (B,S,S,2), flipped and *2-1 like
+    the reference.  u_sel (B,S*S) / u_fallback (B,S*S,2): iid uniforms in [0,1), drawn here unless given (tests)."""
+    lib = _lib.load()
+    sal = _f32c(salience, "salience")
+    if sal.dim() != 3:
+        raise ValueError(f"depthg_amd: salience must be (B,H,W) like the reference's batch['mask'].squeeze(1), got {tuple(sal.shape)}")
+    B, H, W = sal.shape
+    S = int(n_side)
+    n = S * S
+    dev = sal.device
+    u_sel = torch.rand(B, n, device=dev) if u_sel is None else _f32c(u_sel, "u_sel")
+    u_fallback = torch.rand(B, n, 2, device=dev) if u_fallback is None else _f32c(u_fallback, "u_fallback")
+    assert tuple(u_sel.shape) == (B, n) and tuple(u_fallback.shape) == (B, n, 2)
+    coords = torch.empty(B, S, S, 2, dtype=torch.float32, device=dev)
+    rc = lib.dg_salience_coords(_ptr(sal), B, H, W, n, _ptr(u_sel), _ptr(u_fallback), _ptr(coords), _stream(dev))
+    _lib.check(rc, "dg_salience_coords")
+    return coords
+
+
+def simple_depth_coords(depth, feat_hw, n_samples, u_value=None, u_pick=None):
+    """simple_depth_informed_sampling (src/modules.py:828-883) on the GPU: depth (B,1,H,W) -> coords (B,n,1,2), already
+    *2-1 (the caller's step at modules.py:1300).  u_value / u_pick (B,n): iid uniforms, drawn here unless given."""
+    lib = _lib.load()
+    depth = _f32c(depth, "depth")
+    B, _, H, W = depth.shape
+    h, w = int(feat_hw[0]), int(feat_hw[1])
+    n = int(n_samples)
+    dev = depth.device
+    u_value = torch.rand(B, n, device=dev) if u_value is None else _f32c(u_value, "u_value")
+    u_pick = torch.rand(B, n, device=dev) if u_pick is None else _f32c(u_pick, "u_pick")
+    assert tuple(u_value.shape) == (B, n) and tuple(u_pick.shape) == (B, n)
+    coords = torch.empty(B, n, 1, 2, dtype=torch.float32, device=dev)
+    rc = lib.dg_simple_depth_coords(_ptr(depth), B, H, W, h, w, n, _ptr(u_value), _ptr(u_pick), _ptr(coords), _stream(dev))
+    _lib.check(rc, "dg_simple_depth_coords")
+    return coords
 
 
 def super_perms(count, size, device):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 101   /* 101: descriptor carries the total weights, out_scalars has DG_OUT_TOTAL */
+#define DG_VERSION 102   /* 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -39,6 +39,11 @@ extern "C" {
 #define DG_IDENTITY_GRID  (1u << 6)  /* with DG_SHARED_COORDS and S == h == w: both coords are the pixel-centre grid
                                         (coords[b,u,v] = (lin[v], lin[u]), lin = linspace(-1,1,S)): sample() is an exact
                                         transpose and the feats operands are built without bilinear taps */
+
+#define DG_LINE_GRID      (1u << 7)  /* the sample grid is S x 1 instead of S x S: coords are (B,S,1,2), P = S positions and the
+                                        un-reduced tensors are (B,1,S,1,S) - what depth_sampling='simple' feeds the loss
+                                        (simple_depth_informed_sampling returns (B,n,1,2), src/modules.py:828-883,1299-1302);
+                                        the depth term resizes depth to (1,S) (modules.py:1261-1262 with c1.shape[2:] = (1,S)) */
 
 #define DG_MAX_NEG 8
 
@@ -57,7 +62,7 @@ typedef struct dg_corr_desc {
     int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 */
     int32_t D;        /* code channels = cfg.dim; <= 128 */
     int32_t h, w;     /* feature-map size of orig_feats / orig_code */
-    int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated */
+    int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated (P = S with DG_LINE_GRID) */
     int32_t n_neg;    /* cfg.neg_samples (<= DG_MAX_NEG) */
     int32_t depth_h, depth_w; /* size of the depth map (image resolution); 0 if no depth */
     uint32_t flags;
@@ -99,7 +104,7 @@ size_t dg_corr_workspace_bytes(const dg_corr_desc* desc);
  *  orig_feats, orig_feats_pos : fp32 (B,C,h,w) contiguous NCHW
  *  orig_code,  orig_code_pos  : fp32 (B,D,h,w)
  *  depth                      : fp32 (B,1,depth_h,depth_w) or NULL (required with DG_DEPTH_TERM)
- *  coords1, coords2           : fp32 (B,S,S,2) in [-1,1]  (what the reference passes to sample())
+ *  coords1, coords2           : fp32 (B,S,S,2) in [-1,1]  (what the reference passes to sample()); (B,S,1,2) with DG_LINE_GRID
  *  perms                      : int64 (n_neg,B) = super_perm() draws (modules.py:1184-1188,1341)
  *  out_scalars                : fp32 [DG_OUT_COUNT]
  * With DG_NEED_GRAD the unit-upstream gradient pieces are left in the workspace for
@@ -130,7 +135,7 @@ int dg_corr_backward(const dg_corr_desc* desc,
 /*
  * Optional full tensors the reference returns un-reduced (src/modules.py:1352-1367), computed
  * from the operands dg_corr_forward left in the workspace.  which: 0 = pos_intra, 1 = pos_inter,
- * 2+k = negative k, -1 = depth term.  out_cd / out_loss: fp32 (B,S,S,S,S) or NULL.
+ * 2+k = negative k, -1 = depth term.  out_cd / out_loss: fp32 (B,S,S,S,S) ((B,1,S,1,S) with DG_LINE_GRID) or NULL.
  * For which == -1 out_cd receives dd (tuple element 7).
  */
 int dg_corr_materialize(const dg_corr_desc* desc, int32_t which,
@@ -152,6 +157,33 @@ int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_
                   int32_t h, int32_t w, int32_t S,
                   float* out_coords, int32_t* out_inds,
                   void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * Salience-guided sample locations (replaces sample_nonzero_locations, src/modules.py:1191-1204, the cfg.use_salience
+ * branch of the coordinate draw, :1290-1297): every position gets a uniformly drawn non-zero pixel of its image's
+ * salience map (torch.nonzero = row-major order), returned as the reference does: both pixel coordinates divided by
+ * the map HEIGHT (t.shape[1]), mapped *2-1 and flipped to (x, y).  The randomness comes from the caller as iid uniforms
+ * in [0,1) (torch.rand); rank = min(int(u * count), count - 1).  An image without non-zeros gets
+ * min(int(u_fallback * H), H - 1) for both coordinates (modules.py:1198).
+ *  salience   : fp32 (B,H,W)         u_sel : fp32 (B,n)       u_fallback : fp32 (B,n,2)
+ *  out_coords : fp32 (B,n,2); n = S*S, so the caller views it as (B,S,S,2)
+ */
+int dg_salience_coords(const float* salience, int32_t B, int32_t H, int32_t W, int32_t n,
+                       const float* u_sel, const float* u_fallback, float* out_coords, dg_stream_t stream);
+
+/*
+ * Depth-distribution sample locations (replaces simple_depth_informed_sampling, src/modules.py:828-883, the
+ * cfg.depth_sampling == 'simple' branch, :1299-1302): adaptive_max_pool2d of depth to (h,w), rounded to one decimal;
+ * a depth value is drawn with probability count/h*w (the reference's multinomial over torch.unique counts), then one of
+ * the pixels holding that value uniformly (torch.nonzero order).  u_value / u_pick are the caller's iid uniforms for
+ * the two draws: sorted position R = min(int(u_value * h*w), h*w - 1) selects the value, min(int(u_pick * run), run - 1)
+ * the pixel inside its run.
+ *  depth      : fp32 (B,1,depth_h,depth_w)      u_value, u_pick : fp32 (B,n)      h*w <= 4096
+ *  out_coords : fp32 (B,n,1,2) = ((row + .5) / h, (col + .5) / w) * 2 - 1 (the *2-1 of modules.py:1300 included);
+ *               feed it to dg_corr_forward with DG_LINE_GRID and S = n.
+ */
+int dg_simple_depth_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_w, int32_t h, int32_t w,
+                           int32_t n, const float* u_value, const float* u_pick, float* out_coords, dg_stream_t stream);
 
 /*
  * Negative-pair batch permutations (replaces super_perm, src/modules.py:1184-1188, called n_neg times per step at

@@ -229,6 +229,125 @@ def super_perm_from(perm: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# N4  the other two samplers of the coordinate draw
+# --------------------------------------------------------------------------------------
+def rank_from_uniform(u, count: int) -> int:
+    """Rank among `count` candidates from a uniform u in [0,1): float32 product, truncated, clamped.  This is the
+    build's device-side replacement for the reference's host-side torch.randint(count) (include/depthg_corr.h)."""
+    r = int(np.float32(u) * np.float32(count))
+    return min(max(r, 0), count - 1)
+
+
+def nonzero_by_ranks(t_img: torch.Tensor, ranks: np.ndarray) -> np.ndarray:
+    """(n,) ranks -> (n,2) int64 (row, col) of the rank-th non-zero of a (H,W) map in row-major (torch.nonzero) order."""
+    h, w = t_img.shape
+    flat = np.flatnonzero(t_img.reshape(-1).numpy() != 0)
+    sel = flat[np.asarray(ranks, dtype=np.int64)]
+    return np.stack([sel // w, sel % w], axis=-1)
+
+
+def _salience_finish(picked: np.ndarray, target_size, h: int) -> torch.Tensor:
+    """(B,n,2) integer (row, col) -> what src/modules.py:1201-1204 returns: / t.shape[1] (BOTH coordinates), *2-1, flipped."""
+    c = torch.from_numpy(picked.reshape(target_size).astype(np.int64)).to(torch.float32) / h
+    c = c * 2 - 1
+    return torch.flip(c, dims=[-1])
+
+
+def sample_nonzero_locations(t: torch.Tensor, target_size) -> torch.Tensor:
+    """src/modules.py:1191-1204 with the reference's RNG calls in the reference's order (one torch.randint per image:
+    ranks among the image's non-zeros, or (n,2) integers in [0,H) for an image without any)."""
+    n = target_size[1] * target_size[2]
+    picked = np.zeros((t.shape[0], n, 2), dtype=np.int64)
+    for i in range(t.shape[0]):
+        count = int((t[i] != 0).sum())
+        if count == 0:
+            picked[i] = torch.randint(t.shape[1], size=(n, 2)).numpy()
+        else:
+            picked[i] = nonzero_by_ranks(t[i], torch.randint(count, size=(n,)).numpy())
+    return _salience_finish(picked, target_size, t.shape[1])
+
+
+def sample_nonzero_locations_from_uniform(t: torch.Tensor, target_size, u_sel, u_fallback) -> torch.Tensor:
+    """Same selection with caller-provided uniforms (dg_salience_coords): u_sel (B,n), u_fallback (B,n,2)."""
+    n = target_size[1] * target_size[2]
+    hh = t.shape[1]
+    picked = np.zeros((t.shape[0], n, 2), dtype=np.int64)
+    for i in range(t.shape[0]):
+        count = int((t[i] != 0).sum())
+        if count == 0:
+            picked[i] = [[rank_from_uniform(u_fallback[i, s, 0], hh), rank_from_uniform(u_fallback[i, s, 1], hh)] for s in range(n)]
+        else:
+            picked[i] = nonzero_by_ranks(t[i], [rank_from_uniform(u_sel[i, s], count) for s in range(n)])
+    return _salience_finish(picked, target_size, hh)
+
+
+def adaptive_max_pool2d(d: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """F.adaptive_max_pool2d (src/modules.py:830): window [floor(i*H/h), ceil((i+1)*H/h))."""
+    b, c, hin, win = d.shape
+    hout, wout = size
+    out = torch.empty(b, c, hout, wout, dtype=d.dtype)
+    for i in range(hout):
+        ys, ye = (i * hin) // hout, -((-(i + 1) * hin) // hout)
+        for j in range(wout):
+            xs, xe = (j * win) // wout, -((-(j + 1) * win) // wout)
+            out[:, :, i, j] = d[:, :, ys:ye, xs:xe].amax(dim=(2, 3))
+    return out
+
+
+def _rounded_depth(feat_hw, depth: torch.Tensor) -> torch.Tensor:
+    d = adaptive_max_pool2d(depth, tuple(feat_hw))
+    return (d * 10).round() / 10                                                   # src/modules.py:832
+
+
+def _simple_finish(rows_cols: np.ndarray, feat_hw) -> torch.Tensor:
+    """(B,n,2) integer (row, col) -> (B,n,1,2) = (coord + 0.5) / (h, w)   (src/modules.py:872-881)."""
+    c = (torch.from_numpy(rows_cols.astype(np.int64)).to(torch.float32) + 0.5) / torch.tensor(
+        [feat_hw[0], feat_hw[1]], dtype=torch.float32)
+    return c.unsqueeze(2)
+
+
+def simple_depth_informed_sampling(feat_hw, depth: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """src/modules.py:828-883 with the reference's RNG calls in the reference's order: one torch.multinomial per image
+    over the unique-value frequencies (all images first), then one torch.randint per (image, sample) among the pixels
+    holding the drawn value (torch.nonzero = row-major order).  Returns (B,n,1,2) in [0,1] as (row, col)."""
+    d = _rounded_depth(feat_hw, depth)
+    b = d.shape[0]
+    uniq, drawn = [], []
+    for i in range(b):
+        vals, counts = np.unique(d[i].numpy(), return_counts=True)               # sorted, like torch.unique
+        uniq.append(vals)
+        cnt = torch.from_numpy(counts)
+        probs = cnt.float() / cnt.sum()
+        drawn.append(torch.multinomial(probs, n_samples, replacement=True).numpy())
+    out = np.zeros((b, n_samples, 2), dtype=np.int64)
+    for i in range(b):
+        plane = d[i, 0]
+        for s in range(n_samples):
+            same = (plane == float(uniq[i][drawn[i][s]])).to(torch.float32)
+            count = int(same.sum())
+            out[i, s] = nonzero_by_ranks(same, [int(torch.randint(count, (1,)))])[0]
+    return _simple_finish(out, feat_hw)
+
+
+def simple_depth_informed_sampling_from_uniform(feat_hw, depth: torch.Tensor, n_samples: int, u_value, u_pick) -> torch.Tensor:
+    """Same two-stage draw with caller-provided uniforms (dg_simple_depth_coords): the value is the one at sorted
+    position R = rank_from_uniform(u_value, h*w) (probability count / (h*w), like the multinomial), the pixel the
+    rank_from_uniform(u_pick, count)-th holder of that value in row-major order."""
+    d = _rounded_depth(feat_hw, depth)
+    b = d.shape[0]
+    hw = int(feat_hw[0]) * int(feat_hw[1])
+    out = np.zeros((b, n_samples, 2), dtype=np.int64)
+    for i in range(b):
+        plane = d[i, 0]
+        srt = np.sort(plane.reshape(-1).numpy(), kind="stable")
+        for s in range(n_samples):
+            v = srt[rank_from_uniform(u_value[i, s], hw)]
+            same = (plane == float(v)).to(torch.float32)
+            out[i, s] = nonzero_by_ranks(same, [rank_from_uniform(u_pick[i, s], int(same.sum()))])[0]
+    return _simple_finish(out, feat_hw)
+
+
+# --------------------------------------------------------------------------------------
 # A4  helper                                                           src/modules.py:1231-1254
 # --------------------------------------------------------------------------------------
 def clamp_bounds(cfg) -> Tuple[float, Optional[float]]:
@@ -266,12 +385,22 @@ def depth_feature_correlation(cfg, c1, c2, d1, d2, shift):
 # --------------------------------------------------------------------------------------
 # A7  ContrastiveCorrelationLoss.forward                               src/modules.py:1280-1367
 # --------------------------------------------------------------------------------------
-def draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos):
-    """Coordinate selection, default branches only (src/modules.py:1290-1321)."""
+def draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos, salience=None, salience_pos=None):
+    """Coordinate selection (src/modules.py:1287-1321), RNG calls in the reference's order."""
     b = orig_feats.shape[0]
     s = cfg.feature_samples
-    if getattr(cfg, "use_salience", False) or cfg.depth_sampling == "simple":
-        raise NotImplementedError("non-default samplers are outside the hot path (SURVEY section 2 row 3)")
+    if getattr(cfg, "use_salience", False):                                        # :1290-1297
+        shape = [b, s, s, 2]
+        c1n = sample_nonzero_locations(salience, shape)
+        c2n = sample_nonzero_locations(salience_pos, shape)
+        c1r = torch.rand(shape) * 2 - 1
+        c2r = torch.rand(shape) * 2 - 1
+        mask = (torch.rand(shape[:-1]) > .1).unsqueeze(-1).to(torch.float32)
+        return c1n * mask + c1r * (1 - mask), c2n * mask + c2r * (1 - mask)
+    if cfg.depth_sampling == "simple":                                             # :1299-1302
+        c1 = simple_depth_informed_sampling(tuple(orig_feats.shape[-2:]), depth, s) * 2 - 1
+        c2 = simple_depth_informed_sampling(tuple(orig_feats_pos.shape[-2:]), depth_pos, s) * 2 - 1
+        return c1, c2
     if cfg.depth_sampling in ("fps", "fps_depth_feat"):
         hw = tuple(orig_feats.shape[-2:])
         c1 = farthest_point_sampling_depth(hw, depth, s) * 2 - 1
@@ -283,10 +412,10 @@ def draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos):
 
 
 def forward(cfg, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth=None, depth_pos=None,
-            coords1=None, coords2=None, perms: Optional[Sequence[torch.Tensor]] = None):
+            coords1=None, coords2=None, perms: Optional[Sequence[torch.Tensor]] = None, salience=None, salience_pos=None):
     """Returns the reference's 6- or 8-tuple.  coords/perms may be injected (RNG parity)."""
     if coords1 is None or coords2 is None:
-        coords1, coords2 = draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos)
+        coords1, coords2 = draw_coords(cfg, orig_feats, orig_feats_pos, depth, depth_pos, salience, salience_pos)
     feats = sample(orig_feats, coords1)
     code = sample(orig_code, coords1)
     feats_pos = sample(orig_feats_pos, coords2)

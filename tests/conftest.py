@@ -19,7 +19,8 @@ def load_golden(name):
 
 
 FORWARD_CASES = ["c1_none", "c1_fps", "nopointwise", "nozeroclamp", "stabalize", "nodepthloss", "zerodepth_fps",
-                 "batch1", "S9", "S12", "S14_dim100", "corr_feats", "surveykat_none", "surveykat_fps"]
+                 "batch1", "S9", "S12", "S14_dim100", "corr_feats", "surveykat_none", "surveykat_fps",
+                 "salience", "simple"]   # the last two: coords of the use_salience / depth_sampling='simple' samplers
 
 
 def cfg_from_fixture(fx, **over):
@@ -33,6 +34,8 @@ def cfg_from_fixture(fx, **over):
               "pos_inter_weight", "neg_inter_weight", "depth_feat_weight", "correspondence_weight"):
         kw[k] = float(fx[k])
     kw["depth_sampling"] = str(fx["depth_sampling"])
+    if "use_salience" in fx:
+        kw["use_salience"] = bool(fx["use_salience"])
     kw.update(over)
     return O.default_cfg(**kw)
 

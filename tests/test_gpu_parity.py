@@ -386,3 +386,107 @@ def test_bitwise_reproducible(dense, dev):
             ref = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+
+
+# ---- the salience / 'simple' samplers on the device ---------------------------------------
+def _edge_uniforms(u):
+    u = u.clone()
+    u.view(-1)[0] = 0.0
+    u.view(-1)[-1] = 0.99999994          # largest float32 below 1: must map to the last rank, not one past it
+    return u
+
+
+def test_salience_sampler_kernel(dev):
+    """dg_salience_coords == the oracle's uniform-driven sample_nonzero_locations, bit for bit (integer picks, then two
+    exactly rounded float ops): small non-square maps from the reference fixture (one image without non-zeros, one with
+    a single one) and image-resolution maps."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(91)
+    big = (torch.rand(3, 224, 224, generator=g) > 0.7).float()
+    big[1] = 0.0
+    big[2] = 1.0
+    wide = (torch.rand(2, 37, 301, generator=g) > 0.97).float() * 3.0
+    for sal in (torch.from_numpy(load_golden("samplers.npz")["sal_map"]), big, wide):
+        B = sal.shape[0]
+        for S in (1, 5, 11):
+            u = _edge_uniforms(torch.rand(B, S * S, generator=g))
+            ufb = _edge_uniforms(torch.rand(B, S * S, 2, generator=g))
+            got = ops.salience_coords(sal.to(dev), S, u.to(dev), ufb.to(dev)).cpu()
+            want = O.sample_nonzero_locations_from_uniform(sal, [B, S, S, 2], u.numpy(), ufb.numpy())
+            assert got.shape == want.shape and torch.equal(got, want)
+
+
+def test_simple_sampler_kernel(dev):
+    """dg_simple_depth_coords == the oracle's uniform-driven simple_depth_informed_sampling, bit for bit: the reference
+    fixture's depth maps (long runs of equal values, 8-bit, floats with -0.0, rectangular maps) and the 28x28 / 64x64 sizes."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    fxs = load_golden("samplers.npz")
+    g = torch.Generator().manual_seed(92)
+    cases = [(torch.from_numpy(fxs[f"simple_{n}_depth"]), tuple(int(v) for v in fxs[f"simple_{n}_hw"]), int(fxs[f"simple_{n}_n"]))
+             for n in ("runs", "8bit", "float", "rect")]
+    cases.append(((torch.randint(0, 256, (2, 1, 224, 224), generator=g).float() / 8).round(), (28, 28), 28))
+    cases.append((torch.rand(2, 1, 64, 64, generator=g) * 2, (64, 64), 13))       # h*w = 4096, no pooling
+    cases.append((torch.full((1, 1, 30, 30), 7.0), (10, 10), 4))                  # a single value: one run
+    for depth, hw, n in cases:
+        B = depth.shape[0]
+        uv = _edge_uniforms(torch.rand(B, n, generator=g))
+        up = _edge_uniforms(torch.rand(B, n, generator=g))
+        got = ops.simple_depth_coords(depth.to(dev), hw, n, uv.to(dev), up.to(dev)).cpu()
+        want = O.simple_depth_informed_sampling_from_uniform(hw, depth, n, uv.numpy(), up.numpy()) * 2 - 1
+        assert got.shape == (B, n, 1, 2) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("mode", ["salience", "simple"])
+def test_module_forward_with_sampler(mode, dev):
+    """ContrastiveCorrelationLoss.forward on the use_salience / depth_sampling='simple' branches (src/modules.py:1290-1302):
+    the coordinates the module drew are legal sampler outputs, and the loss on them equals the oracle's."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(93)
+    B, C, D, hw, S = 3, 64, 24, 14, 7
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = (torch.randint(0, 256, (B, 1, 112, 112), generator=g).float() / 16).round()
+    dp = (torch.randint(0, 256, (B, 1, 112, 112), generator=g).float() / 16).round()
+    sal = (torch.rand(B, 112, 112, generator=g) > 0.8).float()
+    salp = (torch.rand(B, 112, 112, generator=g) > 0.8).float()
+    cfg = O.default_cfg(feature_samples=S, neg_samples=2, use_salience=(mode == "salience"),
+                        depth_sampling="simple" if mode == "simple" else "none")
+    loss = ContrastiveCorrelationLoss(cfg)
+    drawn = []
+    orig = loss._draw_coords
+    loss._draw_coords = lambda *a: (drawn.append(orig(*a)) or drawn[-1])
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = loss(f.to(dev), fp.to(dev), sal.to(dev), salp.to(dev), cg, cpg, d.to(dev), dp.to(dev))
+    total = O.total_loss(cfg, out)
+    total.backward()
+    c1, c2 = drawn[0][0].cpu(), drawn[0][1].cpu()
+    if mode == "simple":
+        assert c1.shape == c2.shape == (B, S, 1, 2) and out[1].shape == (B, 1, S, 1, S) and out[4].shape == (2 * B, 1, S, 1, S)
+        # every coordinate is a pixel centre ((k + .5) / 14) * 2 - 1
+        k = ((c1 + 1) / 2 * hw - 0.5)
+        assert torch.allclose(k, k.round(), atol=1e-4) and k.min() > -0.01 and k.max() < hw - 0.99
+    else:
+        assert c1.shape == c2.shape == (B, S, S, 2) and out[1].shape == (B, S, S, S, S)
+        # ~90 % of the positions sit on a non-zero salience pixel (x, y both scaled by the map height)
+        xy = ((c1 + 1) / 2 * 112)
+        on = torch.isclose(xy, xy.round(), atol=1e-3).all(-1)
+        px = xy.round().long().clamp(0, 111)
+        hit = sal[torch.arange(B).view(B, 1, 1), px[..., 1], px[..., 0]] != 0
+        assert (on & hit).float().mean() > 0.75
+    perms = loss.last_call[1].cpu()
+    co, cpo = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    want = O.forward(cfg, f, fp, co, cpo, d, dp, coords1=c1, coords2=c2, perms=list(perms))
+    wt = O.total_loss(cfg, want)
+    wt.backward()
+    for i in (0, 2, 6):
+        _relclose(out[i], want[i], 2e-3, 1e-5, f"tuple[{i}]")
+    _relclose(out[4].mean(), want[4].mean(), 2e-3, 1e-5, "neg mean")
+    assert out[7].shape == want[7].shape and torch.equal(out[7].cpu(), want[7])
+    assert (out[1].cpu() - want[1]).abs().max() < 1e-3 and (out[5].cpu() - want[5]).abs().max() < 1e-3
+    _relclose(total, wt, 5e-3, 1e-5, "total")
+    for got, ref in ((cg.grad, co.grad), (cpg.grad, cpo.grad)):
+        rel = (got.cpu() - ref).norm() / ref.norm()
+        assert rel < 3e-2, float(rel)

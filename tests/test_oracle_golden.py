@@ -154,3 +154,74 @@ def test_decay_table_and_traces():
                 assert cfg.depth_feat_shift == pytest.approx(w[1], rel=1e-12)
                 assert cfg.feature_samples == int(w[2])
                 assert (cfg.depth_sampling != "none") == bool(w[3])
+
+
+# ---- the salience / 'simple' samplers --------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_samplers():
+    return load_golden("samplers.npz")
+
+
+@pytest.mark.parametrize("seed,S", [(11, 5), (12, 3)])
+def test_sample_nonzero_locations(golden_samplers, seed, S):
+    """Same RNG calls in the same order as the reference: bit-equal coordinates (incl. the image without non-zeros)."""
+    sal = T(golden_samplers["sal_map"])
+    torch.manual_seed(seed)
+    got = O.sample_nonzero_locations(sal, [sal.shape[0], S, S, 2])
+    assert np.array_equal(got.numpy(), golden_samplers[f"sal_coords_seed{seed}_S{S}"])
+
+
+@pytest.mark.parametrize("name", ["runs", "8bit", "float", "rect"])
+def test_simple_depth_informed_sampling(golden_samplers, name):
+    g = golden_samplers
+    depth, hw, n = T(g[f"simple_{name}_depth"]), tuple(int(v) for v in g[f"simple_{name}_hw"]), int(g[f"simple_{name}_n"])
+    assert np.array_equal(O.adaptive_max_pool2d(depth, hw).numpy(), g[f"simple_{name}_pool"])
+    torch.manual_seed(int(g[f"simple_{name}_seed"]))
+    got = O.simple_depth_informed_sampling(hw, depth, n)
+    assert got.shape == (depth.shape[0], n, 1, 2)
+    assert np.array_equal(got.numpy(), g[f"simple_{name}_coords"])
+
+
+@pytest.mark.parametrize("case", ["salience", "simple"])
+def test_sampler_coords_regenerated(case):
+    """The coordinate draw of the whole forward (src/modules.py:1290-1302), RNG-for-RNG."""
+    fx = load_golden(f"forward_{case}.npz")
+    cfg = cfg_from_fixture(fx)
+    torch.manual_seed(int(fx["rng_seed"]))
+    sal = T(fx["salience"]) if "salience" in fx else None
+    salp = T(fx["salience_pos"]) if "salience_pos" in fx else None
+    c1, c2 = O.draw_coords(cfg, T(fx["feats"]), T(fx["feats_pos"]), T(fx["depth"]), T(fx["depth_pos"]), sal, salp)
+    assert np.array_equal(c1.numpy(), fx["coords1"])
+    assert np.array_equal(c2.numpy(), fx["coords2"])
+
+
+def test_uniform_rank_samplers_consistent():
+    """The uniform-driven variants (what the HIP samplers implement) pick, for uniforms that map to the same ranks, the
+    same pixels as the RNG-driven ones; and every picked pixel is a legal candidate."""
+    g = torch.Generator().manual_seed(5)
+    sal = (torch.rand(2, 9, 7, generator=g) > 0.6).float()
+    u = torch.rand(2, 16, generator=g).numpy()
+    ufb = torch.rand(2, 16, 2, generator=g).numpy()
+    c = O.sample_nonzero_locations_from_uniform(sal, [2, 4, 4, 2], u, ufb)
+    xy = ((c + 1) / 2 * sal.shape[1]).round().long()                 # flipped: (col, row), both scaled by H
+    for b in range(2):
+        for s in range(16):
+            x, y = xy[b].reshape(-1, 2)[s]
+            assert sal[b, y, x] != 0
+    # rank 0 / last rank
+    first = O.sample_nonzero_locations_from_uniform(sal, [2, 1, 1, 2], np.zeros((2, 1), np.float32), ufb[:, :1])
+    last = O.sample_nonzero_locations_from_uniform(sal, [2, 1, 1, 2], np.full((2, 1), 0.99999994, np.float32), ufb[:, :1])
+    nz = torch.nonzero(sal[0])
+    assert tuple(((first[0, 0, 0] + 1) / 2 * 9).round().long().tolist()) == (int(nz[0, 1]), int(nz[0, 0]))
+    assert tuple(((last[0, 0, 0] + 1) / 2 * 9).round().long().tolist()) == (int(nz[-1, 1]), int(nz[-1, 0]))
+    depth = torch.randint(0, 3, (2, 1, 20, 20), generator=g).float()
+    uv, up = torch.rand(2, 12, generator=g).numpy(), torch.rand(2, 12, generator=g).numpy()
+    cs = O.simple_depth_informed_sampling_from_uniform((5, 5), depth, 12, uv, up)
+    assert cs.shape == (2, 12, 1, 2)
+    rc = (cs * 5 - 0.5).round().long()
+    pooled = (O.adaptive_max_pool2d(depth, (5, 5)) * 10).round() / 10
+    srt = [np.sort(pooled[b].reshape(-1).numpy()) for b in range(2)]
+    for b in range(2):
+        for s in range(12):
+            r, cc = rc[b, s, 0]
+            assert float(pooled[b, 0, r, cc]) == float(srt[b][O.rank_from_uniform(uv[b, s], 25)])
