@@ -27,12 +27,24 @@ __host__ __device__ inline int dg_perm32(int pl) {
 // code (fp16) of one tensor pair, stored per image n and per tile of 32 positions as ONE contiguous blob
 // that is byte-for-byte the LDS image the correlation kernel wants, so that staging a tile is a linear
 // global->LDS DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) with no registers involved:
-//   F part  [32 positions q][GF granules]  bf16, granule g of row q stored at slot q*GF + (g ^ (q & 15))
-//           (XOR swizzle: the 16 lanes of a ds_read_b128 group read distinct rows at one k -> distinct banks)
+//   F part  [GF/IG groups][32 positions q][IG granules]  bf16, see dg_f_off below
 //   C part  [GD granules][32 positions]    fp16, K-major code, granule-major (conflict-free as is)
 //   P part  [4 granules c][KD channels d]  fp16, P-major code: granule c of channel d holds the positions
 //           with dg_perm32(pl) in [8c, 8c+8)
 // granule = 16 bytes = 8 elements.  KF in {128,384,768} (GF multiple of 16), KD in {96,128}.
+// F part: granule g (8 channels) of tile row q.  DG_F_IG consecutive granules of a row stay together (IG*16 bytes), the 32
+// rows are interleaved at that grain: [g / IG][q][IG granules], the slot inside a row's group XORed with a few row bits so
+// that the 16 lanes of one ds_read_b128 pass (16 consecutive rows, one granule) cover all 64 LDS banks.  IG = 48 granules
+// would be plain row-major; small IG makes the stationary operand's fragment loads (every lane = its own row) touch few
+// cache lines per instruction - they are address-coalescing bound at the start of every block of k_corr_main.
+#ifndef DG_F_IG
+#define DG_F_IG 4
+#endif
+__host__ __device__ inline int dg_f_off(int q, int g) {
+    constexpr int IG = DG_F_IG;
+    return ((g / IG) * 32 + q) * (IG * 16) + (((g % IG) ^ ((q / (16 / IG)) % IG)) * 16);
+}
+
 struct DgBlob {
     int GF, GD, KD;
     int off_c, off_p, bytes;
@@ -41,7 +53,7 @@ struct DgBlob {
         off_p = off_c + GD * 32 * 16;
         bytes = off_p + 4 * KD * 16;
     }
-    __host__ __device__ int f(int q, int g) const { return (q * GF + (g ^ (q & 15))) * 16; }
+    __host__ __device__ int f(int q, int g) const { return dg_f_off(q, g); }
     __host__ __device__ int c(int q, int g) const { return off_c + (g * 32 + q) * 16; }
     __host__ __device__ int p(int d, int cc) const { return off_p + (cc * KD + d) * 16; }
 };
@@ -182,6 +194,7 @@ struct DgCorrArgs {
     const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
     int32_t debug;        // developer ablation bits (0 in production)
     uint32_t* stamps;     // developer timing stamps (null in production)
+    unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
 };
 
 // Final reduction of the per-block partial sums of k_corr_main into the output scalars.  It runs in the NEXT launch on the

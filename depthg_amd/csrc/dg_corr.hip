@@ -140,7 +140,7 @@ hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream) {
 template <int NKF, int NKD, int NWAVES, int RF, bool GRAD, bool MAT, bool SIMPLE, int KIND, int NKC = NKD>
 __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
-    constexpr int KD = BL::KD, GF = BL::GF;
+    constexpr int KD = BL::KD;
     constexpr int NDF = KD / 32;            // 32-wide output fragments of dR
     constexpr int DP = KD;                  // padded code width of dR
     constexpr int BUF = BL::BYTES + 256;    // blob + 32 per-row floats (+ copy)
@@ -174,11 +174,20 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     auto STAMP = [&](int t, int ph) {
         if (stamping && lane == 0 && t < 25) st_lds[(wid * 25 + t) * 4 + ph] = (uint32_t)__builtin_readcyclecounter();
     };
+    auto BLOG = [&](int k) {
+        if (args.blocklog && tid == 0) {
+            unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8;
+            if (k == 0) { e[0] = __builtin_amdgcn_s_getreg(63492); e[1] = __builtin_amdgcn_s_getreg(63508); e[6] = KIND; e[7] = rb; }
+            e[2 + k] = wall_clock64();
+        }
+    };
 #else
     constexpr bool stamping = false;
     auto STAMP = [&](int, int) {};
+    auto BLOG = [&](int) {};
     (void)st_lds;
 #endif
+    BLOG(0);
     const int ntiles = (dbg & 128) ? 1 : ntiles_all;     // developer ablation: one tile only (fixed per-block cost)
     const int nR = job.ridx ? (int)job.ridx[n] : n;
     const int nS = job.sidx ? (int)job.sidx[n] : n;
@@ -227,7 +236,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         for (int f = 0; f < RF; ++f)
 #pragma unroll
             for (int ks = 0; ks < NKF; ++ks)
-                Rf[f][ks] = *reinterpret_cast<const bf16x8*>(Rblob[f] + (r * GF + ((2 * ks + h) ^ (r & 15))) * 16);
+                Rf[f][ks] = *reinterpret_cast<const bf16x8*>(Rblob[f] + dg_f_off(r, 2 * ks + h));
     }
     // Make hipcc wait for the fragment loads at ONE place (right after the first tile DMAs are issued, so the two
     // latencies overlap): its counted vmcnt waits at their first use inside the tile loop would otherwise also count
@@ -301,10 +310,12 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         for (int d = 0; d < NDF; ++d) dR[f][d] = f32x16{};
     float lsum = 0.f, csum = 0.f;
 
-    int swz[8];     // granule 2ks+h of tile row r sits at slot (2ks+h) ^ (r&15); the XOR only touches the low 4 bits
+    // A fragment of feature k-step st = granule 2st+h of tile row r: dg_f_off(r, 2st+h) = per-lane base[st % FPER] + constant
+    constexpr int FPER = DG_F_IG >= 2 ? DG_F_IG / 2 : 1;      // k-steps per interleave group
+    int fbase[FPER];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) swz[j] = ((2 * j + h) ^ (r & 15)) << 4;
-    const int frow = r * (GF * 16), crow = (h * 32 + r) * 16;
+    for (int j = 0; j < FPER; ++j) fbase[j] = dg_f_off(r, 2 * j + h);
+    const int crow = (h * 32 + r) * 16;
 
     f32x16 Yf[RF], Yc[RF];       // live across the barrier in the staggered schedule
 
@@ -314,7 +325,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     const int late_prio = (STAG && DG_PRIO == 1 && wid >= NWAVES / 2 && !(dbg & 32768)) ? 1 : 0;   // priority outside the chain
     auto chain = [&](const char* tile, const int f, auto&& between) {
         auto a_ptr = [&](int st) -> const v4i* {
-            return st < NSF ? reinterpret_cast<const v4i*>(tile + frow + swz[st & 7] + (st >> 3) * 256)
+            return st < NSF ? reinterpret_cast<const v4i*>(tile + fbase[st % FPER] + (st / FPER) * (FPER * 1024))
                             : reinterpret_cast<const v4i*>(tile + BL::OFF_C + crow + (st - NSF) * 1024);
         };
         Yc[f] = f32x16{};
@@ -459,6 +470,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             wait_vmcnt((pair && dma_first >= 0) ? 0 : nst);
             if (!(dbg & 256)) __builtin_amdgcn_s_barrier();
             STAMP(t, 1);
+            if (t == 0) BLOG(1);
             if (pair) {
                 if (!(dbg & 1)) {
                     if (t + 2 < ntiles) issue(t + 2, (t + 2) & 3);
@@ -518,6 +530,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     //      [image][R tile][channel group d][i>>2][lane][i&3] (16 bytes per lane and store, 1 KiB per wave instruction).
     //      The normalisation backward is linear with the same x for every pair-set whose stationary operand is operand 1,
     //      so k_grad_combine applies it once to the weighted sum of these buffers.
+    BLOG(2);
     if (pair && GRAD) {          // wave 1's share of the gradient accumulators -> wave 0 (through the free tile buffers)
         __syncthreads();
         float* xch = reinterpret_cast<float*>(smem);
@@ -601,6 +614,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
     }
 
+    BLOG(3);
     if (stamping) {
         __syncthreads();
         for (int i = tid; i < NWAVES * 100; i += NWAVES * 64) args.stamps[i] = st_lds[i];
@@ -872,7 +886,19 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
             (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem2);
         }
     }
+    const char* blog_file = getenv("DG_BLOCKLOG");                    // developer aid (stamp build): per-block timeline
+    static unsigned long long* blog_buf = nullptr;
+    if (blog_file) {
+        if (!blog_buf && hipMalloc(&blog_buf, 8192 * 64) != hipSuccess) blog_buf = nullptr;
+        if (blog_buf && grid <= 8192) a2.blocklog = blog_buf;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem2, stream, a2);
+    if (a2.blocklog) {
+        static unsigned long long hostb[8192 * 8];
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 64, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* fp = fopen(blog_file, "wb")) { fwrite(hostb, 8, (size_t)grid * 8, fp); fclose(fp); }
+        }
+    }
     if (a2.stamps) {
         uint32_t host[8 * 100];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, NWAVES * 400, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -468,7 +468,7 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char rm_smem[];     // the tile's F part (32 swizzled bf16 rows)
     const int tile = blockIdx.x, n = blockIdx.y, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    const int KF = a.KF, GF = KF / 8, nt = a.Ppad / 32;
+    const int KF = a.KF, nt = a.Ppad / 32;
     const DgBlob L(a.KF, a.KD);
     const int jb = c & 15, lo = c >> 4;
     const bool has = jb < a.njobs;
@@ -483,13 +483,12 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
     const __bf16* bb = J.bsplit + ((size_t)nb * 2 + lo) * KF + 8 * h;
     f32x16 acc = {};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* row = rm_smem + (size_t)c * GF * 16;                    // A row q = c
     for (int ks0 = 0; ks0 < KF / 16; ks0 += 8) {     // KF / 16 is a multiple of 8 (KF in {128, 384, 768})
         bf16x8 af[8], bf[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int ks = ks0 + u;
-            af[u] = *reinterpret_cast<const bf16x8*>(row + (((2 * ks + h) ^ (c & 15)) * 16));
+            af[u] = *reinterpret_cast<const bf16x8*>(rm_smem + dg_f_off(c, 2 * ks + h));      // A row q = c
             bf[u] = *reinterpret_cast<const bf16x8*>(bb + 16 * ks);
         }
 #pragma unroll
