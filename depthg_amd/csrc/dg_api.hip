@@ -442,6 +442,18 @@ extern "C" int dg_simple_depth_coords(const float* depth, int32_t B, int32_t dep
     return DG_OK;
 }
 
+extern "C" int dg_confusion_update(const int64_t* preds, const int64_t* target, int64_t count, int32_t n_classes,
+                                   int32_t extra_clusters, int64_t* stats, dg_stream_t stream_) {
+    if (count < 0 || n_classes < 1 || extra_clusters < 0) return fail(DG_ERR_INVALID, "bad confusion-matrix dimensions");
+    if (count == 0) return DG_OK;
+    if (!preds || !target || !stats) return fail(DG_ERR_INVALID, "null pointer");
+    if ((long long)n_classes * (n_classes + extra_clusters) > (1 << 24)) return fail(DG_ERR_UNSUPPORTED, "confusion matrix too large");
+    DG_HIP(dg_launch_confusion(reinterpret_cast<const long long*>(preds), reinterpret_cast<const long long*>(target), count,
+                               n_classes, n_classes + extra_clusters, reinterpret_cast<unsigned long long*>(stats),
+                               static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
     (void)B; (void)h; (void)w;
     return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform

@@ -368,5 +368,7 @@ hipError_t dg_launch_salience_coords(const float* sal, int B, int H, int W, int 
                                      float* out, hipStream_t s);
 hipError_t dg_launch_simple_coords(const float* depth, int B, int H, int W, int h, int w, int n, const float* u_val,
                                    const float* u_pick, float* out, hipStream_t s);
+hipError_t dg_launch_confusion(const long long* preds, const long long* target, long long count, int ncls, int nrows,
+                               unsigned long long* stats, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

@@ -141,6 +141,23 @@ def simple_depth_coords(depth, feat_hw, n_samples, u_value=None, u_pick=None):
     return coords
 
 
+def confusion_update(stats, preds, target, n_classes, extra_clusters):
+    """stats (n_classes + extra, n_classes) int64 on the GPU += confusion counts of (preds, target) (src/utils.py:222-232)."""
+    lib = _lib.load()
+    for name, t in (("stats", stats), ("preds", preds), ("target", target)):
+        if not t.is_cuda:
+            raise RuntimeError(f"depthg_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    if stats.dtype != torch.int64 or not stats.is_contiguous() or tuple(stats.shape) != (n_classes + extra_clusters, n_classes):
+        raise ValueError("depthg_amd: stats must be a contiguous int64 (n_classes + extra_clusters, n_classes) tensor")
+    p = preds.detach().reshape(-1).to(torch.int64).contiguous()
+    a = target.detach().reshape(-1).to(torch.int64).contiguous()
+    if p.numel() != a.numel():
+        raise ValueError(f"depthg_amd: preds and target differ in size ({p.numel()} vs {a.numel()})")
+    rc = lib.dg_confusion_update(_ptr(p), _ptr(a), p.numel(), int(n_classes), int(extra_clusters), _ptr(stats), _stream(stats.device))
+    _lib.check(rc, "dg_confusion_update")
+    return stats
+
+
 def super_perms(count, size, device):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
     lib = _lib.load()

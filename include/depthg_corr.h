@@ -186,6 +186,17 @@ int dg_simple_depth_coords(const float* depth, int32_t B, int32_t depth_h, int32
                            int32_t n, const float* u_value, const float* u_pick, float* out_coords, dg_stream_t stream);
 
 /*
+ * Confusion-matrix accumulation of the validation metrics (replaces the bincount of UnsupervisedMetrics.update /
+ * update_cherry, src/utils.py:222-232, 279-289): stats[pred][actual] += 1 for every element with
+ * 0 <= actual < n_classes and 0 <= pred < n_classes (the reference masks preds with n_classes as well, so the extra
+ * clusters' rows stay zero).  Counts are exact integers: bit-identical to torch.bincount; under data parallelism the
+ * matrices of the ranks are summed with one all-reduce (torchmetrics dist_reduce_fx="sum", src/utils.py:214-220).
+ *  preds, target : int64 [count] (any shape, flattened)     stats : int64 (n_classes + extra_clusters, n_classes), in/out
+ */
+int dg_confusion_update(const int64_t* preds, const int64_t* target, int64_t count,
+                        int32_t n_classes, int32_t extra_clusters, int64_t* stats, dg_stream_t stream);
+
+/*
  * Negative-pair batch permutations (replaces super_perm, src/modules.py:1184-1188, called n_neg times per step at
  * :1336-1339): `count` independent uniform random permutations of 0..B-1 with fixed points bumped by one modulo B
  * (quirk Q6: B == 1 gives [0]).  The randomness comes from the caller: `keys` holds count*B iid uniforms (torch.rand);

@@ -347,6 +347,17 @@ def simple_depth_informed_sampling_from_uniform(feat_hw, depth: torch.Tensor, n_
     return _simple_finish(out, feat_hw)
 
 
+def confusion_counts(preds: torch.Tensor, target: torch.Tensor, n_classes: int, extra_clusters: int) -> torch.Tensor:
+    """What one UnsupervisedMetrics.update adds to `stats` (src/utils.py:222-232): counts[pred, actual] over the elements
+    with 0 <= actual < n_classes and 0 <= pred < n_classes; shape (n_classes + extra_clusters, n_classes), int64."""
+    a = target.reshape(-1).numpy().astype(np.int64)
+    p = preds.reshape(-1).numpy().astype(np.int64)
+    ok = (a >= 0) & (a < n_classes) & (p >= 0) & (p < n_classes)
+    out = np.zeros((n_classes + extra_clusters, n_classes), dtype=np.int64)
+    np.add.at(out, (p[ok], a[ok]), 1)
+    return torch.from_numpy(out)
+
+
 # --------------------------------------------------------------------------------------
 # A4  helper                                                           src/modules.py:1231-1254
 # --------------------------------------------------------------------------------------

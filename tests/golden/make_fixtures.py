@@ -29,9 +29,12 @@ def import_reference():
         sys.modules[name] = m
         return m
     stub("wget")
-    class Metric:  # torchmetrics.Metric stand-in (src/utils.py:16,202)
+    class Metric:  # torchmetrics.Metric stand-in (src/utils.py:16,202): states are plain attributes
         def __init__(self, *a, **k):
             pass
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone())
     stub("torchmetrics", Metric=Metric)
     tv = stub("torchvision")
     tv.models = stub("torchvision.models")

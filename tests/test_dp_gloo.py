@@ -100,3 +100,42 @@ def test_bucket_single_process_is_identity():
     bucket.allreduce_mean_()
     bucket.unpack()
     assert torch.equal(p.grad, torch.ones(2, 3) * 3)
+
+
+# ---- validation metric under DP: per-rank confusion matrices, summed at compute() -----------------
+def _metric_shards():
+    from conftest import load_golden
+    g = load_golden("metrics.npz")
+    n, e, hung = (int(v) for v in g["e3_hung_cfg"])
+    shards = [O.confusion_counts(torch.from_numpy(p), torch.from_numpy(t), n, e)
+              for p, t in zip(g["e3_hung_preds"], g["e3_hung_target"])]
+    return g, n, e, bool(hung), shards
+
+
+def _metric_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from depthg_amd.metrics import UnsupervisedMetrics
+    g, n, e, hung, shards = _metric_shards()
+    m = UnsupervisedMetrics("test/cluster/", n, e, hung)
+    # rank 0 saw batches 0 and 2, rank 1 batch 1 (the accumulation itself is the GPU kernel, covered by the -m gpu tests)
+    m.stats = shards[0] + shards[2] if rank == 0 else shards[1].clone()
+    local = m.stats.clone()
+    out = m.compute()
+    ret[rank] = (out["test/cluster/mIoU"], out["test/cluster/Accuracy"], torch.equal(m.stats, local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_metric_sums_confusion_matrices():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_metric_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    g = _metric_shards()[0]
+    for rank in range(world):
+        miou, acc, untouched = ret[rank]
+        assert miou == pytest.approx(float(g["e3_hung_miou"]), rel=1e-6)      # == the reference on all three batches
+        assert acc == pytest.approx(float(g["e3_hung_acc"]), rel=1e-6)
+        assert untouched                                                        # compute() leaves the local state alone

@@ -490,3 +490,37 @@ def test_module_forward_with_sampler(mode, dev):
     for got, ref in ((cg.grad, co.grad), (cpg.grad, cpo.grad)):
         rel = (got.cpu() - ref).norm() / ref.norm()
         assert rel < 3e-2, float(rel)
+
+
+def test_confusion_matrix_kernel(dev):
+    """dg_confusion_update == the reference's masked bincount (through the oracle, itself pinned on the reference's stats):
+    exact integers, incl. ignore labels (-1 / 255), out-of-range predictions, empty and all-invalid inputs, accumulation
+    over several calls, eval-resolution inputs, and a matrix too large for the LDS histogram."""
+    from depthg_amd import ops
+    from depthg_amd.metrics import UnsupervisedMetrics
+    from oracle import depthg_oracle as O
+    fx = load_golden("metrics.npz")
+    for case in ("e0_hung", "e3_hung", "c27_hung", "e5_hung_sparse"):
+        n, e, hung = (int(v) for v in fx[f"{case}_cfg"])
+        m = UnsupervisedMetrics("test/cluster/", n, e, bool(hung))
+        for p, t in zip(fx[f"{case}_preds"], fx[f"{case}_target"]):
+            m.update(torch.from_numpy(p).to(dev), torch.from_numpy(t).to(dev))
+        assert m.stats.is_cuda and np.array_equal(m.stats.cpu().numpy(), fx[f"{case}_stats"])
+        out = m.compute()
+        assert out["test/cluster/mIoU"] == pytest.approx(float(fx[f"{case}_miou"]), rel=1e-6)
+        assert out["test/cluster/Accuracy"] == pytest.approx(float(fx[f"{case}_acc"]), rel=1e-6)
+        m.reset()
+        assert int(m.stats.sum()) == 0
+    g = torch.Generator().manual_seed(17)
+    for n, e, shape in ((27, 0, (16, 320, 320)), (3, 2, (5, 7)), (150, 10, (4, 64, 64)), (200, 0, (2, 100, 100))):
+        target = torch.randint(-1, n + 2, shape, generator=g)
+        target[target == n + 1] = 255
+        preds = torch.randint(-2, n + e + 2, shape, generator=g)
+        stats = torch.zeros(n + e, n, dtype=torch.int64, device=dev)
+        ops.confusion_update(stats, preds.to(dev), target.to(dev), n, e)
+        ops.confusion_update(stats, preds.to(dev).int(), target.to(dev).int(), n, e)      # int32 inputs, second pass
+        assert torch.equal(stats.cpu(), 2 * O.confusion_counts(preds, target, n, e))
+    stats = torch.zeros(4, 4, dtype=torch.int64, device=dev)
+    ops.confusion_update(stats, torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev), 4, 0)
+    ops.confusion_update(stats, torch.full((9,), 7, device=dev), torch.full((9,), -1, device=dev), 4, 0)
+    assert int(stats.sum()) == 0
