@@ -19,7 +19,7 @@ o = [f"# Round profile summary {tag} (MI355X, gfx950)\n",
      "Command: `python bench.py --steps 30 --warmup 5 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats` "
      f"(`scripts/profile_round.sh {tag}`); PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, an SQ set) are separate runs of the "
      f"same command with `--steps 3`. Files: `{tag}_kernel_stats.csv`, `{tag}_pmc_per_launch.json`, `{tag}_bench_under_rocprofv3.json` "
-     f"(the bench line printed inside the profiled run), `{tag}_bench.json` (the plain `python bench.py` line on the same box).\n",
+     f"(the bench line printed inside the profiled run), `{tag}_bench.json` (the plain `python bench.py` line, from its own run on a fresh box: counter collection leaves the GPU in the profiling power state, a plain run right behind the PMC passes measured 20 % low).\n",
      "## Kernels of one step\n", "| kernel | calls | avg µs | min µs | max µs |\n|---|---|---|---|---|"]
 for r in rows:
     o.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
