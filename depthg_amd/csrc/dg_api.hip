@@ -454,6 +454,18 @@ extern "C" int dg_confusion_update(const int64_t* preds, const int64_t* target, 
     return DG_OK;
 }
 
+extern "C" int dg_topk_rows(const float* vals, int64_t rows, int64_t cols, int64_t row_stride, int32_t k, int64_t* out_idx,
+                            float* out_val, dg_stream_t stream_) {
+    if (rows < 0 || cols < 1 || k < 1 || row_stride < cols) return fail(DG_ERR_INVALID, "bad top-k dimensions");
+    if (k > 64 || k > cols) return fail(DG_ERR_UNSUPPORTED, "top-k needs k <= 64 and k <= cols (k=%d, cols=%lld)", k, (long long)cols);
+    if (cols >= (1ll << 32) || rows >= (1ll << 31)) return fail(DG_ERR_UNSUPPORTED, "similarity matrix too large");
+    if (rows == 0) return DG_OK;
+    if (!vals || !out_idx) return fail(DG_ERR_INVALID, "null pointer");
+    DG_HIP(dg_launch_topk_rows(vals, rows, cols, row_stride, k, reinterpret_cast<long long*>(out_idx), out_val,
+                               static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
     (void)B; (void)h; (void)w;
     return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform

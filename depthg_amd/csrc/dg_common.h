@@ -370,5 +370,7 @@ hipError_t dg_launch_simple_coords(const float* depth, int B, int H, int W, int 
                                    const float* u_pick, float* out, hipStream_t s);
 hipError_t dg_launch_confusion(const long long* preds, const long long* target, long long count, int ncls, int nrows,
                                unsigned long long* stats, hipStream_t s);
+hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
+                               long long* out_idx, float* out_val, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

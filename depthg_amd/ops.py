@@ -158,6 +158,22 @@ def confusion_update(stats, preds, target, n_classes, extra_clusters):
     return stats
 
 
+def topk_rows(vals, k, return_values=False):
+    """Column indices of the k largest entries of every row of `vals` (rows, cols) fp32 on the GPU: value descending, ties by
+    ascending column (src/precompute_knns.py:110 `torch.topk(pairwise_sims, 30)[1]`)."""
+    lib = _lib.load()
+    if not vals.is_cuda:
+        raise RuntimeError(f"depthg_amd: `vals` must live on the GPU (got {vals.device}); there is no CPU path")
+    if vals.dim() != 2 or vals.dtype != torch.float32 or vals.stride(1) != 1:
+        raise ValueError("depthg_amd: topk_rows wants a 2-D fp32 tensor with contiguous rows")
+    rows, cols = vals.shape
+    idx = torch.empty(rows, int(k), dtype=torch.int64, device=vals.device)
+    val = torch.empty(rows, int(k), dtype=torch.float32, device=vals.device) if return_values else None
+    rc = lib.dg_topk_rows(_ptr(vals), rows, cols, vals.stride(0) if rows > 1 else cols, int(k), _ptr(idx), _ptr(val), _stream(vals.device))
+    _lib.check(rc, "dg_topk_rows")
+    return (idx, val) if return_values else idx
+
+
 def super_perms(count, size, device):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
     lib = _lib.load()

@@ -197,6 +197,17 @@ int dg_confusion_update(const int64_t* preds, const int64_t* target, int64_t cou
                         int32_t n_classes, int32_t extra_clusters, int64_t* stats, dg_stream_t stream);
 
 /*
+ * Row-wise top-k (replaces `torch.topk(pairwise_sims, 30)[1]` of the offline nearest-neighbour search,
+ * src/precompute_knns.py:108-112; the similarity slice `einsum("nf,mf->nm")` itself is a plain GEMM and stays a library
+ * call in the host mirror).  Row r of the result holds the column indices of the k largest values of row r, ordered by
+ * value descending, ties by ascending column (torch.topk leaves the tie order unspecified).
+ *  vals : fp32 (rows, cols) with row stride `row_stride` elements     k <= 64, k <= cols < 2^32
+ *  out_idx : int64 (rows, k)        out_val : fp32 (rows, k) or NULL
+ */
+int dg_topk_rows(const float* vals, int64_t rows, int64_t cols, int64_t row_stride, int32_t k,
+                 int64_t* out_idx, float* out_val, dg_stream_t stream);
+
+/*
  * Negative-pair batch permutations (replaces super_perm, src/modules.py:1184-1188, called n_neg times per step at
  * :1336-1339): `count` independent uniform random permutations of 0..B-1 with fixed points bumped by one modulo B
  * (quirk Q6: B == 1 gives [0]).  The randomness comes from the caller: `keys` holds count*B iid uniforms (torch.rand);

@@ -347,6 +347,21 @@ def simple_depth_informed_sampling_from_uniform(feat_hw, depth: torch.Tensor, n_
     return _simple_finish(out, feat_hw)
 
 
+def knn_table(normed_feats: torch.Tensor, k: int = 30) -> torch.Tensor:
+    """Nearest-neighbour table of src/precompute_knns.py:106-112: row i = indices of the k largest entries of
+    (X X^T)[i] in float32, value descending; ties by ascending index (the build's rule; torch.topk leaves it open)."""
+    sims = torch.einsum("nf,mf->nm", normed_feats, normed_feats).numpy()
+    order = np.lexsort((np.arange(sims.shape[1])[None, :].repeat(sims.shape[0], 0), -sims), axis=1)
+    return torch.from_numpy(order[:, :k].astype(np.int64))
+
+
+def topk_rows(vals: torch.Tensor, k: int) -> torch.Tensor:
+    """Indices of the k largest entries per row: value descending, ties by ascending index."""
+    v = vals.numpy()
+    order = np.lexsort((np.arange(v.shape[1])[None, :].repeat(v.shape[0], 0), -v), axis=1)
+    return torch.from_numpy(order[:, :k].astype(np.int64))
+
+
 def confusion_counts(preds: torch.Tensor, target: torch.Tensor, n_classes: int, extra_clusters: int) -> torch.Tensor:
     """What one UnsupervisedMetrics.update adds to `stats` (src/utils.py:222-232): counts[pred, actual] over the elements
     with 0 <= actual < n_classes and 0 <= pred < n_classes; shape (n_classes + extra_clusters, n_classes), int64."""

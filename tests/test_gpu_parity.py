@@ -524,3 +524,49 @@ def test_confusion_matrix_kernel(dev):
     ops.confusion_update(stats, torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev), 4, 0)
     ops.confusion_update(stats, torch.full((9,), 7, device=dev), torch.full((9,), -1, device=dev), 4, 0)
     assert int(stats.sum()) == 0
+
+
+def test_topk_rows_kernel(dev):
+    """dg_topk_rows == indices of the k largest per row, value descending, ties by ascending column - exact, on matrices
+    with heavy ties (few distinct values), all-equal rows, negative / mixed-sign values, k = 1 / 30 / 64 / cols, a row
+    stride larger than cols, and a 100k-column row."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(23)
+    mats = [torch.randn(37, 501, generator=g),
+            torch.randint(0, 4, (16, 300), generator=g).float() - 1.5,          # heavy ties, mixed sign
+            torch.zeros(3, 257),                                                  # all equal: indices 0..k-1
+            -torch.rand(5, 64, generator=g),
+            torch.randn(2, 100_003, generator=g)]
+    for m in mats:
+        for k in (1, 30, 64):
+            if k > m.shape[1]:
+                continue
+            idx, val = ops.topk_rows(m.to(dev), k, return_values=True)
+            want = O.topk_rows(m, k)
+            assert torch.equal(idx.cpu(), want)
+            assert torch.equal(val.cpu(), torch.gather(m, 1, want))
+    m = torch.randn(9, 40, generator=g)
+    assert torch.equal(ops.topk_rows(m.to(dev), 40).cpu(), O.topk_rows(m, 40))                   # k == cols: a full sort
+    wide = torch.randn(6, 128, generator=g).to(dev)
+    assert torch.equal(ops.topk_rows(wide[:, :70], 30).cpu(), O.topk_rows(wide[:, :70].cpu(), 30))  # row stride 128, cols 70
+    with pytest.raises(RuntimeError):
+        ops.topk_rows(m.to(dev), 65)
+
+
+@pytest.mark.parametrize("name", ["small", "wide"])
+def test_nearest_neighbors_table(name, dev):
+    """knn.nearest_neighbors (library GEMM slice + dg_topk_rows) against the table the reference's calls produce on the same
+    features: identical except where two similarities are closer than the float32 rounding of the two GEMMs (5e-6)."""
+    from depthg_amd import knn
+    fx = load_golden("knn.npz")
+    feats = torch.from_numpy(fx[f"{name}_feats"])
+    got = knn.nearest_neighbors(feats.to(dev), k=30, n_batches=int(fx[f"{name}_nbatches"]))
+    want = torch.from_numpy(fx[f"{name}_nns"])
+    assert got.shape == want.shape and got.dtype == torch.int64 and not got.is_cuda
+    sims = feats.double() @ feats.double().t()
+    diff = got != want
+    assert float(diff.float().mean()) < 0.02
+    gap = (torch.gather(sims, 1, got) - torch.gather(sims, 1, want)).abs()
+    assert float(gap[diff].max() if diff.any() else 0.0) < 5e-6
+    assert torch.equal(got[:, 0], torch.arange(got.shape[0]))

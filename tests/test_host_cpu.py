@@ -213,3 +213,37 @@ def test_metrics_update_refuses_cpu_tensors():
     m = UnsupervisedMetrics("x/", 5, 0, True)
     with pytest.raises(RuntimeError, match="GPU"):
         m.update(torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long))
+
+
+# ---- nearest-neighbour table -------------------------------------------------------------
+@pytest.mark.parametrize("name", ["small", "wide"])
+def test_knn_oracle_matches_reference_calls(name):
+    from oracle import depthg_oracle as O
+    g = load_golden("knn.npz")
+    got = O.knn_table(torch.from_numpy(g[f"{name}_feats"]), 30)
+    assert got.dtype == torch.int64 and np.array_equal(got.numpy(), g[f"{name}_nns"])
+    assert np.array_equal(got[:, 0].numpy(), np.arange(got.shape[0]))        # column 0 is the image itself
+
+
+def test_nns_file_format_and_online_pick(tmp_path):
+    from depthg_amd import knn
+    g = load_golden("knn.npz")
+    ref_file = os.path.join(ROOT, "tests", "golden", "nns_fixture.npz")      # written like src/precompute_knns.py:115
+    table = knn.load_nns(ref_file, n_images=157)
+    assert table.dtype == np.int64 and np.array_equal(table, g["small_nns"])
+    path = knn.nns_path(str(tmp_path), "vit_small", "cocostuff27", "train", None, 224)
+    assert path.endswith(os.path.join("nns", "nns_vit_small_cocostuff27_train_None_224.npz"))
+    assert knn.nns_path("d", "vit_base", "cityscapes", "val", "five", 320).endswith("nns_vit_base_cityscapes_val_five_320.npz")
+    knn.save_nns(path, torch.from_numpy(g["small_nns"]))
+    with np.load(path) as f:
+        assert list(f.keys()) == ["nns"] and f["nns"].dtype == np.int64 and np.array_equal(f["nns"], g["small_nns"])
+    with pytest.raises(ValueError, match="precompute_knns"):
+        knn.load_nns(os.path.join(str(tmp_path), "missing.npz"))
+    with pytest.raises(AssertionError):
+        knn.load_nns(path, n_images=3)
+    p = load_golden("knn_picks.npz")
+    torch.manual_seed(int(p["seed"]))
+    picks = [knn.pick_positive(table, ind, int(p["num_neighbors"])) for ind in range(40)]
+    assert picks == p["picks"].tolist()
+    with pytest.raises(RuntimeError, match="GPU"):
+        knn.nearest_neighbors(torch.from_numpy(g["small_feats"]))
