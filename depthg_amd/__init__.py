@@ -7,6 +7,7 @@ Public surface (mirrors the reference's Python operator surface for this path):
                                  src/train_segmentation.py:240-350)
     metrics                      UnsupervisedMetrics (src/utils.py:202-319): confusion matrix on the GPU, summed over DP ranks
     knn                          image-level nearest-neighbour table: search, file format, online pick (src/precompute_knns.py)
+    lhp                          LocalHiddenPositiveProjection with depth propagation (src/modules.py:140-339)
     ops                          thin ctypes binding of the C ABI in include/depthg_corr.h
 """
 from .loss import ContrastiveCorrelationLoss  # noqa: F401
@@ -14,5 +15,6 @@ from . import depth_decay  # noqa: F401
 from . import training  # noqa: F401
 from . import metrics  # noqa: F401
 from . import knn  # noqa: F401
+from . import lhp  # noqa: F401
 
-__all__ = ["ContrastiveCorrelationLoss", "depth_decay", "training", "metrics", "knn"]
+__all__ = ["ContrastiveCorrelationLoss", "depth_decay", "training", "metrics", "knn", "lhp"]

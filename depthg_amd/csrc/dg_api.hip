@@ -466,6 +466,36 @@ extern "C" int dg_topk_rows(const float* vals, int64_t rows, int64_t cols, int64
     return DG_OK;
 }
 
+static int lhp_check(int32_t B, int32_t D, int32_t h, int32_t w) {
+    if (B < 1 || D < 1 || h < 1 || w < 1) return fail(DG_ERR_INVALID, "bad LHP dimensions");
+    if (D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", D);
+    if ((size_t)h * w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the LHP propagation (max 4096 positions)", h, w);
+    return DG_OK;
+}
+
+extern "C" int dg_lhp_forward(const float* code, const float* depth, int32_t B, int32_t D, int32_t h, int32_t w, int32_t depth_h,
+                              int32_t depth_w, float* out, float* points, float* stats, dg_stream_t stream_) {
+    if (int rc = lhp_check(B, D, h, w)) return rc;
+    if (depth_h < 1 || depth_w < 1) return fail(DG_ERR_INVALID, "bad depth size");
+    if (!code || !depth || !out || !points || !stats) return fail(DG_ERR_INVALID, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const uint32_t bits = 0x404f54cbu;            // 2*tan(90/2 rad), the reference's float32 factor (dg_fps_coords)
+    float factor;
+    memcpy(&factor, &bits, 4);
+    DG_HIP(dg_launch_lhp_points(depth, B, depth_h, depth_w, h, w, factor, points, s));
+    DG_HIP(dg_launch_lhp_propagate(false, code, points, stats, B, D, h * w, out, s));
+    return DG_OK;
+}
+
+extern "C" int dg_lhp_backward(const float* grad_out, const float* points, const float* stats, int32_t B, int32_t D, int32_t h,
+                               int32_t w, float* grad_code, dg_stream_t stream_) {
+    if (int rc = lhp_check(B, D, h, w)) return rc;
+    if (!grad_out || !points || !stats || !grad_code) return fail(DG_ERR_INVALID, "null pointer");
+    DG_HIP(dg_launch_lhp_propagate(true, grad_out, points, const_cast<float*>(stats), B, D, h * w, grad_code,
+                                   static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
     (void)B; (void)h; (void)w;
     return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform

@@ -137,6 +137,14 @@ __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
 #endif
 
 #ifdef __HIPCC__
+// a * b rounded to float32 ON ITS OWN: the empty asm hides the product from the contraction pass, so a following addition
+// cannot turn the pair into one fused multiply-add (needed where a CPU reference rounds twice)
+__device__ __forceinline__ float dg_mul_rn(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // Sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 separately), result in every lane of the half.  DPP row
 // operations instead of the LDS crossbar: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), row totals carried
 // into the odd rows (row_bcast15), then lanes 31 / 63 are broadcast.
@@ -372,5 +380,8 @@ hipError_t dg_launch_confusion(const long long* preds, const long long* target, 
                                unsigned long long* stats, hipStream_t s);
 hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
                                long long* out_idx, float* out_val, hipStream_t s);
+hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
+hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,
+                                   float* dst, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const float dx = __fsub_rn(lx, qx[k]), dy = __fsub_rn(ly, qy[k]), dz = __fsub_rn(lz, qz[k]);
-            const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const float dd = __fadd_rn(__fadd_rn(dg_mul_rn(dx, dx), dg_mul_rn(dy, dy)), dg_mul_rn(dz, dz));   // no fused multiply-add
             const bool live = !((taken >> k) & 1u);
             const float nd = fminf(dd, qd[k]);
             if (live) qd[k] = nd;

@@ -174,6 +174,31 @@ def topk_rows(vals, k, return_values=False):
     return (idx, val) if return_values else idx
 
 
+def lhp_forward(code, depth):
+    """code (B,D,h,w), depth (B,1,H,W) on the GPU -> (code_mixed, points, stats) of dg_lhp_forward."""
+    lib = _lib.load()
+    code = _f32c(code, "code")
+    depth = _f32c(depth, "depth")
+    B, D, h, w = code.shape
+    out = torch.empty_like(code)
+    points = torch.empty(B, 3, h * w, dtype=torch.float32, device=code.device)
+    stats = torch.empty(B, h * w, 3, dtype=torch.float32, device=code.device)
+    rc = lib.dg_lhp_forward(_ptr(code), _ptr(depth), B, D, h, w, depth.shape[-2], depth.shape[-1], _ptr(out), _ptr(points),
+                            _ptr(stats), _stream(code.device))
+    _lib.check(rc, "dg_lhp_forward")
+    return out, points, stats
+
+
+def lhp_backward(grad_out, points, stats):
+    lib = _lib.load()
+    g = _f32c(grad_out, "grad_out")
+    B, D, h, w = g.shape
+    grad_code = torch.empty_like(g)
+    rc = lib.dg_lhp_backward(_ptr(g), _ptr(points), _ptr(stats), B, D, h, w, _ptr(grad_code), _stream(g.device))
+    _lib.check(rc, "dg_lhp_backward")
+    return grad_code
+
+
 def super_perms(count, size, device):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
     lib = _lib.load()

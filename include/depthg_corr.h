@@ -197,6 +197,22 @@ int dg_confusion_update(const int64_t* preds, const int64_t* target, int64_t cou
                         int32_t n_classes, int32_t extra_clusters, int64_t* stats, dg_stream_t stream);
 
 /*
+ * Depth propagation of the LHP branch (replaces LocalHiddenPositiveProjection.forward_depth up to its projection head,
+ * src/modules.py:273-335: adaptive_avg_pool2d + depth2points(fov=90) per image, pairwise point distances, row-wise min-max
+ * normalisation, map = 1 - d where d <= the row's 1 % quantile (torch.quantile, linear), out[:, p] = mean_q map[p][q] code[:, q]).
+ * The (B,P,P) distance / map tensors are never formed.  Distances are the direct float32 formula; the reference's
+ * torch.cdist takes its matmul path for P > 25, so outputs agree with it to about 1e-4 relative, not bit for bit.
+ *  code   : fp32 (B,D,h,w), D <= 128, h*w <= 4096        depth : fp32 (B,1,depth_h,depth_w)
+ *  out    : fp32 (B,D,h,w) = code_mixed
+ *  points : fp32 (B,3,h*w) scratch, stats : fp32 (B,h*w,3) = per-row (min, max, quantile): both are inputs of the backward
+ * dg_lhp_backward: grad_code[:, q] = (1/P) sum_p map[p][q] grad_out[:, p], with the same points / stats.
+ */
+int dg_lhp_forward(const float* code, const float* depth, int32_t B, int32_t D, int32_t h, int32_t w,
+                   int32_t depth_h, int32_t depth_w, float* out, float* points, float* stats, dg_stream_t stream);
+int dg_lhp_backward(const float* grad_out, const float* points, const float* stats, int32_t B, int32_t D, int32_t h, int32_t w,
+                    float* grad_code, dg_stream_t stream);
+
+/*
  * Row-wise top-k (replaces `torch.topk(pairwise_sims, 30)[1]` of the offline nearest-neighbour search,
  * src/precompute_knns.py:108-112; the similarity slice `einsum("nf,mf->nm")` itself is a plain GEMM and stays a library
  * call in the host mirror).  Row r of the result holds the column indices of the k largest values of row r, ordered by

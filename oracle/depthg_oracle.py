@@ -347,6 +347,58 @@ def simple_depth_informed_sampling_from_uniform(feat_hw, depth: torch.Tensor, n_
     return _simple_finish(out, feat_hw)
 
 
+# --------------------------------------------------------------------------------------
+# N3  LocalHiddenPositiveProjection.forward_depth (before the projection head)   src/modules.py:273-335
+# --------------------------------------------------------------------------------------
+def quantile_lerp(sorted_row: np.ndarray, q: float) -> np.float32:
+    """torch.quantile(.., q, interpolation='linear') on one ascending float32 row: rank = q*(n-1) in float32, then
+    torch.lerp's two-sided formula between the neighbours."""
+    n = sorted_row.shape[0]
+    rank = np.float32(q) * np.float32(n - 1)
+    lo = int(np.floor(rank))
+    hi = int(np.ceil(rank))
+    w = np.float32(rank - np.float32(lo))
+    a, b = np.float32(sorted_row[lo]), np.float32(sorted_row[hi])
+    if w < np.float32(0.5):
+        return np.float32(a + w * np.float32(b - a))
+    return np.float32(b - np.float32(b - a) * np.float32(np.float32(1.0) - w))
+
+
+def lhp_depth_weights(depth: torch.Tensor, feat_hw: Tuple[int, int]):
+    """The (B,P,P) propagation map of forward_depth (src/modules.py:286-319) and its per-row statistics (min, max,
+    1 % quantile of the normalised distances).  Distances are the direct float32 formula sqrt(((dx^2 + dy^2) + dz^2));
+    the reference's torch.cdist takes its matmul path for P > 25, whose rounding (about 1e-7 * |point|^2 on d^2, i.e. a
+    non-zero self-distance) is not reproducible - the parity tests against the reference carry that tolerance."""
+    pooled = adaptive_avg_pool2d(depth, tuple(feat_hw))
+    b = pooled.shape[0]
+    p = int(feat_hw[0]) * int(feat_hw[1])
+    wmap = np.zeros((b, p, p), dtype=np.float32)
+    stats = np.zeros((b, p, 3), dtype=np.float32)
+    for i in range(b):
+        pts = depth2points(pooled[i, 0], fov=90).reshape(3, -1).t().numpy().astype(np.float32)      # (P,3)
+        dx = pts[:, None, 0] - pts[None, :, 0]
+        dy = pts[:, None, 1] - pts[None, :, 1]
+        dz = pts[:, None, 2] - pts[None, :, 2]
+        dist = np.sqrt((dx * dx + dy * dy) + dz * dz).astype(np.float32)
+        mn = dist.min(axis=1, keepdims=True)
+        mx = dist.max(axis=1, keepdims=True)
+        dn = ((dist - mn) / (mx - mn)).astype(np.float32)
+        srt = np.sort(dn, axis=1)
+        thr = np.asarray([quantile_lerp(srt[r], 0.01) for r in range(p)], dtype=np.float32)[:, None]
+        wmap[i] = np.where(dn > thr, np.float32(0.0), np.float32(1.0) - dn)
+        stats[i, :, 0], stats[i, :, 1], stats[i, :, 2] = mn[:, 0], mx[:, 0], thr[:, 0]
+    return torch.from_numpy(wmap), torch.from_numpy(stats)
+
+
+def lhp_propagate(code: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
+    """code_mixed of forward_depth: out[b,:,p] = mean_q map[b,p,q] * code[b,:,q]   (src/modules.py:321-335)."""
+    b, d, h, w = code.shape
+    wmap, _ = lhp_depth_weights(depth, (h, w))
+    flat = code.reshape(b, d, h * w)
+    out = torch.einsum("bpq,bdq->bdp", wmap, flat) / float(h * w)
+    return out.reshape(b, d, h, w)
+
+
 def knn_table(normed_feats: torch.Tensor, k: int = 30) -> torch.Tensor:
     """Nearest-neighbour table of src/precompute_knns.py:106-112: row i = indices of the k largest entries of
     (X X^T)[i] in float32, value descending; ties by ascending index (the build's rule; torch.topk leaves it open)."""

@@ -570,3 +570,43 @@ def test_nearest_neighbors_table(name, dev):
     gap = (torch.gather(sims, 1, got) - torch.gather(sims, 1, want)).abs()
     assert float(gap[diff].max() if diff.any() else 0.0) < 5e-6
     assert torch.equal(got[:, 0], torch.arange(got.shape[0]))
+
+
+@pytest.mark.parametrize("name", ["p196", "p784", "rect_pool"])
+def test_lhp_depth_propagation(name, dev):
+    """dg_lhp_forward / dg_lhp_backward against the oracle (same direct distance formula): per-row statistics (min, max,
+    1 % quantile) bit-equal, propagated code and its adjoint to 1e-6 relative (summation order); against the reference
+    fixture (torch.cdist's matmul path) to 5e-4; the module with the reference's head weights reproduces its projection
+    and the gradient w.r.t. code."""
+    from depthg_amd import ops
+    from depthg_amd.lhp import LocalHiddenPositiveProjection, propagate_depth
+    from oracle import depthg_oracle as O
+    g = load_golden("lhp.npz")
+    code, depth = torch.from_numpy(g[f"{name}_code"]), torch.from_numpy(g[f"{name}_depth"])
+    out, points, stats = ops.lhp_forward(code.to(dev), depth.to(dev))
+    wmap, ostats = O.lhp_depth_weights(depth, code.shape[-2:])
+    assert torch.equal(stats.cpu(), ostats)
+    want = O.lhp_propagate(code, depth)
+    assert float((out.cpu() - want).norm() / want.norm()) < 1e-6
+    ref = torch.from_numpy(g[f"{name}_mixed"])
+    assert float((out.cpu() - ref).norm() / ref.norm()) < 5e-4
+    up = torch.from_numpy(g[f"{name}_up"])
+    gback = ops.lhp_backward(up.to(dev), points, stats).cpu()
+    b, d, h, w = code.shape
+    gwant = (torch.einsum("bpq,bdp->bdq", wmap, up.reshape(b, d, h * w)) / float(h * w)).reshape(b, d, h, w)
+    assert float((gback - gwant).norm() / gwant.norm()) < 1e-6
+    # module: the reference's head weights, projection and gradient of sum(proj * up)
+    cfg = O.default_cfg(dim=d)
+    m = LocalHiddenPositiveProjection(cfg).to(dev)
+    with torch.no_grad():
+        for i, prm in enumerate(m.projection_head.parameters()):
+            prm.copy_(torch.from_numpy(g[f"{name}_head{i}"]))
+    cg = code.to(dev).requires_grad_(True)
+    proj = m(cg, depth.to(dev), None, attn=torch.zeros(1, device=dev))
+    (proj * up.to(dev)).sum().backward()
+    refp, refg = torch.from_numpy(g[f"{name}_proj"]), torch.from_numpy(g[f"{name}_grad_code"])
+    assert float((proj.detach().cpu() - refp).norm() / refp.norm()) < 5e-4
+    assert float((cg.grad.cpu() - refg).norm() / refg.norm()) < 2e-3
+    # positive-image call: no depth -> head only (src/modules.py:191-192)
+    assert torch.allclose(m(cg.detach(), None), m.projection_head(cg.detach()))
+    assert propagate_depth(cg.detach(), depth.to(dev)).shape == code.shape

@@ -225,3 +225,22 @@ def test_uniform_rank_samplers_consistent():
         for s in range(12):
             r, cc = rc[b, s, 0]
             assert float(pooled[b, 0, r, cc]) == float(srt[b][O.rank_from_uniform(uv[b, s], 25)])
+
+
+# ---- depth propagation of the LHP branch -------------------------------------------------
+@pytest.mark.parametrize("name", ["p196", "p784", "rect_pool"])
+def test_lhp_propagation_against_reference(name):
+    """The oracle uses the direct distance formula; the reference's torch.cdist takes its matmul path for P > 25 (non-zero
+    self-distance, about 1e-7 * |point|^2 noise on d^2), so agreement is 5e-4 relative, not bitwise - and exact where the
+    neighbour sets are the same and cdist is exact (the 10x10 case)."""
+    g = load_golden("lhp.npz")
+    out = O.lhp_propagate(T(g[f"{name}_code"]), T(g[f"{name}_depth"]))
+    ref = g[f"{name}_mixed"]
+    rel = np.linalg.norm(out.numpy() - ref) / np.linalg.norm(ref)
+    assert rel < 5e-4, rel
+    wmap, stats = O.lhp_depth_weights(T(g[f"{name}_depth"]), g[f"{name}_code"].shape[-2:])
+    kept = (wmap > 0).sum(-1)
+    p = wmap.shape[-1]
+    assert int(kept.min()) >= int(np.floor(0.01 * (p - 1))) + 1            # at least the quantile's lower rank + 1 survive
+    assert torch.all(torch.diagonal(wmap, dim1=1, dim2=2) == 1.0)          # self-distance 0 -> weight 1
+    assert torch.all(stats[..., 0] == 0.0)
