@@ -610,3 +610,59 @@ def test_lhp_depth_propagation(name, dev):
     # positive-image call: no depth -> head only (src/modules.py:191-192)
     assert torch.allclose(m(cg.detach(), None), m.projection_head(cg.detach()))
     assert propagate_depth(cg.detach(), depth.to(dev)).shape == code.shape
+
+
+def test_lhp_second_loss_call_and_total(dev):
+    """The LHP step of training_step (src/train_segmentation.py:202-215, 255-266, 325-343): the code goes through the LHP
+    module (depth propagation for the image, head only for the positive), a second loss call runs on the projections and
+    both tuples enter the weighted total - GPU path against the oracle chain on the same coordinates / permutations /
+    head weights, values and the gradient w.r.t. the un-projected code."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.lhp import LocalHiddenPositiveProjection
+    from depthg_amd.training import correspondence_total
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(61)
+    B, C, D, hw, S, N = 2, 48, 24, 14, 9, 2
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    y, x = torch.meshgrid(torch.linspace(0, 1, 112), torch.linspace(0, 1, 112), indexing="ij")
+    d = (60 + 90 * x + 50 * y * x + 20 * torch.sin(7 * y)).round().expand(B, 1, 112, 112).contiguous()
+    d[1] = d[1].flip(-1)
+    coords1 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    coords2 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, lhp=True, lhp_weight=0.3, lhp_depth_weight=0.5,
+                        lhp_weight_balance=True)
+    head = LocalHiddenPositiveProjection(cfg)
+    with torch.no_grad():
+        for prm in head.projection_head.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * 0.3)
+
+    # oracle chain on the CPU
+    co, cpo = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    out_o = O.forward(cfg, f, fp, co, cpo, d, d, coords1=coords1, coords2=coords2, perms=perms)
+    proj_o = head.projection_head(O.lhp_propagate(co, d))
+    proj_pos_o = head.projection_head(cpo)
+    lhp_o = O.forward(cfg, f, fp, proj_o, proj_pos_o, d, d, coords1=coords1, coords2=coords2, perms=perms)
+    total_o, _ = correspondence_total(cfg, out_o, lhp_o)
+    total_o.backward()
+
+    # GPU path
+    head_g = LocalHiddenPositiveProjection(cfg).to(dev)
+    head_g.load_state_dict(head.state_dict())
+    loss = ContrastiveCorrelationLoss(cfg)
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    T = lambda t: t.to(dev)
+    out_g = loss.forward_with(T(f), T(fp), cg, cpg, T(d), T(coords1), T(coords2), [T(p) for p in perms])
+    proj_g = head_g(cg, T(d), None, attn=torch.zeros(1, device=dev))
+    proj_pos_g = head_g(cpg, None)
+    lhp_g = loss.forward_with(T(f), T(fp), proj_g, proj_pos_g, T(d), T(coords1), T(coords2), [T(p) for p in perms])
+    total_g, logs = correspondence_total(cfg, out_g, lhp_g)
+    total_g.backward()
+    _relclose(total_g, total_o, 5e-3, 1e-5, "total with LHP terms")
+    for i in (0, 2, 6):
+        _relclose(lhp_g[i], lhp_o[i], 3e-3, 1e-5, f"lhp tuple[{i}]")
+    for got, want in ((cg.grad, co.grad), (cpg.grad, cpo.grad)):
+        rel = (got.cpu() - want).norm() / want.norm()
+        assert rel < 3e-2, float(rel)
+    assert set(logs) >= {"loss/pos_intra", "loss/depth_feat", "cd/neg_inter"}
