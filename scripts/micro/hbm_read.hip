@@ -1,0 +1,41 @@
+// developer micro-benchmark: achievable HBM read bandwidth of a plain streaming kernel (16 B per lane, grid-stride),
+// to put the HBM-bound kernels (k_gs, k_prep_dense) in perspective.  build: hipcc -O3 --offload-arch=gfx950 -o hbm_read hbm_read.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int UN, bool NT>
+__global__ __launch_bounds__(256) void k_read(const v4i* __restrict__ src, size_t n, int* out) {
+    v4i acc = {0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UN - 1) * stride < n; i += UN * stride) {
+        v4i t[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) t[u] = NT ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc ^= t[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+int main() {
+    const size_t bytes = (size_t)1 << 30;       // 1 GiB: far beyond the 256 MB infinity cache
+    v4i* d; int* o;
+    hipMalloc(&d, bytes); hipMalloc(&o, 4); hipMemset(d, 1, bytes);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int blocks : {256, 512, 1024, 2048, 4096, 8192}) {
+        for (int variant = 0; variant < 4; ++variant) {
+            auto run = [&]() {
+                if (variant == 0) hipLaunchKernelGGL((k_read<4, false>), dim3(blocks), dim3(256), 0, 0, d, bytes / 16, o);
+                if (variant == 1) hipLaunchKernelGGL((k_read<4, true>), dim3(blocks), dim3(256), 0, 0, d, bytes / 16, o);
+                if (variant == 2) hipLaunchKernelGGL((k_read<8, false>), dim3(blocks), dim3(256), 0, 0, d, bytes / 16, o);
+                if (variant == 3) hipLaunchKernelGGL((k_read<8, true>), dim3(blocks), dim3(256), 0, 0, d, bytes / 16, o);
+            };
+            run(); hipDeviceSynchronize();
+            hipEventRecord(a); for (int r = 0; r < 5; ++r) run(); hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            printf("blocks %5d unroll %d nt %d: %.2f TB/s\n", blocks, variant < 2 ? 4 : 8, variant & 1, bytes * 5.0 / (ms * 1e-3) / 1e12);
+        }
+    }
+    return 0;
+}
