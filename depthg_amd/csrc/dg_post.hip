@@ -293,17 +293,24 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
 // in a fixed order: bit-reproducible), drops the rows into an LDS stage [channel][pixel] and the block writes (B,D,h,w)
 // rows of h*w contiguous floats.  grid (DP/32, B, 2), block 1024, dynamic LDS 32*(HW+1) floats + the routed list.
 #define DENSE_MAXROUTE 1024
-#define DENSE_THREADS 1024
+// CG channels per block (32, 16 or 8): a wave covers 32 / CG tiles at once - lanes [2 CG ts, 2 CG (ts + 1)) take tile ts of the
+// group, as the lanes 32 h + CG cg + idx of the gradient-tile layout (runs of CG lanes = CG * 16 contiguous bytes).  Smaller CG =
+// more, lighter blocks: the destination that collects the negatives' gradients is several times heavier than the other one,
+// and with 32-channel blocks only 192 blocks (96 heavy) cover the 256 CUs.
+template <int CG, int DENSE_THREADS>
 __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sd[];
     const int HW = a.h * a.w, S = a.S, nt = a.Ppad >> 5, NF = a.DP >> 5;
     DG_LOAD_GS(a, gs)
-    float* stage = reinterpret_cast<float*>(sd);                       // [32][HW + 1]
-    const float** rl_p = reinterpret_cast<const float**>(stage + 32 * (HW + 2));   // routed list: image base (8-byte aligned)
+    float* stage = reinterpret_cast<float*>(sd);                       // [CG][HW + 1]
+    const float** rl_p = reinterpret_cast<const float**>(stage + CG * (HW + 2));   // routed list: image base (8-byte aligned)
     float* rl_w = reinterpret_cast<float*>(rl_p + DENSE_MAXROUTE);                  //              weight
     __shared__ int rl_cnt;
-    const int f = blockIdx.x, b = blockIdx.y, dest = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    constexpr int TPW = 32 / CG;                                       // tiles per wave and round
+    const int f = blockIdx.x / TPW, cg = blockIdx.x % TPW, b = blockIdx.y, dest = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ts = lane / (2 * CG), h = (lane / CG) & 1, idx = lane % CG;
+    const int r = CG * cg + idx;                                       // channel inside the 32-channel group = lane of the layout
     // routed list in (source, image) order: the (routed source, image) pairs are numbered source-major, every thread tests
     // one pair per round (all sources at once), ballot + prefix compaction keeps the order
     constexpr int NW = DENSE_THREADS / 64;
@@ -343,11 +350,13 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
     }
     const int cnt = rl_cnt;
     const float invS = 1.f / (float)S;
-    for (int t = wid; t < nt; t += NW) {
-        const size_t toff = ((size_t)t * NF + f) * 1024 + lane * 4;
+    for (int t0 = wid * TPW; t0 < nt; t0 += NW * TPW) {
+        const int t = t0 + ts;
+        const bool live = t < nt;
+        const size_t toff = ((size_t)(live ? t : 0) * NF + f) * 1024 + (32 * h + r) * 4;
         f32x4 v[4];
         const float* cb = a.comb[dest] + (size_t)b * a.Ppad * a.DP + toff;
-        const bool chan = 32 * f + r < a.D;                   // padding channels are not stored by the producers
+        const bool chan = live && 32 * f + r < a.D;           // padding channels are not stored by the producers
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] = chan ? *reinterpret_cast<const f32x4*>(cb + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         for (int e0 = 0; e0 < cnt; e0 += 4) {                 // 4 routed images per round: 16 loads in flight
@@ -373,16 +382,16 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int p = t * 32 + k + 8 * g + 4 * h;
-                if (p < a.P) {
+                if (live && p < a.P) {
                     const int i = (int)(((float)p + 0.5f) * invS), j = p - i * S;    // p / S without an integer division
-                    stage[r * (HW + 1) + j * a.w + i] = v[g][k];
+                    stage[idx * (HW + 1) + j * a.w + i] = v[g][k];
                 }
             }
     }
     __syncthreads();
     float* out = a.out[dest];
-    for (int c = 0; c < 32; ++c) {
-        const int d = 32 * f + c;
+    for (int c = 0; c < CG; ++c) {
+        const int d = 32 * f + CG * cg + c;
         if (d >= a.D) break;
         for (int pix = tid; pix < HW; pix += DENSE_THREADS) out[((size_t)b * a.D + d) * HW + pix] = stage[c * (HW + 1) + pix];
     }
@@ -400,12 +409,20 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
         // identity grid: transposed copy (needs the [32][HW+1] stage in LDS and a bounded routed list)
         int nrouted = 0;
         for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
-        const size_t dsm = (size_t)32 * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
+        // 16 channels per block: 27 -> 21 us at the headline shape (8: 22 us); DG_SCATTER_CG overrides (developer A/B)
+        static const int cgsel = getenv("DG_SCATTER_CG") ? atoi(getenv("DG_SCATTER_CG")) : 16;
+        const int CGv = cgsel == 32 ? 32 : (cgsel == 8 ? 8 : 16);
+        const size_t dsm = (size_t)CGv * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
         if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {
-            hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_dense), (int)dsm);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_scatter_dense, dim3(a.DP / 32, a.B, 2), dim3(DENSE_THREADS), dsm, s, a);
-            return hipGetLastError();
+            auto launch = [&](auto kern, int threads) -> hipError_t {
+                hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), (int)dsm);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(kern, dim3(a.DP / CGv, a.B, 2), dim3(threads), dsm, s, a);
+                return hipGetLastError();
+            };
+            if (CGv == 32) return launch(k_scatter_dense<32, 1024>, 1024);
+            if (CGv == 16) return launch(k_scatter_dense<16, 512>, 512);
+            return launch(k_scatter_dense<8, 512>, 512);
         }
     }
     if (HW > SCAT_PX * SCAT_MAXPASS || a.P > 65535) return hipErrorInvalidValue;
