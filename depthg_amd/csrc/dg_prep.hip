@@ -465,34 +465,57 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
 // 32x32 MFMA chain over K with the tile's swizzled bf16 rows as A (read once for all pair-sets) and, as B, one column
 // per pair-set holding bbar split into two bf16 halves (columns t and 16 + t: hi + lo keeps ~16 mantissa bits, the
 // products with the bf16 rows are exact in the fp32 accumulator).  grid (Ppad/32, B), block 64.
-__global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char rm_smem[];     // the tile's F part (32 swizzled bf16 rows)
-    const int tile = blockIdx.x, n = blockIdx.y, lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+#define ROWMEAN_WAVES 4
+__global__ __launch_bounds__(64 * ROWMEAN_WAVES) void k_rowmean(const DgRowmeanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char rm_smem[];     // the tile's F part (32 bf16 rows, dg_f_off layout)
+    const int tile = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KF = a.KF, nt = a.Ppad / 32;
+    if (tile == nt) {
+        // extra block of the image: per-image sums of the row means (the fused kernel adds the B of them up to m0 = the
+        // reference's fd.mean() before centering, src/modules.py:1237): sum_p a_p . bbar = P * abar . bbar, one K-long dot per
+        // pair-set; the waves split the pair-sets (it used to trail the tile-0 wave as a serial chain of njobs dots)
+        float av[12];                                   // KF <= 768: 12 values per lane
+#pragma unroll
+        for (int j = 0; j < 12; ++j) av[j] = lane + 64 * j < KF ? a.abar[(size_t)n * KF + lane + 64 * j] : 0.f;
+        for (int t = wid; t < a.njobs; t += ROWMEAN_WAVES) {
+            const DgRowmeanJob& Jt = a.jobs[t];
+            const float* bt = Jt.bbar + (size_t)(Jt.bidx ? (int)Jt.bidx[n] : n) * KF;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) s = fmaf(av[j], lane + 64 * j < KF ? bt[lane + 64 * j] : 0.f, s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) Jt.rimg[n] = s * (float)a.P;
+        }
+        return;
+    }
     const DgBlob L(a.KF, a.KD);
     const int jb = c & 15, lo = c >> 4;
     const bool has = jb < a.njobs;
     const DgRowmeanJob& J = a.jobs[has ? jb : 0];
     const int nb = J.bidx ? (int)J.bidx[n] : n;
-    // the F part comes in linearly by LDS-DMA (1 KiB per instruction, fully coalesced); the B fragments (pre-split bbar)
-    // are plain 16-byte loads
+    // the four waves split K: wave w stages and multiplies the k-steps [w * nks, (w + 1) * nks) - a quarter of the F part
+    // comes in linearly by LDS-DMA (1 KiB per instruction, fully coalesced); the B fragments (pre-split bbar) are plain
+    // 16-byte loads.  (One wave per tile left the kernel latency-bound: three waves per CU.)
+    const int nks = KF / 16 / ROWMEAN_WAVES;                         // 2, 6 or 12 (KF in {128, 384, 768})
+    const int pieces = L.off_c / 1024 / ROWMEAN_WAVES;               // = nks: 16 k-values x 32 rows x 2 B = 1 KiB per k-step
     const char* fp = a.jobs[0].A + ((size_t)n * nt + tile) * L.bytes + lane * 16;
     const uint32_t dst = lds_addr(rm_smem);
-    const int pieces = L.off_c / 1024;
-    for (int pc = 0; pc < pieces; ++pc) dma16(fp + pc * 1024, dst + pc * 1024);
+    for (int pc = wid * pieces; pc < (wid + 1) * pieces; ++pc) dma16(fp + pc * 1024, dst + pc * 1024);
     const __bf16* bb = J.bsplit + ((size_t)nb * 2 + lo) * KF + 8 * h;
     f32x16 acc = {};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int ks0 = 0; ks0 < KF / 16; ks0 += 8) {     // KF / 16 is a multiple of 8 (KF in {128, 384, 768})
-        bf16x8 af[8], bf[8];
+    for (int ks0 = wid * nks; ks0 < (wid + 1) * nks; ks0 += 2) {     // nks is even
+        bf16x8 af[2], bf[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int ks = ks0 + u;
             af[u] = *reinterpret_cast<const bf16x8*>(rm_smem + dg_f_off(c, 2 * ks + h));      // A row q = c
             bf[u] = *reinterpret_cast<const bf16x8*>(bb + 16 * ks);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 2; ++u) {
             bf16x8 b = bf[u];
             if (!has) {
 #pragma unroll
@@ -501,6 +524,19 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u], b, acc, 0, 0, 0);
         }
     }
+    // partial accumulators of waves 1..3 -> wave 0 (through the staging buffer, which every wave is done with), fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(rm_smem);
+    if (wid > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[((wid - 1) * 16 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (wid != 0) return;
+#pragma unroll
+    for (int w = 0; w < ROWMEAN_WAVES - 1; ++w)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += red[(w * 16 + i) * 64 + lane];
     // lane (c, h) holds rows (i&3) + 8 (i>>2) + 4 h of column c; hi + lo columns are 16 lanes apart
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -508,29 +544,13 @@ __global__ __launch_bounds__(64) void k_rowmean(const DgRowmeanArgs a) {
         const int p = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (has && !lo) J.rvec[(size_t)n * a.Ppad + p] = p < a.P ? v : 0.f;
     }
-    // per-image sums of the row means (the fused kernel adds the B of them up to m0 = the reference's fd.mean() before
-    // centering, src/modules.py:1237): sum_p a_p . bbar = P * abar . bbar, one K-long dot per pair-set, by the image's first wave
-    if (tile != 0) return;
-    float av[12];                                   // KF <= 768: 12 values per lane
-#pragma unroll
-    for (int j = 0; j < 12; ++j) av[j] = lane + 64 * j < KF ? a.abar[(size_t)n * KF + lane + 64 * j] : 0.f;
-    for (int t = 0; t < a.njobs; ++t) {
-        const DgRowmeanJob& Jt = a.jobs[t];
-        const float* bt = Jt.bbar + (size_t)(Jt.bidx ? (int)Jt.bidx[n] : n) * KF;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) s = fmaf(av[j], lane + 64 * j < KF ? bt[lane + 64 * j] : 0.f, s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) Jt.rimg[n] = s * (float)a.P;
-    }
 }
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
     if (a.njobs > 16) return hipErrorInvalidValue;
-    const int smem = 32 * (a.KF / 8) * 16;
+    const int smem = max(32 * (a.KF / 8) * 16, (ROWMEAN_WAVES - 1) * 16 * 64 * 4);     // F part / partial accumulators
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_rowmean), smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32, a.B), dim3(64), smem, s, a);
+    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32 + 1, a.B), dim3(64 * ROWMEAN_WAVES), smem, s, a);
     return hipGetLastError();
 }
