@@ -431,18 +431,26 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
             const float* cp = part + (size_t)n * ngroups * K + k;
             float s = 0.f;
             int t = 0;
-            for (; t + 8 <= ngroups; t += 8) {            // 8 independent loads in flight, summed in group order
-                float v[8];
+            for (; t + 16 <= ngroups; t += 16) {          // 16 independent loads in flight, summed in group order
+                float v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = cp[(size_t)(t + u) * K];
+                for (int u = 0; u < 16; ++u) v[u] = cp[(size_t)(t + u) * K];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += v[u];
+                for (int u = 0; u < 16; ++u) s += v[u];
+            }
+            for (; t + 4 <= ngroups; t += 4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = cp[(size_t)(t + u) * K];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s += v[u];
             }
             for (; t < ngroups; ++t) s += cp[(size_t)t * K];
             out[(size_t)n * K + k] = s * scale;
         }
     };
-    if (a.colpart[o]) {
+    // blockIdx.z: 0 = feature means, 1 = code column sums (two short latency chains side by side instead of one after the other)
+    if (blockIdx.z == 0 && a.colpart[o]) {
         reduce(a.colpart[o], a.ngroups[o], a.KF, 1.f / (float)a.P, a.bbar[o]);
         // bbar as two bf16 halves (hi + lo keeps ~16 mantissa bits): the B fragments of k_rowmean, [n][2][KF]
         __syncthreads();
@@ -453,11 +461,11 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
             a.bsplit[o][((size_t)n * 2 + 1) * a.KF + k] = (__bf16)(v - (float)hi);
         }
     }
-    if (a.ccolpart[o]) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
+    if (blockIdx.z == 1 && a.ccolpart[o]) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
 }
 
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_colmean, dim3(a.B, a.nops), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_colmean, dim3(a.B, a.nops, 2), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
