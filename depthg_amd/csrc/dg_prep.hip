@@ -179,7 +179,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     // and only the NORMALISED bf16 row tile goes to LDS (half the bytes of an fp32 stage -> twice the blocks per CU).
     const int tid = threadIdx.x, x = tid & 31, k0 = tid >> 5;
     const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h;
-    const int RS = KF * 2 + 8;                      // LDS row stride in bytes: 8-byte aligned rows, 2-way writes at worst
+    const int RS = KF * 2 + 16;                     // LDS row stride in bytes: 16-byte aligned rows (granule reads), 2-way writes at worst
     const DgBlob L(a.KF, a.KD);
     const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w + x;
     char* tb = reinterpret_cast<char*>(sl);         // [w][RS] bf16 rows
@@ -206,15 +206,17 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
             if (u < nu) *reinterpret_cast<__bf16*>(tb + x * RS + (k0 + 8 * u) * 2) = (__bf16)(t[u] * inv);
     }
     __syncthreads();
+    if (a.debug & 32) return;                       // (ablation: loads + normalisation only)
     // blob rows: position p = x*S + y (sample() output (i, j) = (x, y)); 8-byte pieces, the lanes of a row run along K
-    const int pieces = KF / 4;                      // 8-byte pieces per row
+    const int pieces = KF / 8;                      // granules (16 bytes) per row
     for (int id = tid; id < w * pieces; id += 256) {
-        const int xx = id / pieces, pc = id - xx * pieces, k = 4 * pc;
-        const uint2 v = *reinterpret_cast<const uint2*>(tb + xx * RS + k * 2);
+        const int xx = id / pieces, g = id - xx * pieces;
+        const uint4 v = *reinterpret_cast<const uint4*>(tb + xx * RS + g * 16);
         const int p = xx * S + y;
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
-        *reinterpret_cast<uint2*>(blob + L.f(p & 31, k >> 3) + (k & 7) * 2) = v;
+        *reinterpret_cast<uint4*>(blob + L.f(p & 31, g)) = v;
     }
+    if (a.debug & 64) return;                       // (ablation: no column sums)
     // per-source-row column sums of the normalised (bf16-rounded, i.e. exactly what the MFMA sees) rows
     for (int k = tid; k < KF; k += 256) {
         float cs = 0.f;
@@ -356,7 +358,7 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.w > 32 || a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
     const int nt = a.Ppad / 32, gx = a.h;
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
-    const int smem = max(32 * (a.KF * 2 + 8) + 8 * 32 * 4,
+    const int smem = max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
                          DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);
     if (a.h * ((DENSE_TPB * 32 + a.h - 1) / a.h + 1) > DENSE_CODE_PAIRS) return hipErrorInvalidValue;   // pairs per block
     DgDenseArgs a2 = a;
