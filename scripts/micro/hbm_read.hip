@@ -18,6 +18,14 @@ __global__ __launch_bounds__(256) void k_read(const v4i* __restrict__ src, size_
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
 }
+// read two thirds, write one third (the mix of the feats role of k_prep_dense: fp32 in, bf16 out)
+__global__ __launch_bounds__(256) void k_mix(const v4i* __restrict__ src, v4i* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + stride < n; i += 2 * stride) {
+        const v4i a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        __builtin_nontemporal_store(a ^ b, dst + i / 2);
+    }
+}
 int main() {
     const size_t bytes = (size_t)1 << 30;       // 1 GiB: far beyond the 256 MB infinity cache
     v4i* d; int* o;
@@ -36,6 +44,14 @@ int main() {
             float ms; hipEventElapsedTime(&ms, a, b);
             printf("blocks %5d unroll %d nt %d: %.2f TB/s\n", blocks, variant < 2 ? 4 : 8, variant & 1, bytes * 5.0 / (ms * 1e-3) / 1e12);
         }
+    }
+    v4i* w; hipMalloc(&w, bytes / 2);
+    for (int blocks : {512, 1024, 2048, 4096}) {
+        hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, d, w, bytes / 16); hipDeviceSynchronize();
+        hipEventRecord(a); for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_mix, dim3(blocks), dim3(256), 0, 0, d, w, bytes / 16);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("mix 2:1 blocks %5d: %.2f TB/s (read + written)\n", blocks, bytes * 1.5 * 5.0 / (ms * 1e-3) / 1e12);
     }
     return 0;
 }
