@@ -180,7 +180,7 @@ struct DgJob {
     float* part;          // fp32 [blocks of this job][2] partial sums (sum clamp(cd)*(fd-shift), sum cd); or null
     float* out_cd;        // fp32 [B][P][P] (op1 position major) or null    (materialise; needs center_on_lane == 0)
     float* out_loss;      // fp32 [B][P][P] or null
-    uint16_t* Gout;       // fp16 [B][nt][nt][2 k-steps][64 lanes][8] = G tiles, accumulator registers 8s..8s+7 of every lane
+    uint16_t* Gout;       // fp16 [B][S tile][R tile][2 k-steps][64 lanes][8] = G tiles, accumulator registers 8s..8s+7 of every lane
                           // (one contiguous KiB per k-step and wave instruction; input of k_gs) or null
     float shift;
     int32_t kind;

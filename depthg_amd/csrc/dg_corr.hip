@@ -424,7 +424,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
                     // non-temporal: the tiles are read by the NEXT kernel only; keeping them out of the way leaves the L2 to
                     // the operand blobs this kernel streams over and over
                     // tile = [2 k-steps][64 lanes][16 B]: every store instruction writes one contiguous KiB
-                    v4i* g = reinterpret_cast<v4i*>(Gout) + (((size_t)n * ntiles_all + rtile0 + f) * ntiles_all + t) * 128 + lane;
+                    v4i* g = reinterpret_cast<v4i*>(Gout) + (((size_t)n * ntiles_all + t) * ntiles_all + rtile0 + f) * 128 + lane;     // [image][S tile][R tile]
                     __builtin_nontemporal_store(__builtin_bit_cast(v4i, ga[f][0]), g);
                     __builtin_nontemporal_store(__builtin_bit_cast(v4i, ga[f][1]), g + 64);
                 }
@@ -757,8 +757,8 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     // ds_read_b64_tr_b16 addressing: lane l of a 16-lane group supplies row (l>>2)&3 and chunk 4*((l>>4)&1) + (l&3) of the block
     const int tr_a = (lane >> 2) & 3, tr_c = 4 * ((lane >> 4) & 1) + (lane & 3);
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    const v4i* Gbase = reinterpret_cast<const v4i*>(J.G) + ((size_t)n * ntS * ntS + st) * 128 + lane;
-    const size_t gstride = (size_t)ntS * 64 * 2;            // v4i per R tile step
+    const v4i* Gbase = reinterpret_cast<const v4i*>(J.G) + ((size_t)n * ntS + st) * ntS * 128 + lane;      // [image][S tile][R tile]: one sequential 2 KiB-per-step stream per wave
+    const size_t gstride = 128;                             // v4i per R tile step
     auto load_g = [&](int rt, v4i (&g)[2]) {
         const v4i* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt) * gstride;
         g[0] = __builtin_nontemporal_load(gp);
