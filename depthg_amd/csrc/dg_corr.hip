@@ -61,9 +61,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef DG_PRIO
 #define DG_PRIO 1  // static issue priority: 1 = the half that runs half a tile behind (waves 4-7), 2 = waves 0-3, 0 = none
 #endif
-#ifndef DG_TWOACC
-#define DG_TWOACC 0
-#endif
 #ifndef PF
 #define PF 4       // LDS fragment reads kept in flight per wave (4 vs 6 vs 8: 4 is 1-2 % ahead, fewer registers)
 #endif
@@ -335,7 +332,6 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         } else {
             Yf[f] = f32x16{};
         }
-        f32x16 Yf2 = f32x16{};      // second feature accumulator: consecutive MFMAs do not wait for each other's result
         v4i ra[PF], rb[2];
 #pragma unroll
         for (int i = 0; i < PF; ++i) if (i < NS) ra[i] = *a_ptr(i);
@@ -351,10 +347,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         for (int st = 0; st < NS; ++st) {
             const v4i cur = ra[st % PF];
             if (st < NSF) {
-                if (DG_TWOACC && (st & 1))
-                    Yf2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf2, 0, 0, 0);
-                else
-                    Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
+                Yf[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur), Rf[f][st < NSF ? st : 0], Yf[f], 0, 0, 0);
             } else {
                 const int k = st - NSF;
                 const f16x8 b = RCREG ? Rc[k] : __builtin_bit_cast(f16x8, rb[k & 1]);
@@ -366,7 +359,6 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             __builtin_amdgcn_sched_barrier(0);
         }
         if (STAG && !(dbg & 131072)) { if (late_prio) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if (DG_TWOACC && NSF > 1) Yf[f] += Yf2;
     };
 
     // ---- everything after the Y chains of tile t: epilogue (VALU) and the gradient MFMAs.  For RF == 2 the epilogue of
