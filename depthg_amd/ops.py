@@ -199,13 +199,19 @@ def lhp_backward(grad_out, points, stats):
     return grad_code
 
 
-def super_perms(count, size, device):
+def super_perms(count, size, device, keys=None):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
     lib = _lib.load()
     out = torch.empty(count, size, dtype=torch.long, device=device)
     if count == 0:
         return out
-    keys = torch.rand(count, size, device=device)
+    if keys is None:
+        # one launch: the keys are drawn inside the kernel (Philox) from a 64-bit seed taken from torch's CPU generator, so
+        # torch.manual_seed still fixes the sequence and no device RNG launch is needed
+        seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        rc = lib.dg_super_perms_seeded(seed, int(count), int(size), _ptr(out), _stream(out.device))
+        _lib.check(rc, "dg_super_perms_seeded")
+        return out
     rc = lib.dg_super_perms(_ptr(keys), int(count), int(size), _ptr(out), _stream(out.device))
     _lib.check(rc, "dg_super_perms")
     return out

@@ -232,6 +232,9 @@ int dg_topk_rows(const float* vals, int64_t rows, int64_t cols, int64_t row_stri
  *  keys : fp32 (count, B)      out : int64 (count, B)      B <= 8192
  */
 int dg_super_perms(const float* keys, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+/* Same, with the keys drawn inside the launch: key(r, i) = Philox4x32-10(seed; counter r*B + i) >> 8, as a float in [0,1).
+ * The caller supplies a fresh 64-bit seed per call (from its own RNG): one launch per step instead of rand + sort. */
+int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
 
 /*
  * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a

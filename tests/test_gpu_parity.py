@@ -290,6 +290,25 @@ def test_super_perms_kernel(dev):
     assert p.shape == (5, 32) and int(p.min()) >= 0 and int(p.max()) < 32
     assert not bool((p == torch.arange(32, device=dev)).any())          # no image is its own negative
     assert ops.super_perms(0, 4, dev).shape == (0, 4)
+    # explicit keys still go through dg_super_perms
+    keys = torch.rand(2, 9, device=dev)
+    perm = torch.argsort(keys, dim=1, stable=True)
+    ar = torch.arange(9, device=dev).unsqueeze(0)
+    assert torch.equal(ops.super_perms(2, 9, dev, keys=keys), torch.where(perm == ar, perm + 1, perm) % 9)
+    # the one-launch variant (keys drawn in the kernel from a seed of torch's CPU generator): reproducible under
+    # torch.manual_seed, different from call to call, every row a bumped permutation, positions roughly uniform
+    torch.manual_seed(123)
+    a1, a2 = ops.super_perms(4, 64, dev), ops.super_perms(4, 64, dev)
+    torch.manual_seed(123)
+    b1 = ops.super_perms(4, 64, dev)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    big = ops.super_perms(2000, 16, dev)
+    assert not bool((big == torch.arange(16, device=dev)).any())
+    # before the bump a row is a permutation: at most the bumped entries collide, so >= 14 distinct values of 16
+    assert int(torch.stack([torch.bincount(r, minlength=16).gt(0).sum() for r in big[:50]]).min()) >= 13
+    freq = torch.stack([torch.bincount(big[:, j], minlength=16) for j in range(16)]).float() / 2000
+    assert float((freq - 1 / 16).abs().max()) < 0.03 + 1 / 16            # (the diagonal is empty: fixed points are bumped)
+    assert float(freq.diagonal().max()) == 0.0
 
 
 @pytest.mark.parametrize("B,C,D,hw,N,ident", [(1, 64, 16, 8, 2, True),      # B=1: super_perm(1) == [0], the image is its own negative (quirk Q6)
