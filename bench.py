@@ -145,12 +145,14 @@ def main():
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None)
 
+    seed_grad = torch.ones((), device=dev)   # d(total)/d(total): the upstream of the step, resident like the other inputs
+
     def step():
         c.grad = None
         cp.grad = None
         loss_fn(f, fp, None, None, c, cp, d, dp)
         total = loss_fn.total          # weighted total of the four loss means (training_step's term), formed by the library
-        total.backward()
+        total.backward(gradient=seed_grad)
         if use_dist:
             # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size
             # filled from this step's d/d code, all-reduced (sum) over xGMI and scaled by 1/world

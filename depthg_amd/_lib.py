@@ -14,7 +14,8 @@ DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARE
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
-           "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded"]
+           "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded",
+           "dg_corr_backward_total"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -52,6 +53,8 @@ def load():
     lib.dg_corr_forward.argtypes = [cp] + [vp] * 10 + [ctypes.c_size_t, vp]
     lib.dg_corr_backward.restype = ctypes.c_int
     lib.dg_corr_backward.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
+    lib.dg_corr_backward_total.restype = ctypes.c_int
+    lib.dg_corr_backward_total.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.dg_corr_materialize.restype = ctypes.c_int
     lib.dg_corr_materialize.argtypes = [cp, ctypes.c_int32, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_corr_relaunch_main.restype = ctypes.c_int

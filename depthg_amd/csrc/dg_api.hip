@@ -324,14 +324,34 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     return DG_OK;
 }
 
+static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalars, const float* grad_total, const float* coords1,
+                              const float* coords2, const int64_t* perms, float* grad_code, float* grad_code_pos,
+                              void* workspace, size_t workspace_bytes, dg_stream_t stream_);
+
 extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scalars, const float* coords1,
                                 const float* coords2, const int64_t* perms, float* grad_code, float* grad_code_pos,
                                 void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!grad_scalars) return fail(DG_ERR_INVALID, "null pointer");
+    return corr_backward_impl(desc, grad_scalars, nullptr, coords1, coords2, perms, grad_code, grad_code_pos, workspace,
+                              workspace_bytes, stream_);
+}
+
+extern "C" int dg_corr_backward_total(const dg_corr_desc* desc, const float* grad_total, const float* coords1,
+                                      const float* coords2, const int64_t* perms, float* grad_code, float* grad_code_pos,
+                                      void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!grad_total) return fail(DG_ERR_INVALID, "null pointer");
+    return corr_backward_impl(desc, nullptr, grad_total, coords1, coords2, perms, grad_code, grad_code_pos, workspace,
+                              workspace_bytes, stream_);
+}
+
+static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalars, const float* grad_total, const float* coords1,
+                              const float* coords2, const int64_t* perms, float* grad_code, float* grad_code_pos,
+                              void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     Plan p;
     int rc = make_plan(desc, p);
     if (rc != DG_OK) return rc;
     if (!p.grad) return fail(DG_ERR_INVALID, "dg_corr_backward needs a descriptor with DG_NEED_GRAD (as used in forward)");
-    if (!grad_scalars || !coords1 || !coords2 || !grad_code || !grad_code_pos || !workspace) return fail(DG_ERR_INVALID, "null pointer");
+    if (!coords1 || !coords2 || !grad_code || !grad_code_pos || !workspace) return fail(DG_ERR_INVALID, "null pointer");
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", p.N);
     if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
     char* ws = static_cast<char*>(workspace);
@@ -358,7 +378,7 @@ extern "C" int dg_corr_backward(const dg_corr_desc* desc, const float* grad_scal
     }
     if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0, 1);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
     s.nsrc = n;
-    s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars;
+    s.coords1 = coords1; s.coords2 = coords2; s.gscal = grad_scalars; s.gtot = grad_total;
     s.wtot[0] = desc->w_intra; s.wtot[1] = desc->w_inter; s.wtot[2] = desc->w_neg; s.wtot[3] = desc->w_depth;
     s.comb[0] = F32(p.comb[0]); s.comb[1] = F32(p.comb[1]);
     s.taps = ws + p.taps;

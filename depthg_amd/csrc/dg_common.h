@@ -300,7 +300,8 @@ struct DgScatterArgs {
     int32_t nsrc;
     const float* coords1;
     const float* coords2;
-    const float* gscal;    // [DG_OUT_COUNT] upstream gradient of the output vector (device); see dg_gscal
+    const float* gscal;    // [DG_OUT_COUNT] upstream gradient of the output vector (device); see dg_gscal; or null:
+    const float* gtot;     // [1] upstream gradient of out[DG_OUT_TOTAL] alone (dg_corr_backward_total)
     float wtot[4];         // weights of the four loss means in the total
     float* comb[2];        // gradient tiles: combined direct sources per destination (scratch)
     char* taps;            // [2 coords sets][B] inverse tap records (dg_taps_record_bytes each)
@@ -315,7 +316,9 @@ struct DgScatterArgs {
 
 #ifdef __HIPCC__
 // effective upstream gradient of loss mean i: direct + through the weighted total
-__device__ __forceinline__ float dg_gscal(const DgScatterArgs& a, int i) { return a.gscal[i] + a.gscal[DG_OUT_TOTAL] * a.wtot[i]; }
+__device__ __forceinline__ float dg_gscal(const DgScatterArgs& a, int i) {
+    return a.gscal ? a.gscal[i] + a.gscal[DG_OUT_TOTAL] * a.wtot[i] : a.gtot[0] * a.wtot[i];
+}
 #endif
 
 // k_gs: gradient w.r.t. the STREAMED operand's code from the G tiles the fused kernel stored:

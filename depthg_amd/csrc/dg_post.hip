@@ -33,8 +33,10 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
 #define DG_LOAD_GS(a, gs)                                                                                   \
     float gs[4];                                                                                            \
     {                                                                                                       \
-        const float gt_ = (a).gscal[DG_OUT_TOTAL];                                                          \
-        const float g0_ = (a).gscal[0], g1_ = (a).gscal[1], g2_ = (a).gscal[2], g3_ = (a).gscal[3];        \
+        const bool vec_ = (a).gscal != nullptr;                                                             \
+        const float gt_ = vec_ ? (a).gscal[DG_OUT_TOTAL] : (a).gtot[0];                                     \
+        const float g0_ = vec_ ? (a).gscal[0] : 0.f, g1_ = vec_ ? (a).gscal[1] : 0.f;                       \
+        const float g2_ = vec_ ? (a).gscal[2] : 0.f, g3_ = vec_ ? (a).gscal[3] : 0.f;                       \
         gs[0] = g0_ + gt_ * (a).wtot[0]; gs[1] = g1_ + gt_ * (a).wtot[1];                                  \
         gs[2] = g2_ + gt_ * (a).wtot[2]; gs[3] = g3_ + gt_ * (a).wtot[3];                                  \
     }

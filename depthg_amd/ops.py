@@ -74,6 +74,18 @@ def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_
     return g_code, g_code_pos
 
 
+def corr_backward_total(desc, grad_total, coords1, coords2, perms, workspace, shape_code):
+    """Backward for an upstream gradient of out[DG_OUT_TOTAL] alone (`total.backward()`): grad_total is a device scalar."""
+    lib = _lib.load()
+    dev = grad_total.device
+    g_code = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    g_code_pos = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    rc = lib.dg_corr_backward_total(ctypes.byref(desc), _ptr(grad_total), _ptr(coords1), _ptr(coords2), _ptr(perms),
+                                    _ptr(g_code), _ptr(g_code_pos), _ptr(workspace), workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_backward_total")
+    return g_code, g_code_pos
+
+
 def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False):
     lib = _lib.load()
     dev = workspace.device

@@ -131,6 +131,13 @@ int dg_corr_backward(const dg_corr_desc* desc,
                      const float* coords1, const float* coords2, const int64_t* perms,
                      float* grad_code, float* grad_code_pos,
                      void* workspace, size_t workspace_bytes, dg_stream_t stream);
+/* Same with the upstream gradient of out_scalars[DG_OUT_TOTAL] alone (a device scalar): effective d/d(loss mean i) =
+ * grad_total[0] * w_i.  What `total.backward()` needs - no 9-element gradient vector has to be assembled first. */
+int dg_corr_backward_total(const dg_corr_desc* desc,
+                           const float* grad_total,
+                           const float* coords1, const float* coords2, const int64_t* perms,
+                           float* grad_code, float* grad_code_pos,
+                           void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * Optional full tensors the reference returns un-reduced (src/modules.py:1352-1367), computed
