@@ -11,6 +11,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
+// Developer ablation switches (the `debug` bits of the argument blocks, the DG_DEBUG / DG_PREP_DEBUG / DG_STAMPS /
+// DG_BLOCKLOG / DG_SCATTER_CG environment hooks) exist only in a `make EXTRA=-DDG_DEVTOOLS` build; in the production
+// library the bits fold to zero at compile time and the hooks are not compiled.
+#ifdef DG_DEVTOOLS
+#define DG_DBG(x) (x)
+#else
+#define DG_DBG(x) 0
+#endif
+
 #define DG_EPS_NORM 1e-10f  // F.normalize eps, reference src/modules.py:790
 
 // Position permutation inside each 32-position block of the P-major code operand, chosen so that

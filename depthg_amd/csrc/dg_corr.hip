@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstdio>
 
+
 __device__ __forceinline__ void wait_vmcnt(int n) {   // n is wave-uniform
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -155,7 +156,7 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
 
     // kernarg fields used inside the tile loop are copied to locals: behind the asm memory clobbers hipcc would re-load
     // them (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS read ring) in every iteration
-    const int dbg = args.debug;
+    const int dbg = DG_DBG(args.debug);
     uint16_t* const Gout = job.Gout;
     float* const out_cd = job.out_cd;
     float* const out_loss = job.out_loss;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
     const int per_img = args.njobs * args.nrb;
     int n, jid, rb;
     const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
-    if ((gridDim.x & 7) == 0 && (args.B & 7) == 0 && nh > 0 && !(args.debug & 8388608)) {
+    if ((gridDim.x & 7) == 0 && (args.B & 7) == 0 && nh > 0 && !(DG_DBG(args.debug) & 8388608)) {
         // every XCD owns B/8 whole images; inside that chunk the long blocks go first (longest-processing-time order):
         // pair-set jobs with a full row block, then their ragged last row block, then the cheap depth job
         const int imgs = args.B >> 3, per_chunk = imgs * per_img;
@@ -653,8 +654,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
         rb = bid - jid * args.nrb;
     }
     const DgJob& job = args.jobs[jid];
-    if ((args.debug & 16777216) && rb == args.nrb - 1 && args.nrb > 1) return;     // (ablation: skip the last row block)
-    if ((args.debug & 134217728) && job.kind == DG_JOB_DEPTH) return;               // (ablation: skip the depth job)
+    if ((DG_DBG(args.debug) & 16777216) && rb == args.nrb - 1 && args.nrb > 1) return;     // (ablation: skip the last row block)
+    if ((DG_DBG(args.debug) & 134217728) && job.kind == DG_JOB_DEPTH) return;               // (ablation: skip the depth job)
     if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH, NKC>(args, job, n, rb, smem);
     else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW, NKC>(args, job, n, rb, smem);
     else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE, NKC>(args, job, n, rb, smem);
@@ -711,7 +712,8 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     const int n = a.B - 1 - bz;
     const DgGsJob& J = a.jobs[by];
     const int ntS = a.Ppad >> 5;
-    const int nt = (a.debug & 4096) ? 1 : ntS;              // (ablation: one R tile only)
+    const int gdbg = DG_DBG(a.debug);
+    const int nt = (gdbg & 4096) ? 1 : ntS;              // (ablation: one R tile only)
     const int nR = J.ridx ? (int)J.ridx[n] : n;
     if (wid == GS_CW) {
         // ---- producer: P parts of R tiles 0..nt-1 through the ring
@@ -752,7 +754,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     const v4i* Gbase = reinterpret_cast<const v4i*>(J.G) + ((size_t)n * ntS + st) * ntS * 128 + lane;      // [image][S tile][R tile]: one sequential 2 KiB-per-step stream per wave
     const size_t gstride = 128;                             // v4i per R tile step
     auto load_g = [&](int rt, v4i (&g)[2]) {
-        const v4i* gp = Gbase + (size_t)((a.debug & 64) ? 0 : rt) * gstride;
+        const v4i* gp = Gbase + (size_t)((gdbg & 64) ? 0 : rt) * gstride;
         g[0] = __builtin_nontemporal_load(gp);
         g[1] = __builtin_nontemporal_load(gp + 64);
     };
@@ -777,7 +779,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
                 if (rt + 3 < nt) load_g(rt + 3, gring[k]);
                 __builtin_amdgcn_s_barrier();               // P part of tile rt is in the ring
                 asm volatile("" ::: "memory");
-                if (!(a.debug & 32)) {
+                if (!(gdbg & 32)) {
                     const char* P = gs_smem + (rt % GS_NB) * PB;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
@@ -804,7 +806,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
             }
         }
     }
-    if (a.debug & 2048) { if (acc[0][0] == 1.2345f) J.dS[0] = acc[1][0] + acc[2][0]; return; }   // (ablation: no epilogue)
+    if (gdbg & 2048) { if (acc[0][0] == 1.2345f) J.dS[0] = acc[1][0] + acc[2][0]; return; }   // (ablation: no epilogue)
     // normalisation backward: acc[f][i] is (q = (i&3)+8*(i>>2)+4*h, channel 32 f + r);  dc = (dx - x <x,dx>) / ||c||
     const char* Cp = J.Sop + ((size_t)nS * ntS + st) * BL::BYTES + BL::OFF_C;
     static_assert(32 * GS_TS >= DG_XROWS_LDS, "scratch too small for the code rows");
@@ -843,7 +845,9 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
     dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
+#ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
+#endif
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;
 #define DG_GS(NKF_, NKD_)                                                                                               \
     if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) {                                                                        \
@@ -868,10 +872,11 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const int grid = args.njobs * args.B * args.nrb;
     DgCorrArgs a2 = args;
+    int smem2 = smem;
+#ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only, results invalid)
     const char* stamp_file = getenv("DG_STAMPS");                     // developer aid: phase time stamps of one block
     static uint32_t* stamp_buf = nullptr;
-    int smem2 = smem;
     if (stamp_file && smem + NWAVES * 400 <= 160 * 1024) {
         if (!stamp_buf && hipMalloc(&stamp_buf, NWAVES * 400) != hipSuccess) stamp_buf = nullptr;
         if (stamp_buf) {
@@ -885,7 +890,9 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
         if (!blog_buf && hipMalloc(&blog_buf, 8192 * 64) != hipSuccess) blog_buf = nullptr;
         if (blog_buf && grid <= 8192) a2.blocklog = blog_buf;
     }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), smem2, stream, a2);
+#ifdef DG_DEVTOOLS
     if (a2.blocklog) {
         static unsigned long long hostb[8192 * 8];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 64, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -898,6 +905,7 @@ static hipError_t launch_corr_t(const DgCorrArgs& args, hipStream_t stream) {
             if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, NWAVES * 100, fp); fclose(fp); }
         }
     }
+#endif
     return hipGetLastError();
 }
 

@@ -63,13 +63,12 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         for (int d = 0; d < NDF; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // padding channels are not stored by the producers: those lanes re-read a valid address (cache hit, no
-                // branch around the batched loads) and contribute zero
+                // padding channels are not stored by the producers (the bytes there are whatever the workspace held, NaN
+                // patterns included): those lanes load a valid address and the value is SELECTED away, never multiplied
                 const bool ok = 32 * d + r < a.D;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
-                const float scm = ok ? sc : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(scm, t[e], v[d][4 * g + e]);
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, ok ? t[e] : 0.f, v[d][4 * g + e]);
             }
     }
     if (any_raw) {
@@ -102,13 +101,12 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
         for (int d = 0; d < NDF; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // padding channels are not stored by the producers: those lanes re-read a valid address (cache hit, no
-                // branch around the batched loads) and contribute zero
+                // padding channels are not stored by the producers (the bytes there are whatever the workspace held, NaN
+                // patterns included): those lanes load a valid address and the value is SELECTED away, never multiplied
                 const bool ok = 32 * d + r < a.D;
                 const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
-                const float scm = ok ? sc : 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(scm, t[e], v[d][4 * g + e]);
+                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, ok ? t[e] : 0.f, v[d][4 * g + e]);
             }
     }
     float* out = a.comb[dest] + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
@@ -412,7 +410,11 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
         int nrouted = 0;
         for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
         // 16 channels per block: 27 -> 21 us at the headline shape (8: 22 us); DG_SCATTER_CG overrides (developer A/B)
+#ifdef DG_DEVTOOLS
         static const int cgsel = getenv("DG_SCATTER_CG") ? atoi(getenv("DG_SCATTER_CG")) : 16;
+#else
+        constexpr int cgsel = 16;
+#endif
         const int CGv = cgsel == 32 ? 32 : (cgsel == 8 ? 8 : 16);
         const size_t dsm = (size_t)CGv * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
         if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {

@@ -206,7 +206,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
             if (u < nu) *reinterpret_cast<__bf16*>(tb + x * RS + (k0 + 8 * u) * 2) = (__bf16)(t[u] * inv);
     }
     __syncthreads();
-    if (a.debug & 32) return;                       // (ablation: loads + normalisation only)
+    if (DG_DBG(a.debug) & 32) return;                       // (ablation: loads + normalisation only)
     // blob rows: position p = x*S + y (sample() output (i, j) = (x, y)); 8-byte pieces, the lanes of a row run along K
     const int pieces = KF / 8;                      // granules (16 bytes) per row
     for (int id = tid; id < w * pieces; id += 256) {
@@ -216,7 +216,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
         *reinterpret_cast<uint4*>(blob + L.f(p & 31, g)) = v;
     }
-    if (a.debug & 64) return;                       // (ablation: no column sums)
+    if (DG_DBG(a.debug) & 64) return;                       // (ablation: no column sums)
     // per-source-row column sums of the normalised (bf16-rounded, i.e. exactly what the MFMA sees) rows
     for (int k = tid; k < KF; k += 256) {
         float cs = 0.f;
@@ -281,7 +281,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
         red[kg * DENSE_CODE_PAIRS + ps + 64 * j] = ss;
     }
     __syncthreads();
-    if (a.debug & 8) return;                                  // (ablation: loads only)
+    if (DG_DBG(a.debug) & 8) return;                                  // (ablation: loads only)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (pos[j] < 0) continue;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
     }
     __syncthreads();
     for (int pos2 = tid; pos2 < np; pos2 += 256) a.inv_norm[o][(size_t)n * a.Ppad + p0 + pos2] = inv[pos2];
-    if (a.debug & 16) return;                                 // (ablation: no output phases)
+    if (DG_DBG(a.debug) & 16) return;                                 // (ablation: no output phases)
     char* blob0 = a.blob[o] + ((size_t)n * nt + t0) * L.bytes;
     const int GD = KD / 8;
     for (int id = tid; id < ntile * GD * 32; id += 256) {     // C part: granule g of position qq of tile tl
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
     if (z < 2) {
-        if (x < a.h && !(a.debug & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
+        if (x < a.h && !(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
     } else if (z < 4) {
-        if (x * DENSE_TPB < a.Ppad / 32 && !(a.debug & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
-    } else if (x == 0 && !(a.debug & 4)) {
+        if (x * DENSE_TPB < a.Ppad / 32 && !(DG_DBG(a.debug) & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
+    } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad);
     }
 }
@@ -362,7 +362,9 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
                          DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);
     if (a.h * ((DENSE_TPB * 32 + a.h - 1) / a.h + 1) > DENSE_CODE_PAIRS) return hipErrorInvalidValue;   // pairs per block
     DgDenseArgs a2 = a;
+#ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
+#endif
     const dim3 grid(gx * a.B * (a.depth ? 5 : 4));
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);

@@ -1,11 +1,25 @@
 """Tensor-level wrappers over the C ABI (raw device pointers + the current HIP stream).
 torch is used for device memory and streams only."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 from ._lib import CorrDesc
+
+
+# Test hook (tests/test_gpu_poison.py, DG_POISON=1): every buffer this layer hands to the library - the workspace and all
+# outputs - is pre-filled with 0xFF bytes (a NaN pattern for fp32/fp16, -1 for integers), so that a kernel that reads a
+# byte it (or an earlier kernel of the call) has not written shows up as NaN instead of depending on recycled memory.
+POISON = os.environ.get("DG_POISON", "") not in ("", "0")
+
+
+def _empty(shape, dtype, device):
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if POISON and t.numel():
+        t.reshape(-1).view(torch.uint8).fill_(0xFF)
+    return t
 
 
 def _ptr(t):
@@ -48,14 +62,14 @@ def workspace_bytes(desc):
 
 
 def alloc_workspace(desc, device):
-    return torch.empty(workspace_bytes(desc), dtype=torch.uint8, device=device)
+    return _empty(workspace_bytes(desc), torch.uint8, device)
 
 
 def corr_forward(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, perms, workspace):
     """Returns fp32 [DG_OUT_COUNT] device tensor (order: DG_OUT_* of include/depthg_corr.h)."""
     lib = _lib.load()
     dev = feats.device
-    out = torch.empty(_lib.DG_OUT_COUNT, dtype=torch.float32, device=dev)
+    out = _empty(_lib.DG_OUT_COUNT, torch.float32, dev)
     rc = lib.dg_corr_forward(ctypes.byref(desc), _ptr(feats), _ptr(feats_pos), _ptr(code), _ptr(code_pos), _ptr(depth),
                              _ptr(coords1), _ptr(coords2), _ptr(perms), _ptr(out), _ptr(workspace),
                              workspace.numel(), _stream(dev))
@@ -66,8 +80,8 @@ def corr_forward(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2
 def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_code):
     lib = _lib.load()
     dev = grad_scalars.device
-    g_code = torch.empty(shape_code, dtype=torch.float32, device=dev)
-    g_code_pos = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    g_code = _empty(shape_code, torch.float32, dev)
+    g_code_pos = _empty(shape_code, torch.float32, dev)
     rc = lib.dg_corr_backward(ctypes.byref(desc), _ptr(grad_scalars), _ptr(coords1), _ptr(coords2), _ptr(perms),
                               _ptr(g_code), _ptr(g_code_pos), _ptr(workspace), workspace.numel(), _stream(dev))
     _lib.check(rc, "dg_corr_backward")
@@ -78,8 +92,8 @@ def corr_backward_total(desc, grad_total, coords1, coords2, perms, workspace, sh
     """Backward for an upstream gradient of out[DG_OUT_TOTAL] alone (`total.backward()`): grad_total is a device scalar."""
     lib = _lib.load()
     dev = grad_total.device
-    g_code = torch.empty(shape_code, dtype=torch.float32, device=dev)
-    g_code_pos = torch.empty(shape_code, dtype=torch.float32, device=dev)
+    g_code = _empty(shape_code, torch.float32, dev)
+    g_code_pos = _empty(shape_code, torch.float32, dev)
     rc = lib.dg_corr_backward_total(ctypes.byref(desc), _ptr(grad_total), _ptr(coords1), _ptr(coords2), _ptr(perms),
                                     _ptr(g_code), _ptr(g_code_pos), _ptr(workspace), workspace.numel(), _stream(dev))
     _lib.check(rc, "dg_corr_backward_total")
@@ -91,8 +105,8 @@ def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False):
     dev = workspace.device
     sh = 1 if (desc.flags & _lib.DG_LINE_GRID) else desc.S
     shape = (desc.B, sh, desc.S, sh, desc.S)
-    cd = torch.empty(shape, dtype=torch.float32, device=dev) if want_cd else None
-    loss = torch.empty(shape, dtype=torch.float32, device=dev) if want_loss else None
+    cd = _empty(shape, torch.float32, dev) if want_cd else None
+    loss = _empty(shape, torch.float32, dev) if want_loss else None
     rc = lib.dg_corr_materialize(ctypes.byref(desc), int(which), _ptr(cd), _ptr(loss), _ptr(workspace),
                                  workspace.numel(), _stream(dev))
     _lib.check(rc, "dg_corr_materialize")
@@ -106,9 +120,9 @@ def fps_coords(depth, feat_hw, n_samples, return_inds=False):
     B, _, H, W = depth.shape
     h, w = int(feat_hw[0]), int(feat_hw[1])
     S = int(n_samples)
-    coords = torch.empty(B, S, S, 2, dtype=torch.float32, device=depth.device)
-    inds = torch.empty(B, S * S, dtype=torch.int32, device=depth.device) if return_inds else None
-    ws = torch.empty(lib.dg_fps_workspace_bytes(B, h, w), dtype=torch.uint8, device=depth.device)
+    coords = _empty((B, S, S, 2), torch.float32, depth.device)
+    inds = _empty((B, S * S), torch.int32, depth.device) if return_inds else None
+    ws = _empty((lib.dg_fps_workspace_bytes(B, h, w)), torch.uint8, depth.device)
     rc = lib.dg_fps_coords(_ptr(depth), B, H, W, h, w, S, _ptr(coords), _ptr(inds), _ptr(ws), ws.numel(),
                            _stream(depth.device))
     _lib.check(rc, "dg_fps_coords")
@@ -129,7 +143,7 @@ def salience_coords(salience, n_side, u_sel=None, u_fallback=None):
     u_sel = torch.rand(B, n, device=dev) if u_sel is None else _f32c(u_sel, "u_sel")
     u_fallback = torch.rand(B, n, 2, device=dev) if u_fallback is None else _f32c(u_fallback, "u_fallback")
     assert tuple(u_sel.shape) == (B, n) and tuple(u_fallback.shape) == (B, n, 2)
-    coords = torch.empty(B, S, S, 2, dtype=torch.float32, device=dev)
+    coords = _empty((B, S, S, 2), torch.float32, dev)
     rc = lib.dg_salience_coords(_ptr(sal), B, H, W, n, _ptr(u_sel), _ptr(u_fallback), _ptr(coords), _stream(dev))
     _lib.check(rc, "dg_salience_coords")
     return coords
@@ -147,7 +161,7 @@ def simple_depth_coords(depth, feat_hw, n_samples, u_value=None, u_pick=None):
     u_value = torch.rand(B, n, device=dev) if u_value is None else _f32c(u_value, "u_value")
     u_pick = torch.rand(B, n, device=dev) if u_pick is None else _f32c(u_pick, "u_pick")
     assert tuple(u_value.shape) == (B, n) and tuple(u_pick.shape) == (B, n)
-    coords = torch.empty(B, n, 1, 2, dtype=torch.float32, device=dev)
+    coords = _empty((B, n, 1, 2), torch.float32, dev)
     rc = lib.dg_simple_depth_coords(_ptr(depth), B, H, W, h, w, n, _ptr(u_value), _ptr(u_pick), _ptr(coords), _stream(dev))
     _lib.check(rc, "dg_simple_depth_coords")
     return coords
@@ -179,8 +193,8 @@ def topk_rows(vals, k, return_values=False):
     if vals.dim() != 2 or vals.dtype != torch.float32 or vals.stride(1) != 1:
         raise ValueError("depthg_amd: topk_rows wants a 2-D fp32 tensor with contiguous rows")
     rows, cols = vals.shape
-    idx = torch.empty(rows, int(k), dtype=torch.int64, device=vals.device)
-    val = torch.empty(rows, int(k), dtype=torch.float32, device=vals.device) if return_values else None
+    idx = _empty((rows, int(k)), torch.int64, vals.device)
+    val = _empty((rows, int(k)), torch.float32, vals.device) if return_values else None
     rc = lib.dg_topk_rows(_ptr(vals), rows, cols, vals.stride(0) if rows > 1 else cols, int(k), _ptr(idx), _ptr(val), _stream(vals.device))
     _lib.check(rc, "dg_topk_rows")
     return (idx, val) if return_values else idx
@@ -192,9 +206,9 @@ def lhp_forward(code, depth):
     code = _f32c(code, "code")
     depth = _f32c(depth, "depth")
     B, D, h, w = code.shape
-    out = torch.empty_like(code)
-    points = torch.empty(B, 3, h * w, dtype=torch.float32, device=code.device)
-    stats = torch.empty(B, h * w, 3, dtype=torch.float32, device=code.device)
+    out = _empty(tuple(code.shape), torch.float32, code.device)
+    points = _empty((B, 3, h * w), torch.float32, code.device)
+    stats = _empty((B, h * w, 3), torch.float32, code.device)
     rc = lib.dg_lhp_forward(_ptr(code), _ptr(depth), B, D, h, w, depth.shape[-2], depth.shape[-1], _ptr(out), _ptr(points),
                             _ptr(stats), _stream(code.device))
     _lib.check(rc, "dg_lhp_forward")
@@ -205,7 +219,7 @@ def lhp_backward(grad_out, points, stats):
     lib = _lib.load()
     g = _f32c(grad_out, "grad_out")
     B, D, h, w = g.shape
-    grad_code = torch.empty_like(g)
+    grad_code = _empty(tuple(g.shape), torch.float32, g.device)
     rc = lib.dg_lhp_backward(_ptr(g), _ptr(points), _ptr(stats), B, D, h, w, _ptr(grad_code), _stream(g.device))
     _lib.check(rc, "dg_lhp_backward")
     return grad_code
@@ -214,7 +228,7 @@ def lhp_backward(grad_out, points, stats):
 def super_perms(count, size, device, keys=None):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
     lib = _lib.load()
-    out = torch.empty(count, size, dtype=torch.long, device=device)
+    out = _empty((count, size), torch.long, device)
     if count == 0:
         return out
     if keys is None:
