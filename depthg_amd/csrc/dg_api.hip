@@ -205,6 +205,25 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     return njA;
 }
 
+// Fused correlation launch(es).  Gradient passes of the ViT-S widths run the one-wave-per-SIMD kernel (dg_corr2.hip) for the
+// pair-set jobs and the cheap depth job as its own k_corr_main launch; everything else is one k_corr_main launch.
+static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int depth_index, hipStream_t stream) {
+    if (p.grad && njA > 0) {
+        DgCorrArgs h = a;
+        h.njobs = njA;
+        const hipError_t e = dg_launch_corr2(h, p.KF, p.KD, stream);
+        if (e == hipSuccess) {
+            if (depth_index < 0) return hipSuccess;
+            DgCorrArgs d = a;
+            d.jobs[0] = a.jobs[depth_index];
+            d.njobs = 1;
+            return dg_launch_corr(d, p.KF, p.KD, p.rf, 1, stream);
+        }
+        if (e != hipErrorNotSupported) return e;
+    }
+    return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);
+}
+
 extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                                const float* orig_code, const float* orig_code_pos, const float* depth,
                                const float* coords1, const float* coords2, const int64_t* perms,
@@ -298,8 +317,8 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     // 4. fused correlation passes
     DgCorrArgs a;
     int depth_index;
-    build_corr_jobs(p, desc, ws, perms, a, &depth_index);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream));
+    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    DG_HIP(launch_main(p, a, njA, depth_index, stream));
 
     // 5. scalar outputs: the partial sums are reduced by the next launch (k_gs on a gradient pass)
     DgFinishArgs f;
@@ -429,8 +448,8 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null");
     DgCorrArgs a;
     int depth_index;
-    build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
-    DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, static_cast<hipStream_t>(stream_)));
+    const int njA = build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
+    DG_HIP(launch_main(p, a, njA, depth_index, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -375,6 +375,7 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
+hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);

@@ -1,0 +1,562 @@
+// Fused correlation-loss kernel, one-wave-per-SIMD form (gfx950 / MI355X): helper() of the reference
+// (src/modules.py:1231-1254) for the pair-sets whose stationary operand is operand 1, gradient pass of the
+// zero_clamp / no-stabalize recipe.
+//
+// One workgroup = 4 waves = one per SIMD, each with the whole 512-entry register file: a wave owns TWO 32-row tiles of the
+// stationary operand R (64 rows).  Their normalised bf16 feature fragments (2 x NKF x 4 registers) live in the ACCUMULATOR
+// half of the register file for the whole block and are named literally as the B operands of the feature MFMAs (inline
+// asm: hipcc has no way to be told "these 192 registers are MFMA operands and never move"; left to itself it parks them
+// there and copies every one back per use).  Four of the six gradient accumulators sit there too.  The arch VGPRs hold
+// the two fd / cd accumulator pairs, the other two gradient accumulators, the LDS fragment ring and the epilogue.
+//
+// Per streamed tile of 32 positions of S (DMA'd into one of three LDS buffers two tiles ahead, as in dg_corr.hip) a wave
+// issues 70 MFMAs in four phases, and every non-MFMA instruction of the tile is placed in one of their issue gaps:
+//     A  chain of fragment 0: 24 x bf16 (fd) + 5 x f16 (cd)        gaps: the 9 LDS-DMA pieces of tile t+2, fd init of fragment 1
+//     B  chain of fragment 1                                       gaps: epilogue of fragment 0 (mask, -G, fp16 pack, G store),
+//                                                                        the six B fragments of the gradient product
+//        -- counted vmcnt + the one workgroup barrier of the tile: tile t+1 visible, buffer of tile t free --
+//     C  dR_0 += G_0^T ScP (6 MFMAs, accumulator tile as A operand)  gaps: first fragments of tile t+1, epilogue of fragment 1
+//     D  dR_1 += G_1^T ScP (6 MFMAs)                                 gaps: rest of that epilogue, G store, fd init of fragment 0
+// An accumulator is read by the VALU no sooner than two MFMAs after the chain that wrote it (the asm MFMAs are invisible to
+// hipcc's hazard recogniser).  Outputs are those of k_corr_main: G tiles (fp16) for k_gs, raw gradient tiles, block sums.
+#include "dg_common.h"
+#include <utility>
+#include <cstdio>
+#include <cstdlib>
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+#ifndef C2_PF
+#define C2_PF 4            // LDS fragment reads in flight ahead of the MFMA that consumes them
+#endif
+
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// ---- inline-asm building blocks (register numbers are literal: the accumulator file is owned by this kernel)
+template <int I> __device__ __forceinline__ void agpr_load16(const void* p) {      // a[4I..4I+3] <- 16 bytes at p
+    asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off" :: "v"(p), "n"(4 * I), "n"(4 * I + 3) : "memory");
+}
+template <int I> __device__ __forceinline__ void mfma_fd(f32x16& acc, const v4i_t& a) {     // acc += A x Rf (bf16, B = a[4I..4I+3])
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "n"(4 * I), "n"(4 * I + 3));
+}
+__device__ __forceinline__ void mfma_h(f32x16& acc, const v4i_t& a, const v4i_t& b) {         // acc += A x B (f16)
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_h0(f32x16& acc, const v4i_t& a, const v4i_t& b) {        // acc = A x B (f16)
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+template <int X> __device__ __forceinline__ void mfma_h_acc(const v4i_t& a, const v4i_t& b) { // a[X..X+15] += A x B (f16); s_nop: A is fresh from the VALU
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "n"(X), "n"(X + 15));
+}
+template <int X> __device__ __forceinline__ float agpr_read(void) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "n"(X));
+    return v;
+}
+template <int X> __device__ __forceinline__ void agpr_zero4(void) {
+    asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
+                 :: "n"(X), "n"(X + 1), "n"(X + 2), "n"(X + 3));
+}
+template <int X> __device__ __forceinline__ void agpr_store16_nt(void* p) {                   // 16 bytes a[X..X+3] -> p (non-temporal)
+    asm volatile("global_store_dwordx4 %0, a[%c1:%c2], off nt" :: "v"(p), "n"(X), "n"(X + 3) : "memory");
+}
+__device__ __forceinline__ void wait_vm_lgkm_barrier(int n) {     // tile landed (this wave's pieces), own LDS reads done, workgroup barrier
+    switch (n) {
+#define DG_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        DG_W(0) DG_W(1) DG_W(2) DG_W(3) DG_W(4) DG_W(5) DG_W(6) DG_W(7) DG_W(8) DG_W(9) DG_W(10) DG_W(11) DG_W(12) DG_W(13)
+        DG_W(14) DG_W(15) DG_W(16) DG_W(17) DG_W(18) DG_W(19) DG_W(20)
+#undef DG_W
+        default: asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+}
+// Epilogue of four accumulator elements: -G = cd >= 0 ? fd'' - shift : 0, packed to fp16 (round to nearest even).  Four
+// compares into four scalar mask pairs first, then the selects: no select waits on the compare just ahead of it (hipcc's own
+// sequence is compare - s_nop 1 - select per element, 7 VALU per pair).  10 VALU per four elements.
+__device__ __forceinline__ void epi4(const float y0, const float y1, const float y2, const float y3, const float c0, const float c1,
+                                     const float c2, const float c3, int& o0, int& o1) {
+    unsigned long long m0, m1, m2, m3;
+    int t;
+    asm volatile("v_cmp_le_f32_e64 %3, 0, %11\n\t"
+                 "v_cmp_le_f32_e64 %4, 0, %12\n\t"
+                 "v_cmp_le_f32_e64 %5, 0, %13\n\t"
+                 "v_cmp_le_f32_e64 %6, 0, %14\n\t"
+                 "v_cndmask_b32_e64 %0, 0, %7, %3\n\t"
+                 "v_cndmask_b32_e64 %2, 0, %8, %4\n\t"
+                 "v_cndmask_b32_e64 %1, 0, %9, %5\n\t"
+                 "v_cvt_pk_f16_f32 %0, %0, %2\n\t"
+                 "v_cndmask_b32_e64 %2, 0, %10, %6\n\t"
+                 "v_cvt_pk_f16_f32 %1, %1, %2"
+                 : "=&v"(o0), "=&v"(o1), "=&v"(t), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                 : "v"(y0), "v"(y1), "v"(y2), "v"(y3), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
+
+// every accumulator register is named somewhere in this kernel: tell hipcc (kernel descriptor, no compiler use)
+#define DG_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__device__ __forceinline__ void declare_agprs(void) {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", DG_A8(1), DG_A8(2), DG_A8(3), DG_A8(4), DG_A8(5),
+                 DG_A8(6), DG_A8(7), DG_A8(8), DG_A8(9), DG_A8(10), DG_A8(11), DG_A8(12), DG_A8(13), DG_A8(14), DG_A8(15), DG_A8(16),
+                 DG_A8(17), DG_A8(18), DG_A8(19), DG_A8(20), DG_A8(21), DG_A8(22), DG_A8(23), DG_A8(24), "a250", "a251", "a252",
+                 "a253", "a254", "a255");
+}
+
+// ---- hand-placed loop instructions (nothing in the tile loop is left to hipcc's own wait insertion)
+typedef double acc_t __attribute__((ext_vector_type(8)));       // a 32x32 accumulator as eight 64-bit halves (v_mov_b64 initialisation)
+template <int OFF> __device__ __forceinline__ void lds_rd(v4i_t& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void wait_lgkm(void) { asm volatile("s_waitcnt lgkmcnt(%c0)" :: "n"(N) : "memory"); }
+template <int I> __device__ __forceinline__ void mfma_fd8(acc_t& acc, const v4i_t& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "n"(4 * I), "n"(4 * I + 3));
+}
+__device__ __forceinline__ void mfma_h8(acc_t& acc, const v4i_t& a, const v4i_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_h80(acc_t& acc, const v4i_t& a, const v4i_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+// one 1-KiB LDS-DMA piece: M0 = LDS destination (written in this statement), the vector add is the wait state between the M0
+// write and the DMA; source = scalar tile base + per-lane offset
+template <int KOFF> __device__ __forceinline__ void dma_piece(uint32_t lds_dst, uint32_t voff, const char* sbase) {
+    uint32_t tmp;
+    asm volatile("s_add_u32 m0, %1, %c3\n\tv_add_u32 %0, %c3, %2\n\tglobal_load_lds_dwordx4 %0, %4"
+                 : "=&v"(tmp) : "s"(lds_dst), "v"(voff), "n"(KOFF), "s"(sbase) : "memory", "scc");     // s_add_u32 writes SCC
+}
+// epilogue of four accumulator elements in two halves of five VALU (one per MFMA gap): four compares into scalar mask pairs
+// and the first select; then three selects and the two fp16 packs.  No select sits closer than two instructions to its compare.
+struct EpiMasks { unsigned long long m1, m2, m3; };
+__device__ __forceinline__ void epi4a(const float y0, const float c0, const float c1, const float c2, const float c3, int& o0, EpiMasks& m) {
+    unsigned long long m0;
+    asm volatile("v_cmp_le_f32_e64 %1, 0, %6\n\t"
+                 "v_cmp_le_f32_e64 %2, 0, %7\n\t"
+                 "v_cmp_le_f32_e64 %3, 0, %8\n\t"
+                 "v_cmp_le_f32_e64 %4, 0, %9\n\t"
+                 "v_cndmask_b32_e64 %0, 0, %5, %1"
+                 : "=&v"(o0), "=&s"(m0), "=&s"(m.m1), "=&s"(m.m2), "=&s"(m.m3) : "v"(y0), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+}
+__device__ __forceinline__ void epi4b(const float y1, const float y2, const float y3, int& o0, int& o1, const EpiMasks& m) {
+    int t;
+    asm volatile("v_cndmask_b32_e64 %2, 0, %3, %6\n\t"
+                 "v_cndmask_b32_e64 %1, 0, %4, %7\n\t"
+                 "v_cvt_pk_f16_f32 %0, %0, %2\n\t"
+                 "v_cndmask_b32_e64 %2, 0, %5, %8\n\t"
+                 "v_cvt_pk_f16_f32 %1, %1, %2"
+                 : "+v"(o0), "=&v"(o1), "=&v"(t) : "v"(y1), "v"(y2), "v"(y3), "s"(m.m1), "s"(m.m2), "s"(m.m3));
+}
+
+__device__ __forceinline__ float wave_sum2(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
+template <int NKF, int NKD, int NKC>
+__global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
+    using BL = BlobT<NKF, NKD>;
+    constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
+    constexpr int BUF = BL::BYTES, NS = NKF + NKC, PF = 8;
+    constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
+    constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
+    static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
+    static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
+    static_assert(4 + 3 * (PIECES - 1) < NS && NS >= 26 && NS > PF, "phase-A gaps for the DMA pieces / phase-B gaps for the epilogue");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][BUF] tiles, red[NW][2]
+    declare_agprs();
+
+    // ---- XCD-aware block order (as k_corr_main): every XCD owns B/8 whole images; full row blocks first, ragged last
+    int bid;
+    {
+        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+    }
+    int n, jid, rb;
+    {
+        const int nh = args.njobs, per_img = nh * args.nrb;
+        if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
+            const int imgs = args.B >> 3, per_chunk = imgs * per_img;
+            const int xcd = bid / per_chunk;
+            int i = bid - xcd * per_chunk;
+            const bool ragged = args.nrb > 1 && ((args.Ppad >> 5) % (NW * RF)) != 0;
+            const int nfull = args.nrb - (ragged ? 1 : 0);
+            const int cA = imgs * nh * nfull;
+            int nl;
+            if (i < cA) { nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull; }
+            else { i -= cA; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; }
+            n = xcd * imgs + nl;
+        } else {
+            n = bid / per_img; bid -= n * per_img; jid = bid / args.nrb; rb = bid - jid * args.nrb;
+        }
+    }
+    const DgJob& job = args.jobs[jid];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int Ppad = args.Ppad, ntiles = Ppad >> 5;
+    uint16_t* const Gout = job.Gout;
+    const int nS = job.sidx ? (int)job.sidx[n] : n;
+
+    // ---- the two 32-row tiles of R owned by this wave
+    const int rtile0 = (rb * NW + wid) * RF;
+    bool act[RF];
+    int pr[RF];
+    const char* Rblob[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        act[f] = rtile0 + f < ntiles;                                   // wave-uniform
+        pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;
+        Rblob[f] = job.Rop + ((size_t)n * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
+    }
+    const bool wave_active = act[0];
+
+    // ---- stationary operand: feature fragments -> accumulator registers, code fragments -> arch VGPRs
+    const uint32_t smem_a = lds_addr(smem);
+    const int sw = (r >> 2) & 3;
+    const int fb0 = r * 64 + ((h ^ sw) * 16), fb1 = r * 64 + (((2 + h) ^ sw) * 16);        // dg_f_off(r, 2 ks + h), ks even / odd
+    sfor<RF * NKF>([&](auto I) {
+        constexpr int f = I.value / NKF, ks = I.value % NKF;
+        agpr_load16<I.value>(Rblob[f] + ((ks & 1) ? fb1 : fb0) + (ks >> 1) * 2048);
+    });
+    v4i_t Rc[RF][NKC];                                    // B operands of the cd chain: granule 2k + h of row r
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int k = 0; k < NKC; ++k)
+            // (asm: a load hipcc knows about would make it wait for vmcnt at the first use INSIDE the tile loop - on every
+            //  iteration, draining the DMA pipeline; these complete before the first tile's counted wait: they are older)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rc[f][k]) : "v"(Rblob[f] + BL::OFF_C + ((2 * k + h) * 32 + r) * 16) : "memory");
+    sfor<RF * 2 * 4>([&](auto I) { agpr_zero4<ADR + 4 * I.value>(); });
+    acc_t dRv[RF];                                        // gradient accumulator of channel group 2 (groups 0, 1: accumulator file)
+#pragma unroll
+    for (int f = 0; f < RF; ++f) dRv[f] = acc_t{};
+
+    // ---- per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
+    float c0 = -job.shift;
+    if (job.rvec) {
+        float m = 0.f;
+        for (int i = lane; i < args.B; i += 64) m += job.rimg[i];
+        c0 += wave_sum2(m) * args.inv_BP;
+    }
+    double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        const float cl = job.rvec ? c0 - job.rvec[(size_t)n * Ppad + pr[f]] : c0;
+        const float2 two = make_float2(cl, cl);
+        c0pair[f] = __builtin_bit_cast(double, two);
+        asm volatile("" : "+v"(c0pair[f]));
+    }
+
+    // ---- tile staging: chunk c of a tile is fetched by wave c % 4 (piece k of wave w = chunk w + 4 k)
+    const char* const Sop_img = job.Sop + (size_t)nS * ntiles * BL::BYTES;    // wave-uniform
+    const uint32_t dma_voff = lane * 16 + wid * 1024;
+    auto issue_tile_piece = [&](auto K, int t, int b) {
+#ifdef C2_NODMA            // (timing ablation: tiles 0 and 1 only)
+        if (t >= 2) return;
+#endif
+        const int tt = t < ntiles ? t : 0;                // past the end: a dummy piece keeps the counted waits uniform
+        const char* sb = Sop_img + (size_t)tt * BL::BYTES;
+        const uint32_t dst = smem_a + b * BUF + wid * 1024;
+        dma_piece<K.value * 4096>(dst, dma_voff, sb);
+    };
+#ifdef C2_PRONOP
+    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 0, 0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); });
+    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); });
+#else
+    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 0, 0); });
+    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); });
+#endif
+
+    // per-lane LDS byte addresses of the fragments of the current tile
+    const int crow = (h * 32 + r) * 16;
+    uint32_t va0 = smem_a + fb0, va1 = smem_a + fb1, vc = smem_a + BL::OFF_C + crow, vp = smem_a + BL::OFF_P + (h * KD + r) * 16;
+    auto rd_step = [&](auto ST, v4i_t& d) {               // A fragment of chain step ST (feature k-steps, then code k-steps)
+        constexpr int st = ST.value;
+        if constexpr (st < NKF) { if constexpr (st & 1) lds_rd<(st >> 1) * 2048>(d, va1); else lds_rd<(st >> 1) * 2048>(d, va0); }
+        else lds_rd<(st - NKF) * 1024>(d, vc);
+    };
+
+    acc_t Yf[RF], Yc[RF];
+    v4i_t ga[RF][2];                                     // -G as fp16 A fragments: k-step sp holds accumulator elements 8sp..8sp+7
+    v4i_t ra[PF], bP[2 * NDF];
+    EpiMasks em;
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Yf[f][i] = c0pair[f];
+#ifdef C2_NOEPI
+    ga[0][0] = ga[0][1] = ga[1][0] = ga[1][1] = v4i_t{0, 0, 0, 0};
+#endif
+
+    // tile 0 landed (the fragment loads are older, so they are complete as well)
+    wait_vm_lgkm_barrier(PIECES);
+    sfor<PF>([&](auto I) { rd_step(I, ra[I.value]); });
+
+    auto epi_a = [&](const int f, const int j) {           // first half of quad j (elements 4j..4j+3) of fragment f
+#ifndef C2_NOEPI
+        const f32x16 yf = __builtin_bit_cast(f32x16, Yf[f]), yc = __builtin_bit_cast(f32x16, Yc[f]);
+        const int i = 4 * j;
+        int o0;
+        epi4a(yf[i], yc[i], yc[i + 1], yc[i + 2], yc[i + 3], o0, em);
+        ga[f][j >> 1][2 * (j & 1)] = o0;
+#endif
+    };
+    auto epi_b = [&](const int f, const int j) {
+#ifndef C2_NOEPI
+        const f32x16 yf = __builtin_bit_cast(f32x16, Yf[f]);
+        const int i = 4 * j;
+        int o0 = ga[f][j >> 1][2 * (j & 1)], o1;
+        epi4b(yf[i + 1], yf[i + 2], yf[i + 3], o0, o1, em);
+        ga[f][j >> 1][2 * (j & 1)] = o0;
+        ga[f][j >> 1][2 * (j & 1) + 1] = o1;
+#endif
+    };
+    auto g_store = [&](const int f, const int sp, int t) {
+#ifndef C2_NOGST
+        // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
+        //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
+        v4i_t* g = reinterpret_cast<v4i_t*>(Gout) + (((size_t)n * ntiles + t) * ntiles + rtile0 + f) * 128 + lane + 64 * sp;
+        asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
+#endif
+    };
+
+#ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + 3 * BUF + 64);
+    const bool stamping = args.stamps != nullptr && n == 0 && jid == 0 && rb == 0;
+    auto STAMP = [&](int t, int k) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+        if (stamping && lane == 0 && t < 25) st_lds[(wid * 25 + t) * 6 + k] = (uint32_t)tm;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#else
+    auto STAMP = [&](int, int) {};
+#endif
+    // The tile loop in three forms: both fragments active, fragment 0 only (ragged last row block), fetch-only wave.
+    // LDS reads of a tile are numbered idx = 0 .. TOT-1 (chain of fragment 0, then of fragment 1: the same NS addresses again);
+    // read idx lands in ring register idx % PF and is issued right behind MFMA idx - PF (the first PF: behind the previous
+    // tile's barrier).  Every second MFMA waits for its own and the next fragment with a counted lgkmcnt.
+    auto run = [&](auto A0, auto A1) {
+        constexpr bool ACT0 = A0.value, ACT1 = A1.value;
+        constexpr int TOT = ACT1 ? 2 * NS : NS;
+        constexpr int BP0 = ACT1 ? 2 * NS - 9 : TOT;            // first MFMA index whose gap carries a gradient-B read (phase B gaps NS-9 ..)
+        int bcur = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const int bnext = bcur == 2 ? 0 : bcur + 1, bprev = bcur == 0 ? 2 : bcur - 1;
+            auto chain_slot = [&](auto IDX, auto F) {          // wait (every second step), MFMA idx, refill of its ring register
+                constexpr int idx = IDX.value, f = F.value, st = idx - f * NS;
+                if constexpr ((idx & 1) == 0) {
+                    constexpr int need = idx + 1 < TOT ? idx + 1 : TOT - 1;
+                    constexpr int issued = (idx + PF < TOT ? idx + PF : TOT) + (idx > BP0 ? (idx - BP0 < 2 * NDF ? idx - BP0 : 2 * NDF) : 0);
+                    wait_lgkm<issued - (need + 1)>();
+                }
+                if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
+                else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
+                else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
+                if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
+            };
+            STAMP(t, 0);
+            // ================= phase A: Y chain of fragment 0 =================
+            sfor<NS>([&](auto ST) {
+                constexpr int st = ST.value;
+                if constexpr (ACT0) chain_slot(ST, std::integral_constant<int, 0>{});
+                if constexpr (st >= 4 && (st - 4) % 3 == 0 && (st - 4) / 3 < PIECES)
+                    issue_tile_piece(std::integral_constant<int, (st - 4) / 3>{}, t + 2, bprev);
+                if constexpr (ACT1 && st < 4) {                              // fd accumulator of fragment 1 starts at c0_lane
+                    Yf[1][2 * st] = c0pair[1]; Yf[1][2 * st + 1] = c0pair[1];
+                    if constexpr (st == 3) asm volatile("" : "+v"(Yf[1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            STAMP(t, 1);
+            // ================= phase B: Y chain of fragment 1, epilogue of fragment 0 in its gaps =================
+            sfor<NS>([&](auto ST) {
+                constexpr int st = ST.value;
+                if constexpr (ACT1) chain_slot(std::integral_constant<int, NS + st>{}, std::integral_constant<int, 1>{});
+                if constexpr (ACT0) {
+                    if constexpr (st >= 2 && st < 10) { if constexpr ((st & 1) == 0) epi_a(0, (st - 2) / 2); else epi_b(0, (st - 2) / 2); }
+                    if constexpr (st == 11) { g_store(0, 0, t); g_store(0, 1, t); }
+                    if constexpr (st >= NS - 9 && st < NS - 9 + 2 * NDF) {      // B fragments of the gradient products (shared by both fragments)
+                        constexpr int q = st - (NS - 9), sp = q / NDF, d = q % NDF;
+                        lds_rd<d * 512 + sp * (2 * KD * 16)>(bP[q], vp);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            STAMP(t, 2);
+            // ---- tile t+1 landed, every wave is done reading tile t: one barrier per tile.  Younger than the last piece of
+            //      tile t+1: G stores of fragment 0 (t-1), fragment 1 (t-1), the pieces of tile t+2, G stores of fragment 0 (t)
+#ifdef C2_NOGST
+            constexpr int S0 = 0, S1 = 0;
+#else
+            constexpr int S0 = ACT0 ? 2 : 0, S1 = ACT1 ? 2 : 0;
+#endif
+#ifdef C2_NODMA
+            constexpr int PL = 0;
+#else
+            constexpr int PL = PIECES;
+#endif
+#ifdef C2_T0WAIT0
+            if (t == 0) wait_vm_lgkm_barrier(0); else wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
+#else
+            if (t == 0) wait_vm_lgkm_barrier(PL + S0); else wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(t, 3);
+            // fragment addresses of tile t+1
+            va0 = smem_a + bnext * BUF + fb0; va1 = smem_a + bnext * BUF + fb1;
+            vc = smem_a + bnext * BUF + BL::OFF_C + crow; vp = smem_a + bnext * BUF + BL::OFF_P + (h * KD + r) * 16;
+            // ================= phase C: dR_0 += G_0^T ScP =================
+            sfor<2 * NDF>([&](auto Q) {
+                constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
+                if constexpr (ACT0) {
+#ifndef C2_NODR
+                    if constexpr (d < 2) mfma_h_acc<ADR + d * 16>(ga[0][sp], bP[q]); else mfma_h8(dRv[0], ga[0][sp], bP[q]);
+#endif
+                    // first PF fragments of tile t+1 (valid after the barrier): two behind the first MFMA, then one per gap
+                    // (issued in index order: the counted waits rely on it)
+                    constexpr int X = ACT1 ? 0 : 1;                          // fragment 0 only: all eight here (there is no phase D)
+                    if constexpr (q == 0) {
+                        rd_step(std::integral_constant<int, 0>{}, ra[0]); rd_step(std::integral_constant<int, 1>{}, ra[1]);
+                        if constexpr (!ACT1) rd_step(std::integral_constant<int, 2>{}, ra[2]);
+                    } else {
+                        rd_step(std::integral_constant<int, q + 1 + X>{}, ra[q + 1 + X]);
+                    }
+                    if constexpr (ACT1) {                                    // epilogue of fragment 1: quads 0, 1 and the first half of 2
+                        if constexpr (q >= 1) { if constexpr (q & 1) epi_a(1, (q - 1) / 2); else epi_b(1, (q - 1) / 2); }
+                    } else if constexpr (q >= 1 && q < 5) {                  // (fragment 0 only: its fd accumulator for the next tile)
+                        Yf[0][2 * (q - 1)] = c0pair[0]; Yf[0][2 * (q - 1) + 1] = c0pair[0];
+                        if constexpr (q == 4) asm volatile("" : "+v"(Yf[0]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            STAMP(t, 4);
+            // ================= phase D: dR_1 += G_1^T ScP =================
+            if constexpr (ACT1) {
+                sfor<2 * NDF>([&](auto Q) {
+                    constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
+                    if constexpr (q == 0) epi_b(1, 2);                       // (k-step 0 of the product needs quads 0, 1 only)
+#ifndef C2_NODR
+                    if constexpr (d < 2) mfma_h_acc<ADR + 32 + d * 16>(ga[1][sp], bP[q]); else mfma_h8(dRv[1], ga[1][sp], bP[q]);
+#endif
+                    if constexpr (q == 0) rd_step(std::integral_constant<int, 7>{}, ra[7]);
+                    if constexpr (q == 1) { g_store(1, 0, t); epi_a(1, 3); }
+                    if constexpr (q == 2) epi_b(1, 3);                       // quad 3 done before k-step 1 (q >= NDF)
+                    if constexpr (q == 4) g_store(1, 1, t);
+                    if constexpr (q >= 3) {                                  // fd accumulator of fragment 0 for the next tile
+                        constexpr int i0 = q == 3 ? 0 : (q == 4 ? 3 : 6), i1 = q == 3 ? 3 : (q == 4 ? 6 : 8);
+#pragma unroll
+                        for (int i = i0; i < i1; ++i) Yf[0][i] = c0pair[0];
+                        if constexpr (q == 5) asm volatile("" : "+v"(Yf[0]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            STAMP(t, 5);
+            bcur = bnext;
+        }
+    };
+    if (act[1]) run(std::true_type{}, std::true_type{});
+    else if (act[0]) run(std::true_type{}, std::false_type{});
+    else run(std::false_type{}, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
+#ifdef C2_STAMPS
+    if (stamping) {
+        __syncthreads();
+        for (int i = tid; i < NW * 25 * 6; i += 256) args.stamps[i] = st_lds[i];
+    }
+#endif
+
+    // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last gradient MFMAs have retired before their registers are read
+    float lsum = 0.f, csum = 0.f;
+    float* red = reinterpret_cast<float*>(smem + 3 * BUF);
+    sfor<RF>([&](auto FI) {
+        constexpr int f = FI.value;
+        if (!act[f]) return;
+        float* base = job.dR ? job.dR + ((size_t)n * ntiles + rtile0 + f) * (32 * DP) + lane * 4 : nullptr;
+        // x in the layout of dR (rows in registers, channel on the lane) = X * I (selector fragments), as in k_corr_main
+        v4i_t sel[2];
+#pragma unroll
+        for (int sI = 0; sI < 2; ++sI) {
+            f16x8 s8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] = (8 * h + j + 16 * sI == r) ? (_Float16)1.f : (_Float16)0.f;
+            sel[sI] = __builtin_bit_cast(v4i_t, s8);
+        }
+        sfor<NDF>([&](auto DI) {
+            constexpr int d = DI.value;
+            float v[16];
+            if constexpr (d < 2) {
+                sfor<16>([&](auto I) { v[I.value] = agpr_read<ADR + f * 32 + d * 16 + I.value>(); });
+            } else {
+                const f32x16 dv = __builtin_bit_cast(f32x16, dRv[f]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = dv[i];
+            }
+            if (base && 32 * d + r < args.D) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
+                }
+            }
+            // sum clamp(cd)(fd'' - shift) = sum_p <x_p, dR'_p>, sum cd = sum_p <x_p, sum_q y_q>   (dg_corr.hip "FOLD")
+            const float cs = job.Scsum ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
+            acc_t X8;
+            mfma_h80(X8, Rc[f][2 * d], sel[0]);
+            if constexpr (2 * d + 1 < NKC) mfma_h8(X8, Rc[f][2 * d + 1], sel[1]);
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(X8));
+            const f32x16 X = __builtin_bit_cast(f32x16, X8);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { lsum = fmaf(X[i], v[i], lsum); csum = fmaf(X[i], cs, csum); }
+        });
+    });
+    lsum = wave_sum2(lsum);
+    csum = wave_sum2(csum);
+    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
+    __syncthreads();
+    if (tid == 0 && job.part) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < NW; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
+        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
+    }
+}
+
+// Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
+// shapes this form does not cover (the caller then uses k_corr_main).
+hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream) {
+#ifdef C2_DISABLE          // (developer A/B: everything through k_corr_main)
+    return hipErrorNotSupported;
+#endif
+    if (!(KF == 384 && KD == 96 && args.D <= 80)) return hipErrorNotSupported;
+    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160) return hipErrorNotSupported;
+    for (int j = 0; j < args.njobs; ++j)
+        if (args.jobs[j].kind != DG_JOB_HELPER || !args.jobs[j].center_on_lane || !args.jobs[j].Gout || args.jobs[j].ridx) return hipErrorNotSupported;
+    using BL = BlobT<24, 6>;
+    const int smem = 3 * BL::BYTES + 64;
+    auto kern = k_corr2<24, 6, 5>;
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+    if (e != hipSuccess) return e;
+#if defined(DG_DEVTOOLS) && defined(C2_STAMPS)
+    if (const char* stamp_file = getenv("DG_STAMPS")) {
+        static uint32_t* stamp_buf = nullptr;
+        if (!stamp_buf && hipMalloc(&stamp_buf, 4 * 25 * 6 * 4) != hipSuccess) return hipErrorOutOfMemory;
+        DgCorrArgs a2 = args;
+        a2.stamps = stamp_buf;
+        (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem + 4 * 25 * 6 * 4);
+        hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem + 4 * 25 * 6 * 4, stream, a2);
+        uint32_t host[4 * 25 * 6];
+        if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6, fp); fclose(fp); }
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem, stream, args);
+    return hipGetLastError();
+}

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""developer aid: run dg_corr_forward with two library builds on the same inputs and report where the workspaces differ.
+   python scripts/cmp_ws.py tagA tagB [B]"""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from depthg_amd import _lib, ops
+
+tags = sys.argv[1:3]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = {}
+for tag in tags:
+    _lib._lib = None
+    _lib.LIB_PATH = os.path.join(ROOT, "depthg_amd", "lib", f"libdepthg_{tag}.so")
+    libs[tag] = _lib.load()
+dev = torch.device("cuda:0")
+C, D, hw, N, S = 384, 70, 28, 2, 28
+g = torch.Generator().manual_seed(128)
+f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float().to(dev)
+c1 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
+c2 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
+perms = torch.stack([torch.randperm(B, generator=g) for _ in range(N)]).to(dev)
+desc = ops.make_desc(B, C, D, hw, hw, S, N, pointwise=True, zero_clamp=True, stabalize=False, depth_term=True,
+                     need_grad=True, shared_coords=False, shifts=(0.08, 0.02, 0.66, 0.03), depth_hw=(4 * hw, 4 * hw),
+                     identity_grid=False, weights=(0.67, 0.25, 0.63, 0.19))
+P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+res = {}
+for tag, lib in libs.items():
+    nb = lib.dg_corr_workspace_bytes(ctypes.byref(desc))
+    ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    out = torch.zeros(_lib.DG_OUT_COUNT, dtype=torch.float32, device=dev)
+    rc = lib.dg_corr_forward(ctypes.byref(desc), P(f), P(fp), P(c), P(cp), P(d), P(c1), P(c2), P(perms), P(out), P(ws), nb, stream)
+    assert rc == 0, lib.dg_last_error()
+    torch.cuda.synchronize()
+    res[tag] = (ws, out.cpu())
+    print(tag, out.cpu().tolist())
+a, b = res[tags[0]][0], res[tags[1]][0]
+diff = (a != b).nonzero().flatten()
+print("workspace bytes", a.numel(), "differing bytes", diff.numel())
+if diff.numel():
+    d64 = diff.cpu().numpy()
+    # contiguous-ish regions (gap > 1 MiB starts a new region)
+    import numpy as np
+    cuts = np.nonzero(np.diff(d64) > (1 << 20))[0]
+    starts = np.concatenate([[0], cuts + 1]); ends = np.concatenate([cuts, [len(d64) - 1]])
+    for s, e in zip(starts, ends):
+        lo, hi = int(d64[s]), int(d64[e])
+        n = e - s + 1
+        va = a[lo:lo + 64].cpu().view(torch.float16).float().tolist()[:8]
+        vb = b[lo:lo + 64].cpu().view(torch.float16).float().tolist()[:8]
+        print(f"region [{lo}, {hi}] ({(hi-lo+1)/1e6:.2f} MB span, {n} differing bytes)  f16 A {va}  B {vb}")
+# per S-tile comparison of the G tiles (the last T allocations of the workspace: [t][image][S tile][R tile][2048 B])
+nt = (S * S + 31) // 32
+T = 2 + N
+gsz = B * nt * nt * 2048
+total = a.numel()
+for tj in range(T):
+    ga_ = a[total - (T - tj) * gsz: total - (T - tj - 1) * gsz].view(torch.float16).float().view(B, nt, nt, 1024)
+    gb_ = b[total - (T - tj) * gsz: total - (T - tj - 1) * gsz].view(torch.float16).float().view(B, nt, nt, 1024)
+    dmax = (ga_ - gb_).abs().amax(dim=(0, 3))          # [S tile][R tile]
+    print("job", tj, "max |dG| per S tile:", [round(float(x), 3) for x in dmax.amax(dim=1)])
+    print("        per R tile:", [round(float(x), 3) for x in dmax.amax(dim=0)])
+    if tj == 0:
+        # inside the last S tile: which accumulator rows differ?  tile = [2 k-steps][64 lanes][8]
+        t_a = ga_[0, 1, 0].view(2, 64, 8); t_b = gb_[0, 1, 0].view(2, 64, 8)
+        rows = {}
+        for sp in range(2):
+            for h in range(2):
+                for e in range(8):
+                    row = 16 * sp + (e & 3) + 8 * (e >> 2) + 4 * h
+                    rows[row] = float((t_a[sp, 32 * h:32 * h + 32, e] - t_b[sp, 32 * h:32 * h + 32, e]).abs().max())
+        print("        S tile 1, R tile 0, max |dG| per tile row:", [round(rows[r], 3) for r in range(32)])
+        print("        lane 0 A:", [round(float(x), 3) for x in t_a[:, 0, :].flatten()])
+        print("        lane 0 B:", [round(float(x), 3) for x in t_b[:, 0, :].flatten()])
+        print("        lane 5 A:", [round(float(x), 3) for x in t_a[:, 5, :].flatten()])
+        print("        lane 5 B:", [round(float(x), 3) for x in t_b[:, 5, :].flatten()])
+        # is B's tile 1 equal to A's tile of another index?
+        for tt in range(nt):
+            dd = float((ga_[0, tt, 0] - gb_[0, 1, 0]).abs().max())
+            if dd < 0.05: print("        B tile 1 matches A tile", tt, dd)
