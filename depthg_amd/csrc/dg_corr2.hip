@@ -47,8 +47,8 @@ __device__ __forceinline__ void mfma_h(f32x16& acc, const v4i_t& a, const v4i_t&
 __device__ __forceinline__ void mfma_h0(f32x16& acc, const v4i_t& a, const v4i_t& b) {        // acc = A x B (f16)
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
 }
-template <int X> __device__ __forceinline__ void mfma_h_acc(const v4i_t& a, const v4i_t& b) { // a[X..X+15] += A x B (f16); s_nop: A is fresh from the VALU
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "n"(X), "n"(X + 15));
+template <int X> __device__ __forceinline__ void mfma_h_acc(const v4i_t& a, const v4i_t& b) { // a[X..X+15] += A x B (f16); A must not be fresh from the VALU (2 wait states)
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "n"(X), "n"(X + 15));
 }
 template <int X> __device__ __forceinline__ float agpr_read(void) {
     float v;
@@ -123,6 +123,13 @@ template <int KOFF> __device__ __forceinline__ void dma_piece(uint32_t lds_dst, 
     asm volatile("s_add_u32 m0, %1, %c3\n\tv_add_u32 %0, %c3, %2\n\tglobal_load_lds_dwordx4 %0, %4"
                  : "=&v"(tmp) : "s"(lds_dst), "v"(voff), "n"(KOFF), "s"(sbase) : "memory", "scc");     // s_add_u32 writes SCC
 }
+// the same piece in two halves for two neighbouring MFMA gaps (M0 stays as set: nothing between the two touches it)
+template <int KOFF> __device__ __forceinline__ void dma_setup(uint32_t lds_dst, uint32_t voff, uint32_t& tmp) {
+    asm volatile("s_add_u32 m0, %1, %c3\n\tv_add_u32 %0, %c3, %2" : "=v"(tmp) : "s"(lds_dst), "v"(voff), "n"(KOFF) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_go(uint32_t tmp, const char* sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(tmp), "s"(sbase) : "memory");
+}
 // epilogue of four accumulator elements in two halves of five VALU (one per MFMA gap): four compares into scalar mask pairs
 // and the first select; then three selects and the two fp16 packs.  No select sits closer than two instructions to its compare.
 struct EpiMasks { unsigned long long m1, m2, m3; };
@@ -161,9 +168,13 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
     static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
     static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
-    static_assert(4 + 3 * (PIECES - 1) < NS && NS >= 26 && NS > PF, "phase-A gaps for the DMA pieces / phase-B gaps for the epilogue");
+    static_assert(10 + 2 * PIECES <= NS && NS >= 26 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][BUF] tiles, red[NW][2]
     declare_agprs();
+#ifdef C2_STAMPS
+    unsigned long long t_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+#endif
 
     // ---- XCD-aware block order (as k_corr_main): every XCD owns B/8 whole images; full row blocks first, ragged last
     int bid;
@@ -233,22 +244,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #pragma unroll
     for (int f = 0; f < RF; ++f) dRv[f] = acc_t{};
 
-    // ---- per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
-    float c0 = -job.shift;
-    if (job.rvec) {
-        float m = 0.f;
-        for (int i = lane; i < args.B; i += 64) m += job.rimg[i];
-        c0 += wave_sum2(m) * args.inv_BP;
-    }
-    double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
-#pragma unroll
-    for (int f = 0; f < RF; ++f) {
-        const float cl = job.rvec ? c0 - job.rvec[(size_t)n * Ppad + pr[f]] : c0;
-        const float2 two = make_float2(cl, cl);
-        c0pair[f] = __builtin_bit_cast(double, two);
-        asm volatile("" : "+v"(c0pair[f]));
-    }
-
     // ---- tile staging: chunk c of a tile is fetched by wave c % 4 (piece k of wave w = chunk w + 4 k)
     const char* const Sop_img = job.Sop + (size_t)nS * ntiles * BL::BYTES;    // wave-uniform
     const uint32_t dma_voff = lane * 16 + wid * 1024;
@@ -269,6 +264,22 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); });
 #endif
 
+    // ---- per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
+    float c0 = -job.shift;
+    if (job.rvec) {
+        float m = 0.f;
+        for (int i = lane; i < args.B; i += 64) m += job.rimg[i];
+        c0 += wave_sum2(m) * args.inv_BP;
+    }
+    double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        const float cl = job.rvec ? c0 - job.rvec[(size_t)n * Ppad + pr[f]] : c0;
+        const float2 two = make_float2(cl, cl);
+        c0pair[f] = __builtin_bit_cast(double, two);
+        asm volatile("" : "+v"(c0pair[f]));
+    }
+
     // per-lane LDS byte addresses of the fragments of the current tile
     const int crow = (h * 32 + r) * 16;
     uint32_t va0 = smem_a + fb0, va1 = smem_a + fb1, vc = smem_a + BL::OFF_C + crow, vp = smem_a + BL::OFF_P + (h * KD + r) * 16;
@@ -278,6 +289,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         else lds_rd<(st - NKF) * 1024>(d, vc);
     };
 
+    float cs_pre[NDF];                                   // code column sums of the streamed operand (block-end sums): loaded early
+#pragma unroll
+    for (int d = 0; d < NDF; ++d) cs_pre[d] = job.Scsum ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
     acc_t Yf[RF], Yc[RF];
     v4i_t ga[RF][2];                                     // -G as fp16 A fragments: k-step sp holds accumulator elements 8sp..8sp+7
     v4i_t ra[PF], bP[2 * NDF];
@@ -326,24 +340,52 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + 3 * BUF + 64);
     const bool stamping = args.stamps != nullptr && n == 0 && jid == 0 && rb == 0;
     auto STAMP = [&](int t, int k) {
+#ifndef C2_BLOCKSTAMPS_ONLY
         __builtin_amdgcn_sched_barrier(0);
         unsigned long long tm;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
         if (stamping && lane == 0 && t < 25) st_lds[(wid * 25 + t) * 6 + k] = (uint32_t)tm;
         __builtin_amdgcn_sched_barrier(0);
+#endif
     };
+    auto BSTAMP = [&](int k) {       // block-level: 0 kernel entry (taken at the top), 1 first tile landed, 2 loop done, 3 block done
+        unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+        if (stamping && lane == 0) st_lds[NW * 25 * 6 + wid * 4 + k] = (uint32_t)tm;
+    };
+    if (stamping && lane == 0) st_lds[NW * 25 * 6 + wid * 4] = (uint32_t)t_entry;
+    BSTAMP(1);
 #else
     auto STAMP = [&](int, int) {};
+    auto BSTAMP = [&](int) {};
 #endif
     // The tile loop in three forms: both fragments active, fragment 0 only (ragged last row block), fetch-only wave.
     // LDS reads of a tile are numbered idx = 0 .. TOT-1 (chain of fragment 0, then of fragment 1: the same NS addresses again);
     // read idx lands in ring register idx % PF and is issued right behind MFMA idx - PF (the first PF: behind the previous
     // tile's barrier).  Every second MFMA waits for its own and the next fragment with a counted lgkmcnt.
+    // Schedule of tile t (both fragments): fragment 1 runs one phase behind, so that BOTH epilogues sit in the gaps of a long chain
+    //     A   chain of fragment 0 (t)            gaps: epilogue of fragment 1 (t-1), its G store, the DMA pieces of tile t+2
+    //     A'  dR_1 += G_1^T ScP (t-1), 6 MFMAs   gaps: fd initialisation of fragment 1
+    //     B   chain of fragment 1 (t)            gaps: epilogue of fragment 0 (t), its G stores, the gradient B fragments of tile t
+    //         -- counted vmcnt + the one workgroup barrier of the tile --
+    //     C   dR_0 += G_0^T ScP (t), 6 MFMAs     gaps: first fragments of tile t+1, fd initialisation of fragment 0
+    // (tile 0: the "previous" fragment-1 state is all-zero G and zero B fragments; only its G store is skipped)
     auto run = [&](auto A0, auto A1) {
         constexpr bool ACT0 = A0.value, ACT1 = A1.value;
         constexpr int TOT = ACT1 ? 2 * NS : NS;
         constexpr int BP0 = ACT1 ? 2 * NS - 9 : TOT;            // first MFMA index whose gap carries a gradient-B read (phase B gaps NS-9 ..)
+        auto epi1_half = [&](auto HH) {                         // half HH (0..7) of the epilogue of fragment 1
+            constexpr int hh = HH.value;
+            if constexpr ((hh & 1) == 0) epi_a(1, hh / 2); else epi_b(1, hh / 2);
+        };
+        auto dr1 = [&](auto Q) {
+            constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
+#ifndef C2_NODR
+            if constexpr (d < 2) mfma_h_acc<ADR + 32 + d * 16>(ga[1][sp], bP[q]); else mfma_h8(dRv[1], ga[1][sp], bP[q]);
+#endif
+        };
         int bcur = 0;
+        uint32_t dtmp = 0;
         for (int t = 0; t < ntiles; ++t) {
             const int bnext = bcur == 2 ? 0 : bcur + 1, bprev = bcur == 0 ? 2 : bcur - 1;
             auto chain_slot = [&](auto IDX, auto F) {          // wait (every second step), MFMA idx, refill of its ring register
@@ -358,27 +400,50 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
                 if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
             };
+            // DMA source / destination of tile t+2 (scalar)
+            const int t2 = t + 2 < ntiles ? t + 2 : 0;            // past the end: dummy pieces keep the counted waits uniform
+            const char* const sb2 = Sop_img + (size_t)t2 * BL::BYTES;
+            const uint32_t dst2 = smem_a + bprev * BUF + wid * 1024;
             STAMP(t, 0);
             // ================= phase A: Y chain of fragment 0 =================
             sfor<NS>([&](auto ST) {
                 constexpr int st = ST.value;
                 if constexpr (ACT0) chain_slot(ST, std::integral_constant<int, 0>{});
-                if constexpr (st >= 4 && (st - 4) % 3 == 0 && (st - 4) / 3 < PIECES)
-                    issue_tile_piece(std::integral_constant<int, (st - 4) / 3>{}, t + 2, bprev);
-                if constexpr (ACT1 && st < 4) {                              // fd accumulator of fragment 1 starts at c0_lane
-                    Yf[1][2 * st] = c0pair[1]; Yf[1][2 * st + 1] = c0pair[1];
-                    if constexpr (st == 3) asm volatile("" : "+v"(Yf[1]));
+                if constexpr (ACT1 && st >= 2 && st < 10) epi1_half(std::integral_constant<int, st - 2>{});
+#ifndef C2_NODMA
+                if constexpr (st >= 10 && st < 10 + 2 * PIECES) {           // piece k: M0 + offset in gap 10 + 2k, the load in gap 11 + 2k
+                    constexpr int k = (st - 10) / 2;
+                    if constexpr (((st - 10) & 1) == 0) dma_setup<k * 4096>(dst2, dma_voff, dtmp); else dma_go(dtmp, sb2);
                 }
+#endif
+                if constexpr (ACT1 && st == NS - 1) { if (t > 0) g_store(1, 0, t - 1); }
                 __builtin_amdgcn_sched_barrier(0);
             });
             STAMP(t, 1);
+            // ================= phase A': dR_1 += G_1^T ScP of tile t-1 =================
+            if constexpr (ACT1) {
+                sfor<2 * NDF>([&](auto Q) {
+                    constexpr int q = Q.value;
+                    dr1(Q);
+                    if constexpr (q == 0) { if (t > 0) g_store(1, 1, t - 1); }
+                    if constexpr (q >= 1 && q < 5) {                         // fd accumulator of fragment 1 starts at c0_lane
+                        Yf[1][2 * (q - 1)] = c0pair[1]; Yf[1][2 * (q - 1) + 1] = c0pair[1];
+                        if constexpr (q == 4) asm volatile("" : "+v"(Yf[1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
             // ================= phase B: Y chain of fragment 1, epilogue of fragment 0 in its gaps =================
             sfor<NS>([&](auto ST) {
                 constexpr int st = ST.value;
                 if constexpr (ACT1) chain_slot(std::integral_constant<int, NS + st>{}, std::integral_constant<int, 1>{});
+                // (fragment 0 only: no MFMAs of a second chain stand between the chain that wrote the accumulators and the
+                //  epilogue that reads them - wait the chain's last MFMAs out explicitly)
+                if constexpr (ACT0 && !ACT1 && st == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
                 if constexpr (ACT0) {
                     if constexpr (st >= 2 && st < 10) { if constexpr ((st & 1) == 0) epi_a(0, (st - 2) / 2); else epi_b(0, (st - 2) / 2); }
-                    if constexpr (st == 11) { g_store(0, 0, t); g_store(0, 1, t); }
+                    if constexpr (st == 11) g_store(0, 0, t);
+                    if constexpr (st == 13) g_store(0, 1, t);
                     if constexpr (st >= NS - 9 && st < NS - 9 + 2 * NDF) {      // B fragments of the gradient products (shared by both fragments)
                         constexpr int q = st - (NS - 9), sp = q / NDF, d = q % NDF;
                         lds_rd<d * 512 + sp * (2 * KD * 16)>(bP[q], vp);
@@ -387,23 +452,24 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 __builtin_amdgcn_sched_barrier(0);
             });
             STAMP(t, 2);
-            // ---- tile t+1 landed, every wave is done reading tile t: one barrier per tile.  Younger than the last piece of
-            //      tile t+1: G stores of fragment 0 (t-1), fragment 1 (t-1), the pieces of tile t+2, G stores of fragment 0 (t)
+            // ---- tile t+1 landed, every wave is done reading tile t: one barrier per tile.  Younger than the last piece of tile
+            //      t+1 (issued in phase A of t-1): the G stores of fragment 1 (t-2), fragment 0 (t-1), the pieces of tile t+2, the
+            //      G stores of fragment 1 (t-1) and fragment 0 (t)
+            {
 #ifdef C2_NOGST
-            constexpr int S0 = 0, S1 = 0;
+                constexpr int S0 = 0, S1 = 0;
 #else
-            constexpr int S0 = ACT0 ? 2 : 0, S1 = ACT1 ? 2 : 0;
+                constexpr int S0 = ACT0 ? 2 : 0, S1 = ACT1 ? 2 : 0;
 #endif
 #ifdef C2_NODMA
-            constexpr int PL = 0;
+                constexpr int PL = 0;
 #else
-            constexpr int PL = PIECES;
+                constexpr int PL = PIECES;
 #endif
-#ifdef C2_T0WAIT0
-            if (t == 0) wait_vm_lgkm_barrier(0); else wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
-#else
-            if (t == 0) wait_vm_lgkm_barrier(PL + S0); else wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
-#endif
+                if (t == 0) wait_vm_lgkm_barrier(PL + S0);
+                else if (t == 1) wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
+                else wait_vm_lgkm_barrier(PL + 2 * S0 + 2 * S1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(t, 3);
             // fragment addresses of tile t+1
@@ -416,60 +482,40 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #ifndef C2_NODR
                     if constexpr (d < 2) mfma_h_acc<ADR + d * 16>(ga[0][sp], bP[q]); else mfma_h8(dRv[0], ga[0][sp], bP[q]);
 #endif
-                    // first PF fragments of tile t+1 (valid after the barrier): two behind the first MFMA, then one per gap
-                    // (issued in index order: the counted waits rely on it)
-                    constexpr int X = ACT1 ? 0 : 1;                          // fragment 0 only: all eight here (there is no phase D)
-                    if constexpr (q == 0) {
-                        rd_step(std::integral_constant<int, 0>{}, ra[0]); rd_step(std::integral_constant<int, 1>{}, ra[1]);
-                        if constexpr (!ACT1) rd_step(std::integral_constant<int, 2>{}, ra[2]);
-                    } else {
-                        rd_step(std::integral_constant<int, q + 1 + X>{}, ra[q + 1 + X]);
-                    }
-                    if constexpr (ACT1) {                                    // epilogue of fragment 1: quads 0, 1 and the first half of 2
-                        if constexpr (q >= 1) { if constexpr (q & 1) epi_a(1, (q - 1) / 2); else epi_b(1, (q - 1) / 2); }
-                    } else if constexpr (q >= 1 && q < 5) {                  // (fragment 0 only: its fd accumulator for the next tile)
-                        Yf[0][2 * (q - 1)] = c0pair[0]; Yf[0][2 * (q - 1) + 1] = c0pair[0];
-                        if constexpr (q == 4) asm volatile("" : "+v"(Yf[0]));
+                    // first PF fragments of tile t+1 (valid after the barrier), issued in index order (the counted waits rely on it)
+                    if constexpr (q < 2) { rd_step(std::integral_constant<int, 2 * q>{}, ra[2 * q]); rd_step(std::integral_constant<int, 2 * q + 1>{}, ra[2 * q + 1]); }
+                    else rd_step(std::integral_constant<int, q + 2>{}, ra[q + 2]);
+                    if constexpr (q >= 2) {                                  // fd accumulator of fragment 0 for the next tile
+                        Yf[0][2 * (q - 2)] = c0pair[0]; Yf[0][2 * (q - 2) + 1] = c0pair[0];
+                        if constexpr (q == 5) asm volatile("" : "+v"(Yf[0]));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
             STAMP(t, 4);
-            // ================= phase D: dR_1 += G_1^T ScP =================
-            if constexpr (ACT1) {
-                sfor<2 * NDF>([&](auto Q) {
-                    constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
-                    if constexpr (q == 0) epi_b(1, 2);                       // (k-step 0 of the product needs quads 0, 1 only)
-#ifndef C2_NODR
-                    if constexpr (d < 2) mfma_h_acc<ADR + 32 + d * 16>(ga[1][sp], bP[q]); else mfma_h8(dRv[1], ga[1][sp], bP[q]);
-#endif
-                    if constexpr (q == 0) rd_step(std::integral_constant<int, 7>{}, ra[7]);
-                    if constexpr (q == 1) { g_store(1, 0, t); epi_a(1, 3); }
-                    if constexpr (q == 2) epi_b(1, 3);                       // quad 3 done before k-step 1 (q >= NDF)
-                    if constexpr (q == 4) g_store(1, 1, t);
-                    if constexpr (q >= 3) {                                  // fd accumulator of fragment 0 for the next tile
-                        constexpr int i0 = q == 3 ? 0 : (q == 4 ? 3 : 6), i1 = q == 3 ? 3 : (q == 4 ? 6 : 8);
-#pragma unroll
-                        for (int i = i0; i < i1; ++i) Yf[0][i] = c0pair[0];
-                        if constexpr (q == 5) asm volatile("" : "+v"(Yf[0]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
             STAMP(t, 5);
             bcur = bnext;
         }
+        // ---- tail: fragment 1 of the last tile (epilogue, G store, gradient product)
+        if constexpr (ACT1) {
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+            sfor<8>([&](auto HH) { epi1_half(HH); });
+            g_store(1, 0, ntiles - 1); g_store(1, 1, ntiles - 1);
+            asm volatile("s_nop 1" ::: "memory");
+            sfor<2 * NDF>([&](auto Q) { dr1(Q); });
+        }
     };
+    // "previous tile" state of fragment 1 in front of tile 0: cd = -1 everywhere (mask off, G = 0), zero gradient B fragments
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Yc[1][i] = __builtin_bit_cast(double, make_float2(-1.f, -1.f));
+#pragma unroll
+    for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
+    asm volatile("" : "+v"(Yc[1]));
     if (act[1]) run(std::true_type{}, std::true_type{});
     else if (act[0]) run(std::true_type{}, std::false_type{});
     else run(std::false_type{}, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
-#ifdef C2_STAMPS
-    if (stamping) {
-        __syncthreads();
-        for (int i = tid; i < NW * 25 * 6; i += 256) args.stamps[i] = st_lds[i];
-    }
-#endif
+    BSTAMP(2);
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last gradient MFMAs have retired before their registers are read
@@ -506,7 +552,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 }
             }
             // sum clamp(cd)(fd'' - shift) = sum_p <x_p, dR'_p>, sum cd = sum_p <x_p, sum_q y_q>   (dg_corr.hip "FOLD")
-            const float cs = job.Scsum ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
+            const float cs = cs_pre[d];
             acc_t X8;
             mfma_h80(X8, Rc[f][2 * d], sel[0]);
             if constexpr (2 * d + 1 < NKC) mfma_h8(X8, Rc[f][2 * d + 1], sel[1]);
@@ -526,6 +572,13 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         job.part[(size_t)(n * args.nrb + rb) * 2] = a;
         job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
     }
+#ifdef C2_STAMPS
+    BSTAMP(3);
+    if (stamping) {
+        __syncthreads();
+        for (int i = tid; i < NW * 25 * 6 + NW * 4; i += 256) args.stamps[i] = st_lds[i];
+    }
+#endif
 }
 
 // Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
@@ -546,14 +599,14 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
 #if defined(DG_DEVTOOLS) && defined(C2_STAMPS)
     if (const char* stamp_file = getenv("DG_STAMPS")) {
         static uint32_t* stamp_buf = nullptr;
-        if (!stamp_buf && hipMalloc(&stamp_buf, 4 * 25 * 6 * 4) != hipSuccess) return hipErrorOutOfMemory;
+        if (!stamp_buf && hipMalloc(&stamp_buf, (4 * 25 * 6 + 16) * 4) != hipSuccess) return hipErrorOutOfMemory;
         DgCorrArgs a2 = args;
         a2.stamps = stamp_buf;
-        (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem + 4 * 25 * 6 * 4);
-        hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem + 4 * 25 * 6 * 4, stream, a2);
-        uint32_t host[4 * 25 * 6];
+        (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem + (4 * 25 * 6 + 16) * 4);
+        hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem + (4 * 25 * 6 + 16) * 4, stream, a2);
+        uint32_t host[4 * 25 * 6 + 16];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6, fp); fclose(fp); }
+            if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6 + 16, fp); fclose(fp); }
         return hipGetLastError();
     }
 #endif
