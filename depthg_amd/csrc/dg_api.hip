@@ -205,20 +205,12 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     return njA;
 }
 
-// Fused correlation launch(es).  Gradient passes of the ViT-S widths run the one-wave-per-SIMD kernel (dg_corr2.hip) for the
-// pair-set jobs and the cheap depth job as its own k_corr_main launch; everything else is one k_corr_main launch.
+// Fused correlation launch.  Gradient passes of the ViT-S widths run the one-wave-per-SIMD kernel (dg_corr2.hip); everything else
+// (forward-only calls, stabalize / no zero_clamp, ViT-B widths, small P) k_corr_main.
 static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int depth_index, hipStream_t stream) {
+    (void)depth_index;
     if (p.grad && njA > 0) {
-        DgCorrArgs h = a;
-        h.njobs = njA;
-        const hipError_t e = dg_launch_corr2(h, p.KF, p.KD, stream);
-        if (e == hipSuccess) {
-            if (depth_index < 0) return hipSuccess;
-            DgCorrArgs d = a;
-            d.jobs[0] = a.jobs[depth_index];
-            d.njobs = 1;
-            return dg_launch_corr(d, p.KF, p.KD, p.rf, 1, stream);
-        }
+        const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // pair-set jobs + the depth job, one launch
         if (e != hipErrorNotSupported) return e;
     }
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);

@@ -66,7 +66,8 @@ __device__ __forceinline__ void wait_vm_lgkm_barrier(int n) {     // tile landed
     switch (n) {
 #define DG_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
         DG_W(0) DG_W(1) DG_W(2) DG_W(3) DG_W(4) DG_W(5) DG_W(6) DG_W(7) DG_W(8) DG_W(9) DG_W(10) DG_W(11) DG_W(12) DG_W(13)
-        DG_W(14) DG_W(15) DG_W(16) DG_W(17) DG_W(18) DG_W(19) DG_W(20)
+        DG_W(14) DG_W(15) DG_W(16) DG_W(17) DG_W(18) DG_W(19) DG_W(20) DG_W(21) DG_W(22) DG_W(23) DG_W(24) DG_W(25) DG_W(26) DG_W(27)
+        DG_W(28) DG_W(29) DG_W(30) DG_W(31) DG_W(32)
 #undef DG_W
         default: asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
@@ -130,26 +131,18 @@ template <int KOFF> __device__ __forceinline__ void dma_setup(uint32_t lds_dst, 
 __device__ __forceinline__ void dma_go(uint32_t tmp, const char* sbase) {
     asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(tmp), "s"(sbase) : "memory");
 }
-// epilogue of four accumulator elements in two halves of five VALU (one per MFMA gap): four compares into scalar mask pairs
-// and the first select; then three selects and the two fp16 packs.  No select sits closer than two instructions to its compare.
-struct EpiMasks { unsigned long long m1, m2, m3; };
-__device__ __forceinline__ void epi4a(const float y0, const float c0, const float c1, const float c2, const float c3, int& o0, EpiMasks& m) {
-    unsigned long long m0;
-    asm volatile("v_cmp_le_f32_e64 %1, 0, %6\n\t"
-                 "v_cmp_le_f32_e64 %2, 0, %7\n\t"
-                 "v_cmp_le_f32_e64 %3, 0, %8\n\t"
-                 "v_cmp_le_f32_e64 %4, 0, %9\n\t"
-                 "v_cndmask_b32_e64 %0, 0, %5, %1"
-                 : "=&v"(o0), "=&s"(m0), "=&s"(m.m1), "=&s"(m.m2), "=&s"(m.m3) : "v"(y0), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
-}
-__device__ __forceinline__ void epi4b(const float y1, const float y2, const float y3, int& o0, int& o1, const EpiMasks& m) {
-    int t;
-    asm volatile("v_cndmask_b32_e64 %2, 0, %3, %6\n\t"
-                 "v_cndmask_b32_e64 %1, 0, %4, %7\n\t"
-                 "v_cvt_pk_f16_f32 %0, %0, %2\n\t"
-                 "v_cndmask_b32_e64 %2, 0, %5, %8\n\t"
-                 "v_cvt_pk_f16_f32 %1, %1, %2"
-                 : "+v"(o0), "=&v"(o1), "=&v"(t) : "v"(y1), "v"(y2), "v"(y3), "s"(m.m1), "s"(m.m2), "s"(m.m3));
+// Epilogue of two accumulator elements: -G = cd >= 0 ? fd'' - shift : 0 as one packed fp16 word, 4 VALU, no scalar masks:
+// the two sign halves of cd are gathered (v_perm), smeared over their 16-bit halves (packed arithmetic shift) and clear the
+// packed fp16 pair (v_bfi).  cd is never -0 (the cd chain starts at +0 and adds products: x + (-x) = +0), so "sign bit clear"
+// is the reference's `cd >= 0`.
+__device__ __forceinline__ int epi2(const float y0, const float y1, const float c0, const float c1, const uint32_t sel) {
+    int o, t;
+    asm volatile("v_perm_b32 %1, %5, %4, %6\n\t"
+                 "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+                 "v_pk_ashrrev_i16 %1, 15, %1 op_sel_hi:[0,1]\n\t"
+                 "v_bfi_b32 %0, %1, 0, %0"
+                 : "=&v"(o), "=&v"(t) : "v"(y0), "v"(y1), "v"(c0), "v"(c1), "s"(sel));
+    return o;
 }
 
 __device__ __forceinline__ float wave_sum2(float v) {
@@ -158,18 +151,149 @@ __device__ __forceinline__ float wave_sum2(float v) {
     return v;
 }
 
+// ---- depth term (depth_feature_correlation, src/modules.py:1256-1278) as blocks of the same launch ---------------------------
+// loss = -clamp(cd)(dd - shift) with cd = corr(code, code) of the image itself and dd[p][q] = nz_p nz_q (quirk Q1).  Same block
+// shape (4 waves x 64 stationary rows), no feature chain: per tile 2 x NKC cd MFMAs, the epilogue with per-element sums (G takes
+// two or three distinct values, so the fold of the helper jobs would bias), 2 x 6 gradient MFMAs into the accumulator file.
+// By symmetry d/dc1 = d/dc2, so only the stationary side is formed.  Tiles: C and P parts of the blob + the 32 indicators of the
+// tile rows.  Not the hot part of the launch (3 % of the MFMAs): compiler-scheduled VALU, one barrier per tile.
+template <int NKF, int NKD, int NKC>
+__device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
+    using BL = BlobT<NKF, NKD>;
+    constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD, BUF = BL::BYTES, NBUF = 4;
+    constexpr int C0 = BL::CHUNK_C0, NCH = BL::CHUNKS - C0;          // chunks of the C and P parts
+    constexpr int PIECES = (NCH + NW - 1) / NW;
+    static_assert(NCH % NW == 0, "code chunks must split evenly over the waves");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int Ppad = args.Ppad, ntiles = Ppad >> 5;
+    const int rtile0 = (rb * NW + wid) * RF;
+    bool act[RF];
+    int pr[RF];
+    const char* Rblob[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        act[f] = rtile0 + f < ntiles;
+        pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;
+        Rblob[f] = job.Rop + ((size_t)n * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
+    }
+    const bool wave_active = act[0];
+    const uint32_t smem_a = lds_addr(smem);
+    v4i_t Rc[RF][NKC];
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int k = 0; k < NKC; ++k)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rc[f][k]) : "v"(Rblob[f] + BL::OFF_C + ((2 * k + h) * 32 + r) * 16) : "memory");
+    sfor<RF * NDF * 4>([&](auto I) { agpr_zero4<4 * I.value>(); });          // dR[f][d] = a[(f * NDF + d) * 16 ..]
+    const float c0 = -job.shift;
+    float nz_lane[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) nz_lane[f] = job.nzR[(size_t)n * Ppad + pr[f]];
+    const char* const Sop_img = job.Sop + (size_t)n * ntiles * BL::BYTES + C0 * 1024;
+    const float* const nzS = job.nzS + (size_t)n * Ppad;
+    const uint32_t dma_voff = lane * 16 + wid * 1024;
+    auto issue_tile = [&](int t, int b) {
+        const int tt = t < ntiles ? t : 0;
+        const char* sb = Sop_img + (size_t)tt * BL::BYTES;
+        const uint32_t dst = smem_a + b * BUF + C0 * 1024 + wid * 1024;
+        sfor<PIECES>([&](auto K) { dma_piece<K.value * 4096>(dst, dma_voff, sb); });
+        dma4(nzS + tt * 32 + (lane & 31), smem_a + b * BUF);                 // all waves write the same 32 floats (+ a copy behind)
+    };
+    issue_tile(0, 0); issue_tile(1, 1); issue_tile(2, 2);
+    const int crow = (h * 32 + r) * 16;
+    float lsum = 0.f;
+    int bcur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t landed: two younger tiles (PIECES + 1 instructions each) may be in flight
+        wait_vm_lgkm_barrier(2 * (PIECES + 1));
+        issue_tile(t + 3, (bcur + 3) & 3);
+        const char* tile = smem + bcur * BUF;
+        bcur = (bcur + 1) & 3;
+        if (!wave_active) continue;
+        v4i_t a[NKC], bP[2 * NDF];
+#pragma unroll
+        for (int k = 0; k < NKC; ++k) a[k] = *reinterpret_cast<const v4i_t*>(tile + BL::OFF_C + crow + k * 1024);
+#pragma unroll
+        for (int q = 0; q < 2 * NDF; ++q)
+            bP[q] = *reinterpret_cast<const v4i_t*>(tile + BL::OFF_P + (h * KD + 32 * (q % NDF) + r) * 16 + (q / NDF) * (2 * KD * 16));
+        float vv[16];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(tile + (8 * i4 + 4 * h) * 4);
+            vv[4 * i4] = v4.x; vv[4 * i4 + 1] = v4.y; vv[4 * i4 + 2] = v4.z; vv[4 * i4 + 3] = v4.w;
+        }
+        acc_t Yc[RF];
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            mfma_h80(Yc[f], a[0], Rc[f][0]);
+#pragma unroll
+            for (int k = 1; k < NKC; ++k) mfma_h8(Yc[f], a[k], Rc[f][k]);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(Yc[0]), "+v"(Yc[1]));      // the chains have retired
+        v4i_t ga[RF][2];
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            const f32x16 yc = __builtin_bit_cast(f32x16, Yc[f]);
+            f16x8 g8[2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float fdv = fmaf(nz_lane[f], vv[i], c0);
+                const float g = yc[i] >= 0.f ? fdv : 0.f;
+                if (act[f]) lsum = fmaf(g, yc[i], lsum);                    // clamp(cd) (dd - shift), clamp(cd) = cd * mask
+                g8[i >> 3][i & 7] = (_Float16)g;
+            }
+            ga[f][0] = __builtin_bit_cast(v4i_t, g8[0]); ga[f][1] = __builtin_bit_cast(v4i_t, g8[1]);
+        }
+        asm volatile("s_nop 1" : "+v"(ga[0][0]), "+v"(ga[0][1]), "+v"(ga[1][0]), "+v"(ga[1][1]));
+        sfor<RF * 2 * NDF>([&](auto I) {
+            constexpr int f = I.value / (2 * NDF), q = I.value % (2 * NDF), sp = q / NDF, d = q % NDF;
+            mfma_h_acc<(f * NDF + d) * 16>(ga[f][sp], bP[q]);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF);
+    sfor<RF>([&](auto FI) {
+        constexpr int f = FI.value;
+        if (!act[f] || !job.dR) return;
+        float* base = job.dR + ((size_t)n * ntiles + rtile0 + f) * (32 * DP) + lane * 4;
+        sfor<NDF>([&](auto DI) {
+            constexpr int d = DI.value;
+            float v[16];
+            sfor<16>([&](auto I) { v[I.value] = agpr_read<(f * NDF + d) * 16 + I.value>(); });
+            if (32 * d + r < args.D) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
+                }
+            }
+        });
+    });
+    lsum = wave_sum2(lsum);
+    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = 0.f; }
+    __syncthreads();
+    if (tid == 0 && job.part) {
+        float a = 0.f;
+        for (int w = 0; w < NW; ++w) a += red[w * 2];
+        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
+        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = 0.f;
+    }
+}
+
 // NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
 template <int NKF, int NKD, int NKC>
 __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     using BL = BlobT<NKF, NKD>;
     constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
-    constexpr int BUF = BL::BYTES, NS = NKF + NKC, PF = 8;
+    constexpr int BUF = BL::BYTES, NS = NKF + NKC, PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
     constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
     static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
     static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
     static_assert(10 + 2 * PIECES <= NS && NS >= 26 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][BUF] tiles, red[NW][2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] tiles, red[NW][2]
     declare_agprs();
 #ifdef C2_STAMPS
     unsigned long long t_entry;
@@ -185,23 +309,28 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     }
     int n, jid, rb;
     {
-        const int nh = args.njobs, per_img = nh * args.nrb;
+        const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
+        const int per_img = args.njobs * args.nrb;
         if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
+            // every XCD owns B/8 whole images; inside that chunk the long blocks go first: pair-set jobs with a full row block, then
+            // their ragged last row block, then the cheap depth job
             const int imgs = args.B >> 3, per_chunk = imgs * per_img;
             const int xcd = bid / per_chunk;
             int i = bid - xcd * per_chunk;
             const bool ragged = args.nrb > 1 && ((args.Ppad >> 5) % (NW * RF)) != 0;
             const int nfull = args.nrb - (ragged ? 1 : 0);
-            const int cA = imgs * nh * nfull;
+            const int cA = imgs * nh * nfull, cB = ragged ? imgs * nh : 0;
             int nl;
             if (i < cA) { nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull; }
-            else { i -= cA; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; }
+            else if (i < cA + cB) { i -= cA; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; }
+            else { i -= cA + cB; nl = i / args.nrb; jid = nh; rb = i - nl * args.nrb; }
             n = xcd * imgs + nl;
         } else {
             n = bid / per_img; bid -= n * per_img; jid = bid / args.nrb; rb = bid - jid * args.nrb;
         }
     }
     const DgJob& job = args.jobs[jid];
+    if (job.kind == DG_JOB_DEPTH) { depth_block<NKF, NKD, NKC>(args, job, n, rb, smem); return; }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -256,13 +385,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         const uint32_t dst = smem_a + b * BUF + wid * 1024;
         dma_piece<K.value * 4096>(dst, dma_voff, sb);
     };
-#ifdef C2_PRONOP
-    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 0, 0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); });
-    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); });
-#else
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 0, 0); });
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); });
-#endif
+    sfor<PIECES>([&](auto K) { issue_tile_piece(K, 2, 2); });
 
     // ---- per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
     float c0 = -job.shift;
@@ -295,7 +420,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     acc_t Yf[RF], Yc[RF];
     v4i_t ga[RF][2];                                     // -G as fp16 A fragments: k-step sp holds accumulator elements 8sp..8sp+7
     v4i_t ra[PF], bP[2 * NDF];
-    EpiMasks em;
 #pragma unroll
     for (int f = 0; f < RF; ++f)
 #pragma unroll
@@ -305,26 +429,16 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #endif
 
     // tile 0 landed (the fragment loads are older, so they are complete as well)
-    wait_vm_lgkm_barrier(PIECES);
+    wait_vm_lgkm_barrier(2 * PIECES);
     sfor<PF>([&](auto I) { rd_step(I, ra[I.value]); });
 
-    auto epi_a = [&](const int f, const int j) {           // first half of quad j (elements 4j..4j+3) of fragment f
-#ifndef C2_NOEPI
+    const uint32_t perm_sel = __builtin_amdgcn_readfirstlane(0x07060302);      // {c1 bytes 3,2 | c0 bytes 3,2}
+    auto epi_pair = [&](const int f, const int j) {        // accumulator elements 2j, 2j+1 of fragment f -> one fp16 word of -G
+#ifdef C2_NOEPI            // (timing ablation)
+        ga[f][j >> 2][j & 3] = 0;
+#else
         const f32x16 yf = __builtin_bit_cast(f32x16, Yf[f]), yc = __builtin_bit_cast(f32x16, Yc[f]);
-        const int i = 4 * j;
-        int o0;
-        epi4a(yf[i], yc[i], yc[i + 1], yc[i + 2], yc[i + 3], o0, em);
-        ga[f][j >> 1][2 * (j & 1)] = o0;
-#endif
-    };
-    auto epi_b = [&](const int f, const int j) {
-#ifndef C2_NOEPI
-        const f32x16 yf = __builtin_bit_cast(f32x16, Yf[f]);
-        const int i = 4 * j;
-        int o0 = ga[f][j >> 1][2 * (j & 1)], o1;
-        epi4b(yf[i + 1], yf[i + 2], yf[i + 3], o0, o1, em);
-        ga[f][j >> 1][2 * (j & 1)] = o0;
-        ga[f][j >> 1][2 * (j & 1) + 1] = o1;
+        ga[f][j >> 2][j & 3] = epi2(yf[2 * j], yf[2 * j + 1], yc[2 * j], yc[2 * j + 1], perm_sel);
 #endif
     };
     auto g_store = [&](const int f, const int sp, int t) {
@@ -337,7 +451,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     };
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
-    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + 3 * BUF + 64);
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + 64);
     const bool stamping = args.stamps != nullptr && n == 0 && jid == 0 && rb == 0;
     auto STAMP = [&](int t, int k) {
 #ifndef C2_BLOCKSTAMPS_ONLY
@@ -374,10 +488,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         constexpr bool ACT0 = A0.value, ACT1 = A1.value;
         constexpr int TOT = ACT1 ? 2 * NS : NS;
         constexpr int BP0 = ACT1 ? 2 * NS - 9 : TOT;            // first MFMA index whose gap carries a gradient-B read (phase B gaps NS-9 ..)
-        auto epi1_half = [&](auto HH) {                         // half HH (0..7) of the epilogue of fragment 1
-            constexpr int hh = HH.value;
-            if constexpr ((hh & 1) == 0) epi_a(1, hh / 2); else epi_b(1, hh / 2);
-        };
+        auto epi1_half = [&](auto HH) { epi_pair(1, HH.value); };   // pair HH (0..7) of the epilogue of fragment 1
         auto dr1 = [&](auto Q) {
             constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
 #ifndef C2_NODR
@@ -387,21 +498,25 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         int bcur = 0;
         uint32_t dtmp = 0;
         for (int t = 0; t < ntiles; ++t) {
-            const int bnext = bcur == 2 ? 0 : bcur + 1, bprev = bcur == 0 ? 2 : bcur - 1;
+            const int bnext = (bcur + 1) & 3, bprev = (bcur + 3) & 3;
             auto chain_slot = [&](auto IDX, auto F) {          // wait (every second step), MFMA idx, refill of its ring register
                 constexpr int idx = IDX.value, f = F.value, st = idx - f * NS;
                 if constexpr ((idx & 1) == 0) {
                     constexpr int need = idx + 1 < TOT ? idx + 1 : TOT - 1;
                     constexpr int issued = (idx + PF < TOT ? idx + PF : TOT) + (idx > BP0 ? (idx - BP0 < 2 * NDF ? idx - BP0 : 2 * NDF) : 0);
+#if !defined(C2_NOARD) && !defined(C2_NOLGKM)
                     wait_lgkm<issued - (need + 1)>();
+#endif
                 }
                 if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
                 else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
                 else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
+#ifndef C2_NOARD           // (timing ablation: no fragment refills)
                 if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
+#endif
             };
-            // DMA source / destination of tile t+2 (scalar)
-            const int t2 = t + 2 < ntiles ? t + 2 : 0;            // past the end: dummy pieces keep the counted waits uniform
+            // DMA source / destination of tile t+3 (scalar)
+            const int t2 = t + 3 < ntiles ? t + 3 : 0;            // past the end: dummy pieces keep the counted waits uniform
             const char* const sb2 = Sop_img + (size_t)t2 * BL::BYTES;
             const uint32_t dst2 = smem_a + bprev * BUF + wid * 1024;
             STAMP(t, 0);
@@ -441,7 +556,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 //  epilogue that reads them - wait the chain's last MFMAs out explicitly)
                 if constexpr (ACT0 && !ACT1 && st == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
                 if constexpr (ACT0) {
-                    if constexpr (st >= 2 && st < 10) { if constexpr ((st & 1) == 0) epi_a(0, (st - 2) / 2); else epi_b(0, (st - 2) / 2); }
+                    if constexpr (st >= 2 && st < 10) epi_pair(0, st - 2);
                     if constexpr (st == 11) g_store(0, 0, t);
                     if constexpr (st == 13) g_store(0, 1, t);
                     if constexpr (st >= NS - 9 && st < NS - 9 + 2 * NDF) {      // B fragments of the gradient products (shared by both fragments)
@@ -453,8 +568,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             });
             STAMP(t, 2);
             // ---- tile t+1 landed, every wave is done reading tile t: one barrier per tile.  Younger than the last piece of tile
-            //      t+1 (issued in phase A of t-1): the G stores of fragment 1 (t-2), fragment 0 (t-1), the pieces of tile t+2, the
-            //      G stores of fragment 1 (t-1) and fragment 0 (t)
+            //      t+1 (issued in phase A of t-2): per later tile 2 G stores of each fragment and the 9 pieces of tiles t+2, t+3
             {
 #ifdef C2_NOGST
                 constexpr int S0 = 0, S1 = 0;
@@ -466,9 +580,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #else
                 constexpr int PL = PIECES;
 #endif
-                if (t == 0) wait_vm_lgkm_barrier(PL + S0);
-                else if (t == 1) wait_vm_lgkm_barrier(PL + 2 * S0 + S1);
-                else wait_vm_lgkm_barrier(PL + 2 * S0 + 2 * S1);
+                // two tiles' pieces and up to three tiles' G stores are younger than the last piece of tile t+1
+                const int tc0 = t < 2 ? t + 1 : 3, tc1 = t < 3 ? t : 3;
+                wait_vm_lgkm_barrier(2 * PL + S0 * tc0 + S1 * tc1);
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(t, 3);
@@ -520,7 +634,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last gradient MFMAs have retired before their registers are read
     float lsum = 0.f, csum = 0.f;
-    float* red = reinterpret_cast<float*>(smem + 3 * BUF);
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF);
     sfor<RF>([&](auto FI) {
         constexpr int f = FI.value;
         if (!act[f]) return;
@@ -589,10 +703,13 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
 #endif
     if (!(KF == 384 && KD == 96 && args.D <= 80)) return hipErrorNotSupported;
     if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160) return hipErrorNotSupported;
-    for (int j = 0; j < args.njobs; ++j)
-        if (args.jobs[j].kind != DG_JOB_HELPER || !args.jobs[j].center_on_lane || !args.jobs[j].Gout || args.jobs[j].ridx) return hipErrorNotSupported;
+    for (int j = 0; j < args.njobs; ++j) {
+        const DgJob& J = args.jobs[j];
+        if (J.kind == DG_JOB_DEPTH) { if (j != args.njobs - 1 || j == 0 || J.ridx || J.sidx) return hipErrorNotSupported; continue; }   // (last, after the pair-sets)
+        if (J.kind != DG_JOB_HELPER || !J.center_on_lane || !J.Gout || J.ridx) return hipErrorNotSupported;
+    }
     using BL = BlobT<24, 6>;
-    const int smem = 3 * BL::BYTES + 64;
+    const int smem = 4 * BL::BYTES + 64;
     auto kern = k_corr2<24, 6, 5>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;

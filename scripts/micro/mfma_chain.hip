@@ -2,6 +2,8 @@
 //   hipcc -O3 --offload-arch=gfx950 -o mfma_chain mfma_chain.hip && ./mfma_chain
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double acc_t __attribute__((ext_vector_type(8)));
 #define N 64
@@ -9,9 +11,15 @@ typedef double acc_t __attribute__((ext_vector_type(8)));
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long* out, const v4i* src) {
     extern __shared__ char smem[];
-    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35");
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a100", "a150", "a191");
     v4i a = src[threadIdx.x], b2 = src[threadIdx.x + 256];
     asm volatile("v_accvgpr_write_b32 a0, %0\n\tv_accvgpr_write_b32 a1, %1\n\tv_accvgpr_write_b32 a2, %2\n\tv_accvgpr_write_b32 a3, %3" :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    if (MODE == 7) {
+#define W4(b) asm volatile("v_accvgpr_write_b32 a[" #b "], %0\n\tv_accvgpr_write_b32 a[" #b "+1], %1\n\tv_accvgpr_write_b32 a[" #b "+2], %2\n\tv_accvgpr_write_b32 a[" #b "+3], %3" :: "v"(a[0] ^ b), "v"(a[1]), "v"(b2[2]), "v"(b2[3]));
+        W4(0) W4(4) W4(8) W4(12) W4(16) W4(20) W4(24) W4(28) W4(32) W4(36) W4(40) W4(44) W4(48) W4(52) W4(56) W4(60)
+        W4(64) W4(68) W4(72) W4(76) W4(80) W4(84) W4(88) W4(92) W4(96) W4(100) W4(104) W4(108) W4(112) W4(116) W4(120) W4(124)
+        W4(128) W4(132) W4(136) W4(140) W4(144) W4(148) W4(152) W4(156) W4(160) W4(164) W4(168) W4(172) W4(176) W4(180) W4(184) W4(188)
+    }
     acc_t y0 = {}, y1 = {};
     const unsigned lds = (threadIdx.x & 63) * 16;
     v4i r0 = a, r1 = b2;
@@ -28,6 +36,12 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long*
         } else if (MODE == 3) {   // dependent chain + an LDS read, a counted wait and a nop per gap (what phase A carries)
             REP16(REP4(asm volatile("s_waitcnt lgkmcnt(1)\n\ts_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[0:3], %0\n\tds_read_b128 %1, %3\n\t"
                                     "s_nop 0\n\tv_mfma_f32_32x32x16_bf16 %0, %2, a[0:3], %0\n\tds_read_b128 %2, %3 offset:1024" : "+v"(y0), "+v"(r0), "+v"(r1) : "v"(lds));))
+        } else if (MODE == 7) {   // dependent chain, B walks over 48 different accumulator-file fragments (what k_corr2's fd chain does)
+#define M4(b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[" #b ":" #b "+3], %0" : "+v"(y0) : "v"(a));
+            M4(0) M4(4) M4(8) M4(12) M4(16) M4(20) M4(24) M4(28) M4(32) M4(36) M4(40) M4(44) M4(48) M4(52) M4(56) M4(60)
+            M4(64) M4(68) M4(72) M4(76) M4(80) M4(84) M4(88) M4(92) M4(96) M4(100) M4(104) M4(108) M4(112) M4(116) M4(120) M4(124)
+            M4(128) M4(132) M4(136) M4(140) M4(144) M4(148) M4(152) M4(156) M4(160) M4(164) M4(168) M4(172) M4(176) M4(180) M4(184) M4(188)
+            M4(0) M4(4) M4(8) M4(12) M4(16) M4(20) M4(24) M4(28) M4(32) M4(36) M4(40) M4(44) M4(48) M4(52) M4(56) M4(60)
         } else if (MODE == 4) {   // all-VGPR operands
             REP16(REP4(asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(y0) : "v"(a), "v"(b2));))
         } else if (MODE == 5) {   // 16x16x32, dependent chain (twice as many for the same flops)
@@ -44,14 +58,14 @@ template <int MODE> __global__ __launch_bounds__(256) void k(unsigned long long*
 }
 int main() {
     unsigned long long* d; v4i* s;
-    hipMalloc(&d, 256); hipMalloc(&s, 512 * 16); hipMemset(s, 0x3c, 512 * 16); hipMemset(d, 0, 256);
+    hipMalloc(&d, 256); hipMalloc(&s, 512 * 16); { unsigned short hb[512 * 8]; unsigned x = 12345; for (int i = 0; i < 512 * 8; ++i) { x = x * 1664525u + 1013904223u; hb[i] = (unsigned short)(((x >> 9) & 0x807f) | 0x3e80 | (((x >> 20) & 7) << 4)); } if (getenv("ZERO")) memset(hb, 0, sizeof(hb)); hipMemcpy(s, hb, sizeof(hb), hipMemcpyHostToDevice); } hipMemset(d, 0, 256);
 #define RUN(M) hipLaunchKernelGGL(k<M>, dim3(256), dim3(256), 4096, 0, d, s);
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
     unsigned long long h[8];
     hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
     const char* names[] = {"dependent chain, VGPR acc, AGPR B", "two alternating accumulators (x2 MFMAs)", "dependent chain, AGPR acc", "dependent + ds_read/wait/nop per gap",
-                           "dependent chain, all VGPR", "16x16x32 dependent (x2 MFMAs)", "16x16x32 four accumulators (x4 MFMAs)"};
-    const int count[] = {64, 128, 64, 128, 64, 128, 256};
-    for (int i = 0; i < 7; ++i) printf("%-45s %6llu cycles / %d = %.1f per MFMA\n", names[i], h[i], count[i], (double)h[i] / count[i]);
+                           "dependent chain, all VGPR", "16x16x32 dependent (x2 MFMAs)", "16x16x32 four accumulators (x4 MFMAs)", "dependent, B over 48 AGPR fragments"};
+    const int count[] = {64, 128, 64, 128, 64, 128, 256, 64};
+    for (int i = 0; i < 8; ++i) printf("%-45s %6llu cycles / %d = %.1f per MFMA\n", names[i], h[i], count[i], (double)h[i] / count[i]);
     return 0;
 }
