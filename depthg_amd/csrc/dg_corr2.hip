@@ -145,6 +145,14 @@ __device__ __forceinline__ int epi2(const float y0, const float y1, const float 
     return o;
 }
 
+// sum over the 64 lanes through DPP row operations (dg_common.h half_sum) instead of six LDS-crossbar shuffles
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define DG_DPP_ADD2(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+    DG_DPP_ADD2(0x111, 0xf); DG_DPP_ADD2(0x112, 0xf); DG_DPP_ADD2(0x114, 0xf); DG_DPP_ADD2(0x118, 0xf);
+    DG_DPP_ADD2(0x142, 0xa);
+#undef DG_DPP_ADD2
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_sum2(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -352,6 +360,26 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     }
     const bool wave_active = act[0];
 
+    // ---- small per-block inputs first (their latency runs under the 270 KB that follow): the B per-image sums of the row means
+    //      (m0), this lane's row means, the streamed operand's code column sums.  asm loads: hipcc would wait for a load it knows
+    //      with vmcnt(0) at its first use, i.e. for every DMA piece issued since; they are consumed behind the first counted wait.
+    float rimg_v = 0.f, rvec_v[RF] = {0.f, 0.f}, cs_pre[NDF];
+    {
+        const float* zsrc = reinterpret_cast<const float*>(args.dummy);          // any valid address
+        const float* p_rimg = job.rvec ? job.rimg + (lane < args.B ? lane : 0) : zsrc;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(rimg_v) : "v"(p_rimg) : "memory");
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            const float* p_rv = job.rvec ? job.rvec + (size_t)n * Ppad + pr[f] : zsrc;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(rvec_v[f]) : "v"(p_rv) : "memory");
+        }
+#pragma unroll
+        for (int d = 0; d < NDF; ++d) {
+            const float* p_cs = job.Scsum ? job.Scsum + (size_t)nS * KD + 32 * d + r : zsrc;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(cs_pre[d]) : "v"(p_cs) : "memory");
+        }
+    }
+
     // ---- stationary operand: feature fragments -> accumulator registers, code fragments -> arch VGPRs
     const uint32_t smem_a = lds_addr(smem);
     const int sw = (r >> 2) & 3;
@@ -389,22 +417,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); });
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 2, 2); });
 
-    // ---- per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
-    float c0 = -job.shift;
-    if (job.rvec) {
-        float m = 0.f;
-        for (int i = lane; i < args.B; i += 64) m += job.rimg[i];
-        c0 += wave_sum2(m) * args.inv_BP;
-    }
-    double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
-#pragma unroll
-    for (int f = 0; f < RF; ++f) {
-        const float cl = job.rvec ? c0 - job.rvec[(size_t)n * Ppad + pr[f]] : c0;
-        const float2 two = make_float2(cl, cl);
-        c0pair[f] = __builtin_bit_cast(double, two);
-        asm volatile("" : "+v"(c0pair[f]));
-    }
-
+    // (per-job scalars: computed behind the first counted wait, from the values loaded at the top of the block)
     // per-lane LDS byte addresses of the fragments of the current tile
     const int crow = (h * 32 + r) * 16;
     uint32_t va0 = smem_a + fb0, va1 = smem_a + fb1, vc = smem_a + BL::OFF_C + crow, vp = smem_a + BL::OFF_P + (h * KD + r) * 16;
@@ -414,22 +427,35 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         else lds_rd<(st - NKF) * 1024>(d, vc);
     };
 
-    float cs_pre[NDF];                                   // code column sums of the streamed operand (block-end sums): loaded early
-#pragma unroll
-    for (int d = 0; d < NDF; ++d) cs_pre[d] = job.Scsum ? job.Scsum[(size_t)nS * KD + 32 * d + r] : 0.f;
     acc_t Yf[RF], Yc[RF];
     v4i_t ga[RF][2];                                     // -G as fp16 A fragments: k-step sp holds accumulator elements 8sp..8sp+7
     v4i_t ra[PF], bP[2 * NDF];
-#pragma unroll
-    for (int f = 0; f < RF; ++f)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Yf[f][i] = c0pair[f];
 #ifdef C2_NOEPI
     ga[0][0] = ga[0][1] = ga[1][0] = ga[1][1] = v4i_t{0, 0, 0, 0};
 #endif
 
-    // tile 0 landed (the fragment loads are older, so they are complete as well)
-    wait_vm_lgkm_barrier(2 * PIECES);
+    // tile 0 landed (everything older - the small inputs, the fragment loads - is complete as well)
+    static_assert(2 * PIECES == 18, "literal wait count below");
+    asm volatile("s_waitcnt vmcnt(18)" : "+v"(rimg_v), "+v"(rvec_v[0]), "+v"(rvec_v[1]), "+v"(cs_pre[0]), "+v"(cs_pre[1]), "+v"(cs_pre[2]) :: "memory");
+    // per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
+    double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
+    {
+        float c0 = -job.shift;
+        if (job.rvec) c0 += wave_sum_dpp(lane < args.B ? rimg_v : 0.f) * args.inv_BP;      // (B <= 64 images per call of this form)
+        if (!job.Scsum) { cs_pre[0] = cs_pre[1] = cs_pre[2] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < RF; ++f) {
+            const float cl = job.rvec ? c0 - rvec_v[f] : c0;
+            const float2 two = make_float2(cl, cl);
+            c0pair[f] = __builtin_bit_cast(double, two);
+            asm volatile("" : "+v"(c0pair[f]));
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Yf[f][i] = c0pair[f];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sfor<PF>([&](auto I) { rd_step(I, ra[I.value]); });
 
     const uint32_t perm_sel = __builtin_amdgcn_readfirstlane(0x07060302);      // {c1 bytes 3,2 | c0 bytes 3,2}
@@ -452,7 +478,12 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
     uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + 64);
-    const bool stamping = args.stamps != nullptr && n == 0 && jid == 0 && rb == 0;
+    #ifndef C2_STAMP_N
+#define C2_STAMP_N 0
+#define C2_STAMP_J 0
+#define C2_STAMP_RB 0
+#endif
+    const bool stamping = args.stamps != nullptr && n == C2_STAMP_N && jid == C2_STAMP_J && rb == C2_STAMP_RB;
     auto STAMP = [&](int t, int k) {
 #ifndef C2_BLOCKSTAMPS_ONLY
         __builtin_amdgcn_sched_barrier(0);
@@ -676,8 +707,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             for (int i = 0; i < 16; ++i) { lsum = fmaf(X[i], v[i], lsum); csum = fmaf(X[i], cs, csum); }
         });
     });
-    lsum = wave_sum2(lsum);
-    csum = wave_sum2(csum);
+    lsum = wave_sum_dpp(lsum);
+    csum = wave_sum_dpp(csum);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
     __syncthreads();
     if (tid == 0 && job.part) {
@@ -702,7 +733,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
     return hipErrorNotSupported;
 #endif
     if (!(KF == 384 && KD == 96 && args.D <= 80)) return hipErrorNotSupported;
-    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160) return hipErrorNotSupported;
+    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160 || args.B > 64) return hipErrorNotSupported;
     for (int j = 0; j < args.njobs; ++j) {
         const DgJob& J = args.jobs[j];
         if (J.kind == DG_JOB_DEPTH) { if (j != args.njobs - 1 || j == 0 || J.ridx || J.sidx) return hipErrorNotSupported; continue; }   // (last, after the pair-sets)
