@@ -25,27 +25,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HEADLINE = dict(B=32, C=384, D=70, h=28, w=28, S=28, n_neg=5, depth_hw=224)
+# --config: the workloads of BASELINE.json `configs` 2-5 with the reference's recipe scalars
+# (paper_reproduction.sh:5-14); the headline stays the default and is the line the driver records.
+CONFIGS = {
+    "headline": dict(H=HEADLINE, sampling="none", dense=True, pointwise=True,
+                     scal=dict(pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761, depth_feat_shift=0.03,
+                               pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
+                     what="headline: B=32/GPU, C=384, D=70, 28x28 dense grid (S=28, P=784), 5 negatives, depth term on, pointwise, "
+                          "zero_clamp; fwd + bwd to orig_code/orig_code_pos", cpu_B=32),
+    "C2": dict(H=dict(B=16, C=384, D=90, h=28, w=28, S=11, n_neg=5, depth_hw=224), sampling="fps", dense=False, pointwise=True,
+               scal=dict(pos_intra_shift=0.2, pos_inter_shift=0.09, neg_inter_shift=0.63, depth_feat_shift=0.14,
+                         pos_intra_weight=0.61, pos_inter_weight=0.34, neg_inter_weight=0.72, depth_feat_weight=0.13),
+               what="config 2: Potsdam ViT-S recipe, B=16, C=384, dim=90, 28x28 maps, feature_samples=11 (P=121), depth_sampling=fps "
+                    "(sampler inside the step), depth term on; fwd + bwd", cpu_B=16),
+    "C3": dict(H=dict(B=32, C=768, D=100, h=28, w=28, S=11, n_neg=5, depth_hw=224), sampling="none", dense=False, pointwise=False,
+               scal=dict(pos_intra_shift=0.39, pos_inter_shift=0.25, neg_inter_shift=0.26, depth_feat_shift=0.03,
+                         pos_intra_weight=0.95, pos_inter_weight=1.02, neg_inter_weight=0.57, depth_feat_weight=0.09),
+               what="config 3: Cityscapes ViT-B recipe, B=32, C=768, dim=100, 28x28 maps, feature_samples=11, random coords, "
+                    "pointwise=False; fwd + bwd", cpu_B=32),
+    "C4shard": dict(H=dict(B=8, C=768, D=90, h=28, w=28, S=12, n_neg=5, depth_hw=224), sampling="fps", dense=False, pointwise=True,
+                    scal=dict(pos_intra_shift=0.123, pos_inter_shift=0.21, neg_inter_shift=0.975, depth_feat_shift=0.0359,
+                              pos_intra_weight=0.2305, pos_inter_weight=1.05, neg_inter_weight=0.2485, depth_feat_weight=0.16),
+                    what="config 4, one rank's shard: COCO-Stuff ViT-B recipe, global batch 64 over 8 GPUs -> B=8/GPU, C=768, dim=90, "
+                         "feature_samples=12 (P=144), depth_sampling=fps; fwd + bwd", cpu_B=8),
+    "C5": dict(H=dict(B=32, C=384, D=70, h=56, w=56, S=56, n_neg=5, depth_hw=448), sampling="none", dense=True, pointwise=True,
+               scal=dict(pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761, depth_feat_shift=0.03,
+                         pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
+               what="config 5: 56x56 maps (ViT-S/8 at 448 input), B=32/GPU, C=384, D=70, dense grid (P=3136), positives = a "
+                    "different random tensor (kNN positive), 5 negatives, depth term on; fwd + bwd", cpu_B=1),
+}
 HEAD_GRAD_ELEMS = 201_740          # cluster1 (26,950) + cluster2 (174,790) parameters, reference src/modules.py:75-88
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16/f16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def make_cfg(**over):
+def make_cfg(conf, **over):
     from types import SimpleNamespace
-    # COCO-Stuff ViT-S recipe of the reference (paper_reproduction.sh:5) on top of src/configs/local_config.yml
+    # recipe scalars of the reference (paper_reproduction.sh) on top of src/configs/local_config.yml
+    H = conf["H"]
     cfg = SimpleNamespace(
-        feature_samples=HEADLINE["S"], use_salience=False, depth_sampling="none", fps_gpu=False, pointwise=True,
-        zero_clamp=True, stabalize=False, pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761,
-        neg_samples=HEADLINE["n_neg"], depth_feat_correlation_loss=True, depth_feat_shift=0.03,
-        pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19,
-        correspondence_weight=1.0, dg_outputs="reduced", dg_dense_grid=True)
+        feature_samples=H["S"], use_salience=False, depth_sampling=conf["sampling"], fps_gpu=False, pointwise=conf["pointwise"],
+        zero_clamp=True, stabalize=False, neg_samples=H["n_neg"], depth_feat_correlation_loss=True,
+        correspondence_weight=1.0, dg_outputs="reduced", dg_dense_grid=conf["dense"], **conf["scal"])
     for k, v in over.items():
         setattr(cfg, k, v)
     return cfg
 
 
-def synth_inputs(B, seed, device):
+def synth_inputs(B, seed, device, H=HEADLINE):
     g = torch.Generator().manual_seed(seed)
-    H = HEADLINE
     f = torch.randn(B, H["C"], H["h"], H["w"], generator=g)
     fp = torch.randn(B, H["C"], H["h"], H["w"], generator=g)
     c = torch.randn(B, H["D"], H["h"], H["w"], generator=g)
@@ -70,19 +97,18 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     return main + gs, main, gs
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the headline
-    workload: same C, D, S, pair-sets and backward, smaller batch; scaled to steps/s of the full batch."""
+def cpu_baseline(conf, seconds_budget=15.0):
+    """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the SAME workload: same C, D,
+    S, pair-sets, sampler and backward, `cpu_B` images of the batch; scaled to steps/s of the full batch."""
     from oracle import depthg_oracle as O
-    H = HEADLINE
-    Bs = H["B"]      # the full headline batch: ~0.4 s per repetition on 16 threads, repeated for ~15 s
-    ncores = min(os.cpu_count() or 1, 16)      # torch-CPU bmm/elementwise stop scaling (and thrash) beyond this
+    H = conf["H"]
+    Bs = conf["cpu_B"]
+    host = os.cpu_count() or 1
+    ncores = min(host, 16)      # torch-CPU bmm/elementwise stop scaling (and thrash) beyond this
     torch.set_num_threads(ncores)
-    cfg = O.default_cfg(feature_samples=H["S"], pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761,
-                        depth_feat_shift=0.03, pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7,
-                        depth_feat_weight=0.19)
-    f, fp, c, cp, d, dp = synth_inputs(Bs, 4321, "cpu")
-    coords = O.identity_coords(Bs, H["S"])
+    cfg = O.default_cfg(feature_samples=H["S"], neg_samples=H["n_neg"], dim=H["D"], pointwise=conf["pointwise"],
+                        depth_sampling=conf["sampling"], **conf["scal"])
+    f, fp, c, cp, d, dp = synth_inputs(Bs, 4321, "cpu", H)
     g = torch.Generator().manual_seed(7)
     perms = [O.super_perm(Bs, g) for _ in range(H["n_neg"])]
     times = []
@@ -91,24 +117,34 @@ def cpu_baseline(seconds_budget=15.0):
         c1 = c.clone().requires_grad_(True)
         cp1 = cp.clone().requires_grad_(True)
         t0 = time.time()
-        out = O.forward(cfg, f, fp, c1, cp1, d, dp, coords1=coords, coords2=coords, perms=perms)
+        if conf["dense"]:
+            coords1 = coords2 = O.identity_coords(Bs, H["S"])
+        elif conf["sampling"] == "fps":        # the sampler is part of the step (two calls, src/modules.py:1304-1308)
+            coords1 = O.farthest_point_sampling_depth((H["h"], H["w"]), d, H["S"]) * 2 - 1
+            coords2 = O.farthest_point_sampling_depth((H["h"], H["w"]), dp, H["S"]) * 2 - 1
+        else:
+            coords1 = torch.rand(Bs, H["S"], H["S"], 2, generator=g) * 2 - 1
+            coords2 = torch.rand(Bs, H["S"], H["S"], 2, generator=g) * 2 - 1
+        out = O.forward(cfg, f, fp, c1, cp1, d, dp, coords1=coords1, coords2=coords2, perms=perms)
         O.total_loss(cfg, out).backward()
         times.append(time.time() - t0)
         if time.time() - t_start > seconds_budget and len(times) >= 2:
             break
     timed = times[1:] if len(times) > 1 else times      # first repetition is the warm-up
     t = min(timed)
-    return {"value": (Bs / H["B"]) / t, "unit": "steps/s", "cores": ncores, "kind": "port",
+    return {"value": (Bs / H["B"]) / t, "unit": "steps/s", "cores": ncores, "host_cpus": host, "kind": "port",
             "sample": f"oracle forward+backward at B={Bs} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
-                      f"{H['n_neg']} negatives, {ncores} threads, min of {len(timed)} timed reps = {t:.2f} s; "
-                      f"value = ({Bs}/{H['B']}) / t"}
+                      f"{H['n_neg']} negatives, sampling={conf['sampling']}, {ncores} threads of {host} host CPUs, "
+                      f"min of {len(timed)} timed reps = {t:.2f} s; value = ({Bs}/{H['B']}) / t"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
+                    help="workload: the headline (default, BASELINE.json metric) or one of BASELINE.json's configs 2-5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="give each step's all-reduce one step of slack (it then overlaps the next step's kernels, as it would "
@@ -137,10 +173,11 @@ def main():
     from depthg_amd import ContrastiveCorrelationLoss, ops
     from depthg_amd.parallel import GradBucket
 
-    H = HEADLINE
-    cfg = make_cfg()
+    conf = CONFIGS[args.config]
+    H = conf["H"]
+    cfg = make_cfg(conf)
     loss_fn = ContrastiveCorrelationLoss(cfg)
-    f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev)
+    f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev, H)
     c.requires_grad_(True)
     cp.requires_grad_(True)
     bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None)
@@ -182,7 +219,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed   # every rank completes `steps` steps of its own B=32 shard
 
-    # ---- roofline of the dominant kernel (k_corr_main), measured live with HIP events on the launch stream
+    # ---- roofline of the dominant kernel (the fused correlation launch), measured live with HIP events on the launch stream
     desc, perms_t, ws = loss_fn.last_call
     reps = 20
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -200,34 +237,37 @@ def main():
     achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 correction on gfx950, WRITE_SIZE),
     # collected by scripts/profile_round.sh and committed under profiles/ (counters cannot be read from inside a run)
+    # the one-wave-per-SIMD form runs the ViT-S widths at P >= 160 (dg_corr2.hip), k_corr_main everything else
+    kname = "k_corr2" if (H["C"] > 128 and H["C"] <= 384 and H["D"] <= 80 and H["S"] ** 2 >= 129 and H["B"] <= 64) else "k_corr_main"
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
-        for name, vals in pmc.items():
-            if "k_corr_main" in name and "hbm_traffic_bytes_per_launch" in vals:
-                traffic = float(vals["hbm_traffic_bytes_per_launch"])
-    except (OSError, ValueError):
-        pass
+    if args.config == "headline":
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_per_launch.json")))
+            for name, vals in pmc.items():
+                if kname in name and "hbm_traffic_bytes_per_launch" in vals:
+                    traffic = float(vals["hbm_traffic_bytes_per_launch"])
+        except (OSError, ValueError):
+            pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "kernel": "k_corr_main", "kernel_ms": round(kern_ms, 4),
+                "kernel": kname, "kernel_ms": round(kern_ms, 4),
                 "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2)}
 
     if rank == 0:
         line = {
-            "metric": "correlation-loss steps/sec at B=32,C=384,28x28 (fwd+bwd, per-GPU batch 32)",
+            "metric": "correlation-loss steps/sec at B=32,C=384,28x28 (fwd+bwd, per-GPU batch 32)" if args.config == "headline"
+                      else f"correlation-loss steps/sec, {args.config} (fwd+bwd, per-GPU batch {H['B']})",
             "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (feats) / f16 (code) MFMA inputs, f32 accumulate", "data": "synthetic",
-            "config": {"workload": "headline: B=32/GPU, C=384, D=70, 28x28 dense grid (S=28, P=784), 5 negatives, "
-                                   "depth term on, pointwise, zero_clamp; fwd + bwd to orig_code/orig_code_pos",
+            "config": {"workload": conf["what"], "name": args.config,
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
                        "allreduce_elems": HEAD_GRAD_ELEMS if world > 1 else 0},
             "loss_total": float(total.detach()),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

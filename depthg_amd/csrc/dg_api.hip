@@ -62,8 +62,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.grad = (d->flags & DG_NEED_GRAD) != 0;
     p.pointwise = (d->flags & DG_POINTWISE) != 0;
     p.ident = (d->flags & DG_IDENTITY_GRID) != 0;
-    if (p.ident && (p.Sh != p.S || !p.shared || d->S != d->h || d->S != d->w || d->w > 32))
-        return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs DG_SHARED_COORDS and S == h == w <= 32");
+    if (p.ident && (p.Sh != p.S || !p.shared || d->S != d->h || d->S != d->w || d->w > 64))
+        return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs DG_SHARED_COORDS and S == h == w <= 64");
     p.nops = p.shared ? 2 : p.T;
     p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
     p.nrb = (p.Ppad + p.rf * 32 - 1) / (p.rf * 32);
@@ -75,7 +75,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
-        p.colpart[i] = take(B * (size_t)(p.ident ? p.h : p.Ppad / 32) * p.KF * 4);
+        p.colpart[i] = take(B * (size_t)(p.ident ? p.h * ((p.w + 31) / 32) : p.Ppad / 32) * p.KF * 4);
         p.bbar[i] = take(B * p.KF * 4);
         p.bsplit[i] = take(B * 2 * p.KF * 2);
         p.ccolpart[i] = take(B * (size_t)(p.Ppad / 32) * p.KD * 4);
@@ -288,7 +288,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         for (int o = 0; o < p.nops; ++o) {
             c.colpart[o] = p.pointwise ? F32(p.colpart[o]) : nullptr; c.bbar[o] = F32(p.bbar[o]);
             c.bsplit[o] = reinterpret_cast<__bf16*>(ws + p.bsplit[o]);
-            c.ngroups[o] = p.ident ? p.h : p.Ppad / 32;
+            c.ngroups[o] = p.ident ? p.h * ((p.w + 31) / 32) : p.Ppad / 32;
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
         DG_HIP(dg_launch_colmean(c, stream));

@@ -415,8 +415,10 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
 #else
         constexpr int cgsel = 16;
 #endif
-        const int CGv = cgsel == 32 ? 32 : (cgsel == 8 ? 8 : 16);
-        const size_t dsm = (size_t)CGv * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12;
+        int CGv = cgsel == 32 ? 32 : (cgsel == 8 ? 8 : 16);
+        auto stage_bytes = [&](int cg) { return (size_t)cg * (HW + 2) * 4 + (size_t)DENSE_MAXROUTE * 12; };
+        if (stage_bytes(CGv) > 150 * 1024 && CGv > 8) CGv = 8;      // 56 x 56 maps: 8 channels per block keep the [channel][pixel] stage in LDS
+        const size_t dsm = stage_bytes(CGv);
         if (a.dense && a.S == a.h && a.S == a.w && dsm <= 150 * 1024 && (size_t)nrouted * a.B <= DENSE_MAXROUTE) {
             auto launch = [&](auto kern, int threads) -> hipError_t {
                 hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), (int)dsm);

@@ -173,12 +173,14 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 // (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
 // grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
 template <int MAXU>      // channels per thread = KF / 8 <= MAXU
-__device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int n, int o) {
+__device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int xb, int n, int o) {
     // thread (x = tid & 31, k0 = tid >> 5) owns pixel x of the row and the channels k0 + 8u: all of them are loaded in one
     // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a pixel through LDS,
     // and only the NORMALISED bf16 row tile goes to LDS (half the bytes of an fp32 stage -> twice the blocks per CU).
-    const int tid = threadIdx.x, x = tid & 31, k0 = tid >> 5;
+    // maps wider than 32 pixels (56 x 56 at 448 input) are covered by ceil(w / 32) blocks per source row: xb = 32-pixel segment
+    const int tid = threadIdx.x, xl = tid & 31, x = xb * 32 + xl, k0 = tid >> 5;
     const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h;
+    const int wseg = min(32, w - xb * 32);          // pixels of this segment
     const int RS = KF * 2 + 16;                     // LDS row stride in bytes: 16-byte aligned rows (granule reads), 2-way writes at worst
     const DgBlob L(a.KF, a.KD);
     const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w + x;
@@ -194,25 +196,25 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     }
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) ss = fmaf(t[u], t[u], ss);
-    red[k0 * 32 + x] = ss;
+    red[k0 * 32 + xl] = ss;
     __syncthreads();
     ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ss += red[j * 32 + x];
+    for (int j = 0; j < 8; ++j) ss += red[j * 32 + xl];
     const float inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
     if (x < w) {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
-            if (u < nu) *reinterpret_cast<__bf16*>(tb + x * RS + (k0 + 8 * u) * 2) = (__bf16)(t[u] * inv);
+            if (u < nu) *reinterpret_cast<__bf16*>(tb + xl * RS + (k0 + 8 * u) * 2) = (__bf16)(t[u] * inv);
     }
     __syncthreads();
     if (DG_DBG(a.debug) & 32) return;                       // (ablation: loads + normalisation only)
     // blob rows: position p = x*S + y (sample() output (i, j) = (x, y)); 8-byte pieces, the lanes of a row run along K
     const int pieces = KF / 8;                      // granules (16 bytes) per row
-    for (int id = tid; id < w * pieces; id += 256) {
+    for (int id = tid; id < wseg * pieces; id += 256) {
         const int xx = id / pieces, g = id - xx * pieces;
         const uint4 v = *reinterpret_cast<const uint4*>(tb + xx * RS + g * 16);
-        const int p = xx * S + y;
+        const int p = (xb * 32 + xx) * S + y;
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
         *reinterpret_cast<uint4*>(blob + L.f(p & 31, g)) = v;
     }
@@ -220,11 +222,11 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     // per-source-row column sums of the normalised (bf16-rounded, i.e. exactly what the MFMA sees) rows
     for (int k = tid; k < KF; k += 256) {
         float cs = 0.f;
-        for (int xx = 0; xx < w; ++xx) cs += (float)*reinterpret_cast<const __bf16*>(tb + xx * RS + k * 2);
-        a.colpart[o][((size_t)n * h + y) * KF + k] = cs;
+        for (int xx = 0; xx < wseg; ++xx) cs += (float)*reinterpret_cast<const __bf16*>(tb + xx * RS + k * 2);
+        a.colpart[o][((size_t)n * (h * ((w + 31) / 32)) + xb * h + y) * KF + k] = cs;      // one partial per (segment, source row)
     }
     // zero rows of the ragged last tile (positions P .. Ppad-1), once per image
-    if (y == 0) {
+    if (y == 0 && xb == 0) {
         for (int idx = tid; idx < (a.Ppad - a.P) * (KF / 4); idx += 256) {
             const int p = a.P + idx / (KF / 4), k = (idx % (KF / 4)) * 4;
             char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
@@ -342,11 +344,11 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    const int gx = a.h;                                  // (>= the code role's ceil(tiles / DENSE_TPB) blocks: launcher)
+    const int gx = a.h * ((a.w + 31) / 32);              // (>= the code role's ceil(tiles / DENSE_TPB) blocks: launcher)
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
     if (z < 2) {
-        if (x < a.h && !(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
+        if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x % a.h, x / a.h, n, z);
     } else if (z < 4) {
         if (x * DENSE_TPB < a.Ppad / 32 && !(DG_DBG(a.debug) & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
     } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
 }
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
-    if (a.w > 32 || a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
-    const int nt = a.Ppad / 32, gx = a.h;
+    if (a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
+    const int nt = a.Ppad / 32, gx = a.h * ((a.w + 31) / 32);
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
     const int smem = max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
                          DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);

@@ -6,7 +6,7 @@ tag=${1:-r01}
 export TMPDIR=/tmp
 out=/root/repo/gpurun_out/$tag
 mkdir -p $out
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
 cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
@@ -23,7 +23,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for k, v in acc.items():
         if k.startswith(("k_", "void k_")):
             res.setdefault(k, {}).update({c: val / len(disp[k]) for c, val in v.items()})
-main = [k for k in res if "k_corr_main" in k][0]
+main = [k for k in res if "k_corr2" in k or "k_corr_main" in k][0]
 m = res[main]
 # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide stream -> x2
 m["hbm_read_bytes_corrected"] = 2 * m["FETCH_SIZE"] * 1024

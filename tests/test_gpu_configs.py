@@ -1,0 +1,234 @@
+"""GPU parity at the shapes of BASELINE.json's configs 2-5 and the remaining surface the round-1
+review found untested: sample() with coordinates outside [-1, 1] (border padding, src/modules.py:822-825), the dense
+identity path on 56x56 maps, the loss under an initialised RCCL process group.
+
+Tolerances as in test_gpu_parity.py: loss means 2e-3 relative + 1e-5 absolute on small cases (1e-4 relative at the headline
+width), gradients relative L2 <= 3e-2 with zero_clamp (mask flips of fp16 cd), <= 3e-3 without."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from test_gpu_parity import _relclose, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pair(cfg, f, fp, c, cp, d, dp, coords1, coords2, perms, dev, **kw):
+    """oracle (CPU) and HIP path on the same tensors -> (ref tuple, ref grads, got tuple, got grads)"""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, dp, coords1=coords1, coords2=coords2, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    T = lambda t: t.to(dev)
+    cg, cpg = T(c).requires_grad_(True), T(cp).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(T(f), T(fp), cg, cpg, T(d), T(coords1), T(coords2),
+                                                       [T(p) for p in perms], **kw)
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
+    return ref, (cr.grad, cpr.grad), out, (cg.grad.cpu(), cpg.grad.cpu())
+
+
+def _check(ref, rgrads, out, ggrads, rt=2e-3, gt=3e-2):
+    n = len(ref)
+    for i in range(0, n, 2):
+        _relclose(out[i].mean(), ref[i].mean(), rt, 1e-5, f"tuple[{i}]")
+    for i in range(1, n, 2):
+        _relclose(out[i].mean(), ref[i].mean(), rt, 1e-5, f"tuple[{i}] mean")
+    for got, want in zip(ggrads, rgrads):
+        assert torch.isfinite(got).all()
+        rel = (got - want).norm() / want.norm()
+        assert rel < gt, float(rel)
+
+
+def test_config4_shard_shape_fps(dev):
+    """BASELINE config 4, one rank's shard: COCO-Stuff ViT-B recipe (paper_reproduction.sh:8) - B=8, C=768, dim=90,
+    feature_samples=12, depth_sampling=fps.  Coordinates from the HIP sampler must equal the oracle's, then the loss."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(404)
+    B, C, D, hw, S, N = 8, 768, 90, 28, 12, 5
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(1, 256, (B, 1, 224, 224), generator=g).float()
+    dp = torch.randint(1, 256, (B, 1, 224, 224), generator=g).float()
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, depth_sampling="fps", dg_outputs="reduced",
+                        pos_intra_shift=0.123, pos_inter_shift=0.21, neg_inter_shift=0.975, depth_feat_shift=0.0359,
+                        pos_intra_weight=0.2305, pos_inter_weight=1.05, neg_inter_weight=0.2485, depth_feat_weight=0.16)
+    c1 = O.farthest_point_sampling_depth((hw, hw), d, S) * 2 - 1
+    c2 = O.farthest_point_sampling_depth((hw, hw), dp, S) * 2 - 1
+    g1 = ops.fps_coords(d.to(dev), (hw, hw), S).cpu()
+    g2 = ops.fps_coords(dp.to(dev), (hw, hw), S).cpu()
+    assert torch.equal(g1, c1) and torch.equal(g2, c2), "FPS coordinates must be bit-identical"
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev))
+
+
+def test_config3_vitb_no_pointwise(dev):
+    """BASELINE config 3: Cityscapes ViT-B recipe (paper_reproduction.sh:11) - C=768, dim=100, feature_samples=11,
+    depth_sampling=none, pointwise=False (no centering: the rank-1 correction is off, m0 unused)."""
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(303)
+    B, C, D, hw, S, N = 4, 768, 100, 28, 11, 5
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float()
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, pointwise=False, dg_outputs="reduced",
+                        pos_intra_shift=0.39, pos_inter_shift=0.25, neg_inter_shift=0.26, depth_feat_shift=0.03,
+                        pos_intra_weight=0.95, pos_inter_weight=1.02, neg_inter_weight=0.57, depth_feat_weight=0.09)
+    c1 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    c2 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    _check(*_pair(cfg, f, fp, c, cp, d, d, c1, c2, perms, dev))
+
+
+def test_config2_potsdam_recipe_fps(dev):
+    """BASELINE config 2: Potsdam ViT-S recipe (paper_reproduction.sh:14) - C=384, dim=90, feature_samples=11, fps; depth
+    quantised to {0, 1} as the Potsdam loader leaves it (quirk Q11), so the depth indicators are mixed."""
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(202)
+    B, C, D, hw, S, N = 4, 384, 90, 28, 11, 5
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = (torch.rand(B, 1, 224, 224, generator=g) > 0.3).float()
+    dp = (torch.rand(B, 1, 224, 224, generator=g) > 0.3).float()
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, depth_sampling="fps", dg_outputs="reduced",
+                        pos_intra_shift=0.2, pos_inter_shift=0.09, neg_inter_shift=0.63, depth_feat_shift=0.14,
+                        pos_intra_weight=0.61, pos_inter_weight=0.34, neg_inter_weight=0.72, depth_feat_weight=0.13)
+    c1 = O.farthest_point_sampling_depth((hw, hw), d, S) * 2 - 1
+    c2 = O.farthest_point_sampling_depth((hw, hw), dp, S) * 2 - 1
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev))
+
+
+def test_config5_hires_56_vs_oracle(dev):
+    """BASELINE config 5 at a size the oracle finishes in seconds: 56x56 maps (ViT-S/8 at 448 input), dense identity grid
+    (P = 3136), B=2, against the oracle - through the NCHW fast path, which used to refuse w > 32."""
+    from depthg_amd.loss import identity_coords
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(505)
+    B, C, D, hw, N = 2, 384, 70, 56, 2
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 448, 448), generator=g).float()
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs="reduced")
+    coords = identity_coords(B, hw, "cpu")
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    ref, rg, out, gg = _pair(cfg, f, fp, c, cp, d, d, coords, coords, perms, dev, shared_coords=True, identity_grid=True)
+    _check(ref, rg, out, gg, rt=5e-4)
+    # the general gather path on the same coordinates (no identity flag) must agree with the fast path
+    _, _, out2, gg2 = _pair(cfg, f, fp, c, cp, d, d, coords, coords, perms, dev)
+    for i in (0, 2, 4, 6):
+        _relclose(out2[i].mean(), out[i].mean(), 5e-5, 1e-7, f"general vs dense tuple[{i}]")
+    for a, b in zip(gg, gg2):
+        assert (a - b).norm() / b.norm() < 5e-3
+
+
+def test_config5_hires_56_full_batch_properties(dev):
+    """Config 5 at BASELINE's batch (B=32, 56x56 dense, 5 negatives): size-independent properties - the loss is linear in
+    the shifts, the gradient linear in the upstream weights, everything finite."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(506)
+    B, C, D, hw, N = 32, 384, 70, 56, 5
+    T = lambda t: t.to(dev)
+    f, fp = T(torch.randn(B, C, hw, hw, generator=g)), T(torch.randn(B, C, hw, hw, generator=g))
+    c, cp = T(torch.randn(B, D, hw, hw, generator=g)), T(torch.randn(B, D, hw, hw, generator=g))
+    d = T(torch.randint(0, 256, (B, 1, 448, 448), generator=g).float())
+    torch.manual_seed(1)
+
+    def run(shift_scale, wscale):
+        cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=True,
+                            pos_intra_shift=0.08 * shift_scale, pos_inter_shift=0.02 * shift_scale,
+                            neg_inter_shift=0.66 * shift_scale, depth_feat_shift=0.03 * shift_scale,
+                            correspondence_weight=wscale)
+        loss = ContrastiveCorrelationLoss(cfg)
+        cg, cpg = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+        torch.manual_seed(7)                      # same negatives in every run
+        loss(f, fp, None, None, cg, cpg, d, d)
+        sc = loss.scalars.detach().clone()
+        loss.total.backward()
+        torch.cuda.synchronize()
+        return sc, cg.grad, cpg.grad
+
+    s1, g1, gp1 = run(1.0, 1.0)
+    s2, g2, gp2 = run(2.0, 1.0)
+    s3, g3, gp3 = run(3.0, 1.0)
+    assert torch.isfinite(s1).all() and torch.isfinite(g1).all() and torch.isfinite(gp1).all()
+    # loss_i(shift) = -sum clamp(cd) (fd - shift) / n: affine in the shift -> second difference vanishes
+    for i in range(4):
+        a, b, cc = float(s1[i]), float(s2[i]), float(s3[i])
+        assert abs(a - 2 * b + cc) <= 2e-5 * max(abs(a), abs(b), abs(cc)) + 1e-8, (i, a, b, cc)
+    s4, g4, gp4 = run(1.0, 2.5)
+    assert torch.allclose(g4, 2.5 * g1, rtol=1e-4, atol=1e-9) and torch.allclose(gp4, 2.5 * gp1, rtol=1e-4, atol=1e-9)
+
+
+def test_sample_out_of_range_coords(dev):
+    """sample() = grid_sample(..., padding_mode='border', align_corners=True): coordinates beyond [-1, 1] read the border
+    pixel (src/modules.py:822-825); forward and the adjoint (gradient lands on the border pixels) against the oracle."""
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(909)
+    B, C, D, hw, S, N = 2, 64, 40, 12, 9, 2
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 48, 48), generator=g).float()
+    c1 = torch.rand(B, S, S, 2, generator=g) * 3.0 - 1.5            # a third of the samples fall outside
+    c2 = torch.rand(B, S, S, 2, generator=g) * 3.0 - 1.5
+    c1[0, 0, 0] = torch.tensor([-7.0, 9.0]); c1[0, 0, 1] = torch.tensor([1.0, -1.0]); c2[1, 3, 3] = torch.tensor([1e6, -1e6])
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced")
+    assert float((c1.abs() > 1).float().mean()) > 0.2
+    _check(*_pair(cfg, f, fp, c, cp, d, d, c1, c2, perms, dev))
+
+
+_RCCL_CHILD = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
+import torch.distributed as dist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)      # before any other GPU call
+from depthg_amd import ContrastiveCorrelationLoss
+from depthg_amd.parallel import GradBucket
+from oracle import depthg_oracle as O
+g = torch.Generator().manual_seed(77)
+B, C, D, hw, S, N = 2, 64, 70, 14, 11, 3
+f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+d = torch.randint(0, 256, (B, 1, 56, 56), generator=g).float()
+c1 = torch.rand(B, S, S, 2, generator=g) * 2 - 1; c2 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
+perms = [O.super_perm(B, g) for _ in range(N)]
+cfg = O.default_cfg(feature_samples=S, neg_samples=N, dg_outputs="reduced")
+cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+O.total_loss(cfg, O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)).backward()
+T = lambda t: t.to(dev)
+cg, cpg = T(c).requires_grad_(True), T(cp).requires_grad_(True)
+loss = ContrastiveCorrelationLoss(cfg)
+loss.forward_with(T(f), T(fp), cg, cpg, T(d), T(c1), T(c2), [T(p) for p in perms])
+loss.total.backward()
+bucket = GradBucket(cg.grad.numel() + cpg.grad.numel(), dev, dist)
+bucket.fill_from(torch.cat([cg.grad.reshape(-1), cpg.grad.reshape(-1)]))
+bucket.allreduce_mean_(even_if_alone=True)
+bucket.wait()
+torch.cuda.synchronize()
+got = bucket.flat.cpu()
+want = torch.cat([cr.grad.reshape(-1), cpr.grad.reshape(-1)])
+rel = float((got - want).norm() / want.norm())
+dist.destroy_process_group()
+assert rel < 3e-2, rel
+print("RCCL_OK", rel)
+"""
+
+
+def test_loss_under_rccl_process_group():
+    """The HIP loss + GradBucket under an initialised RCCL process group (world size 1, in a fresh child process: the group
+    is created before any other GPU call, as bench.py does under torch.distributed.run): the all-reduced bucket equals the
+    oracle's gradient.  The 1->8 scaling itself can only be measured by the driver."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
