@@ -247,3 +247,34 @@ def test_nns_file_format_and_online_pick(tmp_path):
     assert picks == p["picks"].tolist()
     with pytest.raises(RuntimeError, match="GPU"):
         knn.nearest_neighbors(torch.from_numpy(g["small_feats"]))
+
+
+def test_corr2_owns_the_accumulator_file(tmp_path):
+    """dg_corr2.hip names accumulator registers literally in inline asm (the stationary feature fragments live there for a
+    whole block).  hipcc must neither spill nor allocate values of its own into that file - it does both silently when the
+    arch VGPRs run short ("0 spills" in the resource report, v_accvgpr_write / _read around every use).  Audit of the generated
+    code: no scratch, no spills, and no accumulator-register instruction outside the kernel's own asm statements."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "depthg_amd", "csrc", "dg_corr2.hip")
+    out = tmp_path / "dg_corr2.s"
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    assert "scratch_" not in text, "dg_corr2 spills to scratch: its counted vmcnt waits no longer hold"
+    inside, stray = False, []
+    for line in text.splitlines():
+        if ";;#ASMSTART" in line:
+            inside = True
+        elif ";;#ASMEND" in line:
+            inside = False
+        elif not inside and re.search(r"\bv_accvgpr_|\ba\[?\d+", line) and not line.lstrip().startswith((";", ".")):
+            stray.append(line.strip())
+    assert not stray, f"hipcc uses accumulator registers outside the kernel's asm statements: {stray[:5]}"
+    m = re.search(r"\.vgpr_spill_count:\s+(\d+)", text)
+    assert m and int(m.group(1)) == 0
+    m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", text)
+    assert m and int(m.group(1)) == 0
