@@ -677,7 +677,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 // S code is applied in registers and the accumulator tile is written as a gradient tile (dg_gtile_off).
 // grid (ceil(nt/GS_CW), B, jobs), block (GS_CW+1)*64, dynamic LDS GS_NB P parts + GS_CW scratch tiles.
 #define GS_CW 7
+#ifndef GS_NB
 #define GS_NB 6
+#endif
 #define GS_TS 80            // row stride (bytes) of the transposition scratch
 template <int CH>
 __device__ __forceinline__ void gs_wait_tiles(int k) {   // at most k tiles (CH DMA instructions each) still in flight

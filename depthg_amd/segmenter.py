@@ -1,0 +1,239 @@
+"""Producers and caller of the correlation loss: the segmentation head, the probes and one optimisation step
+(SURVEY.md section 8 rows A14, N1 and the step-level caller around A13).
+
+Mirrors, with the reference's names, parameter layout and arithmetic:
+    ProjectionHead          the trainable part of DinoFeaturizer - `cluster1` (1x1 conv C -> dim) and, for
+                            projection_type == "nonlinear", `cluster2` (1x1 conv C -> C, ReLU, 1x1 conv C -> dim), each fed by its
+                            OWN Dropout2d(p=.1) mask of the backbone features (src/modules.py:39,75-88,122-126; quirk Q10)
+    StandInFeaturizer       a featurizer with DinoFeaturizer's output contract (src/modules.py:90-137: train -> (feats, code,
+                            attn), eval -> (feats, code); feats get a third Dropout2d mask when cfg.dropout).  The frozen DINO
+                            ViT itself is out of scope (north_star: "the Python host calls PyTorch-ROCm for the ViT forward") and
+                            its weights cannot be fetched here, so the backbone is a frozen random patch embedding of the same
+                            geometry (patch size, n_feats, no gradient) - any module returning (B, n_feats, H/p, W/p) can be
+                            passed instead.
+    ClusterLookup           src/modules.py:647-675 (cosine cluster probe, hard assignment when alpha is None)
+    UnsupervisedSegmenter   LitUnsupervisedSegmenter without Lightning (src/train_segmentation.py:71-158, 169-462): attributes
+                            net / train_cluster_probe / cluster_probe / linear_probe / contrastive_corr_loss_fn / cfg /
+                            n_classes / use_depth, forward(x) = net(x)[1], configure_optimizers() -> three Adams,
+                            training_step(batch, batch_idx) with manual optimisation: two featurizer passes, the HIP correlation
+                            loss (and the second LHP call when cfg.lhp), the weighted total, the live legacy decay of the cfg
+                            scalars, linear-probe cross entropy and cluster-probe loss on the detached code, backward, three steps.
+The 1x1 convolutions are plain GEMMs and stay library calls (torch on ROCm = rocBLAS / MIOpen); everything the correlation
+loss does runs in the HIP library.  Under data parallelism the head gradients are what `parallel.GradBucket` all-reduces.
+"""
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .depth_decay import legacy_decay_step
+from .lhp import LocalHiddenPositiveProjection
+from .loss import ContrastiveCorrelationLoss
+from .training import correspondence_total
+
+
+class ProjectionHead(nn.Module):
+    """cluster1 / cluster2 of DinoFeaturizer (src/modules.py:75-88) with the reference's module and parameter names, so that a
+    reference checkpoint's `net.cluster1.0.weight`, `net.cluster2.0.weight`, ... load unchanged."""
+
+    def __init__(self, n_feats: int, dim: int, projection_type: Optional[str] = "nonlinear"):
+        super().__init__()
+        self.n_feats, self.dim, self.proj_type = n_feats, dim, projection_type
+        self.dropout = nn.Dropout2d(p=.1)
+        self.cluster1 = nn.Sequential(nn.Conv2d(n_feats, dim, (1, 1)))
+        if projection_type == "nonlinear":
+            self.cluster2 = nn.Sequential(nn.Conv2d(n_feats, n_feats, (1, 1)), nn.ReLU(), nn.Conv2d(n_feats, dim, (1, 1)))
+
+    def forward(self, image_feat: torch.Tensor) -> torch.Tensor:
+        if self.proj_type is None:                      # src/modules.py:127-128
+            return image_feat
+        code = self.cluster1(self.dropout(image_feat))  # :123   (own Dropout2d draw)
+        if self.proj_type == "nonlinear":
+            code = code + self.cluster2(self.dropout(image_feat))   # :124-125 (a second, independent draw)
+        return code
+
+
+class StandInFeaturizer(nn.Module):
+    """DinoFeaturizer's contract with a frozen stand-in backbone (see the module docstring)."""
+
+    def __init__(self, dim: int, cfg, backbone: Optional[nn.Module] = None):
+        super().__init__()
+        self.cfg, self.dim = cfg, dim
+        self.patch_size = int(cfg.dino_patch_size)
+        arch = str(getattr(cfg, "model_type", "vit_small"))
+        self.n_feats = 384 if "small" in arch else 768          # src/modules.py:70-73
+        if backbone is None:
+            backbone = nn.Conv2d(3, self.n_feats, self.patch_size, stride=self.patch_size)
+        self.model = backbone
+        for p in self.model.parameters():                       # frozen, as the DINO ViT (:34-35)
+            p.requires_grad = False
+        self.dropout = nn.Dropout2d(p=.1)
+        head = ProjectionHead(self.n_feats, dim, getattr(cfg, "projection_type", "nonlinear"))
+        self.cluster1 = head.cluster1                           # registered under the reference's names
+        if hasattr(head, "cluster2"):
+            self.cluster2 = head.cluster2
+        self.proj_type = head.proj_type
+
+    def forward(self, img, n=1, return_class_feat=False):
+        self.model.eval()
+        with torch.no_grad():
+            assert img.shape[2] % self.patch_size == 0 and img.shape[3] % self.patch_size == 0   # :93-94
+            image_feat = self.model(img)
+            if return_class_feat:
+                return image_feat.mean((2, 3), keepdim=True)
+            attn = torch.zeros(1, device=image_feat.device)      # (the stand-in has no attention maps: a placeholder, as a ViT's would be passed on)
+        if self.proj_type is not None:
+            code = self.cluster1(self.dropout(image_feat))
+            if self.proj_type == "nonlinear":
+                code = code + self.cluster2(self.dropout(image_feat))
+        else:
+            code = image_feat
+        feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
+        return (feats, code, attn) if self.training else (feats, code)
+
+
+class ClusterLookup(nn.Module):
+    """src/modules.py:647-675."""
+
+    def __init__(self, dim: int, n_classes: int):
+        super().__init__()
+        self.n_classes, self.dim = n_classes, dim
+        self.clusters = nn.Parameter(torch.randn(n_classes, dim))
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.clusters.copy_(torch.randn(self.n_classes, self.dim))
+
+    def forward(self, x, alpha, log_probs=False):
+        normed_clusters = F.normalize(self.clusters, dim=1)
+        normed_features = F.normalize(x, dim=1)
+        inner_products = torch.einsum("bchw,nc->bnhw", normed_features, normed_clusters)
+        if alpha is None:
+            cluster_probs = F.one_hot(torch.argmax(inner_products, dim=1), self.clusters.shape[0]).permute(0, 3, 1, 2).to(torch.float32)
+        else:
+            cluster_probs = F.softmax(inner_products * alpha, dim=1)
+        cluster_loss = -(cluster_probs * inner_products).sum(1).mean()
+        if log_probs:
+            return F.log_softmax(inner_products * alpha, dim=1)
+        return cluster_loss, cluster_probs
+
+
+class UnsupervisedSegmenter(nn.Module):
+    """LitUnsupervisedSegmenter(n_classes, cfg) without the Lightning plumbing (src/train_segmentation.py:71-158)."""
+
+    def __init__(self, n_classes: int, cfg, net: Optional[nn.Module] = None):
+        super().__init__()
+        self.cfg, self.n_classes = cfg, n_classes
+        dim = n_classes if not cfg.continuous else cfg.dim                          # :78-81
+        self.use_depth = bool(cfg.use_depth)
+        self.net = net if net is not None else StandInFeaturizer(dim, cfg)           # :99-108 (arch == "dino")
+        self.train_cluster_probe = ClusterLookup(dim, n_classes)                      # :110
+        self.cluster_probe = ClusterLookup(dim, n_classes + cfg.extra_clusters)       # :112
+        self.linear_probe = nn.Conv2d(dim, n_classes, (1, 1))                         # :113
+        self.linear_probe_loss_fn = nn.CrossEntropyLoss()                             # :127
+        self.contrastive_corr_loss_fn = ContrastiveCorrelationLoss(cfg)               # :131 (shares cfg: the decay below mutates it)
+        for p in self.contrastive_corr_loss_fn.parameters():                          # :136
+            p.requires_grad = False
+        if getattr(cfg, "lhp", False):
+            self.lhp_module = LocalHiddenPositiveProjection(cfg)
+        self.automatic_optimization = False                                           # :139
+        self.global_step = 0
+        self._optims = None
+
+    def forward(self, x):
+        return self.net(x)[1]                                                          # :160-167
+
+    def configure_optimizers(self):                                                    # :537-547
+        main_params = list(self.net.parameters())
+        if getattr(self.cfg, "lhp", False):
+            main_params += list(self.lhp_module.parameters())
+        net_optim = torch.optim.Adam([p for p in main_params if p.requires_grad], lr=self.cfg.lr)
+        linear_probe_optim = torch.optim.Adam(list(self.linear_probe.parameters()), lr=5e-3)
+        cluster_probe_optim = torch.optim.Adam(list(self.cluster_probe.parameters()), lr=5e-3)
+        return net_optim, linear_probe_optim, cluster_probe_optim
+
+    def optimizers(self):
+        if self._optims is None:
+            self._optims = self.configure_optimizers()
+        return self._optims
+
+    def head_parameters(self):
+        """The parameters net_optim steps (= what a data-parallel run all-reduces: cluster1 + cluster2)."""
+        return [p for p in self.net.parameters() if p.requires_grad]
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, grad_sync=None):
+        """One optimisation step (src/train_segmentation.py:169-462).  `grad_sync`: callable run between backward and the
+        optimiser steps (data parallelism: GradBucket pack / all-reduce / unpack); returns (loss, logs)."""
+        cfg = self.cfg
+        net_optim, linear_probe_optim, cluster_probe_optim = self.optimizers()
+        net_optim.zero_grad(); linear_probe_optim.zero_grad(); cluster_probe_optim.zero_grad()        # :174-176
+        img, img_pos, label = batch["img"], batch["img_pos"], batch["label"]
+        depth = batch["depth"] if self.use_depth else None
+        depth_pos = batch["depth_pos"] if self.use_depth else None
+
+        feats, code, attn = self.net(img)                                                            # :194-200
+        lhp_code = self.lhp_module(code, depth, img, attn) if getattr(cfg, "lhp", False) else None    # :202-203
+        logs: Dict[str, torch.Tensor] = {}
+        loss = 0
+        if cfg.correspondence_weight > 0:
+            feats_pos, code_pos, _ = self.net(img_pos)                                               # :207-212
+            lhp_code_pos = self.lhp_module(code_pos, None) if getattr(cfg, "lhp", False) else None   # :214-215
+            salience = batch["mask"].to(torch.float32).squeeze(1) if cfg.use_salience else None      # :233-238
+            salience_pos = batch["mask_pos"].to(torch.float32).squeeze(1) if cfg.use_salience else None
+            use_depth_term = bool(cfg.depth_feat_correlation_loss)
+            d_args = (depth, depth_pos) if use_depth_term else (None, None)                          # :242-292
+            out = self.contrastive_corr_loss_fn(feats, feats_pos, salience, salience_pos, code, code_pos, *d_args)
+            lhp_out = None
+            if getattr(cfg, "lhp", False) and use_depth_term:
+                lhp_out = self.contrastive_corr_loss_fn(feats, feats_pos, salience, salience_pos, lhp_code, lhp_code_pos, *d_args)
+            total, logs = correspondence_total(cfg, out, lhp_out)                                    # :303-350
+            loss = loss + total
+            legacy_decay_step(cfg, self.contrastive_corr_loss_fn.cfg, self.global_step)              # :356-375 (mutates cfg)
+
+        # probes on the detached code (:421-444)
+        flat_label = label.reshape(-1)
+        mask = (flat_label >= 0) & (flat_label < self.n_classes)
+        detached_code = code.detach().clone()
+        linear_logits = self.linear_probe(detached_code)
+        linear_logits = F.interpolate(linear_logits, label.shape[-2:], mode="bilinear", align_corners=False)
+        linear_logits = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.n_classes)
+        linear_loss = self.linear_probe_loss_fn(linear_logits[mask], flat_label[mask]).mean()
+        cluster_loss, _ = self.cluster_probe(detached_code, None)
+        loss = loss + linear_loss + cluster_loss
+        logs.update({"loss/linear": linear_loss.detach(), "loss/cluster": cluster_loss.detach(), "loss/total": loss.detach()})
+
+        loss.backward()                                                                               # :446
+        if grad_sync is not None:
+            grad_sync()
+        net_optim.step(); cluster_probe_optim.step(); linear_probe_optim.step()                       # :447-449
+        if cfg.reset_probe_steps is not None and self.global_step == cfg.reset_probe_steps:           # :451-455
+            self.linear_probe.reset_parameters()
+            self.cluster_probe.reset_parameters()
+            self._optims = (net_optim, torch.optim.Adam(list(self.linear_probe.parameters()), lr=5e-3),
+                            torch.optim.Adam(list(self.cluster_probe.parameters()), lr=5e-3))
+        self.global_step += 1
+        return loss.detach(), logs
+
+
+def default_segmenter_cfg(**over) -> SimpleNamespace:
+    """The keys training_step and the featurizer read, with the values of src/configs/local_config.yml."""
+    cfg = SimpleNamespace(
+        # featurizer / head
+        model_type="vit_small", dino_patch_size=8, dino_feat_type="feat", projection_type="nonlinear", dropout=True,
+        pretrained_weights=None, continuous=True, dim=70, extra_clusters=0, arch="dino", lr=5e-4, reset_probe_steps=None,
+        # loss (hot path)
+        feature_samples=11, use_salience=False, depth_sampling="fps", fps_gpu=False, pointwise=True, zero_clamp=True, stabalize=False,
+        pos_intra_shift=0.18, pos_inter_shift=0.12, neg_inter_shift=0.46, neg_samples=5,
+        depth_feat_correlation_loss=True, depth_feat_shift=0.03,
+        # caller
+        use_depth=True, use_true_labels=False, correspondence_weight=1.0, pos_inter_weight=0.25, pos_intra_weight=0.67,
+        neg_inter_weight=0.63, depth_feat_weight=0.19, rec_weight=0.0, aug_alignment_weight=0.0, crf_weight=0.0, hist_freq=100,
+        depth_loss_decay=True, depth_loss_decay_factor=0.6, decay_every_steps=250, fix_depth_feat_shift=False,
+        fps_until_step=0, post_fps_samples=11, fps_sample_decay=True, fps_sample_decay_every_steps=1000,
+        fps_sample_decay_factor=0.9, fps_min_samples=0, lhp=False, lhp_weight=0.2, lhp_weight_balance=False,
+        lhp_depth_weight=0.5)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg

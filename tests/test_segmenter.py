@@ -1,0 +1,200 @@
+"""Head, probes and the step-level caller (depthg_amd/segmenter.py).
+CPU part: parity with vectors captured from the imported reference (tests/golden/head.npz, make_head_fixtures.py) and the
+constructor / attribute / optimiser surface of LitUnsupervisedSegmenter.  GPU part (-m gpu): one full training step through the
+HIP loss against the oracle chain on the CPU, the step-0 sample decay (quirk Q9: 11 -> 9 changes the kernel shapes between two
+steps), the LHP step, head gradients through parallel.GradBucket."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+class _TokenBackbone(torch.nn.Module):
+    """(B, 1 + h*w, C) tokens -> (B, C, h, w) as DinoFeaturizer.forward does for feat_type == 'feat' (src/modules.py:111)"""
+
+    def __init__(self, tokens, hw):
+        super().__init__()
+        self.register_buffer("tokens", tokens)
+        self.hw = hw
+
+    def forward(self, img):
+        t = self.tokens
+        return t[:, 1:, :].reshape(t.shape[0], self.hw, self.hw, -1).permute(0, 3, 1, 2)
+
+
+def _featurizer(fx, proj):
+    from depthg_amd.segmenter import StandInFeaturizer, default_segmenter_cfg
+    tokens = torch.from_numpy(fx["tokens"])
+    cfg = default_segmenter_cfg(dim=12, projection_type=proj, dino_patch_size=8)
+    net = StandInFeaturizer(12, cfg, backbone=_TokenBackbone(tokens, 6))
+    net.n_feats = 48
+    from depthg_amd.segmenter import ProjectionHead
+    head = ProjectionHead(48, 12, "nonlinear")
+    net.cluster1, net.cluster2 = head.cluster1, head.cluster2
+    with torch.no_grad():
+        for i, prm in enumerate(list(net.cluster1.parameters()) + list(net.cluster2.parameters())):
+            prm.copy_(torch.from_numpy(fx[f"{proj}_w{i}"]))
+    return net
+
+
+@pytest.mark.parametrize("proj", ["nonlinear", "linear"])
+def test_featurizer_contract_matches_reference(proj):
+    fx = load_golden("head.npz")
+    net = _featurizer(fx, proj)
+    img = torch.zeros(2, 3, 48, 48)
+    net.eval()
+    out = net(img)
+    assert len(out) == 2                                                  # eval: (feats, code)      src/modules.py:133-137
+    assert np.abs(out[0].numpy() - fx[f"{proj}_feats"]).max() < 1e-6
+    assert np.abs(out[1].detach().numpy() - fx[f"{proj}_code"]).max() < 2e-6
+    net.train()
+    out3 = net(img)
+    assert len(out3) == 3 and out3[0].shape == out[0].shape               # train: (feats, code, attn)   :128-132
+    assert out3[1].requires_grad and not out3[0].requires_grad            # gradients reach the head only (frozen backbone)
+    # reference parameter names (checkpoints carry net.cluster1.0.weight, net.cluster2.2.bias, ...)
+    names = {n for n, _ in net.named_parameters() if "cluster" in n}
+    assert names == {"cluster1.0.weight", "cluster1.0.bias", "cluster2.0.weight", "cluster2.0.bias", "cluster2.2.weight", "cluster2.2.bias"}
+    # Dropout2d zeroes whole channels of the returned feats (cfg.dropout) with its own mask per use (quirk Q10)
+    torch.manual_seed(0)
+    f1, c1, _ = net(img)
+    zeroed = (f1.abs().sum((2, 3)) == 0).float().mean()
+    assert 0.02 < float(zeroed) < 0.25
+    f2, c2, _ = net(img)
+    assert not torch.equal(f1, f2) and not torch.equal(c1, c2)
+
+
+def test_cluster_lookup_matches_reference():
+    from depthg_amd.segmenter import ClusterLookup
+    fx = load_golden("head.npz")
+    cl = ClusterLookup(12, 5)
+    with torch.no_grad():
+        cl.clusters.copy_(torch.from_numpy(fx["cl_clusters"]))
+    x = torch.from_numpy(fx["cl_x"]).requires_grad_(True)
+    loss_h, probs_h = cl(x, None)
+    loss_s, probs_s = cl(x, 2.0)
+    logp = cl(x, 2.0, log_probs=True)
+    (loss_h + loss_s).backward()
+    assert abs(float(loss_h) - float(fx["cl_loss_hard"])) < 1e-6 and abs(float(loss_s) - float(fx["cl_loss_soft"])) < 1e-6
+    assert np.array_equal(probs_h.numpy(), fx["cl_probs_hard"])
+    assert np.abs(probs_s.detach().numpy() - fx["cl_probs_soft"]).max() < 1e-6
+    assert np.abs(logp.detach().numpy() - fx["cl_logp"]).max() < 1e-5
+    assert np.abs(x.grad.numpy() - fx["cl_grad_x"]).max() < 1e-6
+    assert np.abs(cl.clusters.grad.numpy() - fx["cl_grad_clusters"]).max() < 1e-6
+
+
+def test_segmenter_surface():
+    """constructor / attributes / forward / optimisers of LitUnsupervisedSegmenter (src/train_segmentation.py:71-167,537-547)"""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from depthg_amd.segmenter import UnsupervisedSegmenter, default_segmenter_cfg
+    cfg = default_segmenter_cfg(dim=16, extra_clusters=3)
+    m = UnsupervisedSegmenter(27, cfg)
+    for attr in ("net", "train_cluster_probe", "cluster_probe", "linear_probe", "contrastive_corr_loss_fn", "cfg", "n_classes", "use_depth"):
+        assert hasattr(m, attr)
+    assert isinstance(m.contrastive_corr_loss_fn, ContrastiveCorrelationLoss) and m.contrastive_corr_loss_fn.cfg is m.cfg
+    assert m.cluster_probe.clusters.shape == (30, 16) and m.train_cluster_probe.clusters.shape == (27, 16)
+    assert m.linear_probe.weight.shape == (27, 16, 1, 1) and m.automatic_optimization is False
+    img = torch.randn(2, 3, 32, 32)
+    m.eval()
+    assert m(img).shape == (2, 16, 4, 4)                                   # forward(x) = net(x)[1]
+    net_optim, lin_optim, clu_optim = m.configure_optimizers()
+    n_net = sum(p.numel() for g in net_optim.param_groups for p in g["params"])
+    assert n_net == 384 * 16 + 16 + 384 * 384 + 384 + 384 * 16 + 16        # cluster1 + cluster2 only: the backbone is frozen
+    assert n_net == sum(p.numel() for p in m.head_parameters())
+    assert lin_optim.param_groups[0]["lr"] == 5e-3 and clu_optim.param_groups[0]["lr"] == 5e-3
+    # ViT-S / dim 70: the 201,740 parameters SURVEY.md section 8(e) sizes the all-reduce by
+    m70 = UnsupervisedSegmenter(27, default_segmenter_cfg(dim=70))
+    assert sum(p.numel() for p in m70.head_parameters()) == 201_740
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _batch(B, g, dev, hw_img=112, n_classes=27):
+    return {"img": torch.randn(B, 3, hw_img, hw_img, generator=g).to(dev),
+            "img_pos": torch.randn(B, 3, hw_img, hw_img, generator=g).to(dev),
+            "label": torch.randint(-1, n_classes, (B, hw_img, hw_img), generator=g).to(dev),
+            "depth": torch.randint(1, 256, (B, 1, hw_img, hw_img), generator=g).float().to(dev),
+            "depth_pos": torch.randint(1, 256, (B, 1, hw_img, hw_img), generator=g).float().to(dev)}
+
+
+@pytest.mark.gpu
+def test_training_step_matches_oracle_chain():
+    """One optimisation step on the GPU (HIP loss inside) against the same step assembled from the CPU oracle: total loss,
+    gradients of the head and the probes (captured between backward and the optimiser steps), the decayed cfg afterwards."""
+    from depthg_amd.segmenter import UnsupervisedSegmenter, default_segmenter_cfg
+    from depthg_amd.training import correspondence_total
+    from oracle import depthg_oracle as O
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B, S = 4, 11
+    cfg = default_segmenter_cfg(dim=70, dropout=False, feature_samples=S, fps_sample_decay=True, dg_outputs="reduced")
+    torch.manual_seed(3)
+    m = UnsupervisedSegmenter(27, cfg).to(dev)
+    m.train()
+    m.net.dropout.p = 0.0                       # the Dropout2d draws are the only non-reproducible part: off for the comparison
+    ref = copy.deepcopy(m).cpu()
+    ref_cfg = copy.deepcopy(cfg)
+    batch = _batch(B, g, dev)
+    grads = {}
+    torch.manual_seed(5)
+    loss, logs = m.training_step(batch, 0, grad_sync=lambda: grads.update({n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert cfg.feature_samples == 9 and m.contrastive_corr_loss_fn.cfg.feature_samples == 9     # quirk Q9: 11 -> int(9.9) at step 0
+    perms = m.contrastive_corr_loss_fn.last_call[1].cpu()
+    # --- the same step from the oracle
+    cb = {k: v.cpu() for k, v in batch.items()}
+    feats, code, _ = ref.net(cb["img"])
+    feats_pos, code_pos, _ = ref.net(cb["img_pos"])
+    hw = feats.shape[-1]
+    c1 = O.farthest_point_sampling_depth((hw, hw), cb["depth"], S) * 2 - 1
+    c2 = O.farthest_point_sampling_depth((hw, hw), cb["depth_pos"], S) * 2 - 1
+    out = O.forward(ref_cfg, feats, feats_pos, code, code_pos, cb["depth"], cb["depth_pos"], coords1=c1, coords2=c2, perms=list(perms))
+    total, _ = correspondence_total(ref_cfg, out)
+    flat = cb["label"].reshape(-1)
+    mask = (flat >= 0) & (flat < 27)
+    logits = torch.nn.functional.interpolate(ref.linear_probe(code.detach().clone()), cb["label"].shape[-2:], mode="bilinear", align_corners=False)
+    lin = ref.linear_probe_loss_fn(logits.permute(0, 2, 3, 1).reshape(-1, 27)[mask], flat[mask]).mean()
+    clu, _ = ref.cluster_probe(code.detach().clone(), None)
+    want = total + lin + clu
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 2e-3 * abs(float(want)) + 1e-5, (float(loss), float(want))
+    assert abs(float(logs["loss/linear"]) - float(lin)) < 1e-4 and abs(float(logs["loss/cluster"]) - float(clu)) < 1e-4
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        rel = float((grads[n] - p.grad).norm() / (p.grad.norm() + 1e-12))
+        assert rel < (3e-2 if "cluster1" in n or "cluster2" in n else 1e-3), (n, rel)
+    assert {"net.cluster1.0.weight", "net.cluster2.2.bias", "linear_probe.weight", "cluster_probe.clusters"} <= set(grads)
+
+
+@pytest.mark.gpu
+def test_training_steps_across_sample_decay_and_lhp():
+    """Three consecutive steps: step 0 runs at feature_samples = 11 and decays to 9 (different kernel shapes from step 1 on), the
+    depth weight decays at step 2; then one step of the LHP recipe (second loss call on the projected code).  Parameters move,
+    everything stays finite, the cfg trace equals the reference's decay statements."""
+    from depthg_amd.parallel import GradBucket
+    from depthg_amd.segmenter import UnsupervisedSegmenter, default_segmenter_cfg
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    cfg = default_segmenter_cfg(dim=70, decay_every_steps=2, dg_outputs="reduced")
+    torch.manual_seed(4)
+    m = UnsupervisedSegmenter(27, cfg).to(dev)
+    m.train()
+    bucket = GradBucket.for_parameters(m.head_parameters())
+    assert bucket.flat.numel() == 201_740
+    w0 = m.net.cluster1[0].weight.detach().clone()
+    trace = []
+    for step in range(3):
+        loss, logs = m.training_step(_batch(4, g, dev), step, grad_sync=lambda: (bucket.pack(), bucket.allreduce_mean_(), bucket.unpack()))
+        assert torch.isfinite(loss) and all(torch.isfinite(v).all() for v in logs.values())
+        trace.append((cfg.feature_samples, round(cfg.depth_feat_weight, 6), round(cfg.depth_feat_shift, 6)))
+    assert trace == [(9, 0.19, 0.03), (9, 0.19, 0.03), (9, round(0.19 * 0.6, 6), round(0.03 * 0.6, 6))]
+    assert torch.isfinite(bucket.flat).all() and float(bucket.flat.abs().sum()) > 0
+    assert not torch.equal(w0, m.net.cluster1[0].weight.detach())
+    # LHP recipe
+    cfg2 = default_segmenter_cfg(dim=70, lhp=True, lhp_weight=0.3, lhp_weight_balance=True, dg_outputs="reduced")
+    m2 = UnsupervisedSegmenter(27, cfg2).to(dev)
+    m2.train()
+    loss, logs = m2.training_step(_batch(2, g, dev), 0)
+    assert torch.isfinite(loss)
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in m2.lhp_module.parameters())
