@@ -29,7 +29,7 @@ __global__ __launch_bounds__(LHP_THREADS) void k_lhp_points(const float* __restr
     float s = 0.f;                                       // row-major sequential sum, like the reference's CPU pooling
     for (int y = ys; y < ye; ++y)
         for (int x = xs; x < xe; ++x) s = __fadd_rn(s, d[(size_t)y * W + x]);
-    const float dv = __fdiv_rn(s, (float)((ye - ys) * (xe - xs)));
+    const float dv = __fdiv_rn(__fdiv_rn(s, (float)(ye - ys)), (float)(xe - xs));     // sum / kh / kw: the operator's two divisions
     const float fd = __fmul_rn(factor, dv);
     float* p = points + (size_t)n * 3 * HW;
     p[idx] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)j, (float)w / 2.0f)), (float)w);            // X

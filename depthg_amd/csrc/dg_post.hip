@@ -459,117 +459,200 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
 // FPS.  One block per image.  All arithmetic is IEEE fp32 with the reference's operation order and
 // no fused multiply-add, so that the selected set is bit-identical to numpy's for the same depth.
 #define FPS_THREADS 256
-// Wave-wide max / min through DPP: inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then the row totals are
-// carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lane 63 holds the result.
-__device__ __forceinline__ float dpp_wave_max(float v) {
-    const int ninf = 0xff800000;     // -inf
-#define DG_DPP_MAX(ctrl, rmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), ctrl, rmask, 0xf, false)))
-    DG_DPP_MAX(0x111, 0xf); DG_DPP_MAX(0x112, 0xf); DG_DPP_MAX(0x114, 0xf); DG_DPP_MAX(0x118, 0xf);
-    DG_DPP_MAX(0x142, 0xa); DG_DPP_MAX(0x143, 0xc);
-#undef DG_DPP_MAX
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// (wave-wide reductions below: DPP row operations - inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then the row
+//  totals are carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lane 63 holds the result)
+// Pooled depth of output pixel (i, j) from image rows staged in LDS (`st` holds rows ybase.. of the depth map, W floats
+// each): adaptive_avg_pool2d's window, summed row-major and sequentially, then divided by the window height and by the
+// window width (the torch CPU operator's order, bit for bit).
+__device__ __forceinline__ float fps_pool_lds(const float* st, int ybase, int H, int W, int h, int w, int i, int j) {
+    const int ys = (i * H) / h, ye = ((i + 1) * H + h - 1) / h;
+    const int xs = (j * W) / w, xe = ((j + 1) * W + w - 1) / w;
+    float s = 0.f;
+    for (int y = ys; y < ye; ++y) {
+        const float* row = st + (size_t)(y - ybase) * W;
+        int x = xs;
+        for (; x + 8 <= xe; x += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = row[x + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s = __fadd_rn(s, t[u]);
+        }
+        for (; x < xe; ++x) s = __fadd_rn(s, row[x]);
+    }
+    return __fdiv_rn(__fdiv_rn(s, (float)(ye - ys)), (float)(xe - xs));        // sum / kh / kw: the operator's two divisions
 }
-__device__ __forceinline__ int dpp_wave_min(int v) {
-    const int big = 0x7fffffff;
-#define DG_DPP_MIN(ctrl, rmask) v = min(v, __builtin_amdgcn_update_dpp(big, v, ctrl, rmask, 0xf, false))
-    DG_DPP_MIN(0x111, 0xf); DG_DPP_MIN(0x112, 0xf); DG_DPP_MIN(0x114, 0xf); DG_DPP_MIN(0x118, 0xf);
-    DG_DPP_MIN(0x142, 0xa); DG_DPP_MIN(0x143, 0xc);
-#undef DG_DPP_MIN
+
+// Packed fp32 arithmetic of the distance update (two points per instruction; separately rounded multiply and add, exactly
+// numpy's float32 operations: no fused multiply-add).  `l` carries two coordinates of the last selected point; LO / HI pick
+// which of them is broadcast to both halves.
+typedef float fps2 __attribute__((ext_vector_type(2)));
+template <bool HI> __device__ __forceinline__ fps2 fps_sub_bcast(fps2 l, fps2 q) {
+    fps2 r;
+    if constexpr (HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(l), "v"(q));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(l), "v"(q));
+    return r;
+}
+__device__ __forceinline__ fps2 fps_mul(fps2 a, fps2 b) { fps2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ fps2 fps_add(fps2 a, fps2 b) { fps2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fps_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// wave-wide max of floats that are >= 0 or -1 (their bit patterns order like signed integers)
+__device__ __forceinline__ int dpp_wave_max_i(int v) {
+    const int small = (int)0x80000000;
+#define DG_DPP_MAXI(ctrl, rmask) v = max(v, __builtin_amdgcn_update_dpp(small, v, ctrl, rmask, 0xf, false))
+    DG_DPP_MAXI(0x111, 0xf); DG_DPP_MAXI(0x112, 0xf); DG_DPP_MAXI(0x114, 0xf); DG_DPP_MAXI(0x118, 0xf);
+    DG_DPP_MAXI(0x142, 0xa); DG_DPP_MAXI(0x143, 0xc);
+#undef DG_DPP_MAXI
     return __builtin_amdgcn_readlane(v, 63);
 }
-template <int NPT>       // points per thread: h*w <= NPT * FPS_THREADS
+
+template <int NPT>       // points per thread (even): h*w <= NPT * FPS_THREADS
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restrict__ depth, int H, int W, int h, int w,
-                                                            int S, float factor, float* __restrict__ out_coords,
+                                                            int S, float factor, int stage_floats, float* __restrict__ out_coords,
                                                             int32_t* __restrict__ out_inds) {
-    extern __shared__ float sm[];
-    const int HW = h * w, nsel = S * S;
-    float* px = sm; float* py = px + HW; float* pz = py + HW;
-    int* sel = reinterpret_cast<int*>(pz + HW);            // 1 when selected
-    int* order = sel + HW;                                 // [nsel] selection order
-    __shared__ float rv[2 * FPS_THREADS / 64];
-    __shared__ int ri[2 * FPS_THREADS / 64];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    constexpr int NP2 = NPT / 2;
+    static_assert(NPT % 2 == 0, "points are updated in pairs");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = h * w, nsel = S * S, nwords = (HW + 31) >> 5;
+    int* order = reinterpret_cast<int*>(sm);               // [nsel] selection order
+    uint32_t* selbits = reinterpret_cast<uint32_t*>(order + nsel);   // [nwords] selected set as a bit mask
+    // the round's arg-max is formed by the LDS atomic unit: a signed 64-bit key (distance : 0x7fffffff - point index; the
+    // larger key is the larger distance, then the lower index) per round, three keys in rotation
+    __shared__ long long skey[3];
+    __shared__ int tie_low;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* d = depth + (size_t)n * H * W;
-    // adaptive_avg_pool2d + depth2points
-    for (int idx = tid; idx < HW; idx += FPS_THREADS) {
-        const int i = idx / w, j = idx - i * w;
-        const int ys = (i * H) / h, ye = ((i + 1) * H + h - 1) / h;
-        const int xs = (j * W) / w, xe = ((j + 1) * W + w - 1) / w;
-        float s = 0.f;                                   // row-major sequential sum (the reference's CPU order), loads batched
-        for (int y = ys; y < ye; ++y) {
-            const float* row = d + (size_t)y * W;
-            for (int x = xs; x < xe; x += 8) {
-                float t[8];
+    float4* const pts = reinterpret_cast<float4*>(selbits + nwords + ((4 - ((nsel + nwords) & 3)) & 3));   // [HW] {x, y, z, 0}: takes over the staging buffer
+
+    // adaptive_avg_pool2d + depth2points; every thread keeps its points (idx = tid + FPS_THREADS*k) and their running
+    // distances in registers; a point past the map has distance -1 and never wins.
+    // The depth map goes through LDS in bands of whole pooled rows: coalesced, independent loads (one memory latency per
+    // band instead of one per few addends of every window), then every thread sums the windows of its points from LDS.
+    fps2 qx[NP2], qy[NP2], qz[NP2], qd[NP2];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = x + u < xe ? row[x + u] : 0.f;
+    for (int k = 0; k < NPT; ++k) { qx[k >> 1][k & 1] = 0.f; qy[k >> 1][k & 1] = 0.f; qz[k >> 1][k & 1] = 0.f; qd[k >> 1][k & 1] = -1.f; }
+    {
+        float* stage = reinterpret_cast<float*>(selbits + nwords + ((4 - ((nsel + nwords) & 3)) & 3));     // 16-byte aligned
+        const int max_rows = stage_floats / W;                      // image rows that fit the staging buffer
+        const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) & 15) == 0);
+        for (int r0 = 0; r0 < h;) {
+            // pooled rows r0 .. r1-1: image rows ys(r0) .. ye(r1-1)-1
+            const int y0 = (r0 * H) / h;
+            int r1 = r0 + 1;
+            while (r1 < h && ((r1 + 1) * H + h - 1) / h - y0 <= max_rows) ++r1;
+            const int y1 = (r1 * H + h - 1) / h;
+            const float* src = d + (size_t)y0 * W;
+            const int nfl = (y1 - y0) * W;
+            if (vec4) {
+                const int n4 = nfl >> 2;                             // (W % 4 == 0: whole rows are whole float4s)
+                for (int q = tid; q < n4; q += FPS_THREADS * 8) {
+                    f32x4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (x + u < xe) s = __fadd_rn(s, t[u]);
+                    for (int u = 0; u < 8; ++u) t[u] = q + u * FPS_THREADS < n4 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + q + u * FPS_THREADS) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (q + u * FPS_THREADS < n4) reinterpret_cast<f32x4*>(stage)[q + u * FPS_THREADS] = t[u];
+                }
+            } else {
+                for (int q = tid; q < nfl; q += FPS_THREADS) stage[q] = src[q];
             }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int idx = tid + FPS_THREADS * k;
+                const int i = idx / w, j = idx - i * w;
+                if (idx < HW && i >= r0 && i < r1) {
+                    const float dv = fps_pool_lds(stage, y0, H, W, h, w, i, j);
+                    const float fd = __fmul_rn(factor, dv);
+                    qy[k >> 1][k & 1] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)i, (float)h / 2.0f)), (float)h);
+                    qx[k >> 1][k & 1] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)j, (float)w / 2.0f)), (float)w);
+                    qz[k >> 1][k & 1] = __fmul_rn(-dv, 5.0f);
+                    qd[k >> 1][k & 1] = __builtin_inff();
+                }
+            }
+            __syncthreads();
+            r0 = r1;
         }
-        const float dv = __fdiv_rn(s, (float)((ye - ys) * (xe - xs)));
-        const float fd = __fmul_rn(factor, dv);
-        py[idx] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)i, (float)h / 2.0f)), (float)h);
-        px[idx] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)j, (float)w / 2.0f)), (float)w);
-        pz[idx] = __fmul_rn(-dv, 5.0f);
-        sel[idx] = 0;
     }
-    if (tid == 0) order[0] = 0;
-    __syncthreads();
-    // Rounds: every thread keeps its points (idx = tid + FPS_THREADS*k), their running distances and a "taken" mask in
-    // registers; one barrier per round: the waves publish their arg-max in slots that alternate with the round parity, every
-    // thread combines the four results itself (lowest index wins ties, as numpy's first-max over the ascending remainder).
-    float qx[NPT], qy[NPT], qz[NPT], qd[NPT];
-    uint32_t taken = 0;
+    for (int k = tid; k < nwords; k += FPS_THREADS) selbits[k] = 0u;
+    // (the last band's barrier is behind us: the staging buffer is free) the point table, then point 0 starts the selection
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
         const int idx = tid + FPS_THREADS * k;
-        const bool in = idx < HW;
-        qx[k] = in ? px[idx] : 0.f; qy[k] = in ? py[idx] : 0.f; qz[k] = in ? pz[idx] : 0.f;
-        qd[k] = __builtin_inff();
-        if (!in) taken |= 1u << k;
+        if (idx < HW) pts[idx] = make_float4(qx[k >> 1][k & 1], qy[k >> 1][k & 1], qz[k >> 1][k & 1], 0.f);
     }
-    if (tid == 0) taken |= 1u;                           // point 0 starts the selection
-    if (tid == 0) sel[0] = 1;
-    int last = 0;
+    if (tid < 3) skey[tid] = (long long)0x8000000000000000ull;
+    if (lane == 0) order[0] = 0;
+    __syncthreads();
+    fps2 lxy = {pts[0].x, pts[0].y}, lzz = {pts[0].z, 0.f};
+    const uint32_t key_addr = lds_addr(&skey[0]);
+    int cur = 1, nxt = 2;                  // key of round it: it % 3
+    // Rounds, one barrier each.  The loop is one dependent chain on one wave per SIMD: what counts is the instruction count, the
+    // TAKEN branches (~40-80 cycles each) and the LDS round trips (scripts/micro/clock_light_load.hip, fps_round.hip), so: every
+    // wave reduces the VALUES with DPP, the lanes that hold the wave's maximum (almost always one) hand {value, index} to an
+    // LDS atomic max - which also breaks exact ties towards the lower index, as numpy's first-max over the ascending remainder
+    // does - and after the barrier every thread reads the winning key and that point's coordinates.
     for (int it = 1; it < nsel; ++it) {
-        const float lx = px[last], ly = py[last], lz = pz[last];
-        float bv = -1.f; int bi = 0x7fffffff;
+        float nd[NPT];
 #pragma unroll
-        for (int k = 0; k < NPT; ++k) {
-            const float dx = __fsub_rn(lx, qx[k]), dy = __fsub_rn(ly, qy[k]), dz = __fsub_rn(lz, qz[k]);
-            const float dd = __fadd_rn(__fadd_rn(dg_mul_rn(dx, dx), dg_mul_rn(dy, dy)), dg_mul_rn(dz, dz));   // no fused multiply-add
-            const bool live = !((taken >> k) & 1u);
-            const float nd = fminf(dd, qd[k]);
-            if (live) qd[k] = nd;
-            if (live && nd > bv) { bv = nd; bi = tid + FPS_THREADS * k; }      // ascending idx per thread -> first max kept
+        for (int p = 0; p < NP2; ++p) {
+            const fps2 dx = fps_sub_bcast<false>(lxy, qx[p]), dy = fps_sub_bcast<true>(lxy, qy[p]), dz = fps_sub_bcast<false>(lzz, qz[p]);
+            const fps2 dd = fps_add(fps_add(fps_mul(dx, dx), fps_mul(dy, dy)), fps_mul(dz, dz));
+            qd[p][0] = nd[2 * p] = fps_min(dd[0], qd[p][0]);
+            qd[p][1] = nd[2 * p + 1] = fps_min(dd[1], qd[p][1]);
         }
-        // wave arg-max with DPP row operations (no LDS crossbar): max of the values, then min of the indices that attain it
-        {
-            const float wmax = dpp_wave_max(bv);
-            bi = dpp_wave_min(bv == wmax ? bi : 0x7fffffff);
-            bv = wmax;
+        // this thread's largest distance (values are >= 0 or -1: their bit patterns order like signed integers)
+        int mb = __float_as_int(nd[0]);
+#pragma unroll
+        for (int k = 1; k < NPT; ++k) mb = max(mb, __float_as_int(nd[k]));
+        const int wmax = dpp_wave_max_i(mb);
+        if (mb == wmax) {
+            int bk = NPT - 1;                  // the FIRST of this thread's points that attains it (ascending k = ascending index)
+#pragma unroll
+            for (int k = NPT - 2; k >= 0; --k) bk = __float_as_int(nd[k]) == mb ? k : bk;
+            const long long key = ((long long)mb << 32) | (long long)(0x7fffffff - (tid + FPS_THREADS * bk));
+            // (asm: hipcc would wrap an atomicMax in a scalar loop over the active lanes - there is almost always exactly one)
+            asm volatile("ds_max_i64 %0, %1" :: "v"(key_addr + 8 * cur), "v"(key) : "memory");
         }
-        const int par = (it & 1) * (FPS_THREADS / 64);
-        if ((tid & 63) == 0) { rv[par + (tid >> 6)] = bv; ri[par + (tid >> 6)] = bi; }
+        if (lane == 0) skey[nxt] = (long long)0x8000000000000000ull;     // (its readers of two rounds ago are behind the previous barrier)
         __syncthreads();
-        float v = rv[par]; int i0 = ri[par];
+        const long long kb = skey[cur];
+        int i0 = 0x7fffffff - (int)(kb & 0xffffffffll);
+        if (__builtin_expect((int)(kb >> 32) == 0, 0)) {
+            // Largest distance 0: every point that is left coincides with a selected one (e.g. a map of zero depth).  Selected
+            // points are not marked in the registers - their distance simply became 0 in the round after their selection, which
+            // never wins while any distance is positive - so here, and only here, they have to be told apart: the reference takes
+            // the lowest index that is still unselected.
+            if (tid == 0) tie_low = 0x7fffffff;
+            __syncthreads();
 #pragma unroll
-        for (int k = 1; k < FPS_THREADS / 64; ++k) {
-            const float ov = rv[par + k]; const int oi = ri[par + k];
-            if (ov > v || (ov == v && oi < i0)) { v = ov; i0 = oi; }
+            for (int k = 0; k < NPT; ++k) {
+                const int idx = tid + FPS_THREADS * k;
+                bool used = idx >= HW;
+                for (int q = 0; q < it && !used; ++q) used = order[q] == idx;
+                if (!used) atomicMin(&tie_low, idx);
+            }
+            __syncthreads();
+            i0 = tie_low;
+            __syncthreads();
         }
-        last = i0;
-        if ((i0 & (FPS_THREADS - 1)) == tid) { taken |= 1u << (i0 / FPS_THREADS); sel[i0] = 1; }
-        if (tid == 0) order[it] = i0;          // (kept in LDS: a global store per round would be waited for at every barrier)
+        const float4 bp = pts[i0];
+        lxy[0] = bp.x; lxy[1] = bp.y; lzz[0] = bp.z;
+        cur = nxt; nxt = nxt == 2 ? 0 : nxt + 1;
+        if (lane == 0) order[it] = i0;         // (one lane of EVERY wave, the same value: the branch around it is never taken; kept in LDS - a global store per round would be waited for at every barrier)
     }
     __syncthreads();
-    if (out_inds)
-        for (int k = tid; k < nsel; k += FPS_THREADS) out_inds[(size_t)n * nsel + k] = order[k];
-    // selected set in row-major order -> coords (row/h, col/w)*2-1
+    for (int k = tid; k < nsel; k += FPS_THREADS) {
+        const int i0 = order[k];
+        atomicOr(&selbits[i0 >> 5], 1u << (i0 & 31));
+        if (out_inds) out_inds[(size_t)n * nsel + k] = i0;
+    }
+    __syncthreads();
+    // selected set in row-major order -> coords (row/h, col/w)*2-1; rank of a pixel = selected pixels in front of it
     for (int idx = tid; idx < HW; idx += FPS_THREADS) {
-        if (!sel[idx]) continue;
-        int rank = 0;
-        for (int k = 0; k < idx; ++k) rank += sel[k];
+        const uint32_t wd = selbits[idx >> 5];
+        if (!((wd >> (idx & 31)) & 1u)) continue;
+        int rank = __popc(wd & ((1u << (idx & 31)) - 1u));
+        for (int k = 0; k < (idx >> 5); ++k) rank += __popc(selbits[k]);
         const int i = idx / w, j = idx - i * w;
         float* o = out_coords + ((size_t)n * nsel + rank) * 2;
         o[0] = __fsub_rn(__fmul_rn(__fdiv_rn((float)i, (float)h), 2.0f), 1.0f);
@@ -579,11 +662,21 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
 
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s) {
-    const int smem = h * w * 4 * 4 + S * S * 4;
+    // LDS: selection order, selected-set mask, then the staging buffer for bands of the depth map: at least the image rows
+    // of one pooled row, at most 128 KB
+    const int head = (S * S + (h * w + 31) / 32 + 3) / 4 * 16;
+    const int max_win_rows = (H + h - 1) / h + 1;
+    if ((size_t)max_win_rows * W * 4 + head > 150 * 1024) return hipErrorInvalidValue;     // (a pooled row of a > 4k-wide map)
+    const size_t whole = (size_t)H * W * 4;
+    const int stage_bytes = (int)(whole < 128 * 1024 ? (whole + 15) / 16 * 16 : 128 * 1024);
+    int stage_floats = (stage_bytes > max_win_rows * W * 4 ? stage_bytes : max_win_rows * W * 4) / 4;
+    if (stage_floats < h * w * 4) stage_floats = h * w * 4;          // (the point table takes the buffer over)
+    if ((size_t)stage_floats * 4 + head > 158 * 1024) return hipErrorInvalidValue;
+    const int smem = head + stage_floats * 4;
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, out_coords, out_inds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, stage_floats, out_coords, out_inds);
         return hipGetLastError();
     };
     if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);

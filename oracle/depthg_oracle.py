@@ -125,15 +125,33 @@ def interpolate_bilinear_ac(d: torch.Tensor, size: Tuple[int, int]) -> torch.Ten
 # F.adaptive_avg_pool2d(depth, (h, w))                                 src/modules.py:1003
 # --------------------------------------------------------------------------------------
 def adaptive_avg_pool2d(d: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
-    b, c, hin, win = d.shape
+    """Window [floor(i*H/h), ceil((i+1)*H/h)) x the same along x; the window is summed ROW-MAJOR AND SEQUENTIALLY in
+    float32, then divided by the window height and by the window width (two divisions): the order of the torch CPU operator the reference calls (bit-exact against
+    F.adaptive_avg_pool2d, pinned in tests/test_oracle_golden.py; a pairwise/vectorised sum differs in the last bit on
+    general float depth, enough to swap near-tied FPS picks)."""
+    x = d.detach().cpu().numpy().astype(np.float32, copy=False)
+    b, c, hin, win = x.shape
     hout, wout = size
-    out = torch.empty(b, c, hout, wout, dtype=d.dtype)
-    for i in range(hout):
-        ys, ye = (i * hin) // hout, -((-(i + 1) * hin) // hout)
-        for j in range(wout):
-            xs, xe = (j * win) // wout, -((-(j + 1) * win) // wout)
-            out[:, :, i, j] = d[:, :, ys:ye, xs:xe].sum(dim=(2, 3)) / float((ye - ys) * (xe - xs))
-    return out
+    out = np.empty((b, c, hout, wout), dtype=np.float32)
+    if hin % hout == 0 and win % wout == 0:                   # equal windows: all outputs at once, one add per window element
+        kh, kw = hin // hout, win // wout
+        v = x.reshape(b, c, hout, kh, wout, kw)
+        acc = np.zeros((b, c, hout, wout), dtype=np.float32)
+        for y in range(kh):
+            for xx in range(kw):
+                acc = acc + v[:, :, :, y, :, xx]
+        out = acc / np.float32(kh) / np.float32(kw)
+    else:
+        for i in range(hout):
+            ys, ye = (i * hin) // hout, -((-(i + 1) * hin) // hout)
+            for j in range(wout):
+                xs, xe = (j * win) // wout, -((-(j + 1) * win) // wout)
+                acc = np.zeros((b, c), dtype=np.float32)
+                for y in range(ys, ye):
+                    for xx in range(xs, xe):
+                        acc = acc + x[:, :, y, xx]
+                out[:, :, i, j] = acc / np.float32(ye - ys) / np.float32(xe - xs)
+    return torch.from_numpy(np.ascontiguousarray(out)).to(d.dtype)
 
 
 # --------------------------------------------------------------------------------------

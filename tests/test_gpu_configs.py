@@ -5,6 +5,8 @@ identity path on 56x56 maps, the loss under an initialised RCCL process group.
 Tolerances as in test_gpu_parity.py: loss means 2e-3 relative + 1e-5 absolute on small cases (1e-4 relative at the headline
 width), gradients relative L2 <= 3e-2 with zero_clamp (mask flips of fp16 cd), <= 3e-3 without."""
 import os
+
+import numpy as np
 import subprocess
 import sys
 
@@ -232,3 +234,42 @@ def test_loss_under_rccl_process_group():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("hw,dhw,S", [(28, 224, 11), (28, 224, 12), (56, 448, 12), (14, 100, 6), (14, 300, 5), (9, 64, 4)])
+def test_fps_map_sizes_of_the_configs(hw, dhw, S, dev):
+    """farthest_point_sampling_depth (src/modules.py:999-1037) at the map sizes of BASELINE configs 2/4 (28x28 from 224^2 depth),
+    56x56, and depth sizes whose pooling windows are uneven (100 -> 14, 64 -> 9) or larger than the 64-pixel fast path
+    (300 -> 14: 22x22): coordinates AND selection order bit-exact against the oracle, including images with flat regions
+    (exact distance ties)."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(7 * hw + S)
+    d = torch.rand(3, 1, dhw, dhw, generator=g) * 9 + 0.5
+    d[1, :, : dhw // 2] = 4.0                           # half of one image flat: ties
+    d[2] = torch.round(d[2])                            # few distinct depth values
+    want_c, want_i = O.farthest_point_sampling_depth((hw, hw), d, S, return_inds=True)
+    got_c, got_i = ops.fps_coords(d.to(dev), (hw, hw), S, return_inds=True)
+    assert np.array_equal(got_i.cpu().numpy(), np.asarray(want_i))
+    assert np.array_equal(got_c.cpu().numpy(), (want_c * 2 - 1).numpy())
+
+
+@pytest.mark.parametrize("kind", ["all_zero", "half_zero", "two_values"])
+def test_fps_coincident_points(kind, dev):
+    """Zero depth puts every such pixel on the origin (depth2points, src/modules.py:988-996): once the distinct points are
+    used up the largest distance is 0 and the reference's argmax over `points_left` takes the lowest index that is still
+    unselected (src/modules.py:960-981).  Selection order bit-exact against the oracle."""
+    from depthg_amd import ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(5)
+    d = torch.zeros(2, 1, 56, 56)
+    if kind == "half_zero":
+        d[:, :, :, 28:] = torch.rand(2, 1, 56, 28, generator=g) + 0.5
+        d[1, :, 40:, :] = 0.0
+    elif kind == "two_values":
+        d[:, :, ::8, ::8] = 2.0                      # 49 pooled pixels of depth 2/16, the other 147 on the origin
+    for S in (5, 12):
+        want_c, want_i = O.farthest_point_sampling_depth((14, 14), d, S, return_inds=True)
+        got_c, got_i = ops.fps_coords(d.to(dev), (14, 14), S, return_inds=True)
+        assert np.array_equal(got_i.cpu().numpy(), np.asarray(want_i)), (kind, S)
+        assert np.array_equal(got_c.cpu().numpy(), (want_c * 2 - 1).numpy())

@@ -37,7 +37,19 @@ def test_interpolate(golden_functions):
 
 def test_adaptive_pool_nondivisible(golden_functions):
     g = golden_functions
-    close(O.adaptive_avg_pool2d(T(g["fpsd2_depth"]), (14, 14)), g["pool2_out"], atol=1e-5)
+    out = O.adaptive_avg_pool2d(T(g["fpsd2_depth"]), (14, 14))
+    assert np.array_equal(out.numpy(), g["pool2_out"])        # bit exact: the operator's own (sequential, row-major) sum order
+
+
+@pytest.mark.parametrize("hin,hout", [(224, 28), (448, 56), (100, 14), (64, 9), (300, 14), (37, 5)])
+def test_adaptive_pool_is_the_torch_cpu_operator(hin, hout):
+    """The pooled depth feeds FPS, whose picks flip on last-bit differences between near-tied distances: the restatement must
+    reproduce the operator the reference calls (F.adaptive_avg_pool2d, src/modules.py:1003) bit for bit on general float
+    depth, for equal, uneven and large windows."""
+    g = torch.Generator().manual_seed(hin + hout)
+    d = torch.rand(2, 1, hin, hin, generator=g) * 9 + 0.5
+    want = torch.nn.functional.adaptive_avg_pool2d(d, (hout, hout))
+    assert np.array_equal(O.adaptive_avg_pool2d(d, (hout, hout)).numpy(), want.numpy())
 
 
 def test_depth2points_and_factor(golden_functions):
