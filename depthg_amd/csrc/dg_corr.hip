@@ -676,7 +676,9 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
 // accumulate it.  Then the normalisation backward with the
 // S code is applied in registers and the accumulator tile is written as a gradient tile (dg_gtile_off).
 // grid (ceil(nt/GS_CW), B, jobs), block (GS_CW+1)*64, dynamic LDS GS_NB P parts + GS_CW scratch tiles.
+#ifndef GS_CW
 #define GS_CW 7
+#endif
 #ifndef GS_NB
 #define GS_NB 6
 #endif

@@ -1,43 +1,59 @@
 #!/usr/bin/env python3
 """Copies the round's evidence from gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/
-and writes profiles/<tag>_SUMMARY.md.  usage: scripts/make_profile_summary.py r01"""
-import csv, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+and writes profiles/<tag>_SUMMARY.md.  usage: scripts/make_profile_summary.py r02"""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, f"{tag}_kernel_stats.csv"), dst)
 shutil.copy(os.path.join(src, f"{tag}_pmc_per_launch.json"), dst)
-shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprofv3.json"))
-line = [l for l in open(os.path.join(src, f"{tag}_bench.json")) if l.startswith("{")][-1]
+last_json = lambda p: [l for l in open(p) if l.startswith("{")][-1]
+open(os.path.join(dst, f"{tag}_bench_under_rocprofv3.json"), "w").write(last_json(os.path.join(src, "bench_under_rocprof.json")))
+line = last_json(os.path.join(src, f"{tag}_bench.json"))
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
 st = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
 pm = json.load(open(os.path.join(dst, f"{tag}_pmc_per_launch.json")))
 b = json.loads(line)
 br = json.loads(open(os.path.join(dst, f"{tag}_bench_under_rocprofv3.json")).read())
+kname = b["roofline"]["kernel"]
 rows = [r for r in st if r["Name"].startswith(("k_", "void k_"))]
 o = [f"# Round profile summary {tag} (MI355X, gfx950)\n",
-     "Command: `python bench.py --steps 30 --warmup 5 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats` "
+     "Command: `python bench.py --steps 50 --warmup 5 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats` "
      f"(`scripts/profile_round.sh {tag}`); PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, an SQ set) are separate runs of the "
      f"same command with `--steps 3`. Files: `{tag}_kernel_stats.csv`, `{tag}_pmc_per_launch.json`, `{tag}_bench_under_rocprofv3.json` "
-     f"(the bench line printed inside the profiled run), `{tag}_bench.json` (the plain `python bench.py` line, from its own run on a fresh box: counter collection leaves the GPU in the profiling power state, a plain run right behind the PMC passes measured 20 % low).\n",
-     "## Kernels of one step\n", "| kernel | calls | avg µs | min µs | max µs |\n|---|---|---|---|---|"]
+     f"(the bench line printed inside the profiled run), `{tag}_bench.json` (the plain `python bench.py` line, taken BEFORE the counter "
+     "passes: counter collection leaves the GPU in the profiling power state, a plain run right behind the PMC passes measures low), "
+     f"`{tag}_bench_<config>.json` (`python bench.py --config <config>` for BASELINE.json's other configurations).\n",
+     "## Kernels of one headline step\n", "| kernel | calls | avg µs | min µs | max µs |\n|---|---|---|---|---|"]
+tail = 0.0
 for r in rows:
     o.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} |")
-m = [v for k, v in pm.items() if "k_corr_main" in k][0]
-avg = [float(r["AverageNs"]) / 1e3 for r in rows if "k_corr_main" in r["Name"]][0]
-o += ["\n(`k_corr_main` has extra calls: `bench.py`'s roofline leg re-launches it 23 times alone.)\n",
-      "## Dominant kernel: `k_corr_main<24,6,8,1,grad,simple>`\n",
+    if kname not in r["Name"]:
+        tail += float(r["AverageNs"]) / 1e3
+m = [v for k, v in pm.items() if kname in k][0]
+avg = [float(r["AverageNs"]) / 1e3 for r in rows if kname in r["Name"]][0]
+o += [f"\n(`{kname}` has extra calls: `bench.py`'s roofline leg re-launches it 23 times alone.  Sum of the other kernels' averages: {tail:.0f} µs.)\n",
+      f"## Dominant kernel: `{kname}`\n",
       f"* plain run: {b['roofline']['kernel_ms']*1e3:.1f} µs per launch (HIP events, 20 launches) -> {b['roofline']['achieved']} TFLOP/s = "
       f"{100*b['roofline']['frac']:.1f} % of the 2.5 PFLOP/s dense bf16 peak, on {b['roofline']['algorithmic_gflop_per_launch']} algorithmic GFLOP per launch.",
       f"* under rocprofv3: average {avg:.1f} µs (kernel-trace); the bench line inside the same run: {br['roofline']['kernel_ms']*1e3:.1f} µs "
       f"({br['roofline']['achieved']} TFLOP/s).",
       f"* HBM traffic per launch (PMC): FETCH_SIZE {m['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction) = {m['hbm_read_bytes_corrected']/1e6:.0f} MB read, "
-      f"WRITE_SIZE {m['WRITE_SIZE']:.0f} KiB = {m['hbm_write_bytes']/1e6:.0f} MB written (287 MB fp16 G tiles for k_gs + 77 MB raw gradient tiles), "
+      f"WRITE_SIZE {m['WRITE_SIZE']:.0f} KiB = {m['hbm_write_bytes']/1e6:.0f} MB written (287 MB fp16 G tiles for k_gs + the raw gradient tiles), "
       f"total {m['hbm_traffic_bytes_per_launch']/1e6:.0f} MB = {m['hbm_traffic_bytes_per_launch']/(avg*1e-6)/1e12:.2f} TB/s during the kernel.",
-      f"* SQ counters per launch: SQ_VALU_MFMA_BUSY_CYCLES {m['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} (= MFMA instructions x 32 cycles), "
+      f"* SQ counters per launch: SQ_VALU_MFMA_BUSY_CYCLES {m['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} (= MFMA instructions x 32 cycles; over 1024 SIMDs x the kernel's "
+      f"{avg:.0f} µs at the ~1.9 GHz it holds = {m['SQ_VALU_MFMA_BUSY_CYCLES']/(1024*avg*1e-6*1.9e9):.2f} of the SIMD-cycles), "
       f"SQ_INSTS_VALU {m['SQ_INSTS_VALU']:.3g}, SQ_INSTS_LDS {m['SQ_INSTS_LDS']:.3g}, SQ_LDS_BANK_CONFLICT {m['SQ_LDS_BANK_CONFLICT']:.0f}, "
       f"SQ_WAVE_CYCLES {m['SQ_WAVE_CYCLES']:.3g}, SQ_WAIT_INST_ANY {m['SQ_WAIT_INST_ANY']:.3g}.",
       f"\n## Step\n\n{b['value']} steps/s ({b['ms_per_step']} ms per step) on one GPU; CPU restatement on {b['cpu_baseline']['cores']} host threads: "
-      f"{b['cpu_baseline']['value']:.2f} steps/s ({b['cpu_baseline']['sample']}).\n"]
+      f"{b['cpu_baseline']['value']:.2f} steps/s ({b['cpu_baseline']['sample']}).\n",
+      "## BASELINE.json's other configurations (`bench.py --config`)\n",
+      "| config | ms per step | steps/s | dominant kernel | µs per launch | fraction of MFMA peak | CPU restatement steps/s |\n|---|---|---|---|---|---|---|"]
+for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
+    l = last_json(f)
+    shutil.copy(f, dst) if False else open(os.path.join(dst, os.path.basename(f)), "w").write(l)
+    c = json.loads(l)
+    o.append(f"| {c['config']['name']} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
+             f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |")
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))

@@ -3,6 +3,7 @@
 export TMPDIR=/tmp
 tag=$1; shift
 out=/root/repo/gpurun_out/prof_$tag
+rm -rf $out $out.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 /root/repo/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $out.json 2>/dev/null )
 python3 - <<PY
 import csv,glob
