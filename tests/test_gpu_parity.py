@@ -248,8 +248,40 @@ def test_headline_loss_vs_oracle_subset(dev):
     for i in (0, 2, 4, 6):
         _relclose(out[i].mean(), ref[i].mean(), 1e-4, 0.0, f"loss term {i}")
     _relclose(tot, tot_ref, 1e-4, 0.0, "weighted total")
-    rel = (cg.grad.cpu() - cr.grad).norm() / cr.grad.norm()
-    assert rel < 3e-2, float(rel)
+    # gradients: measured 1.1-1.5e-2 relative L2 and 3-8 % of the largest element (scripts/grad_err.py; clamp-mask flips of the
+    # fp16 cd): bounds at ~1.5x the measurement, for both maps, plus an element-wise bound
+    for got, want, name in ((cg.grad.cpu(), cr.grad, "code"), (cpg.grad.cpu(), cpr.grad, "code_pos")):
+        rel = (got - want).norm() / want.norm()
+        worst = (got - want).abs().max() / want.abs().max()
+        assert rel < 2e-2 and worst < 0.12, (name, float(rel), float(worst))
+
+
+def test_headline_width_without_clamp_gradient(dev):
+    """The same width with zero_clamp off (no mask, nothing discontinuous): the kernels' own arithmetic error.  Measured 4e-4
+    (code) / 2e-3 (code_pos) relative L2; bounds 3e-3 relative L2 and 5e-3 of the largest element."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    B, C, D, hw = 2, 384, 70, 28
+    g = torch.Generator().manual_seed(99)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float()
+    perms = [O.super_perm(B, g) for _ in range(5)]
+    cfg = O.default_cfg(feature_samples=hw, dg_outputs="reduced", zero_clamp=False)
+    coords = O.identity_coords(B, hw)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=coords, coords2=coords, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), coords.to(dev),
+                                                       coords.to(dev), [p.to(dev) for p in perms], shared_coords=True)
+    O.total_loss(cfg, out).backward()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 2e-4, 1e-7, f"loss term {i}")
+    for got, want, name in ((cg.grad.cpu(), cr.grad, "code"), (cpg.grad.cpu(), cpr.grad, "code_pos")):
+        rel = (got - want).norm() / want.norm()
+        worst = (got - want).abs().max() / want.abs().max()
+        assert rel < 3e-3 and worst < 5e-3, (name, float(rel), float(worst))
 
 
 def test_error_paths(dev):
