@@ -139,3 +139,52 @@ def test_two_rank_metric_sums_confusion_matrices():
         assert miou == pytest.approx(float(g["e3_hung_miou"]), rel=1e-6)      # == the reference on all three batches
         assert acc == pytest.approx(float(g["e3_hung_acc"]), rel=1e-6)
         assert untouched                                                        # compute() leaves the local state alone
+
+
+def _worker_recorded(rank, world, port, ret):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp_hip_shards.npz"))
+    w = torch.nn.Parameter(torch.zeros(D, C, 1, 1)); w.grad = torch.from_numpy(fx[f"dw{rank}"]).clone()
+    b = torch.nn.Parameter(torch.zeros(D)); b.grad = torch.from_numpy(fx[f"db{rank}"]).clone()
+    bucket = GradBucket.for_parameters([w, b], dist)
+    bucket.pack()
+    bucket.allreduce_mean_()
+    bucket.unpack()
+    if rank == 0:
+        ret["w"] = w.grad.clone()
+        ret["b"] = b.grad.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allreduce_of_recorded_hip_gradients():
+    """The shard gradients the HIP path produced on an MI355X for this file's problem (tests/golden/dp_hip_shards.npz, recorded
+    by tests/golden/make_dp_hip_fixture.py): two gloo ranks all-reduce them through the same GradBucket.  The result is the
+    exact fp32 mean of the two recorded shards and agrees with the mean of the per-shard ORACLE gradients within the gradient
+    tolerance of the HIP path (clamp-mask flips)."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_recorded, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        got_w, got_b = ret["w"], ret["b"]
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp_hip_shards.npz"))
+    mean_w = (torch.from_numpy(fx["dw0"]) + torch.from_numpy(fx["dw1"])) * 0.5
+    mean_b = (torch.from_numpy(fx["db0"]) + torch.from_numpy(fx["db1"])) * 0.5
+    assert torch.equal(got_w, mean_w) and torch.equal(got_b, mean_b)
+    ow = sum(_shard_grads(r, world)[0] for r in range(world)) / world
+    ob = sum(_shard_grads(r, world)[1] for r in range(world)) / world
+    assert (got_w - ow).norm() <= 3e-2 * ow.norm(), float((got_w - ow).norm() / ow.norm())
+    assert (got_b - ob).norm() <= 3e-2 * ob.norm() + 1e-7
