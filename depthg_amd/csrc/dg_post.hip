@@ -8,6 +8,8 @@
 #include "dg_common.h"
 #include <cstdlib>
 
+typedef const float __attribute__((address_space(1)))* gfloat_p;    // a pointer known to be global memory
+
 
 __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, int& y0, bool& inx, bool& iny,
                                         float& w00, float& w01, float& w10, float& w11) {
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
 }
 
 #define SCAT_THREADS 1024
-#define SCAT_DC 8            // channels per block
+#define SCAT_DC 4            // channels per block (4 x 256 pixels per pass: the gather keeps 4 sources x 4 passes of loads in flight in 48 registers)
 #define SCAT_PX (SCAT_THREADS / SCAT_DC)
-#define SCAT_MAXPASS 32      // supports h*w <= SCAT_PX * SCAT_MAXPASS = 4096 pixels
+#define SCAT_MAXPASS 16      // supports h*w <= SCAT_PX * SCAT_MAXPASS = 4096 pixels
 
 // Inverse of the bilinear tap map of sample(), once per (coords set, image): for every pixel the list of
 // (position, weight) that read it, as CSR in global memory (off[HW+1], then 4P weights, then 4P positions).
@@ -206,56 +208,109 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
 }
 
 // Stage 2: adjoint of sample() as a GATHER (no floating-point atomics).  One block = one destination image and
-// SCAT_DC channels; for every source image that lands there it copies that image's tap lists into LDS and every thread
-// gathers its (pixel, channel) outputs into registers; rows of the fp32 gradient buffers are read, nothing is scattered.
-// grid (ceil(D / SCAT_DC), B, 2), block SCAT_THREADS, dynamic LDS = one tap record (>= the output staging tile).
+// SCAT_DC channels.  The sources that land there - the combined direct tiles, then the negatives routed here, in (source,
+// image) order - are taken SCAT_RMAX at a time: their tap lists go to LDS together (one global latency and one barrier per
+// batch instead of per source), then every thread gathers its (pixel, channel) outputs into registers, source after source
+// in the fixed order, taps in position order: rows of the fp32 gradient buffers are read, nothing is scattered, the sums
+// are bit-reproducible.
+// grid (ceil(D / SCAT_DC), B, 2), block SCAT_THREADS, dynamic LDS = rmax tap records (>= the output staging tile).
+#define SCAT_RMAX 8
 template <int NPASS>
-__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a) {
+__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterArgs a, int rmax) {
     extern __shared__ __attribute__((aligned(16))) char sg[];
     const int tid = threadIdx.x, HW = a.h * a.w, P = a.P;
+    // (the lambdas below capture these copies, never `a` itself: a by-reference capture of the kernel argument makes hipcc
+    //  copy the whole 1.5-KB struct to scratch in every thread)
+    const int aD = a.D, aDP = a.DP, aB = a.B, aPpad = a.Ppad;
+    const char* const taps_base = a.taps;
     DG_LOAD_GS(a, gs)
-    const int* off = reinterpret_cast<const int*>(sg);
-    const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
-    const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
     const int dc0 = blockIdx.x * SCAT_DC, bdst = blockIdx.y, dest = blockIdx.z;
     const int dl = tid & (SCAT_DC - 1), px = tid / SCAT_DC, d = dc0 + dl;
     const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
     const size_t rec = dg_taps_record_bytes(HW, P);
+    // the pending batch (uniform over the block; thread 0 writes, everybody reads behind the batch's barrier)
+    __shared__ const float* b_src[SCAT_RMAX];
+    __shared__ const char* b_rec[SCAT_RMAX];
+    __shared__ float b_sc[SCAT_RMAX];
     float acc[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) acc[i] = 0.f;
+    int npend = 0;
 
-    auto one_source = [&](const float* buf, float sc, int cs, int nimg) {
-        // tap lists of (cs, nimg) -> LDS (16-byte copies; the record is padded to 16 bytes)
-        const uint4* g = reinterpret_cast<const uint4*>(a.taps + ((size_t)cs * a.B + nimg) * rec);
-        for (int i = tid; i < (int)(rec / 16); i += SCAT_THREADS) reinterpret_cast<uint4*>(sg)[i] = g[i];
-        __syncthreads();
-        if (d < a.D) {
-            const float* src = buf + (size_t)nimg * a.Ppad * a.DP;   // gradient tiles of image nimg
-            const int DPc = a.DP;
-            // first tap of every pixel of this thread: independent loads, all in flight together
-            float first[NPASS];
-            int e0a[NPASS], e1a[NPASS];
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                const int pix = ps * SCAT_PX + px;
-                const bool ok = ps < npass && pix < HW;
-                e0a[ps] = ok ? off[pix] : 0;
-                e1a[ps] = ok ? off[pix + 1] : 0;
-                first[ps] = e1a[ps] > e0a[ps] ? ewgt[e0a[ps]] * src[dg_gtile_off(eidx[e0a[ps]], d, DPc)] : 0.f;
-            }
-#pragma unroll
-            for (int ps = 0; ps < NPASS; ++ps) {
-                float sum = first[ps];
-                for (int e = e0a[ps] + 1; e < e1a[ps]; ++e) sum = fmaf(ewgt[e], src[dg_gtile_off(eidx[e], d, DPc)], sum);
-                acc[ps] = fmaf(sc, sum, acc[ps]);
-            }
+    auto flush = [&, aD, aDP]() __attribute__((always_inline)) {
+        if (npend == 0) return;
+        __syncthreads();                                   // batch entries written
+        const int n16 = (int)(rec / 16);
+        for (int i = tid; i < npend * n16; i += SCAT_THREADS) {
+            const int r = i / n16, k = i - r * n16;
+            reinterpret_cast<f32x4*>(sg)[i] = *((const f32x4 __attribute__((address_space(1)))*)b_rec[r] + k);
         }
         __syncthreads();
+        if (d < aD) {
+            const int DPc = aDP;
+            // RG sources at a time: the first tap of every (source, pixel) of this thread is loaded before anything is summed -
+            // RG * NPASS independent loads in flight instead of one dependent load chain per source (most pixels are read by at
+            // most one position of a source); further taps of a pixel, rare, follow in the summation pass
+            constexpr int RG = NPASS <= 4 ? 4 : (NPASS <= 8 ? 2 : 1);
+            for (int r0 = 0; r0 < npend; r0 += RG) {
+                float v[RG][NPASS], w[RG][NPASS];
+                int e0[RG][NPASS];                         // first tap; bit 31: the pixel has further taps in this source
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    const int r = min(r0 + g, npend - 1);
+                    const int* off = reinterpret_cast<const int*>(sg + (size_t)r * rec);
+                    const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
+                    const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
+                    // (the pointer comes out of LDS: without the address space hipcc emits FLAT loads, which also count as LDS
+                    //  operations - every later ds_read then waits for all of them: 10x slower)
+                    const gfloat_p src = (gfloat_p)b_src[r];
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        const int pix = ps * SCAT_PX + px;
+                        const bool ok = r0 + g < npend && ps < npass && pix < HW;
+                        const int ea = ok ? off[pix] : 0, eb = ok ? off[pix + 1] : 0;
+                        const bool any = eb > ea;
+                        w[g][ps] = any ? ewgt[ea] : 0.f;
+                        v[g][ps] = any ? src[dg_gtile_off(eidx[ea], d, DPc)] : 0.f;
+                        e0[g][ps] = ea | (eb > ea + 1 ? (int)0x80000000 : 0);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    if (r0 + g < npend) {
+                        const int r = r0 + g;
+                        const int* off = reinterpret_cast<const int*>(sg + (size_t)r * rec);
+                        const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
+                        const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
+                        const gfloat_p src = (gfloat_p)b_src[r];
+                        const float sc = b_sc[r];
+#pragma unroll
+                        for (int ps = 0; ps < NPASS; ++ps) {
+                            float sum = w[g][ps] * v[g][ps];
+                            if (e0[g][ps] < 0) {
+                                const int ea = e0[g][ps] & 0x7fffffff, eb = off[ps * SCAT_PX + px + 1];
+                                for (int e = ea + 1; e < eb; ++e) sum = fmaf(ewgt[e], src[dg_gtile_off(eidx[e], d, DPc)], sum);
+                            }
+                            acc[ps] = fmaf(sc, sum, acc[ps]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // everybody is done with this batch's entries and tap lists
+        npend = 0;
+    };
+    auto push = [&](const float* buf, float sc, int cs, int nimg) __attribute__((always_inline)) {
+        if (tid == 0) {
+            b_src[npend] = buf + (size_t)nimg * aPpad * aDP;              // gradient tiles of image nimg
+            b_rec[npend] = taps_base + ((size_t)cs * aB + nimg) * rec;    // its tap lists (coords set cs)
+            b_sc[npend] = sc;
+        }
+        if (++npend == rmax) flush();
     };
 
     // direct sources (already combined): image bdst -> destination bdst; coords1 for grad_code, coords2 for grad_code_pos
-    one_source(a.comb[dest], 1.0f, dest == 0 ? 0 : 1, bdst);
+    push(a.comb[dest], 1.0f, dest == 0 ? 0 : 1, bdst);
     // routed sources (negatives): image n scatters into destination route[n] with n's coords
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
@@ -268,10 +323,11 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
             while (m) {
                 const int n = n0 + __builtin_ctzll(m);
                 m &= m - 1;
-                one_source(q.buf, sc, q.coords_sel, n);
+                push(q.buf, sc, q.coords_sel, n);
             }
         }
     }
+    flush();
     // ---- write (B,D,h,w): transpose through LDS so that the stores run along the pixels
     float* stage = reinterpret_cast<float*>(sg);     // [SCAT_DC][HW + 1]
 #pragma unroll
@@ -284,6 +340,126 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     for (int i = tid; i < SCAT_DC * HW; i += SCAT_THREADS) {
         const int dd = i / HW, pix = i - dd * HW;
         if (dc0 + dd < a.D) out[((size_t)bdst * a.D + dc0 + dd) * HW + pix] = stage[dd * (HW + 1) + pix];
+    }
+}
+
+// Stage 2 for small sample grids (the S = 11 / 12 recipes: P = 121 / 144 positions on a 28 x 28 map), same sums in the same
+// order as k_scatter_grad, different mapping: one block = one destination image and one group of 32 channels.  The gradient
+// tiles of that group of up to `rb` sources are copied into LDS as [position][33] rows (coalesced 16-byte loads of whole
+// tiles; every byte of a tile is read once per block instead of one 64-byte line per tap and four channels), next to the
+// sources' tap lists.  Then the LANES RUN OVER PIXELS: a thread walks the tap lists of its pixel once for all 32 channels and
+// keeps 32 sums in registers; the result is stored along the pixels (coalesced, no transposition stage).
+// grid (DP / 32, B, 2), block SCAT_THREADS (needs h*w <= SCAT_THREADS), dynamic LDS rb * (record + Ppad * 33 floats).
+template <int CG>        // channels per block: 32, or 16 (twice the blocks, half the LDS) when 32 would leave CUs idle
+__global__ __launch_bounds__(SCAT_THREADS) void k_scatter_small(const DgScatterArgs a, int rb) {
+    constexpr int VS = CG + 1;                              // padded row of the value image
+    extern __shared__ __attribute__((aligned(16))) char sg[];
+    const int tid = threadIdx.x, HW = a.h * a.w, P = a.P, nt = a.Ppad >> 5, NF = a.DP >> 5;
+    const int aB = a.B, aPpad = a.Ppad, aDP = a.DP;
+    const char* const taps_base = a.taps;
+    DG_LOAD_GS(a, gs)
+    const int f = blockIdx.x / (32 / CG), cg = blockIdx.x % (32 / CG), bdst = blockIdx.y, dest = blockIdx.z;
+    const size_t rec = dg_taps_record_bytes(HW, P);
+    const int vstride = aPpad * VS;                         // floats per source
+    float* const vals = reinterpret_cast<float*>(sg + (size_t)rb * rec);
+    __shared__ const float* b_src[SCAT_RMAX];
+    __shared__ const char* b_rec[SCAT_RMAX];
+    __shared__ float b_sc[SCAT_RMAX];
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+    int npend = 0;
+
+    auto flush = [&, rec, nt, NF, f, cg, vstride, HW, P]() __attribute__((always_inline)) {
+        if (npend == 0) return;
+        __syncthreads();                                   // batch entries written
+        const int n16 = (int)(rec / 16);
+        for (int i = tid; i < npend * n16; i += SCAT_THREADS) {
+            const int r = i / n16, k = i - r * n16;
+            reinterpret_cast<f32x4*>(sg)[i] = *((const f32x4 __attribute__((address_space(1)))*)b_rec[r] + k);
+        }
+        // gradient tiles of channel group f: 256 16-byte pieces per tile = {4 consecutive positions of one channel}
+        constexpr int PT = 8 * CG;                          // pieces of this block's channels per tile
+        for (int i = tid; i < npend * nt * PT; i += SCAT_THREADS) {
+            const int r = i / (nt * PT), j = i - r * (nt * PT), t = j / PT, k = j - t * PT;
+            const int c = k % CG, hq = k / CG;               // hq = 2 (q >> 3) + ((q >> 2) & 1): which four positions
+            const int jj = (hq >> 1) * 64 + (hq & 1) * 32 + CG * cg + c;
+            const f32x4 v = *((const f32x4 __attribute__((address_space(1)))*)(b_src[r] + ((size_t)t * NF + f) * 1024) + jj);
+            float* o = vals + (size_t)r * vstride + (t * 32 + hq * 4) * VS + c;
+            o[0] = v[0]; o[VS] = v[1]; o[2 * VS] = v[2]; o[3 * VS] = v[3];
+        }
+        __syncthreads();
+        if (tid < HW) {
+            for (int r = 0; r < npend; ++r) {
+                const int* off = reinterpret_cast<const int*>(sg + (size_t)r * rec);
+                const float* ewgt = reinterpret_cast<const float*>(off + HW + 1);
+                const unsigned short* eidx = reinterpret_cast<const unsigned short*>(ewgt + 4 * P);
+                const float* vr = vals + (size_t)r * vstride;
+                const int e0 = off[tid], e1 = off[tid + 1];
+                const float sc = b_sc[r];
+                for (int e = e0; e < e1; ++e) {            // (weight of the source folded into the tap weight: one fma per tap and channel)
+                    const float w = sc * ewgt[e];
+                    const float* v = vr + (int)eidx[e] * VS;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[c] = fmaf(w, v[c], acc[c]);
+                }
+            }
+        }
+        __syncthreads();                                   // everybody is done with this batch
+        npend = 0;
+    };
+    auto push = [&](const float* buf, float sc, int cs, int nimg) __attribute__((always_inline)) {
+        if (tid == 0) {
+            b_src[npend] = buf + (size_t)nimg * aPpad * aDP;
+            b_rec[npend] = taps_base + ((size_t)cs * aB + nimg) * rec;
+            b_sc[npend] = sc;
+        }
+        if (++npend == rb) flush();
+    };
+    // The sources in a fixed order: the combined direct tiles, then the routed ones (negatives) by (image chunk, source, image).
+    // Per 64 images and 16 sources the route entries are loaded together (independent loads: one memory latency instead of
+    // one per source); the hits are listed in LDS by thread 0 and pushed from ONE call site (the batch logic is inlined once).
+    __shared__ short l_s[16 * 64 + 1], l_n[16 * 64 + 1];
+    for (int n0 = 0; n0 < a.B; n0 += 64) {
+        const int nn = n0 + (tid & 63);
+        for (int s0 = 0; s0 < a.nsrc || s0 == 0; s0 += 16) {
+            int cnt = 0;
+            if (n0 == 0 && s0 == 0) { if (tid == 0) { l_s[0] = -1; l_n[0] = (short)bdst; } cnt = 1; }
+            int rt[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int s = s0 + k;
+                const bool use = s < a.nsrc && a.src[s < a.nsrc ? s : 0].dest == dest && a.src[s < a.nsrc ? s : 0].route != nullptr && nn < a.B;
+                rt[k] = use ? (int)a.src[s].route[nn] : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned long long m = __ballot(rt[k] == bdst);
+                if (tid == 0) {
+                    int c = cnt;
+                    for (unsigned long long mm = m; mm; mm &= mm - 1) { l_s[c] = (short)(s0 + k); l_n[c] = (short)(n0 + __builtin_ctzll(mm)); ++c; }
+                }
+                cnt += __popcll(m);
+            }
+            __syncthreads();
+            for (int i = 0; i < cnt; ++i) {
+                const int s = l_s[i], n = l_n[i];
+                const DgScatterSrc& q = a.src[s < 0 ? 0 : s];
+                const float* buf = s < 0 ? a.comb[dest] : q.buf;
+                const float sc = s < 0 ? 1.0f : q.factor * dg_pick(gs, q.gidx);
+                const int cs = s < 0 ? (dest == 0 ? 0 : 1) : q.coords_sel;
+                push(buf, sc, cs, n);
+            }
+            __syncthreads();
+        }
+    }
+    flush();
+    if (tid < HW) {
+        const int d0 = 32 * f + CG * cg;
+        float* out = a.out[dest] + ((size_t)bdst * a.D + d0) * HW + tid;
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+            if (d0 + c < a.D) out[(size_t)c * HW] = acc[c];
     }
 }
 
@@ -366,9 +542,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
             for (int k = 0; k < 4; ++k) {
                 const int e = min(e0 + k, cnt - 1);
                 sc[k] = e0 + k < cnt ? rl_w[e] : 0.f;
-                const float* sb = rl_p[e] + toff;
+                // (pointer out of LDS: name its address space, or hipcc emits FLAT loads, which every later LDS read waits for)
+                const gfloat_p sb = (gfloat_p)rl_p[e] + toff;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) u[k][g] = chan ? *reinterpret_cast<const f32x4*>(sb + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 4; ++g) u[k][g] = chan ? *(const f32x4 __attribute__((address_space(1)))*)(sb + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -434,24 +611,48 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     if (HW > SCAT_PX * SCAT_MAXPASS || a.P > 65535) return hipErrorInvalidValue;
     const size_t rec = dg_taps_record_bytes(HW, a.P);
     const size_t stage = (size_t)SCAT_DC * (HW + 1) * 4;
-    const int smem = (int)(rec > stage ? rec : stage);
+    int rmax = (int)((size_t)(120 * 1024) / rec);               // tap records held in LDS together
+    rmax = rmax < 1 ? 1 : (rmax > SCAT_RMAX ? SCAT_RMAX : rmax);
+    const int smem = (int)(rmax * rec > stage ? rmax * rec : stage);
     const int build_smem = (int)(rec + (size_t)HW * 4 + 16);     // the record plus the per-pixel counters
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_build_taps), build_smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_build_taps, dim3(a.B, 2), dim3(SCAT_THREADS), build_smem, s, a);
+    {
+        // small sample grids: tiles of a 32-channel group + tap lists of several sources in LDS (k_scatter_small)
+        const bool half = (a.DP / 32) * a.B * 2 < 512;               // 32-channel blocks would not even fill the CUs twice
+        const int CGv = half ? 16 : 32;
+        const size_t per_src = rec + (size_t)a.Ppad * (CGv + 1) * 4;
+        int rb = (int)((size_t)(150 * 1024) / per_src);
+        rb = rb > SCAT_RMAX ? SCAT_RMAX : rb;
+        if (HW <= SCAT_THREADS && rb >= 2) {
+            const int sm = (int)(rb * per_src);
+            const dim3 sgrid(a.DP / CGv, a.B, 2);
+            if (half) {
+                e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_small<16>), sm);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_scatter_small<16>, sgrid, dim3(SCAT_THREADS), sm, s, a, rb);
+            } else {
+                e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_small<32>), sm);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_scatter_small<32>, sgrid, dim3(SCAT_THREADS), sm, s, a, rb);
+            }
+            return hipGetLastError();
+        }
+    }
     dim3 grid((a.D + SCAT_DC - 1) / SCAT_DC, a.B, 2);
     const int npass = (HW + SCAT_PX - 1) / SCAT_PX;
 #define DG_SCAT(NP)                                                                                                      \
     {                                                                                                                    \
         e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_grad<NP>), smem); \
         if (e != hipSuccess) return e;                                                                                   \
-        hipLaunchKernelGGL(k_scatter_grad<NP>, grid, dim3(SCAT_THREADS), smem, s, a);                                    \
+        hipLaunchKernelGGL(k_scatter_grad<NP>, grid, dim3(SCAT_THREADS), smem, s, a, rmax);                                    \
         return hipGetLastError();                                                                                        \
     }
     if (npass <= 2) DG_SCAT(2)
+    if (npass <= 4) DG_SCAT(4)
     if (npass <= 8) DG_SCAT(8)
-    if (npass <= 16) DG_SCAT(16)
-    DG_SCAT(32)
+    DG_SCAT(16)
 #undef DG_SCAT
 }
 
