@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="give each step's all-reduce one step of slack (it then overlaps the next step's kernels, as it would "
                          "overlap the frozen ViT forward in training); default: the compute stream waits for it right away")
+    ap.add_argument("--graph", action="store_true",
+                    help="record the step once in a hipGraph (torch.cuda.graph) and replay it: for the launch-bound small "
+                         "configurations; the negatives' permutations then advance on the device (cfg.dg_graph_safe)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -175,7 +178,7 @@ def main():
 
     conf = CONFIGS[args.config]
     H = conf["H"]
-    cfg = make_cfg(conf)
+    cfg = make_cfg(conf, dg_graph_safe=bool(args.graph))
     loss_fn = ContrastiveCorrelationLoss(cfg)
     f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev, H)
     c.requires_grad_(True)
@@ -204,6 +207,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        if use_dist:
+            raise SystemExit("--graph records the single-GPU step (the all-reduce is not recorded)")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            total_static = step()
+
+        def step():
+            graph.replay()
+            return total_static
     for _ in range(args.warmup):
         step()
     sync()
@@ -260,7 +280,7 @@ def main():
             "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (feats) / f16 (code) MFMA inputs, f32 accumulate", "data": "synthetic",
-            "config": {"workload": conf["what"], "name": args.config,
+            "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if args.graph else ""), "name": args.config,
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
                        "allreduce_elems": HEAD_GRAD_ELEMS if world > 1 else 0},
             "loss_total": float(total.detach()),

@@ -14,7 +14,7 @@ DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARE
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
-           "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded",
+           "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_corr_backward_total"]
 
 
@@ -79,6 +79,8 @@ def load():
     lib.dg_lhp_backward.argtypes = [vp, vp, vp] + [ctypes.c_int32] * 4 + [vp, vp]
     lib.dg_super_perms_seeded.restype = ctypes.c_int
     lib.dg_super_perms_seeded.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, vp, vp]
+    lib.dg_super_perms_state.restype = ctypes.c_int
+    lib.dg_super_perms_state.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
     _lib = lib
     return lib
 

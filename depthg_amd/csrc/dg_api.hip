@@ -449,7 +449,7 @@ extern "C" int dg_super_perms(const float* keys, int32_t count, int32_t B, int64
     if (count < 0 || B < 1 || B > 8192) return fail(DG_ERR_INVALID, "dg_super_perms: count=%d B=%d outside the supported range", count, B);
     if (count == 0) return DG_OK;
     if (!keys || !out) return fail(DG_ERR_INVALID, "null pointer");
-    DG_HIP(dg_launch_super_perms(keys, 0ull, count, B, out, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_super_perms(keys, 0ull, nullptr, count, B, out, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 
@@ -457,7 +457,15 @@ extern "C" int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, in
     if (count < 0 || B < 1 || B > 8192) return fail(DG_ERR_INVALID, "bad super_perm dimensions");
     if (count == 0) return DG_OK;
     if (!out) return fail(DG_ERR_INVALID, "null pointer");
-    DG_HIP(dg_launch_super_perms(nullptr, seed, count, B, out, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_super_perms(nullptr, seed, nullptr, count, B, out, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out, dg_stream_t stream_) {
+    if (count < 0 || B < 1 || B > 8192) return fail(DG_ERR_INVALID, "bad super_perm dimensions");
+    if (count == 0) return DG_OK;
+    if (!out || !state) return fail(DG_ERR_INVALID, "null pointer");
+    DG_HIP(dg_launch_super_perms(nullptr, 0ull, reinterpret_cast<unsigned long long*>(state), count, B, out, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -385,7 +385,7 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
-hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, int count, int B, int64_t* out, hipStream_t s);
+hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long long* state, int count, int B, int64_t* out, hipStream_t s);
 hipError_t dg_launch_salience_coords(const float* sal, int B, int H, int W, int n, const float* u_sel, const float* u_fb,
                                      float* out, hipStream_t s);
 hipError_t dg_launch_simple_coords(const float* depth, int B, int H, int W, int h, int w, int n, const float* u_val,

@@ -901,12 +901,19 @@ __device__ __forceinline__ uint32_t dg_philox(uint64_t seed, uint32_t ctr) {
     return c0;
 }
 
-// keys == nullptr: the uniform keys are drawn here (Philox, counter = row * B + i), one launch instead of rand + sort
-__global__ __launch_bounds__(256) void k_super_perms(const float* __restrict__ keys, uint64_t seed, int B, int64_t* __restrict__ out) {
+// keys == nullptr: the uniform keys are drawn here (Philox, counter = row * B + i), one launch instead of rand + sort.
+// state != nullptr: the Philox key is {state[0] (seed), state[1] (draws so far)} READ FROM THE DEVICE, and the block that
+// finishes last advances state[1] (ticket in state[2]) - a launch recorded in a hipGraph then draws fresh permutations on
+// every replay, which a seed passed by value cannot.
+__global__ __launch_bounds__(256) void k_super_perms(const float* __restrict__ keys, uint64_t seed, unsigned long long* __restrict__ state,
+                                                     int B, int64_t* __restrict__ out) {
     extern __shared__ float sk[];
     const float* kr = keys ? keys + (size_t)blockIdx.x * B : nullptr;
+    unsigned long long draw = 0;
+    if (state) { seed = state[0]; draw = state[1]; }
+    const uint64_t key = seed + 0x9E3779B97F4A7C15ull * draw;
     for (int i = threadIdx.x; i < B; i += 256)
-        sk[i] = kr ? kr[i] : (float)(dg_philox(seed, (uint32_t)(blockIdx.x * B + i)) >> 8) * (1.0f / 16777216.0f);
+        sk[i] = kr ? kr[i] : (float)(dg_philox(key, (uint32_t)(blockIdx.x * B + i)) >> 8) * (1.0f / 16777216.0f);
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 256) {
         const float ki = sk[i];
@@ -914,9 +921,18 @@ __global__ __launch_bounds__(256) void k_super_perms(const float* __restrict__ k
         for (int j = 0; j < B; ++j) rank += (sk[j] < ki) || (sk[j] == ki && j < i);
         out[(size_t)blockIdx.x * B + rank] = (int64_t)((i == rank ? i + 1 : i) % B);
     }
+    if (state && threadIdx.x == 0) {
+        // every block has read the state before it takes its ticket; the last ticket advances the draw count
+        __threadfence();
+        if (atomicAdd(&state[2], 1ull) == (unsigned long long)gridDim.x - 1) {
+            state[1] = draw + 1;
+            state[2] = 0;
+            __threadfence();
+        }
+    }
 }
 
-hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, int count, int B, int64_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_super_perms, dim3(count), dim3(256), B * sizeof(float), s, keys, seed, B, out);
+hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long long* state, int count, int B, int64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_super_perms, dim3(count), dim3(256), B * sizeof(float), s, keys, seed, state, B, out);
     return hipGetLastError();
 }

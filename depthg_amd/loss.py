@@ -91,6 +91,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         super().__init__()
         self.cfg = cfg
         self._ident_cache = (None, None)
+        self._perm_state = None            # device generator state of the negatives' permutations (cfg.dg_graph_safe)
 
     def _total_weights(self, depth_term):
         """Weights of (intra, inter, neg, depth) loss means in the caller's total, src/train_segmentation.py:325-349."""
@@ -149,7 +150,13 @@ class ContrastiveCorrelationLoss(nn.Module):
         coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
                                                      depth, depth_pos)
         B = orig_feats.shape[0]
-        perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device)   # dg_super_perms: rand + one kernel
+        if getattr(self.cfg, "dg_graph_safe", False):
+            # generator state on the device (hipGraph-capturable step: nothing about the draw is baked into the launch)
+            if self._perm_state is None or self._perm_state.device != orig_feats.device:
+                self._perm_state = ops.new_perm_state(orig_feats.device)
+            perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device, state=self._perm_state)
+        else:
+            perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device)   # seed from torch's CPU generator, one kernel
         # `shared` is only ever set together with the identity grid drawn above
         return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
                                  shared_coords=shared, identity_grid=shared)

@@ -225,11 +225,25 @@ def lhp_backward(grad_out, points, stats):
     return grad_code
 
 
-def super_perms(count, size, device, keys=None):
-    """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one rand + one kernel."""
+def new_perm_state(device):
+    """Device-resident generator state for super_perms(state=...): int64 {seed, draws so far, 0}; the seed comes from torch's
+    CPU generator, so torch.manual_seed before the first use fixes the whole sequence."""
+    seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+    return torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
+
+
+def super_perms(count, size, device, keys=None, state=None):
+    """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one kernel.  `state` (new_perm_state):
+    the draw is keyed by device memory and advances it - safe to record in a hipGraph (every replay draws anew)."""
     lib = _lib.load()
     out = _empty((count, size), torch.long, device)
     if count == 0:
+        return out
+    if state is not None:
+        if state.dtype != torch.int64 or state.numel() != 3 or state.device != out.device:
+            raise ValueError("super_perms: state must be the int64[3] tensor of new_perm_state on the same device")
+        rc = lib.dg_super_perms_state(_ptr(state), int(count), int(size), _ptr(out), _stream(out.device))
+        _lib.check(rc, "dg_super_perms_state")
         return out
     if keys is None:
         # one launch: the keys are drawn inside the kernel (Philox) from a 64-bit seed taken from torch's CPU generator, so

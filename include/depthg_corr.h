@@ -242,6 +242,12 @@ int dg_super_perms(const float* keys, int32_t count, int32_t B, int64_t* out, dg
 /* Same, with the keys drawn inside the launch: key(r, i) = Philox4x32-10(seed; counter r*B + i) >> 8, as a float in [0,1).
  * The caller supplies a fresh 64-bit seed per call (from its own RNG): one launch per step instead of rand + sort. */
 int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+/* The same draws with the generator state ON THE DEVICE: state = {seed, draws so far, 0} (three 64-bit words owned by the
+ * caller, zero the third); every call uses {seed, draws} as the Philox key and advances `draws` on the device.  Nothing
+ * about the draw is baked into the launch, so a call recorded in a hipGraph (torch.cuda.graph around the training step)
+ * yields new permutations on every replay - the reference draws them with the device generator at the same place,
+ * src/modules.py:1184-1188,1336-1339. */
+int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
 
 /*
  * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a

@@ -273,3 +273,56 @@ def test_fps_coincident_points(kind, dev):
         got_c, got_i = ops.fps_coords(d.to(dev), (14, 14), S, return_inds=True)
         assert np.array_equal(got_i.cpu().numpy(), np.asarray(want_i)), (kind, S)
         assert np.array_equal(got_c.cpu().numpy(), (want_c * 2 - 1).numpy())
+
+
+@pytest.mark.parametrize("mode", ["dense", "fps"])
+def test_step_replays_from_a_hip_graph(mode, dev):
+    """cfg.dg_graph_safe: the whole step (sampler, negatives' permutations, loss, backward) recorded once with
+    torch.cuda.graph and replayed - nothing host-side is baked in, the permutations advance on the device: three replays
+    equal three eager steps from the same generator state (reference draws: src/modules.py:1184-1188,1336-1339)."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(31)
+    B, C, D, hw = 8, 384, 70, 28
+    S = hw if mode == "dense" else 11
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c = torch.randn(B, D, hw, hw, generator=g).to(dev).requires_grad_(True)
+    cp = torch.randn(B, D, hw, hw, generator=g).to(dev).requires_grad_(True)
+    d, dp = (torch.randint(0, 256, (B, 1, 224, 224), generator=g).float().to(dev) for _ in range(2))
+    cfg = O.default_cfg(feature_samples=S, depth_sampling="fps" if mode == "fps" else "none", dg_outputs="reduced",
+                        dg_dense_grid=mode == "dense", dg_graph_safe=True)
+    loss = ContrastiveCorrelationLoss(cfg)
+    one = torch.ones((), device=dev)
+
+    def step():
+        c.grad = None
+        cp.grad = None
+        loss(f, fp, None, None, c, cp, d, dp)
+        loss.total.backward(gradient=one)
+        return loss.total.detach(), c.grad, cp.grad
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    state0 = loss._perm_state.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tot_g, gc_g, gcp_g = step()
+    torch.cuda.synchronize()
+    assert torch.equal(loss._perm_state, state0), "recording must not execute anything"
+    replays = []
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        replays.append((tot_g.clone(), gc_g.clone(), gcp_g.clone()))
+    assert int(loss._perm_state[1]) == int(state0[1]) + 3 and int(loss._perm_state[2]) == 0
+    loss._perm_state.copy_(state0)
+    for k in range(3):
+        tot, gc, gcp = step()
+        torch.cuda.synchronize()
+        assert torch.equal(tot, replays[k][0]) and torch.equal(gc, replays[k][1]) and torch.equal(gcp, replays[k][2]), k
+    assert not torch.equal(replays[0][1], replays[1][1]), "every replay draws new negatives"
