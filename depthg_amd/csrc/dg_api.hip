@@ -29,8 +29,9 @@ static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
     int B, C, D, h, w, S, Sh, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;
-    bool shared, depth, grad, pointwise, ident;
+    bool shared, depth, grad, pointwise, ident, rows;
     size_t nhwc_f[2], nhwc_c[2];
+    size_t rows_f[DG_MAX_NEG + 2], rows_c[DG_MAX_NEG + 2];     // sampled fp32 rows per operand (small sample grids)
     size_t op[DG_MAX_NEG + 2], inv[DG_MAX_NEG + 2], colpart[DG_MAX_NEG + 2], bbar[DG_MAX_NEG + 2];
     size_t ccolpart[DG_MAX_NEG + 2], csum[DG_MAX_NEG + 2], bsplit[DG_MAX_NEG + 2];
     size_t rvec[DG_MAX_NEG + 2], rimg[DG_MAX_NEG + 2];
@@ -71,7 +72,12 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
     const size_t HW = (size_t)p.h * p.w, B = p.B;
-    for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(B * HW * p.C4 * 4); p.nhwc_c[i] = take(B * HW * p.D4 * 4); }
+    // small sample grids (all operands together sample fewer positions than the two maps have pixels; planes of 32 channels
+    // fit the LDS; batch indices fit the 16-bit consumer lists): sample() straight from NCHW (k_plane_sample) instead of
+    // channel-last copies of the whole maps
+    p.rows = !p.ident && (size_t)p.nops * p.P <= 2 * HW && HW <= 1024 && B <= 32767;
+    for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(p.rows ? 0 : B * HW * p.C4 * 4); p.nhwc_c[i] = take(p.rows ? 0 : B * HW * p.D4 * 4); }
+    for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(p.rows ? B * p.P * p.C4 * 4 : 0); p.rows_c[i] = take(p.rows ? B * p.P * p.D4 * 4 : 0); }
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
@@ -247,7 +253,16 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
-        {
+        if (p.rows) {
+            DgPlaneArgs t;
+            memset(&t, 0, sizeof(t));
+            t.src[0] = orig_feats; t.src[1] = orig_feats_pos; t.src[2] = orig_code; t.src[3] = orig_code_pos;
+            t.K[0] = t.K[1] = p.C; t.K4[0] = t.K4[1] = p.C4; t.K[2] = t.K[3] = p.D; t.K4[2] = t.K4[3] = p.D4;
+            for (int o = 0; o < p.nops; ++o) { t.rows[o][0] = F32(p.rows_f[o]); t.rows[o][1] = F32(p.rows_c[o]); }
+            t.coords1 = coords1; t.coords2 = coords2; t.perms = perms;
+            t.nops = p.nops; t.B = p.B; t.h = p.h; t.w = p.w; t.S = p.S; t.Sh = p.Sh; t.P = p.P;
+            DG_HIP(dg_launch_plane_sample(t, stream));
+        } else {
             DgTransposeArgs t;
             memset(&t, 0, sizeof(t));
             t.nmaps = 4; t.HW = HW;
@@ -266,15 +281,16 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             const float* coords = o == 0 ? coords1 : coords2;
             const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
             DgGatherJob& f = g.jobs[nj++];
-            f.src = F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = idx;
+            f.src = p.rows ? F32(p.rows_f[o]) : F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = p.rows ? nullptr : idx;
             f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
             f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
             DgGatherJob& c = g.jobs[nj++];
-            c.src = F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = idx;
+            c.src = p.rows ? F32(p.rows_c[o]) : F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = p.rows ? nullptr : idx;
             c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = F32(p.ccolpart[o]);
             c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
         }
         g.njobs = nj;
+        g.direct = p.rows ? 1 : 0;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
         if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }

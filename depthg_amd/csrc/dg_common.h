@@ -252,6 +252,18 @@ struct DgGatherJob {
 struct DgGatherArgs {
     DgGatherJob jobs[DG_MAX_GATHER];
     int32_t njobs, B, h, w, S, Sh, P, Ppad, KF, KD;   // sample grid: Sh rows x S columns (Sh == S, or 1 with DG_LINE_GRID)
+    int32_t direct;          // 1: src holds the SAMPLED rows already, [B][P][K4] per job (k_plane_sample): no taps, no batch map
+};
+
+struct DgPlaneArgs {        // k_plane_sample: sample() of all operands straight from the NCHW maps, small sample grids
+    const float* src[4];     // orig_feats, orig_feats_pos, orig_code, orig_code_pos  (B,K,h,w) fp32
+    int32_t K[4], K4[4];
+    float* rows[DG_MAX_NEG + 2][2];   // [operand][0 feats, 1 code]: sampled rows (B, P, K4) fp32, channels K..K4-1 zero
+    const float* coords1;
+    const float* coords2;
+    const int64_t* perms;    // [nops - 2][B] batch maps of the negatives (operand o >= 2 of image n reads image perms[o-2][n])
+    int32_t nops, B, h, w, S, Sh, P;
+    int32_t tap_consumers;   // (set by the launcher) consumers whose tap table is held in LDS together
 };
 
 struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
@@ -380,6 +392,7 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
+hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);

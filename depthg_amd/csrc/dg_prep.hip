@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const DgGatherJob& J = a.jobs[blockIdx.z];
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
-    const float* img = J.src + (size_t)ns * a.h * a.w * K4;
+    const float* img = a.direct ? J.src + (size_t)n * a.P * K4 : J.src + (size_t)ns * a.h * a.w * K4;
     const int S = a.S, Sh = a.Sh;
     const DgBlob L(a.KF, a.KD);
     char* blob = J.blob + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
@@ -72,7 +72,23 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) v[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         float inv = 0.f;
-        if (p < a.P) {
+        if (p < a.P && a.direct) {
+            // the rows are sampled already (k_plane_sample): row p of this image
+            const float* p00 = img + (size_t)p * K4;
+            float ss = 0.f;
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                const int k = 4 * lane + 256 * m;
+                if (k < K4) {
+                    const float4 acc = *reinterpret_cast<const float4*>(p00 + k);
+                    v[m] = acc;
+                    ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
+        } else if (p < a.P) {
             // output position (i, j) = (p / S, p % S) reads x = coords[n][j][i][0], y = coords[n][j][i][1]
             const int i = p / S, j = p - i * S;
             const float* c = J.coords + (((size_t)n * S + j) * Sh + i) * 2;
@@ -163,6 +179,159 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
     else if (maxK4 <= 512) hipLaunchKernelGGL(k_gather_norm<2>, grid, block, 0, s, a);
     else if (maxK4 <= 768) hipLaunchKernelGGL(k_gather_norm<3>, grid, block, 0, s, a);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// sample() for small sample grids (the S = 11 / 12 recipes), straight from the NCHW maps: one block = one SOURCE image and 32
+// channels of one map.  It reads its 32 channel planes once, coalesced, into LDS and serves every operand that samples
+// that image - operand 0 / 1 at the image's own coordinates, the negatives whose batch map points at it at THEIR
+// coordinates - writing sampled fp32 rows [operand][image][position][K4] (128 contiguous bytes per position and block).
+// k_gather_norm (direct mode) then normalises the rows and builds the operand blobs.  Against channel-last copies of the
+// whole maps + a gather with four taps per position (the general path) this moves 2 x less HBM/L2 traffic at P = 121 and
+// leaves no launch whose time scales with B*h*w*C twice.
+// grid (sum over maps of ceil(K4 / 32), B), block 1024, dynamic LDS 32 * (h*w + 1) floats.
+#define PLANE_THREADS 1024
+template <int CH>         // channels per block (32 or 16: smaller planes, more blocks per CU, their load and blend phases overlap)
+__global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pl[];          // [CH][HW + 1], then the tap table [consumers][P][8]
+    __shared__ short l_o[(DG_MAX_NEG + 2) * 64 + 2], l_n[(DG_MAX_NEG + 2) * 64 + 2];
+    const int tid = threadIdx.x, HW = a.h * a.w, b = blockIdx.y;
+    int m = 0, gy = blockIdx.x;
+    while (m < 3 && gy >= (a.K4[m] + CH - 1) / CH) { gy -= (a.K4[m] + CH - 1) / CH; ++m; }
+    const int K = a.K[m], K4 = a.K4[m], k0 = gy * CH, kind = m >> 1, pos_map = m & 1;
+    const float* __restrict__ src = a.src[m] + ((size_t)b * K + k0) * HW;
+    // planes -> LDS (rows of h*w contiguous floats; channels past K are zero)
+    // (all loads of a thread are issued before the first LDS store: one memory latency per block, not one per element)
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int n4 = CH * HW / 4, hw4 = HW / 4;
+        for (int i0 = tid; i0 < n4; i0 += PLANE_THREADS * 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PLANE_THREADS, cc = i / hw4;
+                t[u] = i < n4 && k0 + cc < K ? *(reinterpret_cast<const f32x4*>(src) + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PLANE_THREADS;
+                if (i < n4) {
+                    const int cc = i / hw4, q = (i - cc * hw4) * 4;
+                    float* o = pl + cc * (HW + 1) + q;
+                    o[0] = t[u][0]; o[1] = t[u][1]; o[2] = t[u][2]; o[3] = t[u][3];
+                }
+            }
+        }
+    } else {
+        for (int i0 = tid; i0 < CH * HW; i0 += PLANE_THREADS * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PLANE_THREADS, cc = i / HW;
+                t[u] = i < CH * HW && k0 + cc < K ? src[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PLANE_THREADS;
+                if (i < CH * HW) { const int cc = i / HW; pl[cc * (HW + 1) + (i - cc * HW)] = t[u]; }
+            }
+        }
+    }
+    const int c = tid % CH, ps = tid / CH;
+    const bool chan = k0 + c < K4;
+    const float* plane = pl + c * (HW + 1);
+    float* const taps = pl + ((CH * (HW + 1) + 3) & ~3);
+    // consumers of this source image, in (operand, image) order; 64 images at a time (the batch-map entries of the first chunk
+    // are loaded up front, next to the plane loads: independent loads, one latency)
+    int pm0[DG_MAX_NEG];
+#pragma unroll
+    for (int k = 0; k < DG_MAX_NEG; ++k)
+        pm0[k] = (!pos_map && k + 2 < a.nops && (tid & 63) < a.B) ? (int)a.perms[(size_t)k * a.B + (tid & 63)] : -1;
+    for (int n0 = 0; n0 < a.B; n0 += 64) {
+        const int nn = n0 + (tid & 63);
+        int cnt = 0;
+        if (pos_map) {
+            if (n0 == 0 && a.nops > 1) { if (tid == 0) { l_o[0] = 1; l_n[0] = (short)b; } cnt = 1; }
+        } else {
+            if (n0 == 0) { if (tid == 0) { l_o[0] = 0; l_n[0] = (short)b; } cnt = 1; }
+#pragma unroll
+            for (int k = 0; k < DG_MAX_NEG; ++k) {
+                const int o = k + 2;
+                if (o >= a.nops) break;
+                const int src_img = n0 == 0 ? pm0[k] : (nn < a.B ? (int)a.perms[(size_t)k * a.B + nn] : -1);
+                const unsigned long long hit = __ballot(src_img == b);
+                if (tid == 0) {
+                    int k = cnt;
+                    for (unsigned long long mm = hit; mm; mm &= mm - 1) { l_o[k] = (short)o; l_n[k] = (short)(n0 + __builtin_ctzll(mm)); ++k; }
+                }
+                cnt += __popcll(hit);
+            }
+        }
+        __syncthreads();                       // (also: the planes are in LDS)
+        // consumers in batches of a.tap_consumers: first the tap table of every (consumer, position) of the batch - pixel offset
+        // + the four bilinear weights, computed ONCE, not per channel lane - then the channel lanes blend
+        for (int e0 = 0; e0 < cnt; e0 += a.tap_consumers) {
+            const int ne = min(a.tap_consumers, cnt - e0);
+            for (int i = tid; i < ne * a.P; i += PLANE_THREADS) {
+                const int e = i / a.P, p = i - e * a.P;
+                const int o = l_o[e0 + e], n = l_n[e0 + e];
+                const float* coords = o == 0 ? a.coords1 : a.coords2;
+                // output position (i, j) = (p / S, p % S) reads x = coords[n][j][i][0], y = coords[n][j][i][1]  (k_gather_norm)
+                const int ii = p / a.S, j = p - ii * a.S;
+                const float* cc = coords + (((size_t)n * a.S + j) * a.Sh + ii) * 2;
+                float x = ((cc[0] + 1.f) / 2.f) * (float)(a.w - 1);
+                float y = ((cc[1] + 1.f) / 2.f) * (float)(a.h - 1);
+                x = fminf(fmaxf(x, 0.f), (float)(a.w - 1));
+                y = fminf(fmaxf(y, 0.f), (float)(a.h - 1));
+                const float x0f = floorf(x), y0f = floorf(y);
+                const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const int x0 = (int)x0f, y0 = (int)y0f;
+                const bool inx = x0 + 1 <= a.w - 1, iny = y0 + 1 <= a.h - 1;
+                // a tap that border padding never reads gets weight 0 and the address of the first tap
+                float* tt = taps + (size_t)i * 8;
+                tt[0] = wy0 * wx0;
+                tt[1] = inx ? wy0 * wx1 : 0.f;
+                tt[2] = iny ? wy1 * wx0 : 0.f;
+                tt[3] = inx && iny ? wy1 * wx1 : 0.f;
+                reinterpret_cast<int*>(tt)[4] = y0 * a.w + x0;
+                reinterpret_cast<int*>(tt)[5] = inx ? 1 : 0;
+                reinterpret_cast<int*>(tt)[6] = iny ? a.w : 0;
+            }
+            __syncthreads();
+            for (int e = 0; e < ne; ++e) {
+                const int o = l_o[e0 + e], n = l_n[e0 + e];
+                float* rows = a.rows[o][kind] + (size_t)n * a.P * K4 + k0 + c;
+                for (int p = ps; p < a.P; p += PLANE_THREADS / CH) {
+                    const float* tt = taps + ((size_t)e * a.P + p) * 8;
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(tt);
+                    const int pix = reinterpret_cast<const int*>(tt)[4], dx = reinterpret_cast<const int*>(tt)[5], dy = reinterpret_cast<const int*>(tt)[6];
+                    const float* t = plane + pix;
+                    float acc = t[0] * w[0];
+                    if (w[1] != 0.f) acc += t[dx] * w[1];
+                    if (w[2] != 0.f) acc += t[dy] * w[2];
+                    if (w[3] != 0.f) acc += t[dy + dx] * w[3];
+                    if (chan) rows[(size_t)p * K4] = acc;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s) {
+    constexpr int CH = 32;
+    int gx = 0;
+    for (int m = 0; m < 4; ++m) gx += (a.K4[m] + CH - 1) / CH;
+    // planes + the tap table of a batch of consumers (32 bytes per position), as many consumers as the LDS takes (<= 8)
+    const int plane_bytes = ((CH * (a.h * a.w + 1) + 3) & ~3) * 4;
+    DgPlaneArgs a2 = a;
+    a2.tap_consumers = (150 * 1024 - plane_bytes) / (a.P * 32);
+    if (a2.tap_consumers < 1) return hipErrorInvalidValue;
+    if (a2.tap_consumers > 8) a2.tap_consumers = 8;
+    const int smem = plane_bytes + a2.tap_consumers * a.P * 32;
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_plane_sample<CH>), smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_plane_sample<CH>, dim3(gx, a.B), dim3(PLANE_THREADS), smem, s, a2);
     return hipGetLastError();
 }
 
