@@ -19,7 +19,9 @@ C, D, hw, N, S = 384, 70, 28, 2, 28
 g = torch.Generator().manual_seed(128)
 f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
 c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
-d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float().to(dev)
+d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float()
+d[:, :, :9, :7] = 0.0                       # a region of zero depth: indicators that are not all 1
+d = d.to(dev)
 c1 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
 c2 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
 perms = torch.stack([torch.randperm(B, generator=g) for _ in range(N)]).to(dev)
@@ -82,3 +84,15 @@ for tj in range(T):
         for tt in range(nt):
             dd = float((ga_[0, tt, 0] - gb_[0, 1, 0]).abs().max())
             if dd < 0.05: print("        B tile 1 matches A tile", tt, dd)
+# gradient tiles of the region that differs most (if it has the size of one [B][tiles][DP/32][1024] fp32 buffer): where?
+if diff.numel():
+    lo = int(d64[0]) // 256 * 256
+    ngt = B * nt * 3 * 1024
+    for base in (lo, lo - 256, lo - 512):
+        if base >= 0 and base + ngt * 4 <= a.numel():
+            ta = a[base:base + ngt * 4].view(torch.float32).view(B, nt, 3, 1024)
+            tb = b[base:base + ngt * 4].view(torch.float32).view(B, nt, 3, 1024)
+            dd = (ta - tb).abs()
+            print("gradient-tile view at", base, ": max |d| per R tile:", [round(float(x), 4) for x in dd.amax(dim=(0, 2, 3))])
+            print("   per channel group:", [round(float(x), 4) for x in dd.amax(dim=(0, 1, 3))], " scale of values:", float(tb.abs().max()))
+            break
