@@ -53,7 +53,8 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
     l = last_json(f)
     shutil.copy(f, dst) if False else open(os.path.join(dst, os.path.basename(f)), "w").write(l)
     c = json.loads(l)
-    o.append(f"| {c['config']['name']} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
+    name = c['config']['name'] + (" (`--graph`)" if "hipGraph" in c['config']['workload'] else "")
+    o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
              f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |")
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))
