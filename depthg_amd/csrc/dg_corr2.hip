@@ -9,16 +9,19 @@
 // there and copies every one back per use).  Four of the six gradient accumulators sit there too.  The arch VGPRs hold
 // the two fd / cd accumulator pairs, the other two gradient accumulators, the LDS fragment ring and the epilogue.
 //
-// Per streamed tile of 32 positions of S (DMA'd into one of three LDS buffers two tiles ahead, as in dg_corr.hip) a wave
-// issues 70 MFMAs in four phases, and every non-MFMA instruction of the tile is placed in one of their issue gaps:
-//     A  chain of fragment 0: 24 x bf16 (fd) + 5 x f16 (cd)        gaps: the 9 LDS-DMA pieces of tile t+2, fd init of fragment 1
-//     B  chain of fragment 1                                       gaps: epilogue of fragment 0 (mask, -G, fp16 pack, G store),
-//                                                                        the six B fragments of the gradient product
-//        -- counted vmcnt + the one workgroup barrier of the tile: tile t+1 visible, buffer of tile t free --
-//     C  dR_0 += G_0^T ScP (6 MFMAs, accumulator tile as A operand)  gaps: first fragments of tile t+1, epilogue of fragment 1
-//     D  dR_1 += G_1^T ScP (6 MFMAs)                                 gaps: rest of that epilogue, G store, fd init of fragment 0
+// Per streamed tile of 32 positions of S (DMA'd into one of four LDS buffers three tiles ahead) a wave issues 70 MFMAs in
+// four phases, and every non-MFMA instruction of the tile is placed in one of their issue gaps; fragment 1 runs one phase
+// behind fragment 0, so that each epilogue sits in the gaps of the OTHER fragment's chain:
+//     A   chain of fragment 0 (tile t): 24 x bf16 (fd) + 5 x f16 (cd)   gaps: epilogue of fragment 1 (tile t-1), its G store,
+//                                                                             the 9 LDS-DMA pieces of tile t+3
+//     A'  dR_1 += G_1^T ScP of tile t-1 (6 MFMAs, accumulator tile as A)  gaps: fd initialisation of fragment 1
+//     B   chain of fragment 1 (tile t)                                   gaps: epilogue of fragment 0 (mask, -G, fp16 pack),
+//                                                                             its G stores, the six B fragments of the gradient product
+//         -- counted vmcnt + the one workgroup barrier of the tile: tile t+1 visible, buffer of tile t free --
+//     C   dR_0 += G_0^T ScP (6 MFMAs)                                    gaps: first fragments of tile t+1, fd initialisation of fragment 0
 // An accumulator is read by the VALU no sooner than two MFMAs after the chain that wrote it (the asm MFMAs are invisible to
 // hipcc's hazard recogniser).  Outputs are those of k_corr_main: G tiles (fp16) for k_gs, raw gradient tiles, block sums.
+// The depth term's blocks (depth_block) run in the same launch.  DESIGN.md section 4.1 has the measurements.
 #include "dg_common.h"
 #include <utility>
 #include <cstdio>

@@ -278,3 +278,29 @@ def test_corr2_owns_the_accumulator_file(tmp_path):
     assert m and int(m.group(1)) == 0
     m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", text)
     assert m and int(m.group(1)) == 0
+
+
+@pytest.mark.parametrize("unit", ["dg_post", "dg_prep"])
+def test_byte_movers_use_no_scratch_and_no_flat_loads(unit, tmp_path):
+    """Two ways hipcc silently made kernels of these files 10 x slower this round, now audited in the generated code:
+    (a) a lambda that captures the kernel argument by reference (or is not inlined) puts the whole argument struct, 1.5 KB, into
+        SCRATCH in every thread;
+    (b) a pointer read back from LDS has no address space: the loads through it become FLAT loads, which count as LDS operations
+        too, so every later ds_read waits for all of them.
+    No kernel of the operand-preparation / backward-tail files may use scratch, and none may contain a flat load or store."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "depthg_amd", "csrc", unit + ".hip")
+    out = tmp_path / (unit + ".s")
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    flat = [l.strip() for l in text.splitlines() if re.match(r"\s+flat_(load|store)", l)]
+    assert not flat, f"{unit}: FLAT memory instructions (a pointer without address space): {flat[:3]}"
+    scratch = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", text)}
+    assert scratch, "no kernels found in the generated code"
+    bad = {k: v for k, v in scratch.items() if v > 0}
+    assert not bad, f"{unit}: kernels with scratch (bytes per thread): {bad}"
