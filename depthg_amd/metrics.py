@@ -63,6 +63,8 @@ class UnsupervisedMetrics:
     def _summed_over_ranks(self, t):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             t = t.clone()
+            if dist.get_backend() == "nccl" and not t.is_cuda:      # RCCL reduces device tensors only (an untouched state may still be on the CPU)
+                t = t.to(torch.device("cuda", torch.cuda.current_device()))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
@@ -107,5 +109,5 @@ class UnsupervisedMetrics:
 
     def compute_cherry(self):                                              # src/utils.py:291-319
         out = self._scores(self._summed_over_ranks(self.cherry_stats), self._summed_over_ranks(self.stats))
-        self.cherry_stats = self._zeros("cpu")
+        self.cherry_stats = self._zeros()          # (stays on the metric's device: a CPU state would break an RCCL all-reduce)
         return out

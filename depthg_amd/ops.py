@@ -27,6 +27,15 @@ def _ptr(t):
 
 
 def _stream(device):
+    """Current stream of `device`, as the C ABI wants it.  The library launches on the CURRENT HIP device and keys its
+    kernel-attribute cache on it: a call with tensors of another device would run on a foreign stream - refuse it."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"depthg_amd: tensors must live on the GPU (got {device}); there is no CPU path")
+    cur = torch.cuda.current_device()
+    if device.index is not None and device.index != cur:
+        raise RuntimeError(f"depthg_amd: tensors live on cuda:{device.index} but the current device is cuda:{cur}; "
+                           f"call under `with torch.cuda.device({device.index}):` (one process per GPU sets it once)")
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
