@@ -1,0 +1,94 @@
+"""Shape sweep of the general-coordinates path against the oracle: the small-grid kernels of round 2 (k_plane_sample,
+k_gather_norm on sampled rows, k_scatter_small) and the general ones (k_nchw_to_nhwc + taps, k_scatter_grad) on batch sizes
+beyond one 64-image chunk of the consumer lists, batch maps with many duplicates (super_perm may repeat images, quirk Q6),
+map sizes with h*w not a multiple of 4 (scalar plane loads), code widths around the 32-channel groups, line grids of the
+`simple` sampler aside.  Reference: src/modules.py:822-825 (sample), :1184-1188 (super_perm), :1323-1367 (forward).
+Tolerances as in test_gpu_parity.py."""
+import pytest
+import torch
+
+from test_gpu_parity import _relclose, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+#            B   C   D  h   w  S  N  duplicates
+CASES = [(70, 40, 24, 9, 9, 4, 2, False),       # two 64-image chunks, small grid (rows path)
+         (66, 48, 33, 10, 10, 9, 1, True),      # general path (7 * 81 > 2 * 100), heavy duplicates, > 64 images
+         (5, 130, 70, 13, 11, 5, 5, True),      # h*w = 143: not a multiple of 4; C just over one 128 block; all negatives on few images
+         (3, 384, 90, 28, 28, 12, 3, False),    # the paper's S = 12 on 28x28
+         (2, 768, 100, 14, 14, 6, 4, True),     # ViT-B width
+         (9, 64, 8, 7, 7, 3, 8, False),         # DG_MAX_NEG negatives, tiny code
+         (4, 96, 128, 12, 12, 7, 2, False)]     # widest code
+
+
+@pytest.mark.parametrize("B,C,D,h,w,S,N,dup", CASES)
+def test_general_coords_shapes(B, C, D, h, w, S, N, dup, dev):
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(1000 * B + 10 * S + N)
+    f, fp = torch.randn(B, C, h, w, generator=g), torch.randn(B, C, h, w, generator=g)
+    c, cp = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    d = torch.randint(0, 256, (B, 1, 4 * h, 4 * w), generator=g).float()
+    d[:, :, :5, :6] = 0.0
+    c1 = torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1            # some coordinates outside [-1, 1]: border padding
+    c2 = torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1
+    if dup:      # many negatives on the same few images (super_perm's output need not be a permutation)
+        perms = [torch.randint(0, min(B, 3), (B,), generator=g) for _ in range(N)]
+    else:
+        perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced")
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
+                                                       [p.to(dev) for p in perms])
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 3e-3, 2e-5, f"tuple[{i}]")
+    for i in (1, 3, 5, 7):
+        _relclose(out[i].mean(), ref[i].mean(), 3e-3, 2e-5, f"tuple[{i}] mean")
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        assert torch.isfinite(got).all(), name
+        rel = (got.cpu() - want).norm() / want.norm()
+        assert rel < 4e-2, (name, float(rel))
+
+
+#            B   D  hw  N
+DENSE = [(1, 70, 28, 5),      # one image: super_perm gives [0], the negative is the image itself (quirk Q6)
+         (9, 80, 20, 2),      # P = 400 = 12.5 tiles (ragged row block of 4.5), B not a multiple of 8, widest code of k_corr2
+         (5, 16, 16, 3),      # P = 256 = 8 tiles: exactly one full row block
+         (3, 70, 13, 1),      # P = 169: just above k_corr2's smallest map (Ppad 192), ragged everything
+         (2, 64, 44, 2)]      # P = 1936 = 60.5 tiles: 8 row blocks, the last one half a tile
+
+
+@pytest.mark.parametrize("B,D,hw,N", DENSE)
+def test_dense_grid_shapes(B, D, hw, N, dev):
+    """The dense identity grid (k_prep_dense, k_corr2 / k_corr_main, k_gs, k_scatter_dense) at map sizes and batch sizes around
+    the kernels' blocking: ragged row blocks of every length, one image, odd batch."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    C = 384
+    g = torch.Generator().manual_seed(77 * B + hw)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float()
+    d[:, :, :7, :9] = 0.0
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=True)
+    coords = O.identity_coords(B, hw)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=coords, coords2=coords, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), coords.to(dev), coords.to(dev),
+                                                       [p.to(dev) for p in perms], shared_coords=True, identity_grid=True)
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 1e-3, 1e-5, f"tuple[{i}]")
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        assert torch.isfinite(got).all(), name
+        rel = (got.cpu() - want).norm() / want.norm()
+        assert rel < 3e-2, (name, float(rel))
