@@ -11,9 +11,12 @@
  *  - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
  *  - the callee never allocates or frees: scratch comes from a caller-sized workspace whose
  *    size is returned by dg_corr_workspace_bytes();
- *  - every launch goes to the given hipStream_t and is asynchronous w.r.t. the host;
+ *  - every launch is ordered with the given hipStream_t and asynchronous w.r.t. the host: the work goes to that stream,
+ *    except that dg_corr_forward may run one independent launch (the depth term) on a side stream of its own, forked from
+ *    and joined back into the given stream with events before the call's results are produced (stream capture sees it);
  *  - return value 0 = ok, negative = error (dg_last_error() gives text); no exceptions.
- *  - re-entrant, no global mutable state besides the thread-local last-error string.
+ *  - one host thread per device; state kept across calls: the thread-local last-error string, a per-kernel cache of the
+ *    dynamic-LDS attribute, and per device one side stream + two events (created on first use).
  */
 #ifndef DEPTHG_CORR_H
 #define DEPTHG_CORR_H
@@ -25,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 102   /* 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 103   /* 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
