@@ -97,13 +97,6 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     return main + gs, main, gs
 
 
-def depth_term_gflop(B, P, D):
-    """The depth term's share of the fused kernel's work (its cd correlation, the rank-1 dd, its stationary-side gradient):
-    k_corr2 runs the pair-sets only - the depth term is a launch of its own on a side stream (k_depth2)."""
-    corr = lambda k: 2.0 * B * P * P * k / 1e9
-    return 2 * corr(D) + corr(1)
-
-
 def cpu_baseline(conf, seconds_budget=15.0):
     """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the SAME workload: same C, D,
     S, pair-sets, sampler and backward, `cpu_B` images of the batch; scaled to steps/s of the full batch."""
@@ -261,13 +254,11 @@ def main():
     torch.cuda.synchronize()
     kern_ms = ev0.elapsed_time(ev1) / reps
     step_gf, main_gf, gs_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
-    # the one-wave-per-SIMD form runs the ViT-S widths at P >= 160 (dg_corr2.hip), k_corr_main everything else
-    kname = "k_corr2" if (H["C"] > 128 and H["C"] <= 384 and H["D"] <= 80 and H["S"] ** 2 >= 129 and H["B"] <= 64) else "k_corr_main"
-    if kname == "k_corr2":
-        main_gf -= depth_term_gflop(H["B"], H["S"] ** 2, H["D"])     # (the re-launched kernel holds the pair-sets only)
     achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE x2 correction on gfx950, WRITE_SIZE),
     # collected by scripts/profile_round.sh and committed under profiles/ (counters cannot be read from inside a run)
+    # the one-wave-per-SIMD form runs the ViT-S widths at P >= 160 (dg_corr2.hip), k_corr_main everything else
+    kname = "k_corr2" if (H["C"] > 128 and H["C"] <= 384 and H["D"] <= 80 and H["S"] ** 2 >= 129 and H["B"] <= 64) else "k_corr_main"
     traffic = None
     if args.config == "headline":
         try:

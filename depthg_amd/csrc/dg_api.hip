@@ -39,7 +39,6 @@ struct Plan {
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
-    size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
     size_t total;
 };
 
@@ -97,9 +96,6 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.scratch_out = take(DG_OUT_COUNT * 4);
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
-    p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
-    p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
-    p.gr_rank = take((size_t)DG_MAX_JOBS * B * 2);
     p.total = off;
     return DG_OK;
 }
@@ -212,76 +208,16 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         a.jobs[nj++] = j;
     }
     a.njobs = nj;
-    // Ragged last row blocks grouped by streamed operand (dg_corr2.hip): pair-sets that stream the same operand array form a
-    // key.  Worth it when the ragged row block is short (at most 4 of the 8 row tiles) and several pair-sets share an array
-    // (shared coordinates: intra + the negatives stream operand 0 through batch maps).
-    a.gr_list = nullptr;
-#ifndef DG_NO_GROUP          // (developer A/B: scripts/build_variant.sh with SRC=dg_api)
-    {
-        const int nt = p.Ppad / 32, L = nt % 8;
-        if (p.grad && p.KF == 384 && p.KD == 96 && p.D <= 80 && p.nrb > 1 && L >= 1 && L <= 4 && p.B % 8 == 0 && p.B <= 64 && njA >= 2) {
-            int nkeys = 0, members[DG_MAX_JOBS] = {0};
-            for (int j = 0; j < njA; ++j) {
-                int k = -1;
-                for (int q = 0; q < nkeys; ++q) if (a.jobs[(int)a.gr_first[q]].Sop == a.jobs[j].Sop) k = q;
-                if (k < 0) { k = nkeys++; a.gr_first[k] = (int8_t)j; }
-                a.gr_key[j] = (int8_t)k; ++members[k];
-            }
-            bool shared_any = false;
-            for (int k = 0; k < nkeys; ++k) shared_any |= members[k] > 1;
-            if (shared_any) {
-                a.gr_nkeys = nkeys; a.gr_cpb = 8 / L; a.gr_blocks_per_image = 0;
-                for (int k = 0; k < nkeys; ++k) {
-                    const bool single = members[k] == 1 && a.jobs[(int)a.gr_first[k]].sidx == nullptr;      // exactly one consumer per image
-                    int nb = single ? 1 : (5 * members[k] / 2 + a.gr_cpb - 1) / a.gr_cpb;           // 2.5 x the mean consumer count
-                    const int cap = (DG_GR_CAP + a.gr_cpb - 1) / a.gr_cpb;
-                    a.gr_nblk[k] = nb > cap ? cap : nb;
-                    a.gr_blocks_per_image += a.gr_nblk[k];
-                }
-                a.gr_list = reinterpret_cast<const int32_t*>(ws + p.gr_list);
-                a.gr_count = reinterpret_cast<const int32_t*>(ws + p.gr_count);
-                a.gr_rank = reinterpret_cast<const int16_t*>(ws + p.gr_rank);
-            }
-        }
-    }
-#endif
     return njA;
-}
-
-// A second stream per device for launches that have nothing to wait for on the caller's stream but their inputs - the depth
-// term's blocks, which otherwise form the tail of the fused launch.  fork(): the side stream waits for everything enqueued on
-// the caller's stream so far; join(): the caller's stream waits for the side stream.  Event based, no host synchronisation;
-// inside a stream capture (torch.cuda.graph) the side stream joins the capture through the events.  One host thread per
-// device (as the header says): the objects are created once and reused.
-struct DgSide {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool tried = false;
-};
-static DgSide* dg_side(void) {
-    static DgSide side[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    DgSide& d = side[dev];
-    if (!d.tried) {
-        d.tried = true;
-        if (hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking) != hipSuccess) { d.s = nullptr; return nullptr; }
-        // (device-scope release: the default system-scope release of an event record writes the L2 back - a 7-us bubble on
-        //  the recording stream after the 60 MB the operand preparation has just written)
-        if (hipEventCreateWithFlags(&d.fork, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
-            hipEventCreateWithFlags(&d.join, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) { d.s = nullptr; return nullptr; }
-    }
-    return d.s ? &d : nullptr;
 }
 
 // Fused correlation launch.  Gradient passes of the ViT-S widths run the one-wave-per-SIMD kernel (dg_corr2.hip); everything else
 // (forward-only calls, stabalize / no zero_clamp, ViT-B widths, small P) k_corr_main.
-static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int depth_index, hipStream_t stream, bool depth_done) {
+static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int depth_index, hipStream_t stream) {
     (void)depth_index;
-    if (p.grad && njA > 0 && dg_corr2_supported(a, p.KF, p.KD)) {
-        const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // the pair-set jobs
-        if (e != hipSuccess || depth_done) return e;
-        return dg_launch_depth2(a, stream);                               // the depth job, when it was not put on the side stream
+    if (p.grad && njA > 0) {
+        const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // pair-set jobs + the depth job, one launch
+        if (e != hipErrorNotSupported) return e;
     }
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);
 }
@@ -359,22 +295,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }
 
-    // (the launch plan of step 4 is needed here already: the depth term of a k_corr2 call depends on the operands only and goes
-    //  to the side stream now - it then runs beside the small launches of step 3 and the start of the fused kernel instead of
-    //  being that kernel's tail; joined before the launch that reduces its partial sums)
-    DgCorrArgs a;
-    int depth_index;
-    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
-    bool depth_forked = false;
-    DgSide* side = nullptr;
-    if (p.grad && p.depth && njA > 0 && dg_corr2_supported(a, p.KF, p.KD) && (side = dg_side()) != nullptr) {
-        DG_HIP(hipEventRecord(side->fork, stream));
-        DG_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
-        DG_HIP(dg_launch_depth2(a, side->s));
-        DG_HIP(hipEventRecord(side->join, side->s));
-        depth_forked = true;
-    }
-
     // 3. column sums of the operands (mean feats for the centering, code sums for the cd means), then the row means of
     //    fd (pointwise centering as a rank-1 correction)
     {
@@ -386,12 +306,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             c.bsplit[o] = reinterpret_cast<__bf16*>(ws + p.bsplit[o]);
             c.ngroups[o] = p.ident ? p.h * ((p.w + 31) / 32) : p.Ppad / 32;
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
-        }
-        if (a.gr_list) {           // the consumer lists of k_corr2's grouped ragged blocks ride along (extra blocks of this launch)
-            const int nd = a.jobs[a.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0;
-            c.gr.nh = a.njobs - nd; c.gr.nkeys = a.gr_nkeys; c.gr.B = p.B;
-            for (int j = 0; j < c.gr.nh; ++j) { c.gr.sidx[j] = a.jobs[j].sidx; c.gr.key[j] = a.gr_key[j]; }
-            c.gr.list = const_cast<int32_t*>(a.gr_list); c.gr.count = const_cast<int32_t*>(a.gr_count); c.gr.rank = const_cast<int16_t*>(a.gr_rank);
         }
         DG_HIP(dg_launch_colmean(c, stream));
     }
@@ -409,7 +323,10 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     }
 
     // 4. fused correlation passes
-    DG_HIP(launch_main(p, a, njA, depth_index, stream, depth_forked));
+    DgCorrArgs a;
+    int depth_index;
+    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    DG_HIP(launch_main(p, a, njA, depth_index, stream));
 
     // 5. scalar outputs: the partial sums are reduced by the next launch (k_gs on a gradient pass)
     DgFinishArgs f;
@@ -426,9 +343,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DgGsArgs g;
         build_gs_jobs(p, ws, perms, g);
         g.fin = f;
-        // join before the launch that reduces the partial sums (its first block).  (Joining behind k_gs, with the reduction in a
-        // launch of its own, was 10 us slower: the cross-stream wait costs its ~8 us even when the event has long fired.)
-        if (depth_forked) DG_HIP(hipStreamWaitEvent(stream, side->join, 0));
         DG_HIP(dg_launch_gs(g, stream));
     } else {
         DG_HIP(dg_launch_finish(f, stream));
@@ -543,7 +457,7 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     DgCorrArgs a;
     int depth_index;
     const int njA = build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
-    DG_HIP(launch_main(p, a, njA, depth_index, static_cast<hipStream_t>(stream_), true));    // (the fused kernel alone: of a k_corr2 call the pair-sets)
+    DG_HIP(launch_main(p, a, njA, depth_index, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

@@ -11,12 +11,10 @@
  *  - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
  *  - the callee never allocates or frees: scratch comes from a caller-sized workspace whose
  *    size is returned by dg_corr_workspace_bytes();
- *  - every launch is ordered with the given hipStream_t and asynchronous w.r.t. the host: the work goes to that stream,
- *    except that dg_corr_forward may run one independent launch (the depth term) on a side stream of its own, forked from
- *    and joined back into the given stream with events before the call's results are produced (stream capture sees it);
+ *  - every launch goes to the given hipStream_t and is asynchronous w.r.t. the host;
  *  - return value 0 = ok, negative = error (dg_last_error() gives text); no exceptions.
- *  - one host thread per device; state kept across calls: the thread-local last-error string, a per-kernel cache of the
- *    dynamic-LDS attribute, and per device one side stream + two events (created on first use).
+ *  - one host thread per device; state kept across calls: the thread-local last-error string and a per-kernel cache of the
+ *    dynamic-LDS attribute.
  */
 #ifndef DEPTHG_CORR_H
 #define DEPTHG_CORR_H

@@ -1,8 +1,6 @@
 #!/usr/bin/env python3
-"""developer aid: per-CU timeline of the fused kernel from DG_BLOCKLOG=<file>.  k_corr_main: stamp build (make EXTRA=-DDG_STAMP_BUILD);
-k_corr2: scripts/build_variant.sh blog -DDG_DEVTOOLS -DC2_BLOCKLOG, then DG_BLOCKLOG=<file> DEPTHG_LIB=.../libdepthg_blog.so.
-Every block logs hw id, xcc id and four 100 MHz wall-clock stamps: entry, tile loop start, tile loop done, exit; k_corr2 block
-kinds: 0 full row block, 1 grouped ragged blocks (by streamed operand), 2 one-(pair-set, image) ragged block, 3 depth."""
+"""developer aid: per-CU timeline of the fused kernel from DG_BLOCKLOG=<file> (stamp build: make EXTRA=-DDG_STAMP_BUILD).
+Every block logs hw id, xcc id and four 100 MHz wall-clock stamps: entry, first tile landed, tile loop done, exit."""
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8).astype(np.int64)
