@@ -84,7 +84,7 @@ def synth_inputs(B, seed, device, H=HEADLINE):
 
 def algorithmic_gflop(B, P, C, D, n_neg):
     """one correlation = 2*B*P^2*K flop (real K, no padding; nothing recomputed is counted).
-    Returns (step total, share done by the fused kernel k_corr_main, share done by k_gs):
+    Returns (step total, share done by the fused kernel, share done by the k_gs launch):
       forward   (2+n) feature correlations (K=C), (3+n) code correlations (K=D: the pair-sets + the depth term's cd),
                 1 rank-1 depth product (K=1)                                                   -> k_corr_main
       backward  d/d(stationary code) for the (2+n) pair-sets + the depth term: (3+n) * K=D     -> k_corr_main
@@ -94,7 +94,10 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     fwd = (2 + n_neg) * corr(C) + (3 + n_neg) * corr(D) + corr(1)
     main = fwd + (3 + n_neg) * corr(D)
     gs = (2 + n_neg) * corr(D)
-    return main + gs, main, gs
+    # the depth term (its cd correlation, the rank-1 dd, its stationary-side gradient) runs as blocks of the k_gs launch on a
+    # gradient pass (dg_corr.hip gs_depth_block), not in the fused kernel
+    dep = 2 * corr(D) + corr(1)
+    return main + gs, main - dep, gs + dep
 
 
 def cpu_baseline(conf, seconds_budget=15.0):

@@ -39,6 +39,7 @@ struct Plan {
     size_t dRA[DG_MAX_NEG + 3], dRB[DG_MAX_NEG + 2];   // dRA[T] = depth job
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
+    size_t ticket;                          // the depth blocks' ticket of the k_gs launch
     size_t total;
 };
 
@@ -96,6 +97,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.scratch_out = take(DG_OUT_COUNT * 4);
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
+    p.ticket = take(256);
     p.total = off;
     return DG_OK;
 }
@@ -199,7 +201,9 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     const int njA = nj;
     // (the gradient of the streamed operand's code comes from k_gs, which consumes the G tiles these jobs store)
     *depth_index = -1;
-    if (p.depth) {
+    // (on a gradient pass the depth term runs as blocks of the k_gs launch, dg_corr.hip gs_depth_block: in the fused kernel's
+    //  launch its latency-bound blocks were the tail)
+    if (p.depth && !p.grad) {
         DgJob j = depth_job(p, desc, ws);
         j.part = F32(p.part[p.T]);
         j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
@@ -307,6 +311,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             c.ngroups[o] = p.ident ? p.h * ((p.w + 31) / 32) : p.Ppad / 32;
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
+        c.zero_word = (p.grad && p.depth) ? reinterpret_cast<unsigned int*>(ws + p.ticket) : nullptr;
         DG_HIP(dg_launch_colmean(c, stream));
     }
     if (p.pointwise) {
@@ -336,6 +341,13 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         f.scale[j] = a.jobs[j].fin_scale;
     }
     f.njobs = a.njobs; f.nblk = p.B * p.nrb; f.B = p.B; f.P = p.P;
+    const int dep_nrb = (p.Ppad / 32 + 7) / 8;               // row blocks of the depth term inside the k_gs launch: 8 row tiles each
+    if (p.grad && p.depth) {                                 // its partial sums: one more entry of the reduction
+        const int j = f.njobs++;
+        f.part[j] = F32(p.part[p.T]); f.slot_loss[j] = DG_OUT_LOSS_DEPTH; f.slot_cd[j] = -1;
+        f.scale[j] = (float)(1.0 / ((double)p.B * p.P * p.P));
+        f.nblk_job[j] = p.B * dep_nrb;
+    }
     f.nzsum = p.depth ? F32(p.nzsum) : nullptr;
     f.out = out_scalars;
     f.wtot[0] = desc->w_intra; f.wtot[1] = desc->w_inter; f.wtot[2] = desc->w_neg; f.wtot[3] = desc->w_depth;
@@ -343,6 +355,12 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         DgGsArgs g;
         build_gs_jobs(p, ws, perms, g);
         g.fin = f;
+        if (p.depth) {
+            g.dep_op = ws + p.op[0]; g.dep_nz = F32(p.nz); g.dep_dR = F32(p.dRA[p.T]); g.dep_part = F32(p.part[p.T]);
+            g.dep_ticket = reinterpret_cast<unsigned int*>(ws + p.ticket);
+            g.dep_shift = desc->shift_depth; g.dep_nrb = dep_nrb; g.dep_blocks = p.B * dep_nrb;
+            clamp_bounds(desc, g.dep_lo, g.dep_hi);
+        }
         DG_HIP(dg_launch_gs(g, stream));
     } else {
         DG_HIP(dg_launch_finish(f, stream));

@@ -224,6 +224,7 @@ struct DgFinishArgs {
     int32_t slot_cd[DG_MAX_JOBS];
     float scale[DG_MAX_JOBS];         // 1/numel of the tensor the job contributes to
     int32_t njobs, nblk, B, P;
+    int32_t nblk_job[DG_MAX_JOBS];    // partial sums of job j if not nblk (0: nblk)
     const float* nzsum;               // [B] per-image sums of the depth indicators (mean(dd)) or null
     float* out;                       // [DG_OUT_COUNT]; null: nothing to do
     float wtot[4];                    // weights of the four loss means in out[DG_OUT_TOTAL]
@@ -288,6 +289,7 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
     float* csum[DG_MAX_NEG + 2];            // [B][KD]
     int32_t ngroups[DG_MAX_NEG + 2];   // feats partial-sum groups per image (tiles, or source rows on the dense path)
     int32_t nops, B, P, Ppad, KF, KD;
+    unsigned int* zero_word;           // a word this launch sets to 0 (the depth blocks' ticket of the k_gs launch), or null
 };
 
 struct DgRowmeanJob {
@@ -359,6 +361,17 @@ struct DgGsArgs {
     int32_t D;             // real code channels (<= KD)
     int32_t debug;         // developer ablation bits (0 in production)
     DgFinishArgs fin;      // the first block also reduces k_corr_main's partial sums (fin.out == null: nothing to do)
+    // The depth term (depth_feature_correlation) as extra blocks of this launch (dep_blocks > 0): the G-stream blocks are
+    // HBM-bound and their second round leaves block slots empty, so the depth blocks' latency chain costs next to nothing here
+    // (in the fused kernel's launch they were its tail).  Their partial sums arrive inside this launch: the depth block that
+    // finishes last (ticket) reduces everything to the output scalars instead of the first block.
+    const char* dep_op;    // operand-1 blobs: R and S of the depth term (C and P parts)
+    const float* dep_nz;   // [B][Ppad] depth indicators
+    float* dep_dR;         // raw gradient tiles out (dg_gtile_off)
+    float* dep_part;       // [B * dep_nrb][2] loss partial sums out
+    unsigned int* dep_ticket;   // zero before the launch (k_colmean)
+    float dep_shift, dep_lo, dep_hi;    // shift; clamp bounds of cd (zero_clamp / stabalize)
+    int32_t dep_blocks, dep_nrb;    // B * dep_nrb blocks of 8 row tiles
 };
 
 // bytes of one inverse-tap record: off[HW+1] ints, 4P weights, 4P positions (ushort), padded to 16

@@ -104,7 +104,8 @@ __device__ __forceinline__ void finish_scalars(const DgFinishArgs& f, int lane) 
     for (int j = 0; j < f.njobs; ++j) {
         if (!f.part[j]) continue;
         double l = 0.0, c = 0.0;
-        for (int i = lane; i < f.nblk; i += 64) { l += f.part[j][2 * i]; c += f.part[j][2 * i + 1]; }
+        const int nb = f.nblk_job[j] ? f.nblk_job[j] : f.nblk;
+        for (int i = lane; i < nb; i += 64) { l += f.part[j][2 * i]; c += f.part[j][2 * i + 1]; }
         for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o, 64); c += __shfl_xor(c, o, 64); }
 #pragma unroll
         for (int i = 0; i < DG_OUT_COUNT; ++i) {
@@ -693,6 +694,125 @@ __device__ __forceinline__ void gs_wait_tiles(int k) {   // at most k tiles (CH 
         default: asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * CH) : "memory"); break;
     }
 }
+// ---- the depth term as blocks of the k_gs launch (depth_feature_correlation, src/modules.py:1256-1278) -------------------------
+// loss = -clamp(cd)(dd - shift), cd = corr(code, code) of the image itself, dd[p][q] = nz_p nz_q (quirk Q1); by symmetry only the
+// stationary-side gradient is formed (the combine doubles it).  One block = 8 row tiles of one image, one 32-row fragment per
+// wave (the whole block lives in k_gs's 128 registers per wave and its 54 KB of LDS, so it runs beside the G-stream blocks):
+// the streamed tile's C and P parts + its 32 indicators come through two LDS buffers, register-staged one tile ahead (plain
+// loads: with eight waves per block and other blocks on the CU there is enough in flight); per tile NKD cd MFMAs, the epilogue
+// with per-element sums (G takes two or three distinct values: the fold of the helper jobs would bias), 6 gradient MFMAs.
+template <int NKF, int NKD>
+__device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid, char* smem) {
+    using BL = BlobT<NKF, NKD>;
+    constexpr int KD = BL::KD, NDF = KD / 32, NTH = (GS_CW + 1) * 64;
+    constexpr int TILE = 256 + (BL::BYTES - BL::OFF_C);       // [32 indicators, padded][C part][P part]
+    constexpr int NPC = (BL::BYTES - BL::OFF_C) / 16;          // 16-byte pieces of the C and P parts
+    static_assert(NPC <= 2 * NTH && 2 * TILE <= GS_NB * (BL::BYTES - BL::OFF_P), "two tiles fit the ring; two pieces per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int n = dbid / a.dep_nrb, rb = dbid - n * a.dep_nrb;
+    const int ntiles = a.Ppad >> 5;
+    const int rtile = rb * (GS_CW + 1) + wid;
+    const bool act = rtile < ntiles;
+    const char* const img = a.dep_op + (size_t)n * ntiles * BL::BYTES;
+    const float* const nz = a.dep_nz + (size_t)n * a.Ppad;
+    // stationary fragment: code rows of this wave's tile as B operands, its indicators per lane
+    v4i Rc[NKD];
+    const char* Rb = img + (size_t)(act ? rtile : 0) * BL::BYTES + BL::OFF_C;
+#pragma unroll
+    for (int k = 0; k < NKD; ++k) Rc[k] = *reinterpret_cast<const v4i*>(Rb + ((2 * k + h) * 32 + r) * 16);
+    const float nz_lane = act ? nz[rtile * 32 + r] : 0.f;
+    const float c0 = -a.dep_shift;
+    f32x16 acc[NDF];
+#pragma unroll
+    for (int d = 0; d < NDF; ++d) acc[d] = f32x16{};
+    float lsum = 0.f;
+    // tile staging: thread t owns pieces t and t + NTH of the C/P parts, threads 0..7 also four indicators each
+    v4i st0, st1 = v4i{0, 0, 0, 0};
+    f32x4 stz = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int t) {
+        const char* src = img + (size_t)t * BL::BYTES + BL::OFF_C;
+        st0 = *reinterpret_cast<const v4i*>(src + tid * 16);
+        if (tid + NTH < NPC) st1 = *reinterpret_cast<const v4i*>(src + (tid + NTH) * 16);
+        if (tid < 8) stz = *reinterpret_cast<const f32x4*>(nz + t * 32 + tid * 4);
+    };
+    auto stash = [&](int b) {
+        char* tile = smem + b * TILE;
+        *reinterpret_cast<v4i*>(tile + 256 + tid * 16) = st0;
+        if (tid + NTH < NPC) *reinterpret_cast<v4i*>(tile + 256 + (tid + NTH) * 16) = st1;
+        if (tid < 8) *reinterpret_cast<f32x4*>(tile + tid * 16) = stz;
+    };
+    fetch(0);
+    stash(0);
+    const int crow = (h * 32 + r) * 16;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) fetch(t + 1);                 // in flight during this tile's arithmetic
+        __syncthreads();                                   // tile t is in buffer t & 1; everybody is done with the other one
+        const char* tile = smem + (t & 1) * TILE;
+        if (act) {
+            f32x16 yc = f32x16{};
+#pragma unroll
+            for (int k = 0; k < NKD; ++k) {
+                const f16x8 af = *reinterpret_cast<const f16x8*>(tile + 256 + crow + k * 1024);
+                yc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, Rc[k]), yc, 0, 0, 0);
+            }
+            f16x8 g8[2];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (8 * i4 + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * i4 + e;
+                    const float fdv = fmaf(nz_lane, v4[e], c0);
+                    const float g = (yc[i] >= a.dep_lo && yc[i] <= a.dep_hi) ? fdv : 0.f;      // d clamp(cd) / d cd
+                    lsum = fmaf(fdv, fminf(fmaxf(yc[i], a.dep_lo), a.dep_hi), lsum);           // clamp(cd) (dd - shift)
+                    g8[i >> 3][i & 7] = (_Float16)g;
+                }
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int d = 0; d < NDF; ++d) {
+                    const f16x8 bf = *reinterpret_cast<const f16x8*>(tile + 256 + (BL::OFF_P - BL::OFF_C) + (h * KD + 32 * d + r) * 16 + sp * (2 * KD * 16));
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(g8[sp], bf, acc[d], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) stash((t + 1) & 1);           // (its readers of tile t-1 are behind this iteration's barrier)
+    }
+    // raw gradient tile (accumulator order, as the fused kernel's) and the block's loss partial sum
+    if (act && a.dep_dR) {
+        float* base = a.dep_dR + ((size_t)n * ntiles + rtile) * (32 * KD) + lane * 4;
+#pragma unroll
+        for (int d = 0; d < NDF; ++d)
+            if (32 * d + r < a.D) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 o = {acc[d][4 * g], acc[d][4 * g + 1], acc[d][4 * g + 2], acc[d][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256) = o;
+                }
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+    __syncthreads();                                       // the tile buffers are free: reuse their head for the reduction
+    float* red = reinterpret_cast<float*>(smem);
+    int* flag = reinterpret_cast<int*>(smem + 64);
+    if (lane == 0) red[wid] = act ? lsum : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w <= GS_CW; ++w) s += red[w];
+        a.dep_part[(size_t)dbid * 2] = s;
+        a.dep_part[(size_t)dbid * 2 + 1] = 0.f;
+        __threadfence();                                   // this block's outputs are visible before its ticket is
+        *flag = atomicAdd(a.dep_ticket, 1u) == (unsigned)a.dep_blocks - 1u;
+    }
+    __syncthreads();
+    if (*flag && wid == 0 && a.fin.out) {                  // the last depth block: every partial sum of the call is complete
+        __threadfence();
+        finish_scalars(a.fin, lane);
+    }
+}
+
 template <int NKF, int NKD>
 __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     using BL = BlobT<NKF, NKD>;
@@ -705,9 +825,12 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     // pair-sets of an image together) so that the most recently written tiles are read first, while the Infinity Cache has them
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): the blocks of one image - they all read the same R
     // operand - get consecutive logical ids on one XCD, so its P parts are fetched into one L2 once
+    // the depth term's blocks FIRST (they are long latency chains: started last they would be this launch's tail), then the
+    // G-stream blocks
+    if ((int)blockIdx.x < a.dep_blocks) { gs_depth_block<NKF, NKD>(a, (int)blockIdx.x, gs_smem); return; }
     int bid;
     {
-        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int nwg = (int)gridDim.x - a.dep_blocks, orig = (int)blockIdx.x - a.dep_blocks;
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
@@ -743,10 +866,10 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     const bool spare = (a.Ppad / 32) % GS_CW != 0;
     if (st >= ntS) {                                        // nothing to do but keep the barrier count
         for (int rt = 0; rt < nt; ++rt) __builtin_amdgcn_s_barrier();
-        if (a.fin.out && bid == nbx - 1 && wid == GS_CW - 1) finish_scalars(a.fin, lane);
+        if (a.fin.out && a.dep_blocks == 0 && bid == nbx - 1 && wid == GS_CW - 1) finish_scalars(a.fin, lane);
         return;
     }
-    if (a.fin.out && !spare && bid == 0 && wid == 0) finish_scalars(a.fin, lane);
+    if (a.fin.out && a.dep_blocks == 0 && !spare && bid == 0 && wid == 0) finish_scalars(a.fin, lane);
     const int nS = J.sidx ? (int)J.sidx[n] : n;
     f32x16 acc[NDF];
 #pragma unroll
@@ -847,7 +970,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
 }
 
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
-    dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B), block((GS_CW + 1) * 64);
+    dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B + a.dep_blocks), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
 #ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)

@@ -601,6 +601,7 @@ hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B
 // bbar[o][n][k] = (1/P) sum over tiles of the per-tile column sums.  grid (B, nops), block 256.
 __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
     const int n = blockIdx.x, o = blockIdx.y;
+    if (a.zero_word && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) {
         for (int k = threadIdx.x; k < K; k += 256) {
             const float* cp = part + (size_t)n * ngroups * K + k;
