@@ -40,6 +40,7 @@ struct Plan {
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
     size_t ticket;                          // the depth blocks' ticket of the k_gs launch
+    size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
     size_t total;
 };
 
@@ -98,6 +99,9 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
     p.ticket = take(256);
+    p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
+    p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
+    p.gr_rank = take((size_t)DG_MAX_JOBS * B * 2);
     p.total = off;
     return DG_OK;
 }
@@ -212,6 +216,39 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         a.jobs[nj++] = j;
     }
     a.njobs = nj;
+    // Ragged last row blocks grouped by streamed operand (dg_corr2.hip): pair-sets that stream the same operand array form a
+    // key.  Worth it when the ragged row block is short (at most 4 of the 8 row tiles) and several pair-sets share an array
+    // (shared coordinates: intra + the negatives stream operand 0 through batch maps).
+    a.gr_list = nullptr;
+#ifndef DG_NO_GROUP          // (developer A/B: scripts/build_variant.sh with SRC=dg_api)
+    {
+        const int nt = p.Ppad / 32, L = nt % 8;
+        if (p.grad && p.KF == 384 && p.KD == 96 && p.D <= 80 && p.nrb > 1 && L >= 1 && L <= 4 && p.B % 8 == 0 && p.B <= 64 && njA >= 2) {
+            int nkeys = 0, members[DG_MAX_JOBS] = {0};
+            for (int j = 0; j < njA; ++j) {
+                int k = -1;
+                for (int q = 0; q < nkeys; ++q) if (a.jobs[(int)a.gr_first[q]].Sop == a.jobs[j].Sop) k = q;
+                if (k < 0) { k = nkeys++; a.gr_first[k] = (int8_t)j; }
+                a.gr_key[j] = (int8_t)k; ++members[k];
+            }
+            bool shared_any = false;
+            for (int k = 0; k < nkeys; ++k) shared_any |= members[k] > 1;
+            if (shared_any) {
+                a.gr_nkeys = nkeys; a.gr_cpb = 8 / L; a.gr_blocks_per_image = 0;
+                for (int k = 0; k < nkeys; ++k) {
+                    const bool single = members[k] == 1 && a.jobs[(int)a.gr_first[k]].sidx == nullptr;      // exactly one consumer per image
+                    int nb = single ? 1 : (5 * members[k] / 2 + a.gr_cpb - 1) / a.gr_cpb;           // 2.5 x the mean consumer count
+                    const int cap = (DG_GR_CAP + a.gr_cpb - 1) / a.gr_cpb;
+                    a.gr_nblk[k] = nb > cap ? cap : nb;
+                    a.gr_blocks_per_image += a.gr_nblk[k];
+                }
+                a.gr_list = reinterpret_cast<const int32_t*>(ws + p.gr_list);
+                a.gr_count = reinterpret_cast<const int32_t*>(ws + p.gr_count);
+                a.gr_rank = reinterpret_cast<const int16_t*>(ws + p.gr_rank);
+            }
+        }
+    }
+#endif
     return njA;
 }
 
@@ -299,6 +336,12 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }
 
+    // (the launch plan of step 4 is needed here already: the consumer lists of k_corr2's grouped ragged blocks are written by
+    //  extra blocks of the k_colmean launch)
+    DgCorrArgs a;
+    int depth_index;
+    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+
     // 3. column sums of the operands (mean feats for the centering, code sums for the cd means), then the row means of
     //    fd (pointwise centering as a rank-1 correction)
     {
@@ -312,6 +355,12 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
         c.zero_word = (p.grad && p.depth) ? reinterpret_cast<unsigned int*>(ws + p.ticket) : nullptr;
+        if (a.gr_list) {           // the consumer lists of k_corr2's grouped ragged blocks ride along (extra blocks of this launch)
+            const int nd = a.jobs[a.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0;
+            c.gr.nh = a.njobs - nd; c.gr.nkeys = a.gr_nkeys; c.gr.B = p.B;
+            for (int j = 0; j < c.gr.nh; ++j) { c.gr.sidx[j] = a.jobs[j].sidx; c.gr.key[j] = a.gr_key[j]; }
+            c.gr.list = const_cast<int32_t*>(a.gr_list); c.gr.count = const_cast<int32_t*>(a.gr_count); c.gr.rank = const_cast<int16_t*>(a.gr_rank);
+        }
         DG_HIP(dg_launch_colmean(c, stream));
     }
     if (p.pointwise) {
@@ -328,9 +377,6 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
     }
 
     // 4. fused correlation passes
-    DgCorrArgs a;
-    int depth_index;
-    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
     DG_HIP(launch_main(p, a, njA, depth_index, stream));
 
     // 5. scalar outputs: the partial sums are reduced by the next launch (k_gs on a gradient pass)

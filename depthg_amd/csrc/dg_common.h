@@ -200,6 +200,7 @@ struct DgJob {
 };
 
 #define DG_MAX_JOBS 12      // pair-sets (<= DG_MAX_NEG + 2) + the depth job
+#define DG_GR_CAP 24        // k_corr2's grouped ragged blocks: listed consumers per (key, streamed image); the rest run as one-(pair-set, image) blocks
 
 struct DgCorrArgs {
     DgJob jobs[DG_MAX_JOBS];
@@ -213,6 +214,15 @@ struct DgCorrArgs {
     int32_t debug;        // developer ablation bits (0 in production)
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
+    // ragged last row blocks grouped by streamed operand (dg_corr2.hip; lists written by k_group_ragged); gr_list null: off
+    const int32_t* gr_list;    // [nkeys][B][DG_GR_CAP]: pair-set | image << 8 of the consumers of (key, streamed image)
+    const int32_t* gr_count;   // [nkeys][B]: how many of them are listed
+    const int16_t* gr_rank;    // [helper jobs][B]: rank of (pair-set, image) among the consumers of its (key, streamed image)
+    int32_t gr_nkeys, gr_cpb;  // keys; consumers per grouped block = 8 / (row tiles of the ragged row block)
+    int32_t gr_blocks_per_image;             // sum of gr_nblk over the keys
+    int8_t gr_key[DG_MAX_JOBS];              // key of helper job j (same streamed operand array = same key)
+    int8_t gr_first[DG_MAX_JOBS];            // first pair-set of key k
+    int32_t gr_nblk[DG_MAX_JOBS];            // grouped blocks per streamed image of key k
 };
 
 // Final reduction of the per-block partial sums of k_corr_main into the output scalars.  It runs in the NEXT launch on the
@@ -281,6 +291,45 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
 };
 
+// Consumer lists of the grouped ragged row blocks of k_corr2 (dg_corr2.hip): for every key (= set of pair-sets that stream the
+// same operand array) and every image m of that array, the (pair-set, image) pairs whose streamed operand is image m, in
+// (pair-set, image) order - the first DG_GR_CAP of them as a list, and for every (pair-set, image) its rank in that order.
+// Written by extra blocks of the k_colmean launch (nothing of its own to wait for: the batch maps are inputs of the call).
+struct DgGroupArgs {
+    const int64_t* sidx[DG_MAX_JOBS];   // batch map of the streamed operand of helper job j (null: the image itself)
+    int8_t key[DG_MAX_JOBS];
+    int32_t nh, nkeys, B;               // helper jobs, keys (0: no lists), images (<= 64)
+    int32_t* list;                      // [nkeys][B][DG_GR_CAP]: pair-set | image << 8
+    int32_t* count;                     // [nkeys][B]
+    int16_t* rank;                      // [helper jobs][B]
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ void dg_group_lists(const DgGroupArgs& g, const int m, const int key, const int lane) {
+    const int B = g.B;
+    // (all batch-map entries first - independent loads, one latency - then the ballots in pair-set order)
+    int src[DG_MAX_JOBS];
+#pragma unroll
+    for (int j = 0; j < DG_MAX_JOBS; ++j) {
+        const bool mine = j < g.nh && g.key[j] == key && lane < B;
+        const int64_t* sidx = mine ? g.sidx[j] : nullptr;
+        src[j] = mine ? (sidx ? (int)sidx[lane] : lane) : -1;
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < DG_MAX_JOBS; ++j) {
+        const bool hit = src[j] == m;
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int rk = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            g.rank[j * B + lane] = (int16_t)(rk < 32767 ? rk : 32767);
+            if (rk < DG_GR_CAP) g.list[(key * B + m) * DG_GR_CAP + rk] = j | (lane << 8);
+        }
+        cnt += __popcll(mask);
+    }
+    if (lane == 0) g.count[key * B + m] = cnt < DG_GR_CAP ? cnt : DG_GR_CAP;
+}
+#endif
+
 struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][group][k];  csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]
     const float* colpart[DG_MAX_NEG + 2];   // feats partial column sums (null: skip)
     float* bbar[DG_MAX_NEG + 2];
@@ -290,6 +339,7 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
     int32_t ngroups[DG_MAX_NEG + 2];   // feats partial-sum groups per image (tiles, or source rows on the dense path)
     int32_t nops, B, P, Ppad, KF, KD;
     unsigned int* zero_word;           // a word this launch sets to 0 (the depth blocks' ticket of the k_gs launch), or null
+    DgGroupArgs gr;                    // gr.nkeys > 0: blockIdx.z == 2 writes the consumer lists of k_corr2's grouped ragged blocks
 };
 
 struct DgRowmeanJob {
@@ -401,6 +451,7 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 // launchers (defined next to their kernels)
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
+bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD);
 hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);

@@ -9,19 +9,16 @@
 // there and copies every one back per use).  Four of the six gradient accumulators sit there too.  The arch VGPRs hold
 // the two fd / cd accumulator pairs, the other two gradient accumulators, the LDS fragment ring and the epilogue.
 //
-// Per streamed tile of 32 positions of S (DMA'd into one of four LDS buffers three tiles ahead) a wave issues 70 MFMAs in
-// four phases, and every non-MFMA instruction of the tile is placed in one of their issue gaps; fragment 1 runs one phase
-// behind fragment 0, so that each epilogue sits in the gaps of the OTHER fragment's chain:
-//     A   chain of fragment 0 (tile t): 24 x bf16 (fd) + 5 x f16 (cd)   gaps: epilogue of fragment 1 (tile t-1), its G store,
-//                                                                             the 9 LDS-DMA pieces of tile t+3
-//     A'  dR_1 += G_1^T ScP of tile t-1 (6 MFMAs, accumulator tile as A)  gaps: fd initialisation of fragment 1
-//     B   chain of fragment 1 (tile t)                                   gaps: epilogue of fragment 0 (mask, -G, fp16 pack),
-//                                                                             its G stores, the six B fragments of the gradient product
-//         -- counted vmcnt + the one workgroup barrier of the tile: tile t+1 visible, buffer of tile t free --
-//     C   dR_0 += G_0^T ScP (6 MFMAs)                                    gaps: first fragments of tile t+1, fd initialisation of fragment 0
+// Per streamed tile of 32 positions of S (DMA'd into one of three LDS buffers two tiles ahead, as in dg_corr.hip) a wave
+// issues 70 MFMAs in four phases, and every non-MFMA instruction of the tile is placed in one of their issue gaps:
+//     A  chain of fragment 0: 24 x bf16 (fd) + 5 x f16 (cd)        gaps: the 9 LDS-DMA pieces of tile t+2, fd init of fragment 1
+//     B  chain of fragment 1                                       gaps: epilogue of fragment 0 (mask, -G, fp16 pack, G store),
+//                                                                        the six B fragments of the gradient product
+//        -- counted vmcnt + the one workgroup barrier of the tile: tile t+1 visible, buffer of tile t free --
+//     C  dR_0 += G_0^T ScP (6 MFMAs, accumulator tile as A operand)  gaps: first fragments of tile t+1, epilogue of fragment 1
+//     D  dR_1 += G_1^T ScP (6 MFMAs)                                 gaps: rest of that epilogue, G store, fd init of fragment 0
 // An accumulator is read by the VALU no sooner than two MFMAs after the chain that wrote it (the asm MFMAs are invisible to
 // hipcc's hazard recogniser).  Outputs are those of k_corr_main: G tiles (fp16) for k_gs, raw gradient tiles, block sums.
-// The depth term's blocks (depth_block) run in the same launch.  DESIGN.md section 4.1 has the measurements.
 #include "dg_common.h"
 #include <utility>
 #include <cstdio>
@@ -167,7 +164,10 @@ __device__ __forceinline__ float wave_sum2(float v) {
 // shape (4 waves x 64 stationary rows), no feature chain: per tile 2 x NKC cd MFMAs, the epilogue with per-element sums (G takes
 // two or three distinct values, so the fold of the helper jobs would bias), 2 x 6 gradient MFMAs into the accumulator file.
 // By symmetry d/dc1 = d/dc2, so only the stationary side is formed.  Tiles: C and P parts of the blob + the 32 indicators of the
-// tile rows.  Not the hot part of the launch (3 % of the MFMAs): compiler-scheduled VALU, one barrier per tile.
+// tile rows.  These blocks run last in the launch - they are its tail - and their tile time is the epilogue's VALU (few
+// MFMAs to hide it under): the epilogue is the packed form of the helper jobs (epi2) plus two VALU per element for the sums.
+// (Tried: half blocks, one fragment per wave - 23 us against 27; every wave on its own with register-direct double-buffered
+// tile loads, no LDS and no barrier - 25 us: neither the barrier nor the staging was the cost.)
 template <int NKF, int NKD, int NKC>
 __device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
     using BL = BlobT<NKF, NKD>;
@@ -214,7 +214,8 @@ __device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob&
     };
     issue_tile(0, 0); issue_tile(1, 1); issue_tile(2, 2);
     const int crow = (h * 32 + r) * 16;
-    float lsum = 0.f;
+    float lsum = 0.f, lsum2 = 0.f;
+    const uint32_t perm_sel = __builtin_amdgcn_readfirstlane(0x07060302);
     int bcur = 0;
     for (int t = 0; t < ntiles; ++t) {
         // tile t landed: two younger tiles (PIECES + 1 instructions each) may be in flight
@@ -247,15 +248,15 @@ __device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob&
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
             const f32x16 yc = __builtin_bit_cast(f32x16, Yc[f]);
-            f16x8 g8[2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float fdv = fmaf(nz_lane[f], vv[i], c0);
-                const float g = yc[i] >= 0.f ? fdv : 0.f;
-                if (act[f]) lsum = fmaf(g, yc[i], lsum);                    // clamp(cd) (dd - shift), clamp(cd) = cd * mask
-                g8[i >> 3][i & 7] = (_Float16)g;
+            for (int j = 0; j < 8; ++j) {                  // two elements per step: packed mask + fp16 pack (epi2), sums in fp32
+                const float fd0 = fmaf(nz_lane[f], vv[2 * j], c0), fd1 = fmaf(nz_lane[f], vv[2 * j + 1], c0);
+                ga[f][j >> 2][j & 3] = epi2(fd0, fd1, yc[2 * j], yc[2 * j + 1], perm_sel);
+                if (act[f]) {                              // clamp(cd) (dd - shift), clamp(cd) = max(cd, 0)
+                    lsum = fmaf(fd0, fmaxf(yc[2 * j], 0.f), lsum);
+                    lsum2 = fmaf(fd1, fmaxf(yc[2 * j + 1], 0.f), lsum2);
+                }
             }
-            ga[f][0] = __builtin_bit_cast(v4i_t, g8[0]); ga[f][1] = __builtin_bit_cast(v4i_t, g8[1]);
         }
         asm volatile("s_nop 1" : "+v"(ga[0][0]), "+v"(ga[0][1]), "+v"(ga[1][0]), "+v"(ga[1][1]));
         sfor<RF * 2 * NDF>([&](auto I) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob&
             }
         });
     });
-    lsum = wave_sum2(lsum);
+    lsum = wave_sum2(lsum + lsum2);
     if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = 0.f; }
     __syncthreads();
     if (tid == 0 && job.part) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
     static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
     static_assert(10 + 2 * PIECES <= NS && NS >= 26 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] tiles, red[NW][2]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] tiles, red[8][4]
     declare_agprs();
 #ifdef C2_STAMPS
     unsigned long long t_entry;
@@ -318,62 +319,127 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    int n, jid, rb;
-    {
-        const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
-        const int per_img = args.njobs * args.nrb;
-        if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
-            // every XCD owns B/8 whole images; inside that chunk the long blocks go first: pair-set jobs with a full row block, then
-            // their ragged last row block, then the cheap depth job
-            const int imgs = args.B >> 3, per_chunk = imgs * per_img;
-            const int xcd = bid / per_chunk;
-            int i = bid - xcd * per_chunk;
-            const bool ragged = args.nrb > 1 && ((args.Ppad >> 5) % (NW * RF)) != 0;
-            const int nfull = args.nrb - (ragged ? 1 : 0);
-            const int cA = imgs * nh * nfull, cB = ragged ? imgs * nh : 0;
-            int nl;
-            if (i < cA) { nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull; }
-            else if (i < cA + cB) { i -= cA; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; }
-            else { i -= cA + cB; nl = i / args.nrb; jid = nh; rb = i - nl * args.nrb; }
-            n = xcd * imgs + nl;
-        } else {
-            n = bid / per_img; bid -= n * per_img; jid = bid / args.nrb; rb = bid - jid * args.nrb;
-        }
-    }
-    const DgJob& job = args.jobs[jid];
-    if (job.kind == DG_JOB_DEPTH) { depth_block<NKF, NKD, NKC>(args, job, n, rb, smem); return; }
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int Ppad = args.Ppad, ntiles = Ppad >> 5;
-    uint16_t* const Gout = job.Gout;
-    const int nS = job.sidx ? (int)job.sidx[n] : n;
+    // What the block works on.  A FULL row block: pair-set jid of image n, row tiles rb*8 .. rb*8+7, one (jid, n) for all
+    // eight fragments.  The RAGGED last row block (L = ntiles % 8 row tiles) is cheap in MFMAs but has to stream the whole
+    // operand S like a full one: ragged row blocks are therefore GROUPED BY STREAMED OPERAND - all (pair-set, image) whose S is
+    // image m of the same operand array (the pair-set's own image for intra, the negatives whose batch map points at m; lists
+    // from k_group_ragged) share one block, 8 / L of them at a time, each fragment with its own pair-set and image.  Without
+    // lists (or for the consumers beyond a group's blocks: FALLBACK) a ragged block serves one (jid, n) as before.
+    int n_first = 0, jid_first = 0, rb = 0, mS = 0;        // (first fragment's (n, jid); mS = image index of the streamed operand)
+    int fj[RF], fn[RF], ft[RF];                             // per fragment of this wave: pair-set, image, row tile (-1: none)
+    {
+        const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
+        const int L = ntiles % (NW * RF);
+        const bool ragged = args.nrb > 1 && L != 0;
+        const int nfull = args.nrb - (ragged ? 1 : 0);
+        const bool grouped = ragged && args.gr_list != nullptr;
+        int kind = 0;                                       // 0 full, 1 grouped ragged, 2 ragged of one (jid, n), 3 depth
+        int jid = 0, n = 0, gkey = 0, gpart = 0;
+        if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
+            // every XCD owns B/8 whole images; inside that chunk the long blocks go first: pair-set jobs with a full row block,
+            // then the ragged ones, then the cheap depth job
+            const int imgs = args.B >> 3;
+            const int cA = imgs * nh * nfull;
+            const int cG = grouped ? imgs * args.gr_blocks_per_image : 0;
+            const int cB = ragged ? imgs * nh : 0;
+            const int per_chunk = cA + cG + cB + imgs * nd * args.nrb;
+            const int xcd = bid / per_chunk;
+            int i = bid - xcd * per_chunk, nl;
+            // (the grouped ragged blocks are as long as full ones - up to eight fragments - and go FIRST: started last they
+            //  would each add a whole block to the makespan; the short one-(pair-set, image) blocks pack the tail)
+            if (i < cG) {
+                nl = i / args.gr_blocks_per_image; i -= nl * args.gr_blocks_per_image;
+                gkey = 0;
+                while (i >= args.gr_nblk[gkey]) { i -= args.gr_nblk[gkey]; ++gkey; }
+                gpart = i; rb = args.nrb - 1; kind = 1;
+            }
+            else if (i < cG + cA) { i -= cG; nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull; kind = 0; }
+            else if (i < cA + cG + cB) { i -= cA + cG; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; kind = 2; }
+            else { i -= cA + cG + cB; nl = i / args.nrb; jid = nh; rb = i - nl * args.nrb; kind = 3; }
+            n = xcd * imgs + nl;
+        } else {
+            // (no XCD chunking: grouping is not set up by the launcher for such grids)
+            const int per_img = args.njobs * args.nrb;
+            n = bid / per_img; bid -= n * per_img; jid = bid / args.nrb; rb = bid - jid * args.nrb;
+            kind = jid >= nh ? 3 : (ragged && rb == args.nrb - 1 ? 2 : 0);
+        }
+#ifdef C2_BLOCKLOG          // developer build: per-block timeline (DG_BLOCKLOG=<file>, scripts/blocklog.py)
+        if (args.blocklog && threadIdx.x == 0) {
+            unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8;
+            e[0] = __builtin_amdgcn_s_getreg(63492); e[1] = __builtin_amdgcn_s_getreg(63508); e[6] = kind; e[7] = rb;
+            e[2] = wall_clock64(); e[3] = e[2]; e[4] = e[2]; e[5] = e[2];
+        }
+#endif
+        if (kind == 3) {
+            depth_block<NKF, NKD, NKC>(args, args.jobs[jid], n, rb, smem);
+#ifdef C2_BLOCKLOG
+            if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[5] = wall_clock64(); e[4] = e[5]; e[3] = e[2]; }
+#endif
+            return;
+        }
+#pragma unroll
+        for (int f = 0; f < RF; ++f) { fj[f] = jid; fn[f] = n; ft[f] = (rb * NW + wid) * RF + f; if (ft[f] >= ntiles) ft[f] = -1; }
+        mS = args.jobs[jid].sidx ? (int)args.jobs[jid].sidx[n] : n;
+        jid_first = jid; n_first = n;
+        if (kind == 2 && grouped) {
+            // this (jid, n) is served by a grouped block unless its rank lies beyond the group's blocks
+            const int key = args.gr_key[jid];
+            if ((int)args.gr_rank[jid * args.B + n] < args.gr_nblk[key] * args.gr_cpb) return;
+        }
+        if (kind == 1) {
+            // image n of this chunk is the STREAMED image; the consumers come from the list of (key, n)
+            mS = n;
+            const int cnt = args.gr_count[gkey * args.B + n];
+            const int c0 = gpart * args.gr_cpb;
+            if (c0 >= cnt) return;
+            jid_first = args.gr_first[gkey];
+            bool any = false;
+#pragma unroll
+            for (int f = 0; f < RF; ++f) {
+                const int slot = wid * RF + f, ci = c0 + slot / L;
+                ft[f] = -1;
+                if (slot / L < args.gr_cpb && ci < cnt) {
+                    const int e = args.gr_list[(gkey * args.B + n) * DG_GR_CAP + ci];
+                    fj[f] = e & 255; fn[f] = e >> 8; ft[f] = (args.nrb - 1) * (NW * RF) + slot % L;
+                    any = true;
+                }
+            }
+            (void)any;
+            n_first = -1;
+        }
+    }
+    const DgJob& job = args.jobs[jid_first];                // (of a grouped block: the group's first pair-set - same S array, Scsum)
+    const int nS = __builtin_amdgcn_readfirstlane(mS);
 
     // ---- the two 32-row tiles of R owned by this wave
-    const int rtile0 = (rb * NW + wid) * RF;
     bool act[RF];
     int pr[RF];
     const char* Rblob[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
-        act[f] = rtile0 + f < ntiles;                                   // wave-uniform
-        pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;
-        Rblob[f] = job.Rop + ((size_t)n * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
+        act[f] = ft[f] >= 0;                                            // wave-uniform
+        fj[f] = __builtin_amdgcn_readfirstlane(fj[f]); fn[f] = __builtin_amdgcn_readfirstlane(fn[f]); ft[f] = __builtin_amdgcn_readfirstlane(ft[f]);
+        pr[f] = act[f] ? ft[f] * 32 + r : 0;
+        Rblob[f] = args.jobs[fj[f]].Rop + ((size_t)fn[f] * ntiles + (act[f] ? ft[f] : 0)) * BL::BYTES;
     }
-    const bool wave_active = act[0];
+    (void)n_first;
 
     // ---- small per-block inputs first (their latency runs under the 270 KB that follow): the B per-image sums of the row means
     //      (m0), this lane's row means, the streamed operand's code column sums.  asm loads: hipcc would wait for a load it knows
     //      with vmcnt(0) at its first use, i.e. for every DMA piece issued since; they are consumed behind the first counted wait.
-    float rimg_v = 0.f, rvec_v[RF] = {0.f, 0.f}, cs_pre[NDF];
+    float rimg_v[RF] = {0.f, 0.f}, rvec_v[RF] = {0.f, 0.f}, cs_pre[NDF];
     {
         const float* zsrc = reinterpret_cast<const float*>(args.dummy);          // any valid address
-        const float* p_rimg = job.rvec ? job.rimg + (lane < args.B ? lane : 0) : zsrc;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(rimg_v) : "v"(p_rimg) : "memory");
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
-            const float* p_rv = job.rvec ? job.rvec + (size_t)n * Ppad + pr[f] : zsrc;
+            const DgJob& jf = args.jobs[fj[f]];
+            const float* p_rimg = jf.rvec ? jf.rimg + (lane < args.B ? lane : 0) : zsrc;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(rimg_v[f]) : "v"(p_rimg) : "memory");
+            const float* p_rv = jf.rvec ? jf.rvec + (size_t)fn[f] * Ppad + pr[f] : zsrc;
             asm volatile("global_load_dword %0, %1, off" : "=v"(rvec_v[f]) : "v"(p_rv) : "memory");
         }
 #pragma unroll
@@ -439,16 +505,17 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 
     // tile 0 landed (everything older - the small inputs, the fragment loads - is complete as well)
     static_assert(2 * PIECES == 18, "literal wait count below");
-    asm volatile("s_waitcnt vmcnt(18)" : "+v"(rimg_v), "+v"(rvec_v[0]), "+v"(rvec_v[1]), "+v"(cs_pre[0]), "+v"(cs_pre[1]), "+v"(cs_pre[2]) :: "memory");
-    // per-job scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
+    asm volatile("s_waitcnt vmcnt(18)" : "+v"(rimg_v[0]), "+v"(rimg_v[1]), "+v"(rvec_v[0]), "+v"(rvec_v[1]), "+v"(cs_pre[0]), "+v"(cs_pre[1]), "+v"(cs_pre[2]) :: "memory");
+    // per-fragment scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
     double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
     {
-        float c0 = -job.shift;
-        if (job.rvec) c0 += wave_sum_dpp(lane < args.B ? rimg_v : 0.f) * args.inv_BP;      // (B <= 64 images per call of this form)
         if (!job.Scsum) { cs_pre[0] = cs_pre[1] = cs_pre[2] = 0.f; }
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
-            const float cl = job.rvec ? c0 - rvec_v[f] : c0;
+            const DgJob& jf = args.jobs[fj[f]];
+            float c0 = -jf.shift;
+            if (jf.rvec) c0 += wave_sum_dpp(lane < args.B ? rimg_v[f] : 0.f) * args.inv_BP;      // (B <= 64 images per call of this form)
+            const float cl = jf.rvec ? c0 - rvec_v[f] : c0;
             const float2 two = make_float2(cl, cl);
             c0pair[f] = __builtin_bit_cast(double, two);
             asm volatile("" : "+v"(c0pair[f]));
@@ -470,23 +537,30 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         ga[f][j >> 2][j & 3] = epi2(yf[2 * j], yf[2 * j + 1], yc[2 * j], yc[2 * j + 1], perm_sel);
 #endif
     };
+    // per-fragment base of the G tiles [image][S tile t][R tile]: resolved HERE - a kernel-argument (scalar) load inside the
+    // tile loop would have to be waited for with lgkmcnt(0), i.e. together with every LDS read in flight
+    v4i_t* gbase[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+        gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + ((size_t)fn[f] * ntiles * ntiles + (act[f] ? ft[f] : 0)) * 128 + lane;
+    const size_t gstep = (size_t)ntiles * 128;
     auto g_store = [&](const int f, const int sp, int t) {
 #ifndef C2_NOGST
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
-        v4i_t* g = reinterpret_cast<v4i_t*>(Gout) + (((size_t)n * ntiles + t) * ntiles + rtile0 + f) * 128 + lane + 64 * sp;
+        v4i_t* g = gbase[f] + (size_t)t * gstep + 64 * sp;
         asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
 #endif
     };
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
-    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + 64);
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + 128);
     #ifndef C2_STAMP_N
 #define C2_STAMP_N 0
 #define C2_STAMP_J 0
 #define C2_STAMP_RB 0
 #endif
-    const bool stamping = args.stamps != nullptr && n == C2_STAMP_N && jid == C2_STAMP_J && rb == C2_STAMP_RB;
+    const bool stamping = args.stamps != nullptr && n_first == C2_STAMP_N && jid_first == C2_STAMP_J && rb == C2_STAMP_RB;
     auto STAMP = [&](int t, int k) {
 #ifndef C2_BLOCKSTAMPS_ONLY
         __builtin_amdgcn_sched_barrier(0);
@@ -659,20 +733,27 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #pragma unroll
     for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
     asm volatile("" : "+v"(Yc[1]));
+#ifdef C2_BLOCKLOG
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[3] = wall_clock64(); }
+#endif
     if (act[1]) run(std::true_type{}, std::true_type{});
     else if (act[0]) run(std::true_type{}, std::false_type{});
     else run(std::false_type{}, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
     BSTAMP(2);
+#ifdef C2_BLOCKLOG
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[4] = wall_clock64(); }
+#endif
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last gradient MFMAs have retired before their registers are read
-    float lsum = 0.f, csum = 0.f;
-    float* red = reinterpret_cast<float*>(smem + NBUF * BUF);
+    float lsumf[RF] = {0.f, 0.f}, csumf[RF] = {0.f, 0.f};
+    float* red = reinterpret_cast<float*>(smem + NBUF * BUF);      // [8 fragment slots][4]: loss sum, cd sum, pair-set, image
     sfor<RF>([&](auto FI) {
         constexpr int f = FI.value;
         if (!act[f]) return;
-        float* base = job.dR ? job.dR + ((size_t)n * ntiles + rtile0 + f) * (32 * DP) + lane * 4 : nullptr;
+        float* const dRj = args.jobs[fj[f]].dR;
+        float* base = dRj ? dRj + ((size_t)fn[f] * ntiles + ft[f]) * (32 * DP) + lane * 4 : nullptr;
         // x in the layout of dR (rows in registers, channel on the lane) = X * I (selector fragments), as in k_corr_main
         v4i_t sel[2];
 #pragma unroll
@@ -682,6 +763,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             for (int j = 0; j < 8; ++j) s8[j] = (8 * h + j + 16 * sI == r) ? (_Float16)1.f : (_Float16)0.f;
             sel[sI] = __builtin_bit_cast(v4i_t, s8);
         }
+        float lsum = 0.f, csum = 0.f;
         sfor<NDF>([&](auto DI) {
             constexpr int d = DI.value;
             float v[16];
@@ -709,17 +791,33 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { lsum = fmaf(X[i], v[i], lsum); csum = fmaf(X[i], cs, csum); }
         });
+        lsumf[f] = lsum; csumf[f] = csum;
     });
-    lsum = wave_sum_dpp(lsum);
-    csum = wave_sum_dpp(csum);
-    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = wave_active ? csum : 0.f; }
-    __syncthreads();
-    if (tid == 0 && job.part) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < NW; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
-        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
-        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = b;
+    // per fragment slot: its sums and whose they are; the first slot of every (pair-set, image) adds its run up, in slot order
+#pragma unroll
+    for (int f = 0; f < RF; ++f) {
+        const float ls = wave_sum_dpp(lsumf[f]), cs = wave_sum_dpp(csumf[f]);
+        if (lane == 0) {
+            float* e = red + (wid * RF + f) * 4;
+            e[0] = act[f] ? ls : 0.f; e[1] = act[f] ? cs : 0.f;
+            reinterpret_cast<int*>(e)[2] = act[f] ? fj[f] : -1; reinterpret_cast<int*>(e)[3] = fn[f];
+        }
     }
+    __syncthreads();
+    if (tid < NW * RF) {
+        const int* ri = reinterpret_cast<const int*>(red);
+        const int j = ri[tid * 4 + 2], nn = ri[tid * 4 + 3];
+        const bool first = j >= 0 && (tid == 0 || ri[(tid - 1) * 4 + 2] != j || ri[(tid - 1) * 4 + 3] != nn);
+        if (first && args.jobs[j].part) {
+            float a = 0.f, b = 0.f;
+            for (int s2 = tid; s2 < NW * RF && ri[s2 * 4 + 2] == j && ri[s2 * 4 + 3] == nn; ++s2) { a += red[s2 * 4]; b += red[s2 * 4 + 1]; }
+            float* part = args.jobs[j].part + (size_t)(nn * args.nrb + rb) * 2;
+            part[0] = a; part[1] = b;
+        }
+    }
+#ifdef C2_BLOCKLOG
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[5] = wall_clock64(); }
+#endif
 #ifdef C2_STAMPS
     BSTAMP(3);
     if (stamping) {
@@ -729,21 +827,32 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #endif
 }
 
+// blocks of a launch: per image the pair-sets' row blocks and the depth job's; with grouped ragged row blocks (args.gr_list)
+// also the groups' blocks (the one-(pair-set, image) ragged blocks stay in the grid: they return at once when a group serves them)
+static int dg_corr2_grid(const DgCorrArgs& args) {
+    return args.njobs * args.B * args.nrb + (args.gr_list ? args.B * args.gr_blocks_per_image : 0);
+}
+
 // Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
 // shapes this form does not cover (the caller then uses k_corr_main).
-hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream) {
+bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD) {
 #ifdef C2_DISABLE          // (developer A/B: everything through k_corr_main)
-    return hipErrorNotSupported;
+    return false;
 #endif
-    if (!(KF == 384 && KD == 96 && args.D <= 80)) return hipErrorNotSupported;
-    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160 || args.B > 64) return hipErrorNotSupported;
+    if (!(KF == 384 && KD == 96 && args.D <= 80)) return false;
+    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160 || args.B > 64) return false;
     for (int j = 0; j < args.njobs; ++j) {
         const DgJob& J = args.jobs[j];
-        if (J.kind == DG_JOB_DEPTH) { if (j != args.njobs - 1 || j == 0 || J.ridx || J.sidx) return hipErrorNotSupported; continue; }   // (last, after the pair-sets)
-        if (J.kind != DG_JOB_HELPER || !J.center_on_lane || !J.Gout || J.ridx) return hipErrorNotSupported;
+        if (J.kind == DG_JOB_DEPTH) { if (j != args.njobs - 1 || j == 0 || J.ridx || J.sidx) return false; continue; }   // (last, after the pair-sets)
+        if (J.kind != DG_JOB_HELPER || !J.center_on_lane || !J.Gout || J.ridx) return false;
     }
+    return true;
+}
+
+hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream) {
+    if (!dg_corr2_supported(args, KF, KD)) return hipErrorNotSupported;
     using BL = BlobT<24, 6>;
-    const int smem = 4 * BL::BYTES + 64;
+    const int smem = 4 * BL::BYTES + 128;
     auto kern = k_corr2<24, 6, 5>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
@@ -754,13 +863,31 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         DgCorrArgs a2 = args;
         a2.stamps = stamp_buf;
         (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem + (4 * 25 * 6 + 16) * 4);
-        hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem + (4 * 25 * 6 + 16) * 4, stream, a2);
+        hipLaunchKernelGGL(kern, dim3(dg_corr2_grid(args)), dim3(256), smem + (4 * 25 * 6 + 16) * 4, stream, a2);
         uint32_t host[4 * 25 * 6 + 16];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6 + 16, fp); fclose(fp); }
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(args.njobs * args.B * args.nrb), dim3(256), smem, stream, args);
+#if defined(DG_DEVTOOLS) && defined(C2_BLOCKLOG)
+    if (const char* blog_file = getenv("DG_BLOCKLOG")) {
+        static unsigned long long* blog_buf = nullptr;
+        const int grid = dg_corr2_grid(args);
+        if (!blog_buf && hipMalloc(&blog_buf, 8192 * 64) != hipSuccess) return hipErrorOutOfMemory;
+        if (grid <= 8192) {
+            DgCorrArgs a2 = args;
+            a2.blocklog = blog_buf;
+            (void)hipMemsetAsync(blog_buf, 0, (size_t)grid * 64, stream);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a2);
+            static unsigned long long hostb[8192 * 8];
+            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 64, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* fp = fopen(blog_file, "wb")) { fwrite(hostb, 8, (size_t)grid * 8, fp); fclose(fp); }
+            return hipGetLastError();
+        }
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(dg_corr2_grid(args)), dim3(256), smem, stream, args);
     return hipGetLastError();
 }
+

@@ -625,7 +625,13 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
             out[(size_t)n * K + k] = s * scale;
         }
     };
-    // blockIdx.z: 0 = feature means, 1 = code column sums (two short latency chains side by side instead of one after the other)
+    // blockIdx.z: 0 = feature means, 1 = code column sums (two short latency chains side by side instead of one after the other),
+    // 2 = consumer lists of k_corr2's grouped ragged blocks (one wave per (image, key))
+    if (blockIdx.z == 2) {
+        if ((int)blockIdx.y < a.gr.nkeys && threadIdx.x < 64) dg_group_lists(a.gr, n, o, threadIdx.x);
+        return;
+    }
+    if (o >= a.nops) return;
     if (blockIdx.z == 0 && a.colpart[o]) {
         reduce(a.colpart[o], a.ngroups[o], a.KF, 1.f / (float)a.P, a.bbar[o]);
         // bbar as two bf16 halves (hi + lo keeps ~16 mantissa bits): the B fragments of k_rowmean, [n][2][KF]
@@ -641,7 +647,8 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
 }
 
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_colmean, dim3(a.B, a.nops, 2), dim3(256), 0, s, a);
+    const int ny = a.gr.nkeys > a.nops ? a.gr.nkeys : a.nops;
+    hipLaunchKernelGGL(k_colmean, dim3(a.B, ny, a.gr.nkeys > 0 ? 3 : 2), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
