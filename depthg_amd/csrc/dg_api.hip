@@ -183,7 +183,8 @@ static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArg
     }
 }
 
-// Job table of the fused correlation launch: one job per pair-set (stationary = operand 1), the cheap depth job last.
+// Job table of the fused correlation launch: one job per pair-set (stationary = operand 1); on forward-only calls the cheap
+// depth job last.
 // Returns the number of pair-set jobs; *depth_index = position of the depth job or -1.  (Stationary = operand 2 is only
 // used by dg_corr_materialize, whose stores then run along the second position index.)
 static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, const int64_t* perms, DgCorrArgs& a,
@@ -210,7 +211,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
     if (p.depth && !p.grad) {
         DgJob j = depth_job(p, desc, ws);
         j.part = F32(p.part[p.T]);
-        j.dR = p.grad ? F32(p.dRA[p.T]) : nullptr;
+        j.dR = nullptr;
         j.slot_loss = DG_OUT_LOSS_DEPTH; j.slot_cd = -1; j.fin_scale = (float)(1.0 / numel);
         *depth_index = nj;
         a.jobs[nj++] = j;
@@ -257,7 +258,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
 static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int depth_index, hipStream_t stream) {
     (void)depth_index;
     if (p.grad && njA > 0) {
-        const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // pair-set jobs + the depth job, one launch
+        const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // the pair-set jobs, one launch
         if (e != hipErrorNotSupported) return e;
     }
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);

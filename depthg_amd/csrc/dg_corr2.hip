@@ -153,146 +153,6 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 #undef DG_DPP_ADD2
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ float wave_sum2(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ---- depth term (depth_feature_correlation, src/modules.py:1256-1278) as blocks of the same launch ---------------------------
-// loss = -clamp(cd)(dd - shift) with cd = corr(code, code) of the image itself and dd[p][q] = nz_p nz_q (quirk Q1).  Same block
-// shape (4 waves x 64 stationary rows), no feature chain: per tile 2 x NKC cd MFMAs, the epilogue with per-element sums (G takes
-// two or three distinct values, so the fold of the helper jobs would bias), 2 x 6 gradient MFMAs into the accumulator file.
-// By symmetry d/dc1 = d/dc2, so only the stationary side is formed.  Tiles: C and P parts of the blob + the 32 indicators of the
-// tile rows.  These blocks run last in the launch - they are its tail - and their tile time is the epilogue's VALU (few
-// MFMAs to hide it under): the epilogue is the packed form of the helper jobs (epi2) plus two VALU per element for the sums.
-// (Tried: half blocks, one fragment per wave - 23 us against 27; every wave on its own with register-direct double-buffered
-// tile loads, no LDS and no barrier - 25 us: neither the barrier nor the staging was the cost.)
-template <int NKF, int NKD, int NKC>
-__device__ __forceinline__ void depth_block(const DgCorrArgs& args, const DgJob& job, const int n, const int rb, char* smem) {
-    using BL = BlobT<NKF, NKD>;
-    constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD, BUF = BL::BYTES, NBUF = 4;
-    constexpr int C0 = BL::CHUNK_C0, NCH = BL::CHUNKS - C0;          // chunks of the C and P parts
-    constexpr int PIECES = (NCH + NW - 1) / NW;
-    static_assert(NCH % NW == 0, "code chunks must split evenly over the waves");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int Ppad = args.Ppad, ntiles = Ppad >> 5;
-    const int rtile0 = (rb * NW + wid) * RF;
-    bool act[RF];
-    int pr[RF];
-    const char* Rblob[RF];
-#pragma unroll
-    for (int f = 0; f < RF; ++f) {
-        act[f] = rtile0 + f < ntiles;
-        pr[f] = act[f] ? (rtile0 + f) * 32 + r : 0;
-        Rblob[f] = job.Rop + ((size_t)n * ntiles + (act[f] ? rtile0 + f : 0)) * BL::BYTES;
-    }
-    const bool wave_active = act[0];
-    const uint32_t smem_a = lds_addr(smem);
-    v4i_t Rc[RF][NKC];
-#pragma unroll
-    for (int f = 0; f < RF; ++f)
-#pragma unroll
-        for (int k = 0; k < NKC; ++k)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rc[f][k]) : "v"(Rblob[f] + BL::OFF_C + ((2 * k + h) * 32 + r) * 16) : "memory");
-    sfor<RF * NDF * 4>([&](auto I) { agpr_zero4<4 * I.value>(); });          // dR[f][d] = a[(f * NDF + d) * 16 ..]
-    const float c0 = -job.shift;
-    float nz_lane[RF];
-#pragma unroll
-    for (int f = 0; f < RF; ++f) nz_lane[f] = job.nzR[(size_t)n * Ppad + pr[f]];
-    const char* const Sop_img = job.Sop + (size_t)n * ntiles * BL::BYTES + C0 * 1024;
-    const float* const nzS = job.nzS + (size_t)n * Ppad;
-    const uint32_t dma_voff = lane * 16 + wid * 1024;
-    auto issue_tile = [&](int t, int b) {
-        const int tt = t < ntiles ? t : 0;
-        const char* sb = Sop_img + (size_t)tt * BL::BYTES;
-        const uint32_t dst = smem_a + b * BUF + C0 * 1024 + wid * 1024;
-        sfor<PIECES>([&](auto K) { dma_piece<K.value * 4096>(dst, dma_voff, sb); });
-        dma4(nzS + tt * 32 + (lane & 31), smem_a + b * BUF);                 // all waves write the same 32 floats (+ a copy behind)
-    };
-    issue_tile(0, 0); issue_tile(1, 1); issue_tile(2, 2);
-    const int crow = (h * 32 + r) * 16;
-    float lsum = 0.f, lsum2 = 0.f;
-    const uint32_t perm_sel = __builtin_amdgcn_readfirstlane(0x07060302);
-    int bcur = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        // tile t landed: two younger tiles (PIECES + 1 instructions each) may be in flight
-        wait_vm_lgkm_barrier(2 * (PIECES + 1));
-        issue_tile(t + 3, (bcur + 3) & 3);
-        const char* tile = smem + bcur * BUF;
-        bcur = (bcur + 1) & 3;
-        if (!wave_active) continue;
-        v4i_t a[NKC], bP[2 * NDF];
-#pragma unroll
-        for (int k = 0; k < NKC; ++k) a[k] = *reinterpret_cast<const v4i_t*>(tile + BL::OFF_C + crow + k * 1024);
-#pragma unroll
-        for (int q = 0; q < 2 * NDF; ++q)
-            bP[q] = *reinterpret_cast<const v4i_t*>(tile + BL::OFF_P + (h * KD + 32 * (q % NDF) + r) * 16 + (q / NDF) * (2 * KD * 16));
-        float vv[16];
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(tile + (8 * i4 + 4 * h) * 4);
-            vv[4 * i4] = v4.x; vv[4 * i4 + 1] = v4.y; vv[4 * i4 + 2] = v4.z; vv[4 * i4 + 3] = v4.w;
-        }
-        acc_t Yc[RF];
-#pragma unroll
-        for (int f = 0; f < RF; ++f) {
-            mfma_h80(Yc[f], a[0], Rc[f][0]);
-#pragma unroll
-            for (int k = 1; k < NKC; ++k) mfma_h8(Yc[f], a[k], Rc[f][k]);
-        }
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(Yc[0]), "+v"(Yc[1]));      // the chains have retired
-        v4i_t ga[RF][2];
-#pragma unroll
-        for (int f = 0; f < RF; ++f) {
-            const f32x16 yc = __builtin_bit_cast(f32x16, Yc[f]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                  // two elements per step: packed mask + fp16 pack (epi2), sums in fp32
-                const float fd0 = fmaf(nz_lane[f], vv[2 * j], c0), fd1 = fmaf(nz_lane[f], vv[2 * j + 1], c0);
-                ga[f][j >> 2][j & 3] = epi2(fd0, fd1, yc[2 * j], yc[2 * j + 1], perm_sel);
-                if (act[f]) {                              // clamp(cd) (dd - shift), clamp(cd) = max(cd, 0)
-                    lsum = fmaf(fd0, fmaxf(yc[2 * j], 0.f), lsum);
-                    lsum2 = fmaf(fd1, fmaxf(yc[2 * j + 1], 0.f), lsum2);
-                }
-            }
-        }
-        asm volatile("s_nop 1" : "+v"(ga[0][0]), "+v"(ga[0][1]), "+v"(ga[1][0]), "+v"(ga[1][1]));
-        sfor<RF * 2 * NDF>([&](auto I) {
-            constexpr int f = I.value / (2 * NDF), q = I.value % (2 * NDF), sp = q / NDF, d = q % NDF;
-            mfma_h_acc<(f * NDF + d) * 16>(ga[f][sp], bP[q]);
-        });
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    float* red = reinterpret_cast<float*>(smem + NBUF * BUF);
-    sfor<RF>([&](auto FI) {
-        constexpr int f = FI.value;
-        if (!act[f] || !job.dR) return;
-        float* base = job.dR + ((size_t)n * ntiles + rtile0 + f) * (32 * DP) + lane * 4;
-        sfor<NDF>([&](auto DI) {
-            constexpr int d = DI.value;
-            float v[16];
-            sfor<16>([&](auto I) { v[I.value] = agpr_read<(f * NDF + d) * 16 + I.value>(); });
-            if (32 * d + r < args.D) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
-                }
-            }
-        });
-    });
-    lsum = wave_sum2(lsum + lsum2);
-    if (lane == 0) { red[wid * 2] = wave_active ? lsum : 0.f; red[wid * 2 + 1] = 0.f; }
-    __syncthreads();
-    if (tid == 0 && job.part) {
-        float a = 0.f;
-        for (int w = 0; w < NW; ++w) a += red[w * 2];
-        job.part[(size_t)(n * args.nrb + rb) * 2] = a;
-        job.part[(size_t)(n * args.nrb + rb) * 2 + 1] = 0.f;
-    }
-}
 
 // NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
 template <int NKF, int NKD, int NKC>
@@ -332,21 +192,21 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     int n_first = 0, jid_first = 0, rb = 0, mS = 0;        // (first fragment's (n, jid); mS = image index of the streamed operand)
     int fj[RF], fn[RF], ft[RF];                             // per fragment of this wave: pair-set, image, row tile (-1: none)
     {
-        const int nd = args.jobs[args.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0, nh = args.njobs - nd;
+        const int nh = args.njobs;                          // pair-set jobs only (the depth term runs in the k_gs launch)
         const int L = ntiles % (NW * RF);
         const bool ragged = args.nrb > 1 && L != 0;
         const int nfull = args.nrb - (ragged ? 1 : 0);
         const bool grouped = ragged && args.gr_list != nullptr;
-        int kind = 0;                                       // 0 full, 1 grouped ragged, 2 ragged of one (jid, n), 3 depth
+        int kind = 0;                                       // 0 full, 1 grouped ragged, 2 ragged of one (jid, n)
         int jid = 0, n = 0, gkey = 0, gpart = 0;
         if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
             // every XCD owns B/8 whole images; inside that chunk the long blocks go first: pair-set jobs with a full row block,
-            // then the ragged ones, then the cheap depth job
+            // then the ragged ones
             const int imgs = args.B >> 3;
             const int cA = imgs * nh * nfull;
             const int cG = grouped ? imgs * args.gr_blocks_per_image : 0;
             const int cB = ragged ? imgs * nh : 0;
-            const int per_chunk = cA + cG + cB + imgs * nd * args.nrb;
+            const int per_chunk = cA + cG + cB;
             const int xcd = bid / per_chunk;
             int i = bid - xcd * per_chunk, nl;
             // (the grouped ragged blocks are as long as full ones - up to eight fragments - and go FIRST: started last they
@@ -358,14 +218,13 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 gpart = i; rb = args.nrb - 1; kind = 1;
             }
             else if (i < cG + cA) { i -= cG; nl = i / (nh * nfull); i -= nl * nh * nfull; jid = i / nfull; rb = i - jid * nfull; kind = 0; }
-            else if (i < cA + cG + cB) { i -= cA + cG; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; kind = 2; }
-            else { i -= cA + cG + cB; nl = i / args.nrb; jid = nh; rb = i - nl * args.nrb; kind = 3; }
+            else { i -= cA + cG; nl = i / nh; jid = i - nl * nh; rb = args.nrb - 1; kind = 2; }
             n = xcd * imgs + nl;
         } else {
             // (no XCD chunking: grouping is not set up by the launcher for such grids)
             const int per_img = args.njobs * args.nrb;
             n = bid / per_img; bid -= n * per_img; jid = bid / args.nrb; rb = bid - jid * args.nrb;
-            kind = jid >= nh ? 3 : (ragged && rb == args.nrb - 1 ? 2 : 0);
+            kind = ragged && rb == args.nrb - 1 ? 2 : 0;
         }
 #ifdef C2_BLOCKLOG          // developer build: per-block timeline (DG_BLOCKLOG=<file>, scripts/blocklog.py)
         if (args.blocklog && threadIdx.x == 0) {
@@ -374,13 +233,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             e[2] = wall_clock64(); e[3] = e[2]; e[4] = e[2]; e[5] = e[2];
         }
 #endif
-        if (kind == 3) {
-            depth_block<NKF, NKD, NKC>(args, args.jobs[jid], n, rb, smem);
-#ifdef C2_BLOCKLOG
-            if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[5] = wall_clock64(); e[4] = e[5]; e[3] = e[2]; }
-#endif
-            return;
-        }
 #pragma unroll
         for (int f = 0; f < RF; ++f) { fj[f] = jid; fn[f] = n; ft[f] = (rb * NW + wid) * RF + f; if (ft[f] >= ntiles) ft[f] = -1; }
         mS = args.jobs[jid].sidx ? (int)args.jobs[jid].sidx[n] : n;
@@ -827,7 +679,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #endif
 }
 
-// blocks of a launch: per image the pair-sets' row blocks and the depth job's; with grouped ragged row blocks (args.gr_list)
+// blocks of a launch: per image the pair-sets' row blocks; with grouped ragged row blocks (args.gr_list)
 // also the groups' blocks (the one-(pair-set, image) ragged blocks stay in the grid: they return at once when a group serves them)
 static int dg_corr2_grid(const DgCorrArgs& args) {
     return args.njobs * args.B * args.nrb + (args.gr_list ? args.B * args.gr_blocks_per_image : 0);
@@ -843,7 +695,6 @@ bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD) {
     if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160 || args.B > 64) return false;
     for (int j = 0; j < args.njobs; ++j) {
         const DgJob& J = args.jobs[j];
-        if (J.kind == DG_JOB_DEPTH) { if (j != args.njobs - 1 || j == 0 || J.ridx || J.sidx) return false; continue; }   // (last, after the pair-sets)
         if (J.kind != DG_JOB_HELPER || !J.center_on_lane || !J.Gout || J.ridx) return false;
     }
     return true;
