@@ -8,13 +8,14 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 103                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 104                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID = \
     (1 << i for i in range(8))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
+           "dg_lhp_map_forward", "dg_lhp_map_backward",
            "dg_corr_backward_total"]
 
 
@@ -77,6 +78,10 @@ def load():
     lib.dg_lhp_forward.argtypes = [vp, vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, vp]
     lib.dg_lhp_backward.restype = ctypes.c_int
     lib.dg_lhp_backward.argtypes = [vp, vp, vp] + [ctypes.c_int32] * 4 + [vp, vp]
+    lib.dg_lhp_map_forward.restype = ctypes.c_int
+    lib.dg_lhp_map_forward.argtypes = [ctypes.c_int32, vp, vp, vp, vp] + [ctypes.c_int32] * 7 + [vp, vp, vp, vp]
+    lib.dg_lhp_map_backward.restype = ctypes.c_int
+    lib.dg_lhp_map_backward.argtypes = [ctypes.c_int32, vp, vp, vp] + [ctypes.c_int32] * 4 + [vp, vp]
     lib.dg_super_perms_seeded.restype = ctypes.c_int
     lib.dg_super_perms_seeded.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, vp, vp]
     lib.dg_super_perms_state.restype = ctypes.c_int

@@ -624,6 +624,37 @@ extern "C" int dg_lhp_backward(const float* grad_out, const float* points, const
     return DG_OK;
 }
 
+extern "C" int dg_lhp_map_forward(int32_t mode, const float* code, const float* attn, const float* depth, const float* divide,
+                                  int32_t B, int32_t D, int32_t h, int32_t w, int32_t heads, int32_t depth_h, int32_t depth_w,
+                                  float* out, float* map, float* points, dg_stream_t stream_) {
+    if (int rc = lhp_check(B, D, h, w)) return rc;
+    if (mode < DG_LHP_ATTN || mode > DG_LHP_ORIG_ATTN) return fail(DG_ERR_INVALID, "unknown LHP map mode %d", mode);
+    if (!code || !out) return fail(DG_ERR_INVALID, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (mode == DG_LHP_ORIG_DEPTH) {
+        if (!depth || !points || depth_h < 1 || depth_w < 1) return fail(DG_ERR_INVALID, "the depth map and the points scratch are required");
+        const uint32_t bits = 0x404f54cbu;        // 2*tan(90/2 rad), as in dg_lhp_forward
+        float factor;
+        memcpy(&factor, &bits, 4);
+        DG_HIP(dg_launch_lhp_points(depth, B, depth_h, depth_w, h, w, factor, points, s));
+    } else if (!attn || heads < 1) {
+        return fail(DG_ERR_INVALID, "the attention tensor (B,heads,h*w+1,h*w+1) is required");
+    }
+    if (!map) return fail(DG_ERR_INVALID, "the map buffer is required");
+    if (mode != DG_LHP_ATTN && !divide) return fail(DG_ERR_INVALID, "divide_num is required");
+    DG_HIP(dg_launch_lhp_map(mode, code, attn, points, divide, B, D, h, w, heads, out, map, s));
+    return DG_OK;
+}
+
+extern "C" int dg_lhp_map_backward(int32_t mode, const float* grad_out, const float* map, const float* divide, int32_t B, int32_t D,
+                                   int32_t h, int32_t w, float* grad_code, dg_stream_t stream_) {
+    if (int rc = lhp_check(B, D, h, w)) return rc;
+    if (mode < DG_LHP_ATTN || mode > DG_LHP_ORIG_ATTN) return fail(DG_ERR_INVALID, "unknown LHP map mode %d", mode);
+    if (!grad_out || !map || !grad_code || (mode != DG_LHP_ATTN && !divide)) return fail(DG_ERR_INVALID, "null pointer");
+    DG_HIP(dg_launch_lhp_map_bwd(mode, grad_out, map, divide, B, D, h, w, grad_code, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
     (void)B; (void)h; (void)w;
     return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform

@@ -474,5 +474,9 @@ hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols
 hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
 hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,
                                    float* dst, hipStream_t s);
+hipError_t dg_launch_lhp_map(int mode, const float* code, const float* attn, const float* points, const float* divide, int B, int D,
+                             int h, int w, int heads, float* out, float* map, hipStream_t s);
+hipError_t dg_launch_lhp_map_bwd(int mode, const float* g, const float* map, const float* divide, int B, int D, int h, int w,
+                                 float* gcode, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);

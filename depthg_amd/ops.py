@@ -234,6 +234,50 @@ def lhp_backward(grad_out, points, stats):
     return grad_code
 
 
+LHP_ATTN, LHP_ORIG_DEPTH, LHP_ORIG_ATTN = 0, 1, 2          # enum of include/depthg_corr.h
+
+
+def lhp_map_forward(mode, code, attn=None, depth=None, divide=None):
+    """dg_lhp_map_forward: code (B,D,h,w) with attn (B,heads,h*w+1,h*w+1) or depth (B,1,H,W) -> (code_mixed, map).
+    `map` is what dg_lhp_map_backward needs: (B,P,P) for LHP_ATTN, (B,P,9) for the Original variants."""
+    lib = _lib.load()
+    code = _f32c(code, "code")
+    B, D, h, w = code.shape
+    P = h * w
+    heads, dh, dw, points = 0, 0, 0, None
+    if mode == LHP_ORIG_DEPTH:
+        depth = _f32c(depth, "depth")
+        dh, dw = depth.shape[-2], depth.shape[-1]
+        points = _empty((B, 3, P), torch.float32, code.device)
+    else:
+        attn = _f32c(attn, "attn")
+        if attn.dim() != 4 or attn.shape[0] != B or attn.shape[2] != P + 1 or attn.shape[3] != P + 1:
+            raise ValueError(f"attn must be (B, heads, {P + 1}, {P + 1}) for a {h}x{w} code map, got {tuple(attn.shape)}")
+        heads = attn.shape[1]
+    if mode != LHP_ATTN:
+        divide = _f32c(divide, "divide")
+        if divide.numel() != P:
+            raise ValueError(f"divide must hold {P} divisors, got {divide.numel()}")
+    out = _empty(tuple(code.shape), torch.float32, code.device)
+    wmap = _empty((B, P, P if mode == LHP_ATTN else 9), torch.float32, code.device)
+    rc = lib.dg_lhp_map_forward(mode, _ptr(code), _ptr(attn) if mode != LHP_ORIG_DEPTH else None,
+                                _ptr(depth) if mode == LHP_ORIG_DEPTH else None, _ptr(divide) if mode != LHP_ATTN else None,
+                                B, D, h, w, heads, dh, dw, _ptr(out), _ptr(wmap), _ptr(points), _stream(code.device))
+    _lib.check(rc, "dg_lhp_map_forward")
+    return out, wmap
+
+
+def lhp_map_backward(mode, grad_out, wmap, divide=None):
+    lib = _lib.load()
+    g = _f32c(grad_out, "grad_out")
+    B, D, h, w = g.shape
+    grad_code = _empty(tuple(g.shape), torch.float32, g.device)
+    rc = lib.dg_lhp_map_backward(mode, _ptr(g), _ptr(wmap), _ptr(divide) if mode != LHP_ATTN else None, B, D, h, w,
+                                 _ptr(grad_code), _stream(g.device))
+    _lib.check(rc, "dg_lhp_map_backward")
+    return grad_code
+
+
 def new_perm_state(device):
     """Device-resident generator state for super_perms(state=...): int64 {seed, draws so far, 0}; the seed comes from torch's
     CPU generator, so torch.manual_seed before the first use fixes the whole sequence."""

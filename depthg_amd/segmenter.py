@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .depth_decay import legacy_decay_step
-from .lhp import LocalHiddenPositiveProjection
+from .lhp import LocalHiddenPositiveProjection, OriginalLocalHiddenPositiveProjection
 from .loss import ContrastiveCorrelationLoss
 from .training import correspondence_total
 
@@ -76,6 +76,20 @@ class StandInFeaturizer(nn.Module):
             self.cluster2 = head.cluster2
         self.proj_type = head.proj_type
 
+    def _last_selfattention(self, img, image_feat):
+        """The ViT's `get_last_selfattention` (B, heads, P+1, P+1) (src/modules.py:103-104).  A backbone that has the method is
+        asked; the convolutional stand-in only builds one when the LHP module will read it (`propagation_strategy == "attn"`):
+        softmax similarities of [mean token, patch tokens], channels split over 6 / 12 heads - the ViT's shapes, nothing more."""
+        if hasattr(self.model, "get_last_selfattention"):
+            return self.model.get_last_selfattention(img)
+        if not (getattr(self.cfg, "lhp", False) and getattr(self.cfg, "propagation_strategy", "depth") == "attn"):
+            return torch.zeros(1, device=image_feat.device)       # placeholder: only `is None` is ever asked of it
+        b, c, h, w = image_feat.shape
+        heads = 6 if self.n_feats == 384 else 12
+        tok = image_feat.flatten(2).transpose(1, 2)                                   # (B,P,C)
+        tok = torch.cat([tok.mean(1, keepdim=True), tok], dim=1).reshape(b, h * w + 1, heads, c // heads).transpose(1, 2)
+        return torch.softmax(tok @ tok.transpose(-1, -2) / (c // heads) ** 0.5, dim=-1)
+
     def forward(self, img, n=1, return_class_feat=False):
         self.model.eval()
         with torch.no_grad():
@@ -83,7 +97,7 @@ class StandInFeaturizer(nn.Module):
             image_feat = self.model(img)
             if return_class_feat:
                 return image_feat.mean((2, 3), keepdim=True)
-            attn = torch.zeros(1, device=image_feat.device)      # (the stand-in has no attention maps: a placeholder, as a ViT's would be passed on)
+            attn = self._last_selfattention(img, image_feat)
         if self.proj_type is not None:
             code = self.cluster1(self.dropout(image_feat))
             if self.proj_type == "nonlinear":
@@ -136,8 +150,9 @@ class UnsupervisedSegmenter(nn.Module):
         self.contrastive_corr_loss_fn = ContrastiveCorrelationLoss(cfg)               # :131 (shares cfg: the decay below mutates it)
         for p in self.contrastive_corr_loss_fn.parameters():                          # :136
             p.requires_grad = False
-        if getattr(cfg, "lhp", False):
-            self.lhp_module = LocalHiddenPositiveProjection(cfg)
+        if getattr(cfg, "lhp", False):                                                 # :82-87
+            original = "lhp_original" in str(getattr(cfg, "experiment_name", ""))
+            self.lhp_module = OriginalLocalHiddenPositiveProjection(cfg) if original else LocalHiddenPositiveProjection(cfg)
         self.automatic_optimization = False                                           # :139
         self.global_step = 0
         self._optims = None

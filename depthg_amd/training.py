@@ -41,6 +41,9 @@ def correspondence_total(cfg, out: Sequence[torch.Tensor], lhp_out: Optional[Seq
         logs["loss/depth_feat"] = depth_feat.detach()
         logs["cd/depth_feat"] = out[7].mean().detach()
         total = (core + cfg.depth_feat_weight * depth_feat) * (cfg.correspondence_weight - _balance(cfg))   # :330-333
+        if "lhp_original" in str(getattr(cfg, "experiment_name", "")):                    # :335-337: only the LHP terms train,
+            total = total * 0.0                                                           # and the cfg is rewritten for good
+            cfg.lhp_weight = 1.0
     else:
         total = core * cfg.correspondence_weight                                          # :347-349
     if getattr(cfg, "lhp", False) and depth:                                              # :339-343 (depth branch only)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 103   /* 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 104   /* 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -219,6 +219,33 @@ int dg_lhp_forward(const float* code, const float* depth, int32_t B, int32_t D, 
                    int32_t depth_h, int32_t depth_w, float* out, float* points, float* stats, dg_stream_t stream);
 int dg_lhp_backward(const float* grad_out, const float* points, const float* stats, int32_t B, int32_t D, int32_t h, int32_t w,
                     float* grad_code, dg_stream_t stream);
+
+/*
+ * The other propagation maps of the LHP branch, up to the projection head.  `mode`:
+ *  DG_LHP_ATTN        LocalHiddenPositiveProjection.forward_attn (src/modules.py:235-271): attn[:, :, 1:, 1:] averaged over
+ *                     the heads, row-wise min-max normalised, zeroed above the row's 99 % quantile (torch.quantile, linear);
+ *                     out[:, p] = mean_q map[p][q] code[:, q]
+ *  DG_LHP_ORIG_DEPTH  OriginalLocalHiddenPositiveProjection.forward_depth (:436-487): map = 1 - normalised point distance,
+ *                     zeroed where the distance is above the row mean, times the clipped 3x3 neighbourhood mask (:356-383);
+ *                     out[:, p] = sum_q map[p][q] code[:, q] / divide_num[p]
+ *  DG_LHP_ORIG_ATTN   OriginalLocalHiddenPositiveProjection.forward_attn (:403-434): heads-mean attention normalised with
+ *                     the row's 10 % / 90 % quantiles, zeroed below the row mean, same mask and divisor
+ * The reference leaves divide_num all zero (it is re-created inside the constructor loop and never filled, :354,382), so its
+ * Original variants return sum / 0; `divide` is an input here so that both that behaviour and a repaired table can be run.
+ *  code  : fp32 (B,D,h,w), D <= 128, h*w <= 4096      attn : fp32 (B,heads,h*w+1,h*w+1) (CLS row / column first)
+ *  depth : fp32 (B,1,depth_h,depth_w) (ORIG_DEPTH)    divide : fp32 (h*w) (ORIG_*)
+ *  out   : fp32 (B,D,h,w)
+ *  map   : ATTN: fp32 (B,P,P), ORIG_*: fp32 (B,P,9): the weights, written by the forward and read by the backward
+ *  points: fp32 (B,3,h*w) scratch (ORIG_DEPTH)
+ * dg_lhp_map_backward: grad_code[:, q] = sum_p map[p][q] grad_out[:, p] * (1/P, or 1/divide[p]); no gradient reaches attn / depth
+ * (the reference's come from a frozen backbone / the data loader).
+ */
+enum { DG_LHP_ATTN = 0, DG_LHP_ORIG_DEPTH = 1, DG_LHP_ORIG_ATTN = 2 };
+int dg_lhp_map_forward(int32_t mode, const float* code, const float* attn, const float* depth, const float* divide,
+                       int32_t B, int32_t D, int32_t h, int32_t w, int32_t heads, int32_t depth_h, int32_t depth_w,
+                       float* out, float* map, float* points, dg_stream_t stream);
+int dg_lhp_map_backward(int32_t mode, const float* grad_out, const float* map, const float* divide, int32_t B, int32_t D,
+                        int32_t h, int32_t w, float* grad_code, dg_stream_t stream);
 
 /*
  * Row-wise top-k (replaces `torch.topk(pairwise_sims, 30)[1]` of the offline nearest-neighbour search,

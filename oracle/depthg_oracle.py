@@ -417,6 +417,91 @@ def lhp_propagate(code: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
     return out.reshape(b, d, h, w)
 
 
+def _row_quantiles(rows: np.ndarray, q: float) -> np.ndarray:
+    """torch.quantile(rows, q, dim=-1, keepdim=True) on a float32 (..., n) array."""
+    srt = np.sort(rows, axis=-1)
+    flat = srt.reshape(-1, srt.shape[-1])
+    out = np.asarray([quantile_lerp(r, q) for r in flat], dtype=np.float32)
+    return out.reshape(srt.shape[:-1] + (1,))
+
+
+def _heads_mean(attn: torch.Tensor) -> np.ndarray:
+    """torch.mean(attn[:, :, 1:, 1:], dim=1): the heads added in order, one division (src/modules.py:239-240, 407-408)."""
+    a = attn[:, :, 1:, 1:].numpy().astype(np.float32)
+    acc = np.zeros_like(a[:, 0])
+    for hd in range(a.shape[1]):
+        acc = (acc + a[:, hd]).astype(np.float32)
+    return (acc / np.float32(a.shape[1])).astype(np.float32)
+
+
+def lhp_attn_weights(attn: torch.Tensor) -> torch.Tensor:
+    """The (B,P,P) map of LocalHiddenPositiveProjection.forward_attn (src/modules.py:239-254): heads-mean attention between
+    the patch tokens, row-wise min-max normalised, zero where above the row's 99 % quantile."""
+    a = _heads_mean(attn)
+    mn = a.min(axis=2, keepdims=True)
+    mx = a.max(axis=2, keepdims=True)
+    an = ((a - mn) / (mx - mn)).astype(np.float32)
+    thr = _row_quantiles(an, 0.99)
+    return torch.from_numpy(np.where(an > thr, np.float32(0.0), an))
+
+
+def lhp_propagate_attn(code: torch.Tensor, attn: torch.Tensor) -> torch.Tensor:
+    """code_mixed of forward_attn: out[b,:,p] = mean_q map[b,p,q] * code[b,:,q]   (src/modules.py:256-269)."""
+    b, d, h, w = code.shape
+    out = torch.einsum("bpq,bdq->bdp", lhp_attn_weights(attn), code.reshape(b, d, h * w)) / float(h * w)
+    return out.reshape(b, d, h, w)
+
+
+def lhp_index_mask(sz: int) -> np.ndarray:
+    """index_mask of the LHP constructors (src/modules.py:356-383): mask[p][q] = 1 for q in the 3x3 neighbourhood of p clipped
+    to the sz x sz map (the constructor's nine cases spell out exactly that)."""
+    i = np.arange(sz * sz) // sz
+    j = np.arange(sz * sz) % sz
+    near = (np.abs(i[:, None] - i[None, :]) <= 1) & (np.abs(j[:, None] - j[None, :]) <= 1)
+    return near.astype(np.float32)
+
+
+def lhp_original_depth_weights(depth: torch.Tensor, sz: int) -> torch.Tensor:
+    """lhp_map of OriginalLocalHiddenPositiveProjection.forward_depth (src/modules.py:441-471): 1 - normalised distance, zero
+    where the distance is above the row mean, times the index mask.  Same direct distance formula as lhp_depth_weights."""
+    pooled = adaptive_avg_pool2d(depth, (sz, sz))
+    b, p = pooled.shape[0], sz * sz
+    out = np.zeros((b, p, p), dtype=np.float32)
+    mask = lhp_index_mask(sz)
+    for i in range(b):
+        pts = depth2points(pooled[i, 0], fov=90).reshape(3, -1).t().numpy().astype(np.float32)
+        dx = pts[:, None, 0] - pts[None, :, 0]
+        dy = pts[:, None, 1] - pts[None, :, 1]
+        dz = pts[:, None, 2] - pts[None, :, 2]
+        dist = np.sqrt((dx * dx + dy * dy) + dz * dz).astype(np.float32)
+        mn = dist.min(axis=1, keepdims=True)
+        mx = dist.max(axis=1, keepdims=True)
+        dn = ((dist - mn) / (mx - mn)).astype(np.float32)
+        mean = torch.mean(torch.from_numpy(dn), dim=1, keepdim=True).numpy()
+        out[i] = np.where(dn > mean, np.float32(0.0), np.float32(1.0) - dn) * mask
+    return torch.from_numpy(out)
+
+
+def lhp_original_attn_weights(attn: torch.Tensor, sz: int) -> torch.Tensor:
+    """attn of OriginalLocalHiddenPositiveProjection.forward_attn before the weighted sum (src/modules.py:407-418): heads-mean
+    attention, (a - q10) / (q90 - q10) per row, zero below the row mean, times the index mask."""
+    a = _heads_mean(attn)
+    hi = _row_quantiles(a, 0.9)
+    lo = _row_quantiles(a, 0.1)
+    an = ((a - lo) / (hi - lo)).astype(np.float32)
+    mean = torch.mean(torch.from_numpy(an), dim=2, keepdim=True).numpy()
+    return torch.from_numpy(np.where(an < mean, np.float32(0.0), an) * lhp_index_mask(sz)[None])
+
+
+def lhp_original_propagate(wmap: torch.Tensor, code: torch.Tensor, divide_num: torch.Tensor) -> torch.Tensor:
+    """out[b,:,p] = sum_q map[b,p,q] * code[b,:,q] / divide_num[p]   (src/modules.py:420-432, 473-485); the reference's
+    divide_num is all zero (re-created inside the constructor loop, :354,382 - never filled): inf / nan, as there."""
+    b, d, h, w = code.shape
+    s = torch.einsum("bpq,bdq->bpd", wmap, code.reshape(b, d, h * w))
+    out = s / divide_num.reshape(1, h * w, 1)
+    return out.permute(0, 2, 1).reshape(b, d, h, w)
+
+
 def knn_table(normed_feats: torch.Tensor, k: int = 30) -> torch.Tensor:
     """Nearest-neighbour table of src/precompute_knns.py:106-112: row i = indices of the k largest entries of
     (X X^T)[i] in float32, value descending; ties by ascending index (the build's rule; torch.topk leaves it open)."""

@@ -663,6 +663,139 @@ def test_lhp_depth_propagation(name, dev):
     assert propagate_depth(cg.detach(), depth.to(dev)).shape == code.shape
 
 
+def _lhp_module_case(m, g, key, code, source_kw, dev, tol_proj, tol_grad):
+    """The module with the reference's head weights: projection and gradient of sum(proj * up) against the fixture."""
+    with torch.no_grad():
+        for i, prm in enumerate(m.projection_head.parameters()):
+            prm.copy_(torch.from_numpy(g[f"{key}_head{i}"]))
+    cg = code.to(dev).requires_grad_(True)
+    proj = m(cg, **source_kw)
+    (proj * torch.from_numpy(g[f"{key}_up"]).to(dev)).sum().backward()
+    refp, refg = torch.from_numpy(g[f"{key}_proj"]), torch.from_numpy(g[f"{key}_grad_code"])
+    assert float((proj.detach().cpu() - refp).norm() / refp.norm()) < tol_proj
+    assert float((cg.grad.cpu() - refg).norm() / refg.norm()) < tol_grad
+
+
+@pytest.mark.parametrize("name", ["s10", "s12"])
+def test_lhp_attention_propagation(name, dev):
+    """dg_lhp_map_forward / backward, DG_LHP_ATTN (LocalHiddenPositiveProjection.forward_attn, src/modules.py:235-271): the
+    (B,P,P) map bit-equal to the oracle's (ordered heads sum, min-max, 99 % quantile), propagated code and adjoint to 2e-6
+    relative (float32 summation order), the reference fixture to the same; module output and code gradient through the head."""
+    from types import SimpleNamespace
+    from depthg_amd import ops
+    from depthg_amd.lhp import LocalHiddenPositiveProjection
+    from oracle import depthg_oracle as O
+    g = load_golden("lhp_attn.npz")
+    code, attn = torch.from_numpy(g[f"{name}_code"]), torch.from_numpy(g[f"{name}_attn"])
+    b, d, h, w = code.shape
+    out, wmap = ops.lhp_map_forward(ops.LHP_ATTN, code.to(dev), attn=attn.to(dev))
+    omap = O.lhp_attn_weights(attn)
+    assert torch.equal(wmap.cpu(), omap)
+    want = O.lhp_propagate_attn(code, attn)
+    assert float((out.cpu() - want).norm() / want.norm()) < 2e-6
+    ref = torch.from_numpy(g[f"{name}_local_attn_mixed"])
+    assert float((out.cpu() - ref).norm() / ref.norm()) < 2e-6
+    up = torch.from_numpy(g[f"{name}_local_attn_up"])
+    gback = ops.lhp_map_backward(ops.LHP_ATTN, up.to(dev), wmap).cpu()
+    gwant = (torch.einsum("bpq,bdp->bdq", omap, up.reshape(b, d, h * w)) / float(h * w)).reshape(b, d, h, w)
+    assert float((gback - gwant).norm() / gwant.norm()) < 2e-6
+    m = LocalHiddenPositiveProjection(SimpleNamespace(dim=d, propagation_strategy="attn")).to(dev)
+    _lhp_module_case(m, g, f"{name}_local_attn", code, dict(depth=torch.zeros(1, device=dev), attn=attn.to(dev)), dev, 1e-5, 1e-5)
+    with pytest.raises(ValueError):
+        ops.lhp_map_forward(ops.LHP_ATTN, code.to(dev), attn=attn[:, :, 1:, 1:].contiguous().to(dev))     # CLS row / column missing
+
+
+@pytest.mark.parametrize("name", ["s10", "s12"])
+@pytest.mark.parametrize("source", ["attn", "depth"])
+def test_lhp_original_variant(name, source, dev):
+    """OriginalLocalHiddenPositiveProjection (src/modules.py:342-487) on the GPU: nine neighbour weights per row equal to the
+    oracle's masked map (bit-equal but for a threshold at the row mean, whose float32 sum order differs: at most a few
+    entries), output / gradient with the repaired divisors against oracle and reference, and the constructor's all-zero
+    divide_num: every output element non-finite with the reference's inf / nan pattern."""
+    from types import SimpleNamespace
+    from depthg_amd import ops
+    from depthg_amd.lhp import OriginalLocalHiddenPositiveProjection, neighbour_counts
+    from oracle import depthg_oracle as O
+    g = load_golden("lhp_attn.npz")
+    code = torch.from_numpy(g[f"{name}_code"])
+    b, d, sz, _ = code.shape
+    P = sz * sz
+    mode = ops.LHP_ORIG_ATTN if source == "attn" else ops.LHP_ORIG_DEPTH
+    src = torch.from_numpy(g[f"{name}_{source}"])
+    kw = dict(attn=src.to(dev)) if source == "attn" else dict(depth=src.to(dev))
+    counts = neighbour_counts(sz)
+    assert torch.equal(counts, torch.from_numpy(g[f"{name}_counts"]))
+    out, w9 = ops.lhp_map_forward(mode, code.to(dev), divide=counts.float().to(dev), **kw)
+    omap = (O.lhp_original_attn_weights(src, sz) if source == "attn" else O.lhp_original_depth_weights(src, sz))
+    dense = torch.zeros(b, P, P)
+    pi, pj = torch.arange(P) // sz, torch.arange(P) % sz
+    for t in range(9):
+        qi, qj = pi + t // 3 - 1, pj + t % 3 - 1
+        ok = (qi >= 0) & (qi < sz) & (qj >= 0) & (qj < sz)
+        dense[:, torch.arange(P)[ok], (qi * sz + qj)[ok]] = w9.cpu()[:, ok, t]
+        assert torch.all(w9.cpu()[:, ~ok, t] == 0)
+    differ = dense != omap
+    assert int(differ.sum()) <= 4, int(differ.sum())
+    want = O.lhp_original_propagate(omap, code, counts)
+    tol = 2e-6 if not differ.any() else 2e-2
+    assert float((out.cpu() - want).norm() / want.norm()) < tol
+    ref = torch.from_numpy(g[f"{name}_orig_{source}_mixed"])
+    assert float((out.cpu() - ref).norm() / ref.norm()) < (tol if source == "attn" else max(tol, 1e-3))
+    cfg = SimpleNamespace(dim=d, propagation_strategy=source, res=sz * 8, dino_patch_size=8)
+    m = OriginalLocalHiddenPositiveProjection(cfg).to(dev)
+    assert int(m.divide_num.abs().sum()) == 0 and m.divide_num.shape == (P, 1)
+    args = dict(depth=src.to(dev), attn=torch.zeros(1, device=dev)) if source == "depth" else dict(depth=torch.zeros(1, device=dev), attn=src.to(dev))
+    # the constructor's table: sum / 0
+    m.projection_head = torch.nn.Identity()
+    zero = m(code.to(dev), **args).cpu().numpy()
+    ref0 = g[f"{name}_orig_{source}_zero_mixed"]
+    assert not np.isfinite(zero).any()
+    same = (np.isnan(zero) == np.isnan(ref0)) & (np.isnan(zero) | (np.sign(zero) == np.sign(ref0)))
+    assert same.mean() > 0.999, same.mean()
+    # repaired table: finite, the reference's projection and gradient
+    m = OriginalLocalHiddenPositiveProjection(cfg).to(dev)
+    m.divide_num.copy_(counts)
+    gtol = 1e-5 if (source == "attn" and not differ.any()) else 3e-2 if differ.any() else 3e-3
+    _lhp_module_case(m, g, f"{name}_orig_{source}", code, args, dev, gtol, gtol)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(b, d, sz + 1, sz + 1, device=dev), **args)
+
+
+def test_lhp_maps_beyond_1024_positions(dev):
+    """The 64-registers-per-lane instantiations (P > 1024): a 34x34 map (P = 1156, not a multiple of 64), D = 100, three heads,
+    all three map modes against the oracle on seeded inputs."""
+    from depthg_amd import ops
+    from depthg_amd.lhp import neighbour_counts
+    from oracle import depthg_oracle as O
+    gen = torch.Generator().manual_seed(77)
+    b, d, sz, heads = 1, 100, 34, 3
+    P = sz * sz
+    code = torch.randn(b, d, sz, sz, generator=gen)
+    attn = torch.softmax(1.5 * torch.randn(b, heads, P + 1, P + 1, generator=gen), dim=-1)
+    depth = (torch.rand(b, 1, 136, 136, generator=gen) * 200).round()
+    up = torch.randn(b, d, sz, sz, generator=gen)
+    counts = neighbour_counts(sz)
+    out, wmap = ops.lhp_map_forward(ops.LHP_ATTN, code.to(dev), attn=attn.to(dev))
+    omap = O.lhp_attn_weights(attn)
+    assert torch.equal(wmap.cpu(), omap)
+    want = O.lhp_propagate_attn(code, attn)
+    assert float((out.cpu() - want).norm() / want.norm()) < 2e-6
+    gback = ops.lhp_map_backward(ops.LHP_ATTN, up.to(dev), wmap).cpu()
+    gwant = (torch.einsum("bpq,bdp->bdq", omap, up.reshape(b, d, P)) / float(P)).reshape(b, d, sz, sz)
+    assert float((gback - gwant).norm() / gwant.norm()) < 2e-6
+    for mode, src, omap in ((ops.LHP_ORIG_ATTN, dict(attn=attn.to(dev)), O.lhp_original_attn_weights(attn, sz)),
+                            (ops.LHP_ORIG_DEPTH, dict(depth=depth.to(dev)), O.lhp_original_depth_weights(depth, sz))):
+        out, w9 = ops.lhp_map_forward(mode, code.to(dev), divide=counts.float().to(dev), **src)
+        want = O.lhp_original_propagate(omap, code, counts)
+        # (a weight at the row-mean threshold may fall the other way: the mean's float32 summation order differs)
+        bad = ((out.cpu() - want).abs() > 1e-5 * (1 + want.abs())).reshape(b, d, P).any(1).sum()
+        assert int(bad) <= 3, int(bad)
+        gback = ops.lhp_map_backward(mode, up.to(dev), w9, counts.float().to(dev)).cpu()
+        gwant = torch.einsum("bpq,bdp->bdq", omap, up.reshape(b, d, P) / counts.reshape(1, 1, P)).reshape(b, d, sz, sz)
+        bad = ((gback - gwant).abs() > 1e-5 * (1 + gwant.abs())).reshape(b, d, P).any(1).sum()
+        assert int(bad) <= 27, int(bad)
+
+
 def test_lhp_second_loss_call_and_total(dev):
     """The LHP step of training_step (src/train_segmentation.py:202-215, 255-266, 325-343): the code goes through the LHP
     module (depth propagation for the image, head only for the positive), a second loss call runs on the projections and

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/depthg_corr.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.dg_version() == _lib.DG_VERSION == 103
+    assert lib.dg_version() == _lib.DG_VERSION == 104
 
 
 def test_descriptor_validation_and_workspace():
@@ -151,6 +151,28 @@ def test_correspondence_total_matches_fixture_totals():
         depth = bool(cfg.depth_feat_correlation_loss)
         vec = torch.stack([out[0].mean(), out[2].mean(), out[4].mean(), out[6].mean() if depth else torch.zeros(())])
         assert float(torch.dot(vec, correspondence_weights(cfg, depth, "cpu"))) == pytest.approx(float(total), rel=1e-6, abs=1e-9)
+
+
+def test_correspondence_total_lhp_original_experiment():
+    """src/train_segmentation.py:335-337: an experiment name containing "lhp_original" drops the base correspondence term and
+    rewrites cfg.lhp_weight to 1.0 (for every later step too); the module picked is the Original class (:82-85)."""
+    from types import SimpleNamespace
+    from depthg_amd.training import correspondence_total
+    cfg = SimpleNamespace(pos_intra_weight=0.5, pos_inter_weight=0.25, neg_inter_weight=2.0, depth_feat_weight=0.1,
+                          correspondence_weight=1.0, depth_feat_correlation_loss=True, lhp=True, lhp_weight=0.3,
+                          lhp_weight_balance=True, lhp_depth_weight=0.5, experiment_name="run7_lhp_original_a")
+    s = lambda v: torch.tensor(float(v))
+    out = (s(1), s(0), s(2), s(0), torch.tensor([3.0, 5.0]), s(0), s(6), s(0))
+    lhp = (s(10), s(0), s(20), s(0), torch.tensor([30.0, 50.0]), s(0), s(60), s(0))
+    total, _ = correspondence_total(cfg, out, lhp)
+    assert cfg.lhp_weight == 1.0
+    assert abs(float(total) - (0.25 * 20 + 0.5 * 10 + 2.0 * 40 + 0.1 * 0.5 * 60) * 1.0) < 1e-5
+    from depthg_amd.segmenter import UnsupervisedSegmenter, default_segmenter_cfg as default_cfg
+    from depthg_amd.lhp import OriginalLocalHiddenPositiveProjection, LocalHiddenPositiveProjection
+    c2 = default_cfg(lhp=True, experiment_name="x_lhp_original", propagation_strategy="depth", res=64, dino_patch_size=8)
+    assert isinstance(UnsupervisedSegmenter(5, c2).lhp_module, OriginalLocalHiddenPositiveProjection)
+    c3 = default_cfg(lhp=True, experiment_name="plain", res=64, dino_patch_size=8)
+    assert isinstance(UnsupervisedSegmenter(5, c3).lhp_module, LocalHiddenPositiveProjection)
 
 
 def test_correspondence_total_lhp_and_balance():

@@ -256,3 +256,62 @@ def test_lhp_propagation_against_reference(name):
     assert int(kept.min()) >= int(np.floor(0.01 * (p - 1))) + 1            # at least the quantile's lower rank + 1 survive
     assert torch.all(torch.diagonal(wmap, dim1=1, dim2=2) == 1.0)          # self-distance 0 -> weight 1
     assert torch.all(stats[..., 0] == 0.0)
+
+
+# ---- N3, the other propagation maps: attention strategy and the Original class (tests/golden/lhp_attn.npz) -------------
+def _head_from(g, key, d):
+    head = torch.nn.Sequential(torch.nn.Conv2d(d, d, (1, 1)), torch.nn.ReLU(), torch.nn.Conv2d(d, d, (1, 1)))
+    with torch.no_grad():
+        for k, prm in enumerate(head.parameters()):
+            prm.copy_(T(g[f"{key}_head{k}"]))
+    return head
+
+
+@pytest.mark.parametrize("name", ["s10", "s12"])
+def test_lhp_attention_map_against_reference(name):
+    """forward_attn of LocalHiddenPositiveProjection (src/modules.py:235-271): same thresholded map (the oracle's ordered heads
+    sum and quantile are the reference's), weighted mean to float32 summation-order accuracy, gradient through the head."""
+    g = load_golden("lhp_attn.npz")
+    code, attn = T(g[f"{name}_code"]), T(g[f"{name}_attn"])
+    key = f"{name}_local_attn"
+    out = O.lhp_propagate_attn(code, attn)
+    np.testing.assert_allclose(out.numpy(), g[f"{key}_mixed"], rtol=2e-5, atol=1e-6)
+    wmap = O.lhp_attn_weights(attn)
+    p = wmap.shape[-1]
+    zeroed = (wmap == 0).sum(-1)
+    # the row minimum (normalised to 0) and everything above the 99 % quantile: P - 1 - floor(0.99 (P - 1)) values
+    assert int(zeroed.min()) >= 1 and int(zeroed.max()) <= p - int(np.floor(np.float32(0.99) * np.float32(p - 1))) + 1
+    cg = code.clone().requires_grad_(True)
+    proj = _head_from(g, key, code.shape[1])(torch.einsum("bpq,bdq->bdp", wmap, cg.reshape(*cg.shape[:2], -1)).reshape(cg.shape) / p)
+    np.testing.assert_allclose(proj.detach().numpy(), g[f"{key}_proj"], rtol=1e-4, atol=1e-5)
+    (proj * T(g[f"{key}_up"])).sum().backward()
+    np.testing.assert_allclose(cg.grad.numpy(), g[f"{key}_grad_code"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["s10", "s12"])
+@pytest.mark.parametrize("source", ["attn", "depth"])
+def test_lhp_original_variant_against_reference(name, source):
+    """OriginalLocalHiddenPositiveProjection (src/modules.py:342-487): the index mask is the clipped 3x3 neighbourhood; with the
+    constructor's all-zero divide_num the output is sum / 0 (same inf / nan pattern); with the neighbourhood sizes it is finite
+    and matches to float32 summation-order accuracy (depth: the cdist tolerance of the depth strategy's test)."""
+    g = load_golden("lhp_attn.npz")
+    code = T(g[f"{name}_code"])
+    sz = code.shape[-1]
+    assert np.array_equal(O.lhp_index_mask(sz), g[f"{name}_index_mask"].astype(np.float32))
+    counts = T(g[f"{name}_counts"])
+    assert np.array_equal(O.lhp_index_mask(sz).sum(1), counts.numpy()[:, 0])
+    wmap = (O.lhp_original_attn_weights(T(g[f"{name}_attn"]), sz) if source == "attn"
+            else O.lhp_original_depth_weights(T(g[f"{name}_depth"]), sz))
+    zero = O.lhp_original_propagate(wmap, code, torch.zeros(sz * sz, 1, dtype=torch.long)).numpy()
+    ref0 = g[f"{name}_orig_{source}_zero_mixed"]
+    assert not np.isfinite(zero).any() and not np.isfinite(ref0).any()
+    same = (np.isnan(zero) == np.isnan(ref0)) & (np.isnan(zero) | (np.sign(zero) == np.sign(ref0)))
+    assert same.mean() > 0.999, same.mean()                                   # (a sum that rounds across 0 may flip one sign)
+    key = f"{name}_orig_{source}"
+    out = O.lhp_original_propagate(wmap, code, counts)
+    tol = dict(rtol=2e-5, atol=2e-6) if source == "attn" else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(out.numpy(), g[f"{key}_mixed"], **tol)
+    cg = code.clone().requires_grad_(True)
+    proj = _head_from(g, key, code.shape[1])(O.lhp_original_propagate(wmap, cg, counts))
+    (proj * T(g[f"{key}_up"])).sum().backward()
+    np.testing.assert_allclose(cg.grad.numpy(), g[f"{key}_grad_code"], rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)

@@ -198,3 +198,18 @@ def test_training_steps_across_sample_decay_and_lhp():
     loss, logs = m2.training_step(_batch(2, g, dev), 0)
     assert torch.isfinite(loss)
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in m2.lhp_module.parameters())
+    # the same recipe over the backbone's attention (propagation_strategy "attn") and with the Original class + repaired divisors
+    from depthg_amd.lhp import OriginalLocalHiddenPositiveProjection, neighbour_counts
+    for over in (dict(propagation_strategy="attn"), dict(propagation_strategy="depth", experiment_name="t_lhp_original", res=112)):
+        cfg3 = default_segmenter_cfg(dim=70, lhp=True, lhp_weight=0.3, lhp_weight_balance=True, dg_outputs="reduced", **over)
+        m3 = UnsupervisedSegmenter(27, cfg3).to(dev)
+        m3.train()
+        if "experiment_name" in over:
+            assert isinstance(m3.lhp_module, OriginalLocalHiddenPositiveProjection)
+            m3.lhp_module.divide_num.copy_(neighbour_counts(14))
+        loss, logs = m3.training_step(_batch(2, g, dev), 0)
+        assert torch.isfinite(loss), over
+        assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in m3.lhp_module.parameters())
+        if "experiment_name" in over:
+            assert cfg3.lhp_weight == 1.0                     # src/train_segmentation.py:337
+
