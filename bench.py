@@ -149,12 +149,16 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="workload: the headline (default, BASELINE.json metric) or one of BASELINE.json's configs 2-5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-allreduce", action="store_true",
-                    help="give each step's all-reduce one step of slack (it then overlaps the next step's kernels, as it would "
-                         "overlap the frozen ViT forward in training); default: the compute stream waits for it right away")
+    ap.add_argument("--sync-allreduce", action="store_true",
+                    help="N > 1: fill + all-reduce on the compute stream, which waits for the collective right away.  Default: the "
+                         "exchange runs on a side stream behind the step's backward (GradBucket.exchange_on) and overlaps the next "
+                         "step's kernels, as it overlaps the frozen ViT forward in training; exchanges are ordered among themselves "
+                         "and every collective of the timed steps completes inside the timed region either way")
     ap.add_argument("--graph", action="store_true",
                     help="record the step once in a hipGraph (torch.cuda.graph) and replay it: for the launch-bound small "
                          "configurations; the negatives' permutations then advance on the device (cfg.dg_graph_safe)")
+    ap.add_argument("--eager", action="store_true",
+                    help="N > 1: launch the step's kernels from Python every step instead of replaying them from a hipGraph")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -181,58 +185,102 @@ def main():
 
     conf = CONFIGS[args.config]
     H = conf["H"]
-    cfg = make_cfg(conf, dg_graph_safe=bool(args.graph))
+    # N > 1 (and --force-dist): the compute part of the step is replayed from a hipGraph unless --eager, because the eager
+    # step's Python side (0.24 ms) plus the collective's (0.05-0.14 ms) would make the host the limit of a 0.35-ms step
+    graph_mode = args.graph or (use_dist and not args.eager and not args.sync_allreduce)
+    cfg = make_cfg(conf, dg_graph_safe=graph_mode)
     loss_fn = ContrastiveCorrelationLoss(cfg)
     f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev, H)
     c.requires_grad_(True)
     cp.requires_grad_(True)
-    bucket = GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None)
-
+    # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size filled from this step's
+    # d/d code, averaged over the ranks (RCCL over xGMI).  Two buffers: step i + 1 fills the other one while step i's is in flight
+    buckets = [GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None) for _ in range(2)]
+    comm = torch.cuda.Stream() if use_dist else None     # the gradient exchange runs here
     seed_grad = torch.ones((), device=dev)   # d(total)/d(total): the upstream of the step, resident like the other inputs
+    counter = [0]
 
-    def step():
+    def compute(bucket=None):
         c.grad = None
         cp.grad = None
         loss_fn(f, fp, None, None, c, cp, d, dp)
         total = loss_fn.total          # weighted total of the four loss means (training_step's term), formed by the library
         total.backward(gradient=seed_grad)
-        if use_dist:
-            # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size
-            # filled from this step's d/d code, all-reduced (sum) over xGMI and scaled by 1/world
-            bucket.wait()                  # the previous step's exchange must be done before its buffer is refilled
+        if bucket is not None:
             bucket.fill_from(c.grad)
-            bucket.allreduce_mean_(even_if_alone=args.force_dist, async_op=args.overlap_allreduce)
         return total
 
-    def sync():
-        if use_dist:
-            bucket.wait()                  # every all-reduce of the timed steps completes inside the timed region
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.graph:
-        if use_dist:
-            raise SystemExit("--graph records the single-GPU step (the all-reduce is not recorded)")
+    def capture(fn):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                step()
+                fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            total_static = step()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    exchange_mode = "none"
+    if not use_dist:
+        if args.graph:
+            graph, total_static = capture(compute)
+
+            def step():
+                graph.replay()
+                return total_static
+        else:
+            step = compute
+    elif args.sync_allreduce:
+        exchange_mode = "every step, on the compute stream (which waits for it)"
 
         def step():
-            graph.replay()
-            return total_static
+            total = compute(buckets[0])
+            buckets[0].allreduce_mean_(even_if_alone=args.force_dist)
+            return total
+    elif graph_mode:
+        exchange_mode = ("every step, on a side stream behind the step's graph: overlaps the next step's kernels, completes inside "
+                         "the timed region; the step (with the fill of its bucket) is replayed from one of two hipGraphs")
+        try:
+            graphs = [capture(lambda k=k: compute(buckets[k])) for k in range(2)]
+        except RuntimeError as e:          # (a capture that fails leaves the eager path, which needs no recording, to run)
+            print(f"[bench] hipGraph capture failed on rank {rank} ({e}); running the eager step", file=sys.stderr)
+            graphs = None
+            graph_mode = False
+
+        def step():
+            k = counter[0] & 1
+            counter[0] += 1
+            buckets[k].wait_exchange()     # (the collective that read this bucket two steps ago: long done, keeps the order explicit)
+            graphs[k][0].replay()
+            buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
+            return graphs[k][1]
+    if use_dist and not args.sync_allreduce and not graph_mode:
+        exchange_mode = "every step, on a side stream: overlaps the next step's kernels, completes inside the timed region (eager step)"
+
+        def step():
+            k = counter[0] & 1
+            counter[0] += 1
+            total = compute()
+            buckets[k].exchange_on(comm, c.grad, even_if_alone=args.force_dist)
+            return total
+
+    def sync():
+        if use_dist:
+            for b in buckets:
+                b.wait_exchange()          # every all-reduce of the timed steps completes inside the timed region
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
         step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total = step()
+    host_elapsed = time.perf_counter() - t0     # the Python loop alone (enqueue side); equals `elapsed` when the host is the limit
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -281,11 +329,12 @@ def main():
             "metric": "correlation-loss steps/sec at B=32,C=384,28x28 (fwd+bwd, per-GPU batch 32)" if args.config == "headline"
                       else f"correlation-loss steps/sec, {args.config} (fwd+bwd, per-GPU batch {H['B']})",
             "value": round(value, 2), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 (feats) / f16 (code) MFMA inputs, f32 accumulate", "data": "synthetic",
-            "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if args.graph else ""), "name": args.config,
+            "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if graph_mode else ""), "name": args.config,
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
-                       "allreduce_elems": HEAD_GRAD_ELEMS if world > 1 else 0},
+                       "allreduce_elems": HEAD_GRAD_ELEMS if use_dist else 0,
+                       "allreduce": exchange_mode},
             "loss_total": float(total.detach()),
             "roofline": roofline,
         }

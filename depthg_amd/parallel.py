@@ -75,6 +75,28 @@ class GradBucket:
                 self.flat.mul_(1.0 / world)
         return self.flat
 
+    def exchange_on(self, stream, source: Optional[torch.Tensor] = None, even_if_alone: bool = False):
+        """The whole exchange on a side stream: `stream` waits for everything enqueued so far on the current stream, then (fills
+        the bucket from `source` and) all-reduces it there.  The compute stream is never made to wait - no barrier packet in
+        its queue; successive exchanges are ordered by `stream` itself, so the buffer is not refilled before the previous
+        collective has read it.  Whoever consumes the averaged gradients (the optimiser step) calls `wait_exchange()` first."""
+        cur = torch.cuda.current_stream()
+        done = cur.record_event()
+        if source is not None:
+            source.record_stream(stream)           # the caching allocator must not hand the tensor out while `stream` reads it
+        with torch.cuda.stream(stream):
+            stream.wait_event(done)
+            if source is not None:
+                self.fill_from(source)
+            self.allreduce_mean_(even_if_alone=even_if_alone)
+            self._exchange_done = stream.record_event()
+
+    def wait_exchange(self):
+        """Current stream waits for the last `exchange_on` (no host block)."""
+        ev = getattr(self, "_exchange_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def wait(self):
         """Make the current stream wait for an outstanding async all-reduce (no host block)."""
         w = getattr(self, "_work", None)

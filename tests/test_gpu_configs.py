@@ -221,6 +221,15 @@ torch.cuda.synchronize()
 got = bucket.flat.cpu()
 want = torch.cat([cr.grad.reshape(-1), cpr.grad.reshape(-1)])
 rel = float((got - want).norm() / want.norm())
+# the same exchange on a side stream (bench.py's default for N > 1): fill + collective behind the compute stream's work
+b2 = GradBucket(bucket.flat.numel(), dev, dist)
+src = torch.cat([cg.grad.reshape(-1), cpg.grad.reshape(-1)])
+comm = torch.cuda.Stream()
+for _ in range(3):
+    b2.exchange_on(comm, src, even_if_alone=True)
+b2.wait_exchange()
+torch.cuda.synchronize()
+assert torch.equal(b2.flat.cpu(), got)
 dist.destroy_process_group()
 assert rel < 3e-2, rel
 print("RCCL_OK", rel)
