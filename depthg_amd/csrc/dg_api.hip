@@ -293,6 +293,7 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         g.depth = p.depth ? depth : nullptr; g.nz = F32(p.nz); g.nzsum = F32(p.nzsum);
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
         g.dH = desc->depth_h; g.dW = desc->depth_w;
+        g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
         if (p.rows) {
@@ -362,6 +363,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             for (int j = 0; j < c.gr.nh; ++j) { c.gr.sidx[j] = a.jobs[j].sidx; c.gr.key[j] = a.gr_key[j]; }
             c.gr.list = const_cast<int32_t*>(a.gr_list); c.gr.count = const_cast<int32_t*>(a.gr_count); c.gr.rank = const_cast<int16_t*>(a.gr_rank);
         }
+        if (p.ident && p.pointwise) {         // dense code operands from channel planes (norms: k_prep_dense; csum: k_rowmean launch)
+            c.dc.code[0] = orig_code; c.dc.code[1] = orig_code_pos;
+            for (int o = 0; o < 2; ++o) { c.dc.blob[o] = ws + p.op[o]; c.dc.inv_norm[o] = F32(p.inv[o]); c.dc.ccolpart[o] = F32(p.ccolpart[o]); }
+            c.dc.B = p.B; c.dc.D = p.D; c.dc.KF = p.KF; c.dc.KD = p.KD; c.dc.h = p.h; c.dc.w = p.w; c.dc.P = p.P; c.dc.Ppad = p.Ppad;
+        }
         DG_HIP(dg_launch_colmean(c, stream));
     }
     if (p.pointwise) {
@@ -373,6 +379,10 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
             r.jobs[t].bbar = F32(p.bbar[op_of(p, t)]); r.jobs[t].bidx = map_of(p, t, perms);
             r.jobs[t].bsplit = reinterpret_cast<const __bf16*>(ws + p.bsplit[op_of(p, t)]);
             r.jobs[t].rvec = F32(p.rvec[t]); r.jobs[t].rimg = F32(p.rimg[t]);
+        }
+        if (p.ident) {
+            r.ncs = 2;
+            for (int o = 0; o < 2; ++o) { r.cs_part[o] = F32(p.ccolpart[o]); r.cs_out[o] = F32(p.csum[o]); }
         }
         DG_HIP(dg_launch_rowmean(r, stream));
     }

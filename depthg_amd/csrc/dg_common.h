@@ -289,6 +289,18 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     float* nzsum;            // [B] their per-image sums
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
     int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
+    int32_t code_split;      // 1: the code role only writes inv_norm (per-pixel norms from whole channel planes); the code parts of
+                             //    the blobs + ccolpart come from the k_colmean launch (DgDenseCodeArgs), csum from the k_rowmean launch
+};
+
+// Code operands of the identity grid from whole channel planes (extra blocks of the k_colmean launch, after the norms of
+// k_prep_dense): one block per (image, operand, group of 8 channels = one 16-byte granule of the C part)
+struct DgDenseCodeArgs {
+    const float* code[2];    // code NCHW fp32 (B,D,h,w)
+    char* blob[2];
+    const float* inv_norm[2];
+    float* ccolpart[2];
+    int32_t B, D, KF, KD, h, w, P, Ppad;     // B == 0: not used
 };
 
 // Consumer lists of the grouped ragged row blocks of k_corr2 (dg_corr2.hip): for every key (= set of pair-sets that stream the
@@ -340,6 +352,7 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
     int32_t nops, B, P, Ppad, KF, KD;
     unsigned int* zero_word;           // a word this launch sets to 0 (the depth blocks' ticket of the k_gs launch), or null
     DgGroupArgs gr;                    // gr.nkeys > 0: blockIdx.z == 2 writes the consumer lists of k_corr2's grouped ragged blocks
+    DgDenseCodeArgs dc;                // dc.B > 0: blockIdx.z == 3 builds the dense code operands (and blockIdx.z == 1 is the k_rowmean launch's)
 };
 
 struct DgRowmeanJob {
@@ -355,6 +368,9 @@ struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
     const float* abar;           // [B][KF] mean normalised feats of operand 1
+    const float* cs_part[2];     // ncs > 0: block x == Ppad/32 + 1 of an image also reduces the code column sums of the dense
+    float* cs_out[2];            //          operands (csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]), see DgDenseArgs.code_split
+    int32_t ncs;
 };
 
 struct DgScatterSrc {

@@ -410,8 +410,10 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
 // L2-normalise over the D channels (norm(), src/modules.py:789-790; squared norms reduced from registers), keep the
 // NORMALISED fp16 tile in LDS and write from it the C part (K-major granules), the P part (position-major granules in
 // dg_perm32 order), 1/max(||c||, eps) and the per-tile column sums.  Same roundings as k_gather_norm.
+#ifndef DENSE_TPB
 #define DENSE_TPB 2
 #define DENSE_CODE_PAIRS 192      // (source row, column) pairs of one block: S * (columns touched) <= 192
+#endif
 template <int UN>        // channels per thread: D <= 4 * UN
 __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int tb, int n, int o) {
     const int tid = threadIdx.x, ps = tid & 63, kg = tid >> 6;
@@ -496,6 +498,97 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
     }
 }
 
+// ---- the code operands from whole channel planes (DgDenseArgs.code_split) ---------------------------------------------------
+// prep_dense_code reads, per channel and source row, the 3-4 pixels of its two tiles' columns: 16-byte pieces of 128-byte
+// lines, every line requested by eight blocks - the address path, not HBM, bounded it (15 of its 23 us alone were the loads
+// of 14 MB).  Split in two along the only dependency there is:
+//   prep_dense_code_norms   (k_prep_dense launch) one thread per pixel walks the D planes (wave = 64 consecutive pixels of a
+//                           plane = two lines) and writes 1/max(||c||, eps) at the pixel's position p = x*S + y
+//   dense_code_planes       (k_colmean launch)    one block per (image, operand, 8 channels): reads its 8 planes once, scales,
+//                           rounds to fp16, transposes through LDS ([position][8 channels] = the C part's granule) and writes
+//                           granule g of the C part (512 contiguous bytes per tile), the 8 channels' P-part granules (128-byte
+//                           runs) and their per-tile column sums
+// Same operations in the same order as prep_dense_code (four fma chains over the channels k = kg + 4u, summed
+// ((s0 + s1) + s2) + s3; value * inv rounded to fp16; column sums over the 32 positions in order): bit-identical operands.
+template <int UN>
+__device__ __forceinline__ void prep_dense_code_norms(const DgDenseArgs& a, int xb, int n, int o) {
+    const int HW = a.h * a.w, S = a.h, i = xb * 256 + threadIdx.x;
+    float* inv = a.inv_norm[o] + (size_t)n * a.Ppad;
+    if (xb == 0)
+        for (int p = a.P + threadIdx.x; p < a.Ppad; p += 256) inv[p] = 0.f;          // positions of the ragged last tile
+    if (i >= HW) return;
+    const float* src = a.code[o] + (size_t)n * a.D * HW + i;
+    float t[4 * UN];
+#pragma unroll
+    for (int k = 0; k < 4 * UN; ++k) t[k] = k < a.D ? src[(size_t)k * HW] : 0.f;
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) ss[kg] = fmaf(t[kg + 4 * u], t[kg + 4 * u], ss[kg]);
+    const float tot = ss[0] + ss[1] + ss[2] + ss[3];
+    const int y = i / a.w, x = i - y * a.w;
+    inv[x * S + y] = 1.f / fmaxf(sqrtf(tot), DG_EPS_NORM);
+}
+
+__device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char* xt, int n, int o, int g) {
+    const int tid = threadIdx.x, HW = a.h * a.w, S = a.h, nt = a.Ppad / 32, KD = a.KD;
+    const DgBlob L(a.KF, a.KD);
+    const int nch = min(8, a.D - 8 * g);                  // live channels of this group (<= 0: padding group, zeros)
+    for (int p = a.P + tid; p < a.Ppad; p += 256) reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+    if (nch <= 0) {
+        for (int p = tid; p < a.P; p += 256) reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        const float* src = a.code[o] + ((size_t)n * a.D + 8 * g) * HW;
+        const float* inv = a.inv_norm[o] + (size_t)n * a.Ppad;
+        for (int i0 = 0; i0 < HW; i0 += 1024) {           // four pixels per thread and round: 32 loads in flight
+            float t[4][8], iv[4];
+            int pp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + tid + 256 * j;
+                const bool ok = i < HW;
+                const int y = i / a.w, x = i - y * a.w;
+                pp[j] = ok ? x * S + y : -1;
+                iv[j] = ok ? inv[pp[j]] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) t[j][c] = (ok && c < nch) ? src[(size_t)c * HW + i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (pp[j] < 0) continue;
+                f16x8 v;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = c < nch ? (_Float16)(t[j][c] * iv[j]) : (_Float16)0.f;
+                *reinterpret_cast<f16x8*>(xt + pp[j] * 16) = v;
+            }
+        }
+    }
+    __syncthreads();
+    char* blob0 = a.blob[o] + (size_t)n * nt * L.bytes;
+    for (int id = tid; id < nt * 32; id += 256) {          // C part: granule g of every position
+        const int tl = id >> 5, qq = id & 31;
+        *reinterpret_cast<uint4*>(blob0 + (size_t)tl * L.bytes + L.c(qq, g)) = reinterpret_cast<const uint4*>(xt)[id];
+    }
+    for (int id = tid; id < nt * 32; id += 256) {          // P part: granule cc of channel d = 8 g + c
+        const int tl = id >> 5, cc = (id >> 3) & 3, c = id & 7;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pl = 16 * (cc >> 1) + 8 * ((e >> 2) & 1) + 4 * (cc & 1) + (e & 3);   // dg_perm32(pl) == 8 cc + e
+            v[e] = *reinterpret_cast<const _Float16*>(xt + (tl * 32 + pl) * 16 + c * 2);
+        }
+        *reinterpret_cast<f16x8*>(blob0 + (size_t)tl * L.bytes + L.p(8 * g + c, cc)) = v;
+    }
+    for (int id = tid; id < nt * 8; id += 256) {           // per-tile column sums (for the cd means)
+        const int tl = id >> 3, c = id & 7;
+        float cs = 0.f;
+#pragma unroll 8
+        for (int qq = 0; qq < 32; ++qq) cs += (float)*reinterpret_cast<const _Float16*>(xt + (tl * 32 + qq) * 16 + c * 2);
+        a.ccolpart[o][((size_t)n * nt + tl) * KD + 8 * g + c] = cs;
+    }
+}
+
 __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
                                                int n, int H, int W, int Sh, int S, int Ppad);
 
@@ -519,7 +612,9 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     if (z < 2) {
         if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x % a.h, x / a.h, n, z);
     } else if (z < 4) {
-        if (x * DENSE_TPB < a.Ppad / 32 && !(DG_DBG(a.debug) & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
+        if (a.code_split) {
+            if (x * 256 < a.h * a.w) prep_dense_code_norms<UNC>(a, x, n, z - 2);
+        } else if (x * DENSE_TPB < a.Ppad / 32 && !(DG_DBG(a.debug) & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
     } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad);
     }
@@ -528,7 +623,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
     const int nt = a.Ppad / 32, gx = a.h * ((a.w + 31) / 32);
-    if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx) return hipErrorInvalidValue;
+    if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx || (a.h * a.w + 255) / 256 > gx) return hipErrorInvalidValue;
     const int smem = max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
                          DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);
     if (a.h * ((DENSE_TPB * 32 + a.h - 1) / a.h + 1) > DENSE_CODE_PAIRS) return hipErrorInvalidValue;   // pairs per block
@@ -598,33 +693,42 @@ hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B
 
 // ------------------------------------------------------------------------------------------
 
+// out[n][k] = scale * sum over the groups of part[n][group][k], summed in group order; every thread of the block takes part
+__device__ __forceinline__ void colsum_reduce(const float* part, int n, int ngroups, int K, float scale, float* out) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float* cp = part + (size_t)n * ngroups * K + k;
+        float s = 0.f;
+        int t = 0;
+        for (; t + 16 <= ngroups; t += 16) {          // 16 independent loads in flight, summed in group order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = cp[(size_t)(t + u) * K];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; t + 4 <= ngroups; t += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = cp[(size_t)(t + u) * K];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; t < ngroups; ++t) s += cp[(size_t)t * K];
+        out[(size_t)n * K + k] = s * scale;
+    }
+}
+
 // bbar[o][n][k] = (1/P) sum over tiles of the per-tile column sums.  grid (B, nops), block 256.
 __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char cm_smem[];     // blockIdx.z == 3: [Ppad] 16-byte code rows
     const int n = blockIdx.x, o = blockIdx.y;
     if (a.zero_word && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.zero_word = 0u;
-    auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) {
-        for (int k = threadIdx.x; k < K; k += 256) {
-            const float* cp = part + (size_t)n * ngroups * K + k;
-            float s = 0.f;
-            int t = 0;
-            for (; t + 16 <= ngroups; t += 16) {          // 16 independent loads in flight, summed in group order
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = cp[(size_t)(t + u) * K];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s += v[u];
-            }
-            for (; t + 4 <= ngroups; t += 4) {
-                float v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = cp[(size_t)(t + u) * K];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s += v[u];
-            }
-            for (; t < ngroups; ++t) s += cp[(size_t)t * K];
-            out[(size_t)n * K + k] = s * scale;
-        }
-    };
+    auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) { colsum_reduce(part, n, ngroups, K, scale, out); };
+    if (blockIdx.z == 3) {                                // dense code operands from channel planes: y = operand * (KD / 8) + channel group
+        const int GD = a.dc.KD / 8;
+        if ((int)blockIdx.y < 2 * GD) dense_code_planes(a.dc, cm_smem, n, (int)blockIdx.y / GD, (int)blockIdx.y % GD);
+        return;
+    }
     // blockIdx.z: 0 = feature means, 1 = code column sums (two short latency chains side by side instead of one after the other),
     // 2 = consumer lists of k_corr2's grouped ragged blocks (one wave per (image, key))
     if (blockIdx.z == 2) {
@@ -643,12 +747,19 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
             a.bsplit[o][((size_t)n * 2 + 1) * a.KF + k] = (__bf16)(v - (float)hi);
         }
     }
-    if (blockIdx.z == 1 && a.ccolpart[o]) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
+    if (blockIdx.z == 1 && a.ccolpart[o] && a.dc.B == 0) reduce(a.ccolpart[o], a.Ppad / 32, a.KD, 1.f, a.csum[o]);
 }
 
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
-    const int ny = a.gr.nkeys > a.nops ? a.gr.nkeys : a.nops;
-    hipLaunchKernelGGL(k_colmean, dim3(a.B, ny, a.gr.nkeys > 0 ? 3 : 2), dim3(256), 0, s, a);
+    int ny = a.gr.nkeys > a.nops ? a.gr.nkeys : a.nops;
+    int nz = a.gr.nkeys > 0 ? 3 : 2, smem = 0;
+    if (a.dc.B > 0) {
+        if (a.nops != 2) return hipErrorInvalidValue;       // (the dense path has two operands; their csum moves to the k_rowmean launch)
+        ny = max(ny, 2 * (a.dc.KD / 8)); nz = 4; smem = a.dc.Ppad * 16;
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_colmean), smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_colmean, dim3(a.B, ny, nz), dim3(256), smem, s, a);
     return hipGetLastError();
 }
 
@@ -662,6 +773,10 @@ __global__ __launch_bounds__(64 * ROWMEAN_WAVES) void k_rowmean(const DgRowmeanA
     const int tile = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KF = a.KF, nt = a.Ppad / 32;
+    if (tile == nt + 1) {                                 // code column sums of the dense operands (DgDenseArgs.code_split)
+        for (int o = 0; o < a.ncs; ++o) colsum_reduce(a.cs_part[o], n, nt, a.KD, 1.f, a.cs_out[o]);
+        return;
+    }
     if (tile == nt) {
         // extra block of the image: per-image sums of the row means (the fused kernel adds the B of them up to m0 = the
         // reference's fd.mean() before centering, src/modules.py:1237): sum_p a_p . bbar = P * abar . bbar, one K-long dot per
@@ -742,6 +857,6 @@ hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
     const int smem = max(32 * (a.KF / 8) * 16, (ROWMEAN_WAVES - 1) * 16 * 64 * 4);     // F part / partial accumulators
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_rowmean), smem);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32 + 1, a.B), dim3(64 * ROWMEAN_WAVES), smem, s, a);
+    hipLaunchKernelGGL(k_rowmean, dim3(a.Ppad / 32 + 1 + (a.ncs > 0 ? 1 : 0), a.B), dim3(64 * ROWMEAN_WAVES), smem, s, a);
     return hipGetLastError();
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer aid: run dg_corr_forward with two library builds on the same inputs and report where the workspaces differ.
-   python scripts/cmp_ws.py tagA tagB [B]"""
+   python scripts/cmp_ws.py tagA tagB [B] [dense]      (dense: the identity-grid path, shared coordinates)"""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,7 @@ from depthg_amd import _lib, ops
 
 tags = sys.argv[1:3]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+DENSE = len(sys.argv) > 4 and sys.argv[4] == "dense"
 libs = {}
 for tag in tags:
     _lib._lib = None
@@ -26,8 +27,8 @@ c1 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
 c2 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
 perms = torch.stack([torch.randperm(B, generator=g) for _ in range(N)]).to(dev)
 desc = ops.make_desc(B, C, D, hw, hw, S, N, pointwise=True, zero_clamp=True, stabalize=False, depth_term=True,
-                     need_grad=True, shared_coords=False, shifts=(0.08, 0.02, 0.66, 0.03), depth_hw=(4 * hw, 4 * hw),
-                     identity_grid=False, weights=(0.67, 0.25, 0.63, 0.19))
+                     need_grad=True, shared_coords=DENSE, shifts=(0.08, 0.02, 0.66, 0.03), depth_hw=(4 * hw, 4 * hw),
+                     identity_grid=DENSE, weights=(0.67, 0.25, 0.63, 0.19))
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 res = {}
