@@ -53,8 +53,9 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
     l = last_json(f)
     shutil.copy(f, dst) if False else open(os.path.join(dst, os.path.basename(f)), "w").write(l)
     c = json.loads(l)
-    name = c['config']['name'] + (" (`--graph`)" if "hipGraph" in c['config']['workload'] else "")
+    name = c['config']['name'] + (" (`--force-dist`: the N > 1 schedule with one rank)" if c['config'].get('allreduce', 'none') != 'none'
+                                  else " (`--graph`)" if "hipGraph" in c['config']['workload'] else "")
     o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
-             f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |")
+             f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))

@@ -11,6 +11,8 @@ mkdir -p $out
 python3 /root/repo/bench.py > $out/${tag}_bench.json 2>/dev/null
 for c in C2 C3 C4shard C5; do python3 /root/repo/bench.py --config $c > $out/${tag}_bench_$c.json 2>/dev/null; done
 for c in C2 C3 C4shard; do python3 /root/repo/bench.py --config $c --graph --no-cpu-baseline > $out/${tag}_bench_${c}_graph.json 2>/dev/null; done
+# the N > 1 schedule with one rank (RCCL initialised, step replayed from two hipGraphs, collective on the side stream)
+python3 /root/repo/bench.py --force-dist --no-cpu-baseline 2>/dev/null | grep "^{" > $out/${tag}_bench_force_dist.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
 cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
