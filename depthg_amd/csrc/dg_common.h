@@ -401,6 +401,9 @@ struct DgScatterArgs {
     int32_t B, D, DP, h, w, S, Sh, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
     int32_t debug;         // developer ablation bits (0 in production)
     int32_t dense;         // 1: identity grid (DG_IDENTITY_GRID): the adjoint of sample() is a transposed copy
+    // (set by the launcher) the direct sources of k_grad_combine per destination, in source order: raw ones, then final ones
+    int8_t craw[2][DG_MAX_SCATTER / 2], cfin[2][DG_MAX_SCATTER / 2];
+    int8_t ncraw[2], ncfin[2];
 };
 
 #ifdef __HIPCC__

@@ -44,81 +44,79 @@ __device__ __forceinline__ void dg_taps(const float* c, int h, int w, int& x0, i
     }
 __device__ __forceinline__ float dg_pick(const float (&gs)[4], int i) { return i == 0 ? gs[0] : (i == 1 ? gs[1] : (i == 2 ? gs[2] : gs[3])); }
 
+// One block per (tile, image, destination), one WAVE PER 32-CHANNEL GROUP: a wave loads its group's slice of up to four
+// sources at a time (16 independent 16-byte loads per lane) - the one-wave form walked the eight raw sources one memory latency
+// after the other, twelve loads each, and was a latency chain (21 of its 26 us with every load an L2 hit).  The only thing the
+// groups share is <x, dx> per position: 32 partial sums per wave through LDS, added in group order.
 template <int NDF>
-__global__ __launch_bounds__(64) void k_grad_combine(const DgScatterArgs a) {
+__global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a) {
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5, DP = NDF * 32;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, DP = NDF * 32;
+    const int d = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) char xs[NDF][DG_XROWS_LDS];
+    __shared__ float part[NDF][32];
     DG_LOAD_GS(a, gs)
-    float v[NDF][16];
+    // padding channels are not stored by the producers (the bytes there are whatever the workspace held, NaN patterns
+    // included): those lanes load a valid address and the value is SELECTED away, never multiplied
+    const bool ok = 32 * d + r < a.D;
+    const size_t tile_off = ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4 + (ok ? d * 1024 : 0);
+    float v[16];
 #pragma unroll
-    for (int d = 0; d < NDF; ++d)
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    auto add_sources = [&](const int8_t* list, const int cnt) __attribute__((always_inline)) {
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            f32x4 t[4][4];
+            float sc[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[d][i] = 0.f;
-    bool any_raw = false;
-    for (int s = 0; s < a.nsrc; ++s) {
-        const DgScatterSrc& q = a.src[s];
-        if (q.dest != dest || q.route != nullptr || !q.raw) continue;
-        any_raw = true;
-        const float sc = q.factor * dg_pick(gs, q.gidx);
-        const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
+            for (int u = 0; u < 4; ++u) {
+                const bool live = k0 + u < cnt;
+                const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
+                sc[u] = live ? q.factor * dg_pick(gs, q.gidx) : 0.f;
+                const float* base = q.buf + tile_off;
 #pragma unroll
-        for (int d = 0; d < NDF; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // padding channels are not stored by the producers (the bytes there are whatever the workspace held, NaN
-                // patterns included): those lanes load a valid address and the value is SELECTED away, never multiplied
-                const bool ok = 32 * d + r < a.D;
-                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, ok ? t[e] : 0.f, v[d][4 * g + e]);
+                for (int g = 0; g < 4; ++g) t[u][g] = *reinterpret_cast<const f32x4*>(base + (ok ? g * 256 : 0));
             }
-    }
-    if (any_raw) {
-        const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c;
-        __shared__ __attribute__((aligned(16))) char xs[DG_XROWS_LDS];
-        _Float16 x[NDF][16];
-        dg_load_code_rows<NDF>(xb, xs, lane, x);
-        float dot[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dot[i] = 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const bool use = ok && k0 + u < cnt;
 #pragma unroll
-        for (int d = 0; d < NDF; ++d)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dot[i] = fmaf((float)x[d][i], v[d][i], dot[i]);
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(sc[u], use ? t[u][g][e] : 0.f, v[4 * g + e]);
+            }
+        }
+    };
+    const int nraw = a.ncraw[dest];
+    add_sources(a.craw[dest], nraw);
+    if (nraw > 0) {
+        const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c + d * 2048;
+        _Float16 x[1][16];
+        dg_load_code_rows<1>(xb, xs[d], lane, x);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float t = half_sum(dot[i]);
+            const float t = half_sum((float)x[0][i] * v[i]);
+            if (r == 0) part[d][h * 16 + i] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = part[0][h * 16 + i];
+#pragma unroll
+            for (int f = 1; f < NDF; ++f) t += part[f][h * 16 + i];
             const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             const float inv = rr < a.P ? a.xinv[(size_t)n * a.Ppad + rr] : 0.f;
-#pragma unroll
-            for (int d = 0; d < NDF; ++d) v[d][i] = (v[d][i] - (float)x[d][i] * t) * inv;
+            v[i] = (v[i] - (float)x[0][i] * t) * inv;
         }
     }
-    for (int s = 0; s < a.nsrc; ++s) {
-        const DgScatterSrc& q = a.src[s];
-        if (q.dest != dest || q.route != nullptr || q.raw) continue;
-        const float sc = q.factor * dg_pick(gs, q.gidx);
-        const float* base = q.buf + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
-#pragma unroll
-        for (int d = 0; d < NDF; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // padding channels are not stored by the producers (the bytes there are whatever the workspace held, NaN
-                // patterns included): those lanes load a valid address and the value is SELECTED away, never multiplied
-                const bool ok = 32 * d + r < a.D;
-                const f32x4 t = *reinterpret_cast<const f32x4*>(base + (ok ? (d * 4 + g) * 256 : 0));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[d][4 * g + e] = fmaf(sc, ok ? t[e] : 0.f, v[d][4 * g + e]);
-            }
-    }
-    float* out = a.comb[dest] + ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + lane * 4;
-#pragma unroll
-    for (int d = 0; d < NDF; ++d)
+    add_sources(a.cfin[dest], a.ncfin[dest]);
+    if (ok) {
+        float* out = a.comb[dest] + tile_off;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 t = {v[d][4 * g], v[d][4 * g + 1], v[d][4 * g + 2], v[d][4 * g + 3]};
-            if (32 * d + r < a.D) *reinterpret_cast<f32x4*>(out + (d * 4 + g) * 256) = t;
+            const f32x4 t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(out + g * 256) = t;
         }
+    }
 }
 
 #define SCAT_THREADS 1024
@@ -575,10 +573,21 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
 }
 
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
+    DgScatterArgs ac = a;
     {
+        for (int dest = 0; dest < 2; ++dest) {
+            ac.ncraw[dest] = ac.ncfin[dest] = 0;
+            for (int i = 0; i < a.nsrc; ++i) {
+                const DgScatterSrc& q = a.src[i];
+                if (q.dest != dest || q.route != nullptr) continue;
+                int8_t& cnt = q.raw ? ac.ncraw[dest] : ac.ncfin[dest];
+                if (cnt >= DG_MAX_SCATTER / 2) return hipErrorInvalidValue;
+                (q.raw ? ac.craw[dest] : ac.cfin[dest])[cnt++] = (int8_t)i;
+            }
+        }
         const dim3 cgrid(a.Ppad / 32, a.B, 2);
-        if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid, dim3(64), 0, s, a);
-        else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid, dim3(64), 0, s, a);
+        if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid, dim3(192), 0, s, ac);
+        else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid, dim3(256), 0, s, ac);
         else return hipErrorInvalidValue;
     }
     const int HW = a.h * a.w;
