@@ -651,14 +651,17 @@ __device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, in
         const int i = p / S, j = p - i * S;
         const float sy = Sh > 1 ? (float)(H - 1) / (float)(Sh - 1) : 0.f;
         const float sx = S > 1 ? (float)(W - 1) / (float)(S - 1) : 0.f;
-        const float fy = sy * (float)i, fx = sx * (float)j;
+        // every product is rounded on its own (dg_mul_rn), as in the torch operator: contracted into the subtraction below,
+        // scale * index leaves a 1e-7 weight where the rounded source coordinate is a whole pixel - enough to pull a non-zero
+        // neighbour into a pixel of zero depth and flip its indicator (found by scripts/fuzz_parity.py, seed 323)
+        const float fy = dg_mul_rn(sy, (float)i), fx = dg_mul_rn(sx, (float)j);
         int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
         const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
         const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         const float* d = depth + (size_t)n * H * W;
-        const float top = d[(size_t)y0 * W + x0] * lx0 + d[(size_t)y0 * W + x1] * lx1;
-        const float bot = d[(size_t)y1 * W + x0] * lx0 + d[(size_t)y1 * W + x1] * lx1;
-        const float v = top * ly0 + bot * ly1;
+        const float top = dg_mul_rn(d[(size_t)y0 * W + x0], lx0) + dg_mul_rn(d[(size_t)y0 * W + x1], lx1);
+        const float bot = dg_mul_rn(d[(size_t)y1 * W + x0], lx0) + dg_mul_rn(d[(size_t)y1 * W + x1], lx1);
+        const float v = dg_mul_rn(top, ly0) + dg_mul_rn(bot, ly1);
         out = v / fmaxf(fabsf(v), DG_EPS_NORM);
     }
     return out;

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""developer aid: randomized shape / flag sweep of the HIP loss against the CPU oracle (forward scalars and code gradients,
+tolerances of tests/test_gpu_sweep.py).  Every case is reproducible from its seed; failures are printed and counted.
+   python scripts/fuzz_parity.py [n_cases] [first_seed]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from depthg_amd import ContrastiveCorrelationLoss  # noqa: E402
+from oracle import depthg_oracle as O  # noqa: E402
+
+dev = torch.device("cuda:0")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def pick(g, lo, hi):
+    return int(torch.randint(lo, hi + 1, (), generator=g))
+
+
+def one(seed):
+    g = torch.Generator().manual_seed(seed)
+    dense = pick(g, 0, 2) == 0
+    B = pick(g, 1, 9)
+    C = [32, 64, 100, 128, 200, 384, 384, 768][pick(g, 0, 7)]
+    D = pick(g, 4, 128) if pick(g, 0, 3) else [70, 90, 96, 128][pick(g, 0, 3)]
+    N = pick(g, 1, 6)                       # (the reference's torch.cat over the negatives needs at least one)
+    if dense:
+        h = w = pick(g, 6, 30)
+        S = h
+    else:
+        h, w = pick(g, 5, 30), pick(g, 5, 30)
+        S = pick(g, 2, min(h, w, 14))
+    flags = dict(pointwise=bool(pick(g, 0, 3)), zero_clamp=bool(pick(g, 0, 3)), stabalize=pick(g, 0, 4) == 0,
+                 depth_feat_correlation_loss=bool(pick(g, 0, 3)))
+    desc = f"seed {seed}: dense={dense} B={B} C={C} D={D} {h}x{w} S={S} N={N} {flags}"
+    f, fp = torch.randn(B, C, h, w, generator=g), torch.randn(B, C, h, w, generator=g)
+    c, cp = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    d = torch.randint(0, 256, (B, 1, 3 * h + pick(g, 0, 5), 3 * w + pick(g, 0, 5)), generator=g).float()
+    d[:, :, :pick(g, 0, 6), :pick(g, 0, 6)] = 0.0
+    if pick(g, 0, 2) == 0 or B == 1:
+        perms = [torch.randint(0, B, (B,), generator=g) for _ in range(N)]
+    else:
+        perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=dense, **flags)
+    if dense:
+        c1 = c2 = O.identity_coords(B, h)
+        kw = dict(shared_coords=True, identity_grid=True)
+    else:
+        shared = pick(g, 0, 2) == 0         # DG_SHARED_COORDS: ONE grid for every image and both coordinate sets
+        c1 = (torch.rand(1, S, S, 2, generator=g).expand(B, S, S, 2).contiguous() if shared else torch.rand(B, S, S, 2, generator=g)) * 2.2 - 1.1
+        c2 = c1 if shared else torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1
+        kw = dict(shared_coords=shared)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    try:
+        out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
+                                                           [p.to(dev) for p in perms], **kw)
+    except RuntimeError as e:
+        if "not supported" in str(e) or "unsupported" in str(e).lower():
+            return "skip", desc + f"  [{str(e)[-80:]}]"
+        raise
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
+    bad = []
+    for i in range(len(ref)):
+        a, b = float(out[i].mean()), float(ref[i].mean())
+        if not abs(a - b) <= 3e-3 * abs(b) + 3e-5:
+            bad.append(f"tuple[{i}] {a} vs {b}")
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        if want is None or float(want.norm()) == 0.0:
+            if got is not None and float(got.abs().max()) > 1e-12:
+                bad.append(f"{name}: oracle gradient is zero, got {float(got.abs().max())}")
+            continue
+        if not torch.isfinite(got).all():
+            bad.append(f"{name}: non-finite gradient")
+            continue
+        rel = float((got.cpu() - want).norm() / want.norm())
+        if rel > 4e-2:
+            bad.append(f"{name}: rel L2 {rel:.3g}")
+    return ("FAIL " + "; ".join(bad), desc) if bad else ("ok", desc)
+
+
+t0 = time.time()
+counts = {}
+for s in range(seed0, seed0 + n_cases):
+    try:
+        status, desc = one(s)
+    except Exception as e:  # noqa: BLE001
+        status, desc = f"ERROR {type(e).__name__}: {str(e)[:300]}", f"seed {s}"
+    counts[status.split()[0]] = counts.get(status.split()[0], 0) + 1
+    if status != "ok":
+        print(status, "|", desc, flush=True)
+print(f"{n_cases} cases in {time.time() - t0:.0f} s:", counts)

@@ -335,3 +335,30 @@ def test_step_replays_from_a_hip_graph(mode, dev):
         torch.cuda.synchronize()
         assert torch.equal(tot, replays[k][0]) and torch.equal(gc, replays[k][1]) and torch.equal(gcp, replays[k][2]), k
     assert not torch.equal(replays[0][1], replays[1][1]), "every replay draws new negatives"
+
+
+def test_depth_indicators_on_whole_pixel_source_coordinates(dev):
+    """The depth term's indicators d / max(|d|, eps) after the bilinear resize (F.interpolate, align_corners=True;
+    src/modules.py:1262-1270): where scale * index rounds to a whole source pixel the upper tap's weight must be exactly 0, as in
+    the torch operator - a multiply contracted into the following subtraction leaves 1e-7 there and pulls a non-zero neighbour
+    into a zero-depth pixel (one flipped indicator of 49 moved mean(dd) by 0.5 %; found by scripts/fuzz_parity.py).  mean(dd)
+    of the HIP path against the oracle over every depth size from hw + 1 to 4 hw, zero regions ending at every row / column."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(323)
+    B, C, D = 8, 32, 16
+    for hw in (7, 10):
+        f, c = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+        coords = O.identity_coords(B, hw)
+        perms = [O.super_perm(B, g)]
+        cfg = O.default_cfg(feature_samples=hw, neg_samples=1, dim=D, dg_outputs="reduced", dg_dense_grid=True)
+        loss = ContrastiveCorrelationLoss(cfg)
+        for H in range(hw + 1, 4 * hw + 1):
+            d = torch.randint(1, 256, (B, 1, H, H + 2), generator=g).float()
+            for n in range(B):
+                d[n, :, : (n * H) // B + 1, : ((B - n) * H) // B + 1] = 0.0
+            ref = O.depth_feature_correlation(cfg, c, c, d, d, cfg.depth_feat_shift)[1].mean()
+            out = loss.forward_with(f.to(dev), f.to(dev), c.to(dev), c.to(dev), d.to(dev), coords.to(dev), coords.to(dev),
+                                    [p.to(dev) for p in perms], shared_coords=True, identity_grid=True)
+            assert abs(float(out[7].mean()) - float(ref)) <= 2e-6, (hw, H, float(out[7].mean()), float(ref))
+
