@@ -37,7 +37,10 @@ def one(seed):
         S = pick(g, 2, min(h, w, 14))
     flags = dict(pointwise=bool(pick(g, 0, 3)), zero_clamp=bool(pick(g, 0, 3)), stabalize=pick(g, 0, 4) == 0,
                  depth_feat_correlation_loss=bool(pick(g, 0, 3)))
-    desc = f"seed {seed}: dense={dense} B={B} C={C} D={D} {h}x{w} S={S} N={N} {flags}"
+    nograd = pick(g, 0, 3) == 0             # forward-only call (no gradient kernels, other fused kernel and reduction)
+    full = not dense and pick(g, 0, 2) == 0  # reference-shaped un-reduced outputs (dg_corr_materialize)
+    line = not dense and pick(g, 0, 4) == 0  # S x 1 grids of depth_sampling='simple'
+    desc = f"seed {seed}: dense={dense} B={B} C={C} D={D} {h}x{w} S={S} N={N} nograd={nograd} full={full} line={line} {flags}"
     f, fp = torch.randn(B, C, h, w, generator=g), torch.randn(B, C, h, w, generator=g)
     c, cp = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
     d = torch.randint(0, 256, (B, 1, 3 * h + pick(g, 0, 5), 3 * w + pick(g, 0, 5)), generator=g).float()
@@ -46,19 +49,19 @@ def one(seed):
         perms = [torch.randint(0, B, (B,), generator=g) for _ in range(N)]
     else:
         perms = [O.super_perm(B, g) for _ in range(N)]
-    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=dense, **flags)
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="full" if full else "reduced", dg_dense_grid=dense, **flags)
     if dense:
         c1 = c2 = O.identity_coords(B, h)
         kw = dict(shared_coords=True, identity_grid=True)
     else:
-        shared = pick(g, 0, 2) == 0         # DG_SHARED_COORDS: ONE grid for every image and both coordinate sets
-        c1 = (torch.rand(1, S, S, 2, generator=g).expand(B, S, S, 2).contiguous() if shared else torch.rand(B, S, S, 2, generator=g)) * 2.2 - 1.1
-        c2 = c1 if shared else torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1
+        shared = pick(g, 0, 2) == 0 and not full   # DG_SHARED_COORDS: ONE grid for every image and both coordinate sets
+        S2 = 1 if line else S
+        c1 = (torch.rand(1, S, S2, 2, generator=g).expand(B, S, S2, 2).contiguous() if shared else torch.rand(B, S, S2, 2, generator=g)) * 2.2 - 1.1
+        c2 = c1 if shared else torch.rand(B, S, S2, 2, generator=g) * 2.2 - 1.1
         kw = dict(shared_coords=shared)
-    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    cr, cpr = c.clone().requires_grad_(not nograd), cp.clone().requires_grad_(not nograd)
     ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)
-    O.total_loss(cfg, ref).backward()
-    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    cg, cpg = c.to(dev).requires_grad_(not nograd), cp.to(dev).requires_grad_(not nograd)
     try:
         out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
                                                            [p.to(dev) for p in perms], **kw)
@@ -66,13 +69,22 @@ def one(seed):
         if "not supported" in str(e) or "unsupported" in str(e).lower():
             return "skip", desc + f"  [{str(e)[-80:]}]"
         raise
-    O.total_loss(cfg, out).backward()
-    torch.cuda.synchronize()
     bad = []
     for i in range(len(ref)):
-        a, b = float(out[i].mean()), float(ref[i].mean())
+        a, b = float(out[i].detach().mean()), float(ref[i].detach().mean())
         if not abs(a - b) <= 3e-3 * abs(b) + 3e-5:
             bad.append(f"tuple[{i}] {a} vs {b}")
+        if full and tuple(out[i].shape) != tuple(ref[i].shape):
+            bad.append(f"tuple[{i}] shape {tuple(out[i].shape)} vs {tuple(ref[i].shape)}")
+        elif full and out[i].dim() > 0:
+            err = float((out[i].detach().cpu() - ref[i].detach()).abs().max())
+            if not err <= 4e-3:              # cd / loss elements: fp16 code, bf16 feats on the MFMA
+                bad.append(f"tuple[{i}] max element error {err:.3g}")
+    if nograd:
+        return ("FAIL " + "; ".join(bad), desc) if bad else ("ok", desc)
+    O.total_loss(cfg, ref).backward()
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
     for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
         if want is None or float(want.norm()) == 0.0:
             if got is not None and float(got.abs().max()) > 1e-12:
