@@ -264,10 +264,36 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);
 }
 
+struct DrawArgs { int64_t* out; uint64_t seed; unsigned long long* state; };
+
+static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                             const float* orig_code, const float* orig_code_pos, const float* depth,
+                             const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
+                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_);
+
 extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                                const float* orig_code, const float* orig_code_pos, const float* depth,
                                const float* coords1, const float* coords2, const int64_t* perms,
                                float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    return corr_forward_impl(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms, nullptr,
+                             out_scalars, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_corr_forward_draw(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                                    const float* orig_code, const float* orig_code_pos, const float* depth,
+                                    const float* coords1, const float* coords2, int64_t* perms_out, uint64_t seed, void* perm_state,
+                                    float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!desc) return fail(DG_ERR_INVALID, "null descriptor");
+    if (desc->n_neg > 0 && !perms_out) return fail(DG_ERR_INVALID, "perms_out is null with n_neg=%d", desc->n_neg);
+    const DrawArgs draw{perms_out, seed, static_cast<unsigned long long*>(perm_state)};
+    return corr_forward_impl(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms_out, &draw,
+                             out_scalars, workspace, workspace_bytes, stream_);
+}
+
+static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                             const float* orig_code, const float* orig_code_pos, const float* depth,
+                             const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
+                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     Plan p;
     int rc = make_plan(desc, p);
     if (rc != DG_OK) return rc;
@@ -294,8 +320,11 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
+        if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
+        // (general coordinates: the first launch already reads the batch maps - they are drawn by their own launch)
+        if (draw && p.N > 0) DG_HIP(dg_launch_super_perms(nullptr, draw->seed, draw->state, p.N, p.B, draw->out, stream));
         if (p.rows) {
             DgPlaneArgs t;
             memset(&t, 0, sizeof(t));

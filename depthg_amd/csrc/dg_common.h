@@ -277,6 +277,56 @@ struct DgPlaneArgs {        // k_plane_sample: sample() of all operands straight
     int32_t tap_consumers;   // (set by the launcher) consumers whose tap table is held in LDS together
 };
 
+#ifdef __HIPCC__
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter (ctr, 0, 0, 0), key = the 64-bit seed
+__device__ __forceinline__ uint32_t dg_philox(uint64_t seed, uint32_t ctr) {
+    uint32_t c0 = ctr, c1 = 0u, c2 = 0u, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// keys == nullptr: the uniform keys are drawn here (Philox, counter = row * B + i), one launch instead of rand + sort.
+// state != nullptr: the Philox key is {state[0] (seed), state[1] (draws so far)} READ FROM THE DEVICE, and the block that
+// finishes last advances state[1] (ticket in state[2]) - a launch recorded in a hipGraph then draws fresh permutations on
+// every replay, which a seed passed by value cannot.
+
+// One row of super_perm (src/modules.py:1184-1188): rank of every key inside the row (ties by index) = position of that index in
+// the argsort, then the fixed-point bump modulo B.  keys: given, or drawn here from (seed | state).  `state` = {seed, draws so
+// far, ticket}: the last of the `nrows` rows to finish advances the draw count (device-resident generator: hipGraph-safe).
+// Called by the whole block (256 threads), sk = B floats of LDS.
+__device__ __forceinline__ void dg_super_perm_row(const float* __restrict__ keys, uint64_t seed, unsigned long long* __restrict__ state,
+                                                  int B, int64_t* __restrict__ out, int row, int nrows, float* sk) {
+    const float* kr = keys ? keys + (size_t)row * B : nullptr;
+    unsigned long long draw = 0;
+    if (state) { seed = state[0]; draw = state[1]; }
+    const uint64_t key = seed + 0x9E3779B97F4A7C15ull * draw;
+    for (int i = threadIdx.x; i < B; i += 256)
+        sk[i] = kr ? kr[i] : (float)(dg_philox(key, (uint32_t)(row * B + i)) >> 8) * (1.0f / 16777216.0f);
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float ki = sk[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (sk[j] < ki) || (sk[j] == ki && j < i);
+        out[(size_t)row * B + rank] = (int64_t)((i == rank ? i + 1 : i) % B);
+    }
+    if (state && threadIdx.x == 0) {
+        // every row has read the state before it takes its ticket; the last ticket advances the draw count
+        __threadfence();
+        if (atomicAdd(&state[2], 1ull) == (unsigned long long)nrows - 1) {
+            state[1] = draw + 1;
+            state[2] = 0;
+            __threadfence();
+        }
+    }
+}
+#endif
+
 struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     const float* src[2];     // feats NCHW fp32 (B,K,h,w): orig_feats, orig_feats_pos
     const float* code[2];    // code NCHW fp32 (B,D,h,w): orig_code, orig_code_pos
@@ -289,6 +339,12 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     float* nzsum;            // [B] their per-image sums
     int32_t B, K, D, KF, KD, h, w, P, Ppad, dH, dW;
     int32_t debug;           // developer ablation bits (0 in production): 1 skip feats, 2 skip code, 4 skip depth
+    // draw_count > 0: that many extra blocks draw the negatives' batch maps (dg_super_perm_row) into draw_out - the step's
+    // k_super_perms launch rides here (dg_corr_forward_draw)
+    int64_t* draw_out;
+    unsigned long long* draw_state;
+    uint64_t draw_seed;
+    int32_t draw_count;
     int32_t code_split;      // 1: the code role only writes inv_norm (per-pixel norms from whole channel planes); the code parts of
                              //    the blobs + ccolpart come from the k_colmean launch (DgDenseCodeArgs), csum from the k_rowmean launch
 };

@@ -897,48 +897,11 @@ hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, 
 // ------------------------------------------------------------------------------------------
 // super_perm (src/modules.py:1184-1188) for `count` rows at once: rank of every key inside its row (ties by index) =
 // position of that index in the argsort, then the fixed-point bump modulo B.  grid (count), block 256, LDS B floats.
-// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter (ctr, 0, 0, 0), key = the 64-bit seed
-__device__ __forceinline__ uint32_t dg_philox(uint64_t seed, uint32_t ctr) {
-    uint32_t c0 = ctr, c1 = 0u, c2 = 0u, c3 = 0u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-
-// keys == nullptr: the uniform keys are drawn here (Philox, counter = row * B + i), one launch instead of rand + sort.
-// state != nullptr: the Philox key is {state[0] (seed), state[1] (draws so far)} READ FROM THE DEVICE, and the block that
-// finishes last advances state[1] (ticket in state[2]) - a launch recorded in a hipGraph then draws fresh permutations on
-// every replay, which a seed passed by value cannot.
+// (Philox and the row body: dg_common.h dg_super_perm_row - the dense forward draws inside its first launch)
 __global__ __launch_bounds__(256) void k_super_perms(const float* __restrict__ keys, uint64_t seed, unsigned long long* __restrict__ state,
                                                      int B, int64_t* __restrict__ out) {
     extern __shared__ float sk[];
-    const float* kr = keys ? keys + (size_t)blockIdx.x * B : nullptr;
-    unsigned long long draw = 0;
-    if (state) { seed = state[0]; draw = state[1]; }
-    const uint64_t key = seed + 0x9E3779B97F4A7C15ull * draw;
-    for (int i = threadIdx.x; i < B; i += 256)
-        sk[i] = kr ? kr[i] : (float)(dg_philox(key, (uint32_t)(blockIdx.x * B + i)) >> 8) * (1.0f / 16777216.0f);
-    __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const float ki = sk[i];
-        int rank = 0;
-        for (int j = 0; j < B; ++j) rank += (sk[j] < ki) || (sk[j] == ki && j < i);
-        out[(size_t)blockIdx.x * B + rank] = (int64_t)((i == rank ? i + 1 : i) % B);
-    }
-    if (state && threadIdx.x == 0) {
-        // every block has read the state before it takes its ticket; the last ticket advances the draw count
-        __threadfence();
-        if (atomicAdd(&state[2], 1ull) == (unsigned long long)gridDim.x - 1) {
-            state[1] = draw + 1;
-            state[2] = 0;
-            __threadfence();
-        }
-    }
+    dg_super_perm_row(keys, seed, state, B, out, (int)blockIdx.x, (int)gridDim.x, sk);
 }
 
 hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long long* state, int count, int B, int64_t* out, hipStream_t s) {

@@ -609,6 +609,10 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     const int gx = a.h * ((a.w + 31) / 32);              // (>= the code role's ceil(tiles / DENSE_TPB) blocks: launcher)
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
+    if (n >= a.B) {                                      // the trailing blocks: the negatives' batch maps of this step
+        dg_super_perm_row(nullptr, a.draw_seed, a.draw_state, a.B, a.draw_out, bid - gx * nz * a.B, a.draw_count, sl);
+        return;
+    }
     if (z < 2) {
         if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x % a.h, x / a.h, n, z);
     } else if (z < 4) {
@@ -624,14 +628,14 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
     const int nt = a.Ppad / 32, gx = a.h * ((a.w + 31) / 32);
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx || (a.h * a.w + 255) / 256 > gx) return hipErrorInvalidValue;
-    const int smem = max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
-                         DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4);
+    const int smem = max(max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
+                             DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4), a.draw_count > 0 ? a.B * 4 : 0);
     if (a.h * ((DENSE_TPB * 32 + a.h - 1) / a.h + 1) > DENSE_CODE_PAIRS) return hipErrorInvalidValue;   // pairs per block
     DgDenseArgs a2 = a;
 #ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_PREP_DEBUG")) a2.debug = atoi(dbg);
 #endif
-    const dim3 grid(gx * a.B * (a.depth ? 5 : 4));
+    const dim3 grid(gx * a.B * (a.depth ? 5 : 4) + (a.draw_count > 0 ? a.draw_count : 0));
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;

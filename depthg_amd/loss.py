@@ -56,8 +56,13 @@ class _CorrLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, orig_code, orig_code_pos, orig_feats, orig_feats_pos, depth, coords1, coords2, perms, desc, holder):
         ws = ops.alloc_workspace(desc, orig_feats.device)
-        out = ops.corr_forward(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
-                               perms, ws)
+        if perms is None:                  # the forward draws the negatives itself (holder["draw_state"]: device generator or None)
+            out, perms = ops.corr_forward_draw(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
+                                               ws, state=holder.get("draw_state"))
+            holder["perms"] = perms
+        else:
+            out = ops.corr_forward(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
+                                   perms, ws)
         holder["workspace"] = ws
         ctx.desc, ctx.ws, ctx.shape = desc, ws, tuple(orig_code.shape)
         ctx.save_for_backward(coords1, coords2, perms)
@@ -149,21 +154,21 @@ class ContrastiveCorrelationLoss(nn.Module):
                 depth=None, depth_pos=None):
         coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
                                                      depth, depth_pos)
-        B = orig_feats.shape[0]
+        state = None
         if getattr(self.cfg, "dg_graph_safe", False):
             # generator state on the device (hipGraph-capturable step: nothing about the draw is baked into the launch)
             if self._perm_state is None or self._perm_state.device != orig_feats.device:
                 self._perm_state = ops.new_perm_state(orig_feats.device)
-            perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device, state=self._perm_state)
-        else:
-            perms = ops.super_perms(int(self.cfg.neg_samples), B, orig_feats.device)   # seed from torch's CPU generator, one kernel
-        # `shared` is only ever set together with the identity grid drawn above
-        return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                                 shared_coords=shared, identity_grid=shared)
+            state = self._perm_state
+        # the negatives' batch maps (super_perm, src/modules.py:1340-1342) are drawn by the forward itself: perms=None
+        # (seed from torch's CPU generator unless the device generator is in use); `shared` is only ever set together with the
+        # identity grid drawn above
+        return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, None,
+                                 shared_coords=shared, identity_grid=shared, draw_state=state)
 
     # -- everything after the RNG draws (explicit coords / perms: parity tests, DP shards) ----------
     def forward_with(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                     shared_coords=False, identity_grid=False):
+                     shared_coords=False, identity_grid=False, draw_state=None):
         cfg = self.cfg
         B, C, h, w = orig_feats.shape
         D = orig_code.shape[1]
@@ -181,13 +186,16 @@ class ContrastiveCorrelationLoss(nn.Module):
             raise ValueError(f"depthg_amd: coords must both be (B,S,S,2) or (B,S,1,2) with B={B}, S={S}; got "
                              f"{tuple(coords1.shape)} and {tuple(coords2.shape)}")
         line_grid = coords1.shape[2] == 1 and S != 1       # S x 1 grid of depth_sampling='simple'
-        if isinstance(perms, (list, tuple)):
+        if perms is None:
+            perms_t = None                 # drawn inside the forward (dg_corr_forward_draw)
+        elif isinstance(perms, (list, tuple)):
             perms_t = torch.stack([p.to(device=dev, dtype=torch.long) for p in perms]) if N > 0 else \
                 torch.zeros(0, B, dtype=torch.long, device=dev)
         else:
             perms_t = perms.to(device=dev, dtype=torch.long)
-        perms_t = perms_t.contiguous()
-        assert perms_t.shape == (N, B), f"perms shape {tuple(perms_t.shape)} != {(N, B)}"
+        if perms_t is not None:
+            perms_t = perms_t.contiguous()
+            assert perms_t.shape == (N, B), f"perms shape {tuple(perms_t.shape)} != {(N, B)}"
         need_grad = torch.is_grad_enabled() and (orig_code.requires_grad or orig_code_pos.requires_grad)
         desc = ops.make_desc(B, C, D, h, w, S, N, pointwise=bool(cfg.pointwise), zero_clamp=bool(cfg.zero_clamp),
                              stabalize=bool(cfg.stabalize), depth_term=depth_term, need_grad=need_grad,
@@ -197,12 +205,14 @@ class ContrastiveCorrelationLoss(nn.Module):
                              depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
                              identity_grid=bool(identity_grid), weights=self._total_weights(depth_term),
                              line_grid=line_grid)
-        holder = {}
+        holder = {"draw_state": draw_state}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
         out, total = _CorrLossFunction.apply(code_in.contiguous(), code_pos_in.contiguous(), feats, feats_pos, depth_c,
                                              coords1, coords2, perms_t, desc, holder)
         ws = holder["workspace"]
+        if perms_t is None:
+            perms_t = holder["perms"]
         d = self.__dict__                      # plain attributes: nn.Module.__setattr__ costs microseconds per assignment
         d["last_scalars"] = out.detach()
         d["scalars"] = out                     # the fused output vector with its grad_fn (DG_OUT_* order)

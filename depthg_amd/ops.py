@@ -86,6 +86,26 @@ def corr_forward(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2
     return out
 
 
+def corr_forward_draw(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, workspace, state=None):
+    """dg_corr_forward_draw: the forward draws the negatives' batch maps itself (on the identity grid inside its first launch).
+    Returns (out, perms): perms (n_neg, B) int64 is what backward / materialize need.  `state` (new_perm_state) = device-resident
+    generator (hipGraph-safe); without it the seed comes from torch's CPU generator, as in super_perms()."""
+    lib = _lib.load()
+    dev = feats.device
+    out = _empty(_lib.DG_OUT_COUNT, torch.float32, dev)
+    perms = _empty((int(desc.n_neg), int(desc.B)), torch.long, dev)
+    seed = 0
+    if state is None:
+        seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+    elif state.dtype != torch.int64 or state.numel() != 3 or state.device != dev:
+        raise ValueError("corr_forward_draw: state must be the int64[3] tensor of new_perm_state on the same device")
+    rc = lib.dg_corr_forward_draw(ctypes.byref(desc), _ptr(feats), _ptr(feats_pos), _ptr(code), _ptr(code_pos), _ptr(depth),
+                                  _ptr(coords1), _ptr(coords2), _ptr(perms), seed, _ptr(state), _ptr(out), _ptr(workspace),
+                                  workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_forward_draw")
+    return out, perms
+
+
 def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_code):
     lib = _lib.load()
     dev = grad_scalars.device

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 104   /* 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 105   /* 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -118,6 +118,22 @@ int dg_corr_forward(const dg_corr_desc* desc,
                     const float* coords1, const float* coords2, const int64_t* perms,
                     float* out_scalars,
                     void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * dg_corr_forward that also DRAWS the negatives' batch maps - the `super_perm` calls at the top of the reference's negative
+ * loop (src/modules.py:1184-1188, 1340-1342) happen inside the forward there too.  perms_out (n_neg, B) is written (the same
+ * values dg_super_perms_seeded(seed) / dg_super_perms_state(perm_state) would write: perm_state non-NULL selects the
+ * device-resident generator and advances it, else `seed`) and must be handed to dg_corr_backward / dg_corr_materialize.  On
+ * the identity grid the draw rides in the first launch of the forward (no launch of its own); with general coordinates, whose
+ * first launch already reads the maps, it is launched first.
+ */
+int dg_corr_forward_draw(const dg_corr_desc* desc,
+                         const float* orig_feats, const float* orig_feats_pos,
+                         const float* orig_code, const float* orig_code_pos,
+                         const float* depth,
+                         const float* coords1, const float* coords2, int64_t* perms_out, uint64_t seed, void* perm_state,
+                         float* out_scalars,
+                         void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * Backward (replaces autograd through helper()/sample(), SURVEY.md section 9 "Gradient"):

@@ -362,3 +362,53 @@ def test_depth_indicators_on_whole_pixel_source_coordinates(dev):
                                     [p.to(dev) for p in perms], shared_coords=True, identity_grid=True)
             assert abs(float(out[7].mean()) - float(ref)) <= 2e-6, (hw, H, float(out[7].mean()), float(ref))
 
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_forward_that_draws_its_negatives(dense, dev):
+    """dg_corr_forward_draw (the reference draws super_perm inside forward too, src/modules.py:1340-1342): same batch maps and
+    the same outputs as dg_super_perms_seeded / dg_super_perms_state followed by dg_corr_forward - with a host seed and with the
+    device-resident generator, whose state advances by one draw either way; on the identity grid the draw has no launch of its
+    own.  The module's forward() goes through it: two calls draw different negatives, torch.manual_seed repeats them."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(31)
+    B, C, D, hw, N = 6, 64, 24, 12, 4
+    S = hw if dense else 5
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+    d = torch.randint(0, 256, (B, 1, 48, 48), generator=g).float().to(dev)
+    c1 = (O.identity_coords(B, hw) if dense else torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
+    c2 = c1 if dense else (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
+    desc = ops.make_desc(B, C, D, hw, hw, S, N, pointwise=True, zero_clamp=True, stabalize=False, depth_term=True, need_grad=True,
+                         shared_coords=dense, shifts=(0.08, 0.02, 0.66, 0.03), depth_hw=(48, 48), identity_grid=dense,
+                         weights=(0.67, 0.25, 0.63, 0.19))
+    # host seed
+    torch.manual_seed(77)
+    perms_a = ops.super_perms(N, B, dev)
+    out_a = ops.corr_forward(desc, f, fp, c, cp, d, c1, c2, perms_a, ops.alloc_workspace(desc, dev))
+    torch.manual_seed(77)
+    out_b, perms_b = ops.corr_forward_draw(desc, f, fp, c, cp, d, c1, c2, ops.alloc_workspace(desc, dev))
+    assert torch.equal(perms_a, perms_b) and torch.equal(out_a, out_b)
+    # device generator
+    st_a = ops.new_perm_state(dev)
+    st_b = st_a.clone()
+    for _ in range(2):
+        perms_a = ops.super_perms(N, B, dev, state=st_a)
+        out_a = ops.corr_forward(desc, f, fp, c, cp, d, c1, c2, perms_a, ops.alloc_workspace(desc, dev))
+        out_b, perms_b = ops.corr_forward_draw(desc, f, fp, c, cp, d, c1, c2, ops.alloc_workspace(desc, dev), state=st_b)
+        assert torch.equal(perms_a, perms_b) and torch.equal(out_a, out_b) and torch.equal(st_a, st_b)
+    assert int(st_b[1]) == 2 and int(st_b[2]) == 0
+    # the module
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=dense)
+    loss = ContrastiveCorrelationLoss(cfg)
+    if dense:
+        torch.manual_seed(5)
+        o1 = [float(v.mean()) for v in loss(f, fp, None, None, c, cp, d, d)]
+        p1 = loss.last_call[1].clone()
+        o2 = [float(v.mean()) for v in loss(f, fp, None, None, c, cp, d, d)]
+        p2 = loss.last_call[1].clone()
+        torch.manual_seed(5)
+        o3 = [float(v.mean()) for v in loss(f, fp, None, None, c, cp, d, d)]
+        assert not torch.equal(p1, p2) and o1[4] != o2[4] and o1 == o3 and torch.equal(p1, loss.last_call[1])
+        assert o1[0] == o2[0] and o1[2] == o2[2]               # the positive terms do not depend on the negatives
+
