@@ -323,8 +323,18 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
-        // (general coordinates: the first launch already reads the batch maps - they are drawn by their own launch)
-        if (draw && p.N > 0) DG_HIP(dg_launch_super_perms(nullptr, draw->seed, draw->state, p.N, p.B, draw->out, stream));
+        // (general coordinates: the first launch already reads the batch maps - they are drawn by their own launch,
+        //  together with the depth indicators, which nothing of this call feeds either)
+        bool nz_done = false;
+        if (draw && p.N > 0) {
+            if (p.depth && p.B <= 8192) {
+                DG_HIP(dg_launch_draw_depth(draw->seed, draw->state, p.N, draw->out, depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h,
+                                            desc->depth_w, p.Sh, p.S, p.Ppad, stream));
+                nz_done = true;
+            } else {
+                DG_HIP(dg_launch_super_perms(nullptr, draw->seed, draw->state, p.N, p.B, draw->out, stream));
+            }
+        }
         if (p.rows) {
             DgPlaneArgs t;
             memset(&t, 0, sizeof(t));
@@ -364,7 +374,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.njobs = nj;
         g.direct = p.rows ? 1 : 0;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
-        if (p.depth) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
+        if (p.depth && !nz_done) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }
 
     // (the launch plan of step 4 is needed here already: the consumer lists of k_corr2's grouped ragged blocks are written by

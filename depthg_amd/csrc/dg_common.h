@@ -546,6 +546,8 @@ hipError_t dg_launch_confusion(const long long* preds, const long long* target, 
                                unsigned long long* stats, hipStream_t s);
 hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
                                long long* out_idx, float* out_val, hipStream_t s);
+hipError_t dg_launch_draw_depth(uint64_t seed, unsigned long long* state, int count, int64_t* perms, const float* depth, float* nz,
+                                float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
 hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,
                                    float* dst, hipStream_t s);

@@ -693,6 +693,23 @@ __global__ __launch_bounds__(256) void k_depth_nz(const float* __restrict__ dept
     depth_nz_image(depth, nz, nzsum, blockIdx.x, H, W, Sh, S, Ppad);
 }
 
+// general coordinates: the negatives' draws and the depth indicators - two latency-sized jobs without inputs from this call's
+// other launches - in one launch: blocks [0, count) draw, blocks [count, count + B) resize
+__global__ __launch_bounds__(256) void k_draw_depth(uint64_t seed, unsigned long long* __restrict__ state, int count, int B, int64_t* __restrict__ perms,
+                                                    const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
+                                                    int H, int W, int Sh, int S, int Ppad) {
+    extern __shared__ float dd_sk[];
+    if ((int)blockIdx.x < count) dg_super_perm_row(nullptr, seed, state, B, perms, (int)blockIdx.x, count, dd_sk);
+    else depth_nz_image(depth, nz, nzsum, (int)blockIdx.x - count, H, W, Sh, S, Ppad);
+}
+
+hipError_t dg_launch_draw_depth(uint64_t seed, unsigned long long* state, int count, int64_t* perms, const float* depth, float* nz,
+                                float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s) {
+    hipLaunchKernelGGL(k_draw_depth, dim3(count + B), dim3(256), B * sizeof(float), s, seed, state, count, B, perms, depth, nz, nzsum,
+                       H, W, Sh, S, Ppad);
+    return hipGetLastError();
+}
+
 hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s) {
     hipLaunchKernelGGL(k_depth_nz, dim3(B), dim3(256), 0, s, depth, nz, nzsum, H, W, Sh, S, Ppad);
     return hipGetLastError();
