@@ -122,10 +122,82 @@ def lhp_maps_case(seed):
     return ("FAIL " + "; ".join(bad), desc) if bad else ("ok", desc)
 
 
+def edge_uniforms(u, g):
+    """uniforms with the ends of [0, 1) forced in: rank 0 and the last rank get drawn"""
+    u = u.clone()
+    flat = u.view(-1)
+    if flat.numel() >= 2:
+        flat[pick(g, 0, flat.numel() - 1)] = 0.0
+        flat[pick(g, 0, flat.numel() - 1)] = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+    return u
+
+
+def salience_case(seed):
+    g = torch.Generator().manual_seed(seed)
+    B, H, W, S = pick(g, 1, 4), pick(g, 3, 260), pick(g, 3, 330), pick(g, 1, 13)
+    dens = [0.0, 0.003, 0.05, 0.5, 1.0][pick(g, 0, 4)]
+    sal = (torch.rand(B, H, W, generator=g) < dens).float() * float(pick(g, 1, 3))
+    if pick(g, 0, 2) == 0:
+        sal[pick(g, 0, B - 1)] = 0.0
+    u = edge_uniforms(torch.rand(B, S * S, generator=g), g)
+    ufb = edge_uniforms(torch.rand(B, S * S, 2, generator=g), g)
+    desc = f"salience seed {seed}: B={B} {H}x{W} S={S} density {dens}"
+    got = ops.salience_coords(sal.to(dev), S, u.to(dev), ufb.to(dev)).cpu()
+    want = O.sample_nonzero_locations_from_uniform(sal, [B, S, S, 2], u.numpy(), ufb.numpy())
+    return ("ok", desc) if got.shape == want.shape and torch.equal(got, want) else ("FAIL coords differ", desc)
+
+
+def simple_case(seed):
+    g = torch.Generator().manual_seed(seed)
+    h, w = pick(g, 2, 64), pick(g, 2, 64)
+    H, W = h * pick(g, 1, 6) + pick(g, 0, h - 1), w * pick(g, 1, 6) + pick(g, 0, w - 1)
+    B, n = pick(g, 1, 3), pick(g, 1, 40)
+    d = depth_map(g, B, H, W)
+    uv = edge_uniforms(torch.rand(B, n, generator=g), g)
+    up = edge_uniforms(torch.rand(B, n, generator=g), g)
+    desc = f"simple seed {seed}: B={B} depth {H}x{W} -> {h}x{w}, n={n}"
+    got = ops.simple_depth_coords(d.to(dev), (h, w), n, uv.to(dev), up.to(dev)).cpu()
+    want = O.simple_depth_informed_sampling_from_uniform((h, w), d, n, uv.numpy(), up.numpy()) * 2 - 1
+    return ("ok", desc) if got.shape == (B, n, 1, 2) and torch.equal(got, want) else ("FAIL coords differ", desc)
+
+
+def topk_case(seed):
+    g = torch.Generator().manual_seed(seed)
+    rows, cols = pick(g, 1, 40), [pick(g, 1, 70), pick(g, 65, 3000), pick(g, 3000, 60000)][pick(g, 0, 2)]
+    k = pick(g, 1, min(64, cols))
+    kind = pick(g, 0, 2)
+    m = torch.randn(rows, cols, generator=g) if kind == 0 else \
+        (torch.randint(0, pick(g, 1, 5) + 1, (rows, cols), generator=g).float() - 1.5 if kind == 1 else torch.zeros(rows, cols))
+    desc = f"topk seed {seed}: {rows}x{cols} k={k} kind={kind}"
+    idx, val = ops.topk_rows(m.to(dev), k, return_values=True)
+    want = O.topk_rows(m, k)
+    ok = torch.equal(idx.cpu(), want) and torch.equal(val.cpu(), torch.gather(m, 1, want))
+    return ("ok", desc) if ok else ("FAIL indices / values differ", desc)
+
+
+def confusion_case(seed):
+    from depthg_amd.metrics import UnsupervisedMetrics
+    g = torch.Generator().manual_seed(seed)
+    n, e = pick(g, 2, 200), pick(g, 0, 12)
+    m = UnsupervisedMetrics("t/", n, e, True)
+    want = np.zeros((n + e, n), dtype=np.int64)
+    desc = f"confusion seed {seed}: n={n} extra={e}"
+    for _ in range(pick(g, 1, 3)):
+        shape = (pick(g, 1, 6), pick(g, 1, 200), pick(g, 1, 200))
+        target = torch.randint(-1, n + 2, shape, generator=g)
+        target[target == n + 1] = 255
+        preds = torch.randint(-1, n + e + 2, shape, generator=g)
+        m.update(preds.to(dev), target.to(dev))
+        t, p_ = target.reshape(-1).numpy(), preds.reshape(-1).numpy()
+        ok = (t >= 0) & (t < n) & (p_ >= 0) & (p_ < n)       # src/utils.py:222-232: both are masked with n_classes
+        np.add.at(want, (p_[ok], t[ok]), 1)
+    return ("ok", desc) if np.array_equal(m.stats.cpu().numpy(), want) else ("FAIL stats differ", desc)
+
+
 t0 = time.time()
 counts = {}
 for s in range(seed0, seed0 + n_cases):
-    for fn in (fps_case, lhp_case, lhp_maps_case):
+    for fn in (fps_case, lhp_case, lhp_maps_case, salience_case, simple_case, topk_case, confusion_case):
         try:
             status, desc = fn(s)
         except Exception as e:  # noqa: BLE001
