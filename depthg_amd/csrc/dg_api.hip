@@ -323,17 +323,18 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         DG_HIP(dg_launch_prep_dense(g, stream));
     } else {
-        // (general coordinates: the first launch already reads the batch maps - they are drawn by their own launch,
-        //  together with the depth indicators, which nothing of this call feeds either)
-        bool nz_done = false;
-        if (draw && p.N > 0) {
-            if (p.depth && p.B <= 8192) {
-                DG_HIP(dg_launch_draw_depth(draw->seed, draw->state, p.N, draw->out, depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h,
-                                            desc->depth_w, p.Sh, p.S, p.Ppad, stream));
-                nz_done = true;
-            } else {
-                DG_HIP(dg_launch_super_perms(nullptr, draw->seed, draw->state, p.N, p.B, draw->out, stream));
-            }
+        // general coordinates: the first launch already reads the batch maps, so they are drawn by a launch of their own - which
+        // also carries the other jobs that depend on nothing but the call's inputs: the depth indicators and, on gradient passes,
+        // the inverse tap records of the sample() adjoint (dg_corr_backward then finds them in the workspace)
+        {
+            DgPreArgs q;
+            memset(&q, 0, sizeof(q));
+            if (draw && p.N > 0) { q.seed = draw->seed; q.state = draw->state; q.perms = draw->out; q.count = p.N; }
+            if (p.depth) { q.depth = depth; q.nz = F32(p.nz); q.nzsum = F32(p.nzsum); q.dH = desc->depth_h; q.dW = desc->depth_w; }
+            if (p.grad && (size_t)p.h * p.w <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
+            q.B = p.B; q.h = p.h; q.w = p.w; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;
+            if (p.B > 8192 && q.count > 0) return fail(DG_ERR_UNSUPPORTED, "B=%d too large for the in-call draw", p.B);
+            DG_HIP(dg_launch_pre_general(q, stream));
         }
         if (p.rows) {
             DgPlaneArgs t;
@@ -374,7 +375,6 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.njobs = nj;
         g.direct = p.rows ? 1 : 0;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
-        if (p.depth && !nz_done) DG_HIP(dg_launch_depth_nz(depth, F32(p.nz), F32(p.nzsum), p.B, desc->depth_h, desc->depth_w, p.Sh, p.S, p.Ppad, stream));
     }
 
     // (the launch plan of step 4 is needed here already: the consumer lists of k_corr2's grouped ragged blocks are written by
@@ -532,6 +532,7 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);
     s.DC = 8;
     s.dense = p.ident ? 1 : 0;
+    s.taps_ready = p.ident ? 0 : 1;            // (general coordinates: built by the forward's first launch, dg_launch_pre_general)
     DG_HIP(dg_launch_scatter(s, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }

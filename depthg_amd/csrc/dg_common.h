@@ -327,6 +327,48 @@ __device__ __forceinline__ void dg_super_perm_row(const float* __restrict__ keys
 }
 #endif
 
+#ifdef __HIPCC__
+// depth (B,1,H,W) -> nz[n][p] over the S x S resize, p = i*S + j (row major)
+__device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, int n, int p, int H, int W, int Sh, int S) {
+    float out = 0.f;
+    if (p < Sh * S) {
+        const int i = p / S, j = p - i * S;
+        const float sy = Sh > 1 ? (float)(H - 1) / (float)(Sh - 1) : 0.f;
+        const float sx = S > 1 ? (float)(W - 1) / (float)(S - 1) : 0.f;
+        // every product is rounded on its own (dg_mul_rn), as in the torch operator: contracted into the subtraction below,
+        // scale * index leaves a 1e-7 weight where the rounded source coordinate is a whole pixel - enough to pull a non-zero
+        // neighbour into a pixel of zero depth and flip its indicator (found by scripts/fuzz_parity.py, seed 323)
+        const float fy = dg_mul_rn(sy, (float)i), fx = dg_mul_rn(sx, (float)j);
+        int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+        const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* d = depth + (size_t)n * H * W;
+        const float top = dg_mul_rn(d[(size_t)y0 * W + x0], lx0) + dg_mul_rn(d[(size_t)y0 * W + x1], lx1);
+        const float bot = dg_mul_rn(d[(size_t)y1 * W + x0], lx0) + dg_mul_rn(d[(size_t)y1 * W + x1], lx1);
+        const float v = dg_mul_rn(top, ly0) + dg_mul_rn(bot, ly1);
+        out = v / fmaxf(fabsf(v), DG_EPS_NORM);
+    }
+    return out;
+}
+
+// all positions of image n by one block of 256 threads, plus their sum (mean(dd) = mean_n (sum_p nz)^2 / P^2)
+__device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
+                                               int n, int H, int W, int Sh, int S, int Ppad) {
+    __shared__ float wred[4];
+    float s = 0.f;
+    for (int p = threadIdx.x; p < Ppad; p += 256) {
+        const float v = depth_nz_at(depth, n, p, H, W, Sh, S);
+        nz[(size_t)n * Ppad + p] = v;
+        s += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) nzsum[n] = wred[0] + wred[1] + wred[2] + wred[3];
+}
+#endif
+
 struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     const float* src[2];     // feats NCHW fp32 (B,K,h,w): orig_feats, orig_feats_pos
     const float* code[2];    // code NCHW fp32 (B,D,h,w): orig_code, orig_code_pos
@@ -429,6 +471,16 @@ struct DgRowmeanArgs {
     int32_t ncs;
 };
 
+// General coordinates, first launch of the forward: the jobs that depend on nothing but the call's inputs, side by side -
+// blocks [0, count) draw the negatives' batch maps, the next B (depth != null) resize the depth indicators, the last 2 B
+// (taps != null: gradient passes) build the inverse tap records the adjoint of sample() gathers through.
+struct DgPreArgs {
+    uint64_t seed; unsigned long long* state; int64_t* perms; int32_t count;      // draws (count == 0: none)
+    const float* depth; float* nz; float* nzsum; int32_t dH, dW;                  // depth indicators
+    const float* coords1; const float* coords2; char* taps;                       // inverse tap records [2][B]
+    int32_t B, h, w, S, Sh, P, Ppad;
+};
+
 struct DgScatterSrc {
     const float* buf;      // gradient tiles [B][Ppad/32][DP/32][4][64][4] (dg_gtile_off).  raw == 1: the fused kernel's
                            // d/d(normalised operand-1 code), normalisation backward pending; raw == 0: k_gs output (final)
@@ -460,6 +512,7 @@ struct DgScatterArgs {
     // (set by the launcher) the direct sources of k_grad_combine per destination, in source order: raw ones, then final ones
     int8_t craw[2][DG_MAX_SCATTER / 2], cfin[2][DG_MAX_SCATTER / 2];
     int8_t ncraw[2], ncfin[2];
+    int32_t taps_ready;    // 1: the forward built the tap records (dg_launch_pre_general)
 };
 
 #ifdef __HIPCC__
@@ -532,7 +585,6 @@ hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
@@ -546,8 +598,7 @@ hipError_t dg_launch_confusion(const long long* preds, const long long* target, 
                                unsigned long long* stats, hipStream_t s);
 hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
                                long long* out_idx, float* out_val, hipStream_t s);
-hipError_t dg_launch_draw_depth(uint64_t seed, unsigned long long* state, int count, int64_t* perms, const float* depth, float* nz,
-                                float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s);
+hipError_t dg_launch_pre_general(const struct DgPreArgs& a, hipStream_t s);
 hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
 hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,
                                    float* dst, hipStream_t s);

@@ -128,31 +128,31 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
 // (position, weight) that read it, as CSR in global memory (off[HW+1], then 4P weights, then 4P positions).
 // Lists are sorted by position, so the gather below sums in a fixed order (bit-reproducible gradients).
 // grid (B, 2), block SCAT_THREADS, dynamic LDS (2*HW + 1) ints + 4P floats + 4P ushorts.
-__global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char sg[];
-    const int tid = threadIdx.x, HW = a.h * a.w, P = a.P, S = a.S;
-    const int nimg = blockIdx.x, cs = blockIdx.y;
-    const float* coords = cs == 0 ? a.coords1 : a.coords2;
+struct DgTapsArgs { const float* coords1; const float* coords2; char* taps; int B, h, w, S, Sh, P; };
+template <int NT>
+__device__ __forceinline__ void build_taps_block(const DgTapsArgs& t, const int nimg, const int cs, char* sg) {
+    const int tid = threadIdx.x, HW = t.h * t.w, P = t.P, S = t.S;
+    const float* coords = cs == 0 ? t.coords1 : t.coords2;
     int* cnt = reinterpret_cast<int*>(sg);                 // [HW] taps per pixel (then fill cursor)
     int* off = cnt + HW;                                   // [HW + 1] exclusive scan
     float* ewgt = reinterpret_cast<float*>(off + HW + 1);  // [4P]
     unsigned short* eidx = reinterpret_cast<unsigned short*>(ewgt + 4 * P);   // [4P]
-    __shared__ int wtot[SCAT_THREADS / 64];
-    for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;
+    __shared__ int wtot[NT / 64];
+    for (int i = tid; i < HW; i += NT) cnt[i] = 0;
     __syncthreads();
     int x0 = 0, y0 = 0; bool inx = false, iny = false; float w4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int pp = tid; pp < P; pp += SCAT_THREADS) {
+    for (int pp = tid; pp < P; pp += NT) {
         const int i = pp / S, j = pp - i * S;
-        dg_taps(coords + (((size_t)nimg * S + j) * a.Sh + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
-        const int pix = y0 * a.w + x0;
+        dg_taps(coords + (((size_t)nimg * S + j) * t.Sh + i) * 2, t.h, t.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        const int pix = y0 * t.w + x0;
         if (w4[0] != 0.f) atomicAdd(&cnt[pix], 1);
         if (inx && w4[1] != 0.f) atomicAdd(&cnt[pix + 1], 1);
-        if (iny && w4[2] != 0.f) atomicAdd(&cnt[pix + a.w], 1);
-        if (inx && iny && w4[3] != 0.f) atomicAdd(&cnt[pix + a.w + 1], 1);
+        if (iny && w4[2] != 0.f) atomicAdd(&cnt[pix + t.w], 1);
+        if (inx && iny && w4[3] != 0.f) atomicAdd(&cnt[pix + t.w + 1], 1);
     }
     __syncthreads();
     // exclusive scan of cnt -> off (each thread owns a contiguous run of pixels)
-    const int per = (HW + SCAT_THREADS - 1) / SCAT_THREADS;
+    const int per = (HW + NT - 1) / NT;
     const int b0 = min(tid * per, HW), b1 = min(b0 + per, HW);
     int run = 0;
     for (int i = b0; i < b1; ++i) run += cnt[i];
@@ -165,26 +165,26 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
     for (int wv = 0; wv < (tid >> 6); ++wv) base += wtot[wv];
     int o2 = base + incl - run;
     for (int i = b0; i < b1; ++i) { const int c = cnt[i]; off[i] = o2; o2 += c; }
-    if (tid == SCAT_THREADS - 1) off[HW] = o2;
+    if (tid == NT - 1) off[HW] = o2;
     __syncthreads();
-    for (int i = tid; i < HW; i += SCAT_THREADS) cnt[i] = 0;       // becomes the fill cursor
+    for (int i = tid; i < HW; i += NT) cnt[i] = 0;       // becomes the fill cursor
     __syncthreads();
-    for (int pp = tid; pp < P; pp += SCAT_THREADS) {
+    for (int pp = tid; pp < P; pp += NT) {
         const int i = pp / S, j = pp - i * S;
-        dg_taps(coords + (((size_t)nimg * S + j) * a.Sh + i) * 2, a.h, a.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
-        const int pix = y0 * a.w + x0;
+        dg_taps(coords + (((size_t)nimg * S + j) * t.Sh + i) * 2, t.h, t.w, x0, y0, inx, iny, w4[0], w4[1], w4[2], w4[3]);
+        const int pix = y0 * t.w + x0;
         auto put = [&](int q, float wgt) {
             const int slot = off[q] + atomicAdd(&cnt[q], 1);
             ewgt[slot] = wgt; eidx[slot] = (unsigned short)pp;
         };
         if (w4[0] != 0.f) put(pix, w4[0]);
         if (inx && w4[1] != 0.f) put(pix + 1, w4[1]);
-        if (iny && w4[2] != 0.f) put(pix + a.w, w4[2]);
-        if (inx && iny && w4[3] != 0.f) put(pix + a.w + 1, w4[3]);
+        if (iny && w4[2] != 0.f) put(pix + t.w, w4[2]);
+        if (inx && iny && w4[3] != 0.f) put(pix + t.w + 1, w4[3]);
     }
     __syncthreads();
     // sort every pixel's list by position (insertion sort, lists are short)
-    for (int q = tid; q < HW; q += SCAT_THREADS) {
+    for (int q = tid; q < HW; q += NT) {
         const int e0 = off[q], e1 = off[q + 1];
         for (int i = e0 + 1; i < e1; ++i) {
             const unsigned short ki = eidx[i]; const float wi = ewgt[i];
@@ -196,13 +196,46 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
     __syncthreads();
     // copy out: [off (HW+1 ints)][weights 4P floats][positions 4P ushorts], one record per (cs, image)
     const size_t rec = dg_taps_record_bytes(HW, P);
-    char* dst = a.taps + ((size_t)cs * a.B + nimg) * rec;
+    char* dst = t.taps + ((size_t)cs * t.B + nimg) * rec;
     int* g_off = reinterpret_cast<int*>(dst);
     float* g_w = reinterpret_cast<float*>(g_off + HW + 1);
     unsigned short* g_p = reinterpret_cast<unsigned short*>(g_w + 4 * P);
-    for (int i = tid; i <= HW; i += SCAT_THREADS) g_off[i] = off[i];
+    for (int i = tid; i <= HW; i += NT) g_off[i] = off[i];
     const int ne = off[HW];
-    for (int i = tid; i < ne; i += SCAT_THREADS) { g_w[i] = ewgt[i]; g_p[i] = eidx[i]; }
+    for (int i = tid; i < ne; i += NT) { g_w[i] = ewgt[i]; g_p[i] = eidx[i]; }
+}
+
+__global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sg[];
+    const DgTapsArgs t{a.coords1, a.coords2, a.taps, a.B, a.h, a.w, a.S, a.Sh, a.P};
+    build_taps_block<SCAT_THREADS>(t, (int)blockIdx.x, (int)blockIdx.y, sg);
+}
+
+__global__ __launch_bounds__(256) void k_pre_general(const DgPreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pg[];
+    int b = (int)blockIdx.x;
+    if (b < a.count) { dg_super_perm_row(nullptr, a.seed, a.state, a.B, a.perms, b, a.count, reinterpret_cast<float*>(pg)); return; }
+    b -= a.count;
+    if (a.depth) {
+        if (b < a.B) { depth_nz_image(a.depth, a.nz, a.nzsum, b, a.dH, a.dW, a.Sh, a.S, a.Ppad); return; }
+        b -= a.B;
+    }
+    const DgTapsArgs t{a.coords1, a.coords2, a.taps, a.B, a.h, a.w, a.S, a.Sh, a.P};
+    build_taps_block<256>(t, b % a.B, b / a.B, pg);
+}
+
+hipError_t dg_launch_pre_general(const DgPreArgs& a, hipStream_t s) {
+    const int nblk = a.count + (a.depth ? a.B : 0) + (a.taps ? 2 * a.B : 0);
+    if (nblk == 0) return hipSuccess;
+    size_t smem = a.count > 0 ? (size_t)a.B * 4 : 0;
+    if (a.taps) {
+        const size_t need = dg_taps_record_bytes(a.h * a.w, a.P) + (size_t)a.h * a.w * 4 + 16;
+        smem = need > smem ? need : smem;
+    }
+    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_pre_general), (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pre_general, dim3(nblk), dim3(256), smem, s, a);
+    return hipGetLastError();
 }
 
 // Stage 2: adjoint of sample() as a GATHER (no floating-point atomics).  One block = one destination image and
@@ -624,9 +657,12 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     rmax = rmax < 1 ? 1 : (rmax > SCAT_RMAX ? SCAT_RMAX : rmax);
     const int smem = (int)(rmax * rec > stage ? rmax * rec : stage);
     const int build_smem = (int)(rec + (size_t)HW * 4 + 16);     // the record plus the per-pixel counters
-    hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_build_taps), build_smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_build_taps, dim3(a.B, 2), dim3(SCAT_THREADS), build_smem, s, a);
+    hipError_t e = hipSuccess;
+    if (!a.taps_ready) {
+        e = dg_set_max_smem(reinterpret_cast<const void*>(k_build_taps), build_smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_build_taps, dim3(a.B, 2), dim3(SCAT_THREADS), build_smem, s, a);
+    }
     {
         // small sample grids: tiles of a 32-channel group + tap lists of several sources in LDS (k_scatter_small)
         const bool half = (a.DP / 32) * a.B * 2 < 512;               // 32-channel blocks would not even fill the CUs twice

@@ -3,7 +3,7 @@
 //   k_gather_norm    sample() + norm() of the reference (src/modules.py:822-825, 789-790):
 //                    bilinear gather at coords (grid_sample, border, align_corners=True),
 //                    L2-normalise over channels, write the tile blobs (+ 1/norm, column sums)
-//   k_depth_nz       depth -> F.interpolate(size=(S,S), bilinear, align_corners=True) -> norm over
+//   depth_nz_image   (dg_common.h; a role of k_prep_dense / k_pre_general) depth -> F.interpolate(size=(S,S), bilinear, align_corners=True) -> norm over
 //                    the single channel (src/modules.py:1261-1265): d / max(|d|, 1e-10)
 //   k_rowmean        r[n][p] = a[n][p] . mean_q b[n][q]   (row means of fd for `pointwise`,
 //                    src/modules.py:1236-1239 restated as a rank-1 term)
@@ -589,8 +589,6 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
     }
 }
 
-__device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                               int n, int H, int W, int Sh, int S, int Ppad);
 
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
@@ -648,73 +646,6 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// depth (B,1,H,W) -> nz[n][p] over the S x S resize, p = i*S + j (row major)
-__device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, int n, int p, int H, int W, int Sh, int S) {
-    float out = 0.f;
-    if (p < Sh * S) {
-        const int i = p / S, j = p - i * S;
-        const float sy = Sh > 1 ? (float)(H - 1) / (float)(Sh - 1) : 0.f;
-        const float sx = S > 1 ? (float)(W - 1) / (float)(S - 1) : 0.f;
-        // every product is rounded on its own (dg_mul_rn), as in the torch operator: contracted into the subtraction below,
-        // scale * index leaves a 1e-7 weight where the rounded source coordinate is a whole pixel - enough to pull a non-zero
-        // neighbour into a pixel of zero depth and flip its indicator (found by scripts/fuzz_parity.py, seed 323)
-        const float fy = dg_mul_rn(sy, (float)i), fx = dg_mul_rn(sx, (float)j);
-        int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
-        const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
-        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* d = depth + (size_t)n * H * W;
-        const float top = dg_mul_rn(d[(size_t)y0 * W + x0], lx0) + dg_mul_rn(d[(size_t)y0 * W + x1], lx1);
-        const float bot = dg_mul_rn(d[(size_t)y1 * W + x0], lx0) + dg_mul_rn(d[(size_t)y1 * W + x1], lx1);
-        const float v = dg_mul_rn(top, ly0) + dg_mul_rn(bot, ly1);
-        out = v / fmaxf(fabsf(v), DG_EPS_NORM);
-    }
-    return out;
-}
-
-// all positions of image n by one block of 256 threads, plus their sum (mean(dd) = mean_n (sum_p nz)^2 / P^2)
-__device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                               int n, int H, int W, int Sh, int S, int Ppad) {
-    __shared__ float wred[4];
-    float s = 0.f;
-    for (int p = threadIdx.x; p < Ppad; p += 256) {
-        const float v = depth_nz_at(depth, n, p, H, W, Sh, S);
-        nz[(size_t)n * Ppad + p] = v;
-        s += v;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) nzsum[n] = wred[0] + wred[1] + wred[2] + wred[3];
-}
-
-__global__ __launch_bounds__(256) void k_depth_nz(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                                  int H, int W, int Sh, int S, int Ppad) {
-    depth_nz_image(depth, nz, nzsum, blockIdx.x, H, W, Sh, S, Ppad);
-}
-
-// general coordinates: the negatives' draws and the depth indicators - two latency-sized jobs without inputs from this call's
-// other launches - in one launch: blocks [0, count) draw, blocks [count, count + B) resize
-__global__ __launch_bounds__(256) void k_draw_depth(uint64_t seed, unsigned long long* __restrict__ state, int count, int B, int64_t* __restrict__ perms,
-                                                    const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                                    int H, int W, int Sh, int S, int Ppad) {
-    extern __shared__ float dd_sk[];
-    if ((int)blockIdx.x < count) dg_super_perm_row(nullptr, seed, state, B, perms, (int)blockIdx.x, count, dd_sk);
-    else depth_nz_image(depth, nz, nzsum, (int)blockIdx.x - count, H, W, Sh, S, Ppad);
-}
-
-hipError_t dg_launch_draw_depth(uint64_t seed, unsigned long long* state, int count, int64_t* perms, const float* depth, float* nz,
-                                float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s) {
-    hipLaunchKernelGGL(k_draw_depth, dim3(count + B), dim3(256), B * sizeof(float), s, seed, state, count, B, perms, depth, nz, nzsum,
-                       H, W, Sh, S, Ppad);
-    return hipGetLastError();
-}
-
-hipError_t dg_launch_depth_nz(const float* depth, float* nz, float* nzsum, int B, int H, int W, int Sh, int S, int Ppad, hipStream_t s) {
-    hipLaunchKernelGGL(k_depth_nz, dim3(B), dim3(256), 0, s, depth, nz, nzsum, H, W, Sh, S, Ppad);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------
 
 // out[n][k] = scale * sum over the groups of part[n][group][k], summed in group order; every thread of the block takes part
