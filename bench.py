@@ -340,9 +340,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(conf)
-        print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its banner to the C-level stdout: flush that first, so that the JSON line is the LAST thing on stdout
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
