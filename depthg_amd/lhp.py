@@ -45,13 +45,16 @@ class _MapPropagation(torch.autograd.Function):
         else:
             out, wmap = ops.lhp_map_forward(mode, code, attn=source, divide=divide)
         ctx.mode = mode
-        ctx.divide = divide
-        ctx.wmap = wmap if ctx.needs_input_grad[0] else None
+        ctx.has_divide = divide is not None
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(*((wmap, divide) if ctx.has_divide else (wmap,)))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        return ops.lhp_map_backward(ctx.mode, grad_out.contiguous(), ctx.wmap, ctx.divide), None, None, None
+        saved = ctx.saved_tensors
+        divide = saved[1] if ctx.has_divide else None
+        return ops.lhp_map_backward(ctx.mode, grad_out.contiguous(), saved[0], divide), None, None, None
 
 
 def propagate_depth(code: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
