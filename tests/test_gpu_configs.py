@@ -412,3 +412,26 @@ def test_forward_that_draws_its_negatives(dense, dev):
         assert not torch.equal(p1, p2) and o1[4] != o2[4] and o1 == o3 and torch.equal(p1, loss.last_call[1])
         assert o1[0] == o2[0] and o1[2] == o2[2]               # the positive terms do not depend on the negatives
 
+
+def test_bench_line_of_the_multi_gpu_schedule():
+    """bench.py under an initialised RCCL group with one rank (--force-dist): the N > 1 schedule - the step replayed from two
+    hipGraphs, the bucket's all-reduce on a side stream - prints ONE JSON line, last on stdout, with the contract's keys, the
+    headline workload and a loss equal to the plain run's (the same seeded inputs; the negatives differ per draw, so 2 %)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29691")
+    lines = {}
+    for mode in ("--force-dist", "--graph"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), mode, "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        last = r.stdout.strip().splitlines()[-1]
+        lines[mode] = json.loads(last)
+    d = lines["--force-dist"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["config"]["name"] == "headline"
+    assert "side stream" in d["config"]["allreduce"] and "hipGraph" in d["config"]["workload"]
+    assert d["roofline"]["kernel"] == "k_corr2" and 0.2 < d["roofline"]["frac"] < 0.6
+    assert abs(d["loss_total"] - lines["--graph"]["loss_total"]) < 0.02 * abs(d["loss_total"])
+
