@@ -13,7 +13,7 @@ perms = torch.stack([torch.randperm(32, generator=g) for _ in range(5)]).to(dev)
 perms = torch.where(perms == torch.arange(32, device=dev), perms + 1, perms) % 32
 bad = 0
 for dense in (True, False):
-    cfg = bench.make_cfg()
+    cfg = bench.make_cfg(bench.CONFIGS["headline"])
     loss = ContrastiveCorrelationLoss(cfg)
     if dense:
         c1 = c2 = identity_coords(32, 28, dev)
