@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer aid: randomized shape / flag sweep of the HIP loss against the CPU oracle (forward scalars and code gradients,
 tolerances of tests/test_gpu_sweep.py).  Every case is reproducible from its seed; failures are printed and counted.
-   python scripts/fuzz_parity.py [n_cases] [first_seed]"""
+   python scripts/fuzz_parity.py [n_cases] [first_seed] [edge]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from oracle import depthg_oracle as O  # noqa: E402
 dev = torch.device("cuda:0")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+EDGE = len(sys.argv) > 3 and sys.argv[3] == "edge"       # sizes at the kernels' blocking boundaries instead of uniform draws
 
 
 def pick(g, lo, hi):
@@ -25,16 +26,33 @@ def pick(g, lo, hi):
 def one(seed):
     g = torch.Generator().manual_seed(seed)
     dense = pick(g, 0, 2) == 0
-    B = pick(g, 1, 9)
-    C = [32, 64, 100, 128, 200, 384, 384, 768][pick(g, 0, 7)]
-    D = pick(g, 4, 128) if pick(g, 0, 3) else [70, 90, 96, 128][pick(g, 0, 3)]
-    N = pick(g, 1, 6)                       # (the reference's torch.cat over the negatives needs at least one)
-    if dense:
-        h = w = pick(g, 6, 30)
-        S = h
+    if EDGE:
+        B = [1, 2, 7, 8, 9, 16, 33, 64, 65][pick(g, 0, 8)]
+        C = [31, 33, 127, 128, 129, 383, 384, 385, 767, 768][pick(g, 0, 9)]
+        D = [1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 79, 80, 81, 95, 96, 97, 127, 128][pick(g, 0, 17)]
+        N = [1, 2, 5, 7, 8][pick(g, 0, 4)]
+        if dense:
+            h = w = [5, 8, 11, 12, 13, 16, 17, 23, 32, 33, 40][pick(g, 0, 10)]
+            if h * h * B > 40000:
+                B = max(1, 40000 // (h * h))
+            S = h
+        else:
+            h, w = pick(g, 4, 40), pick(g, 4, 40)
+            S = [2, 3, 5, 8, 11, 12, 16][pick(g, 0, 6)]
+            S = min(S, h, w)
+            if S * S * B > 6000:
+                B = max(1, 6000 // (S * S))
     else:
-        h, w = pick(g, 5, 30), pick(g, 5, 30)
-        S = pick(g, 2, min(h, w, 14))
+        B = pick(g, 1, 9)
+        C = [32, 64, 100, 128, 200, 384, 384, 768][pick(g, 0, 7)]
+        D = pick(g, 4, 128) if pick(g, 0, 3) else [70, 90, 96, 128][pick(g, 0, 3)]
+        N = pick(g, 1, 6)                   # (the reference's torch.cat over the negatives needs at least one)
+        if dense:
+            h = w = pick(g, 6, 30)
+            S = h
+        else:
+            h, w = pick(g, 5, 30), pick(g, 5, 30)
+            S = pick(g, 2, min(h, w, 14))
     flags = dict(pointwise=bool(pick(g, 0, 3)), zero_clamp=bool(pick(g, 0, 3)), stabalize=pick(g, 0, 4) == 0,
                  depth_feat_correlation_loss=bool(pick(g, 0, 3)))
     nograd = pick(g, 0, 3) == 0             # forward-only call (no gradient kernels, other fused kernel and reduction)
@@ -94,8 +112,10 @@ def one(seed):
             bad.append(f"{name}: non-finite gradient")
             continue
         rel = float((got.cpu() - want).norm() / want.norm())
-        if rel > 4e-2:
-            bad.append(f"{name}: rel L2 {rel:.3g}")
+        # (D == 1: the normalised code is +-1 and its gradient vanishes identically - both sides hold rounding noise only)
+        tiny = float(want.abs().max()) < 1e-7 and float(got.abs().max()) < 1e-7
+        if rel > 4e-2 and not tiny:
+            bad.append(f"{name}: rel L2 {rel:.3g} (max |want| {float(want.abs().max()):.3g}, max |got| {float(got.abs().max()):.3g})")
     return ("FAIL " + "; ".join(bad), desc) if bad else ("ok", desc)
 
 
