@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 105                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 106                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID = \
     (1 << i for i in range(8))
 
@@ -16,7 +16,7 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
-           "dg_corr_backward_total"]
+           "dg_corr_backward_total", "dg_corr_main_kernel_name"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -54,6 +54,8 @@ def load():
     lib.dg_corr_forward.argtypes = [cp] + [vp] * 10 + [ctypes.c_size_t, vp]
     lib.dg_corr_forward_draw.restype = ctypes.c_int
     lib.dg_corr_forward_draw.argtypes = [cp] + [vp] * 8 + [ctypes.c_uint64, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_corr_main_kernel_name.restype = ctypes.c_char_p
+    lib.dg_corr_main_kernel_name.argtypes = [cp]
     lib.dg_corr_backward.restype = ctypes.c_int
     lib.dg_corr_backward.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.dg_corr_backward_total.restype = ctypes.c_int

@@ -576,6 +576,18 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     return DG_OK;
 }
 
+extern "C" const char* dg_corr_main_kernel_name(const dg_corr_desc* desc) {
+    Plan p;
+    if (make_plan(desc, p) != DG_OK) return nullptr;
+    // the job table holds addresses only: a made-up workspace base and batch-map pointer decide nothing but null / non-null
+    char* const ws = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 21);
+    const int64_t* const perms = reinterpret_cast<const int64_t*>(static_cast<uintptr_t>(1) << 20);
+    DgCorrArgs a;
+    int depth_index;
+    const int njA = build_corr_jobs(p, desc, ws, perms, a, &depth_index);
+    return (p.grad && njA > 0 && dg_corr2_supported(a, p.KF, p.KD)) ? "k_corr2" : "k_corr_main";
+}
+
 extern "C" int dg_super_perms(const float* keys, int32_t count, int32_t B, int64_t* out, dg_stream_t stream_) {
     if (count < 0 || B < 1 || B > 8192) return fail(DG_ERR_INVALID, "dg_super_perms: count=%d B=%d outside the supported range", count, B);
     if (count == 0) return DG_OK;

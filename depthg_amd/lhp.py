@@ -7,8 +7,9 @@ depth point cloud (`propagation_strategy == "depth"`, the default, :273-339) or 
 (`"attn"`, :235-271).  `OriginalLocalHiddenPositiveProjection(cfg)` follows :342-487 (the variant `train_segmentation.py:83-85`
 picks for experiment names containing "lhp_original"): the same two sources restricted to the clipped 3x3 neighbourhood.
 The propagations and their adjoints are HIP kernels (`dg_lhp_forward/backward`, `dg_lhp_map_forward/backward`); the projection
-head is two 1x1 convolutions (library GEMMs) owned by torch so that the caller's optimiser sees its parameters
-(src/train_segmentation.py:538-543).
+head is two 1x1 convolutions (library GEMMs) owned by torch.  As in the reference, no optimiser steps them:
+`configure_optimizers` hands `net_optim` the parameters of `self.net` only (src/train_segmentation.py:537-547), so the LHP
+projection head keeps its initial weights; gradients do reach it and flow through it into the code.
 
 Reference behaviour kept on purpose:
   * `divide_num` of both classes is all zero: the constructor re-creates it inside its loop and never fills it (:160,187 /

@@ -336,3 +336,11 @@ def corr_relaunch_main(desc, perms, workspace):
     rc = lib.dg_corr_relaunch_main(ctypes.byref(desc), _ptr(perms), _ptr(workspace), workspace.numel(),
                                    _stream(workspace.device))
     _lib.check(rc, "dg_corr_relaunch_main")
+
+
+def corr_main_kernel_name(desc):
+    """Which kernel the fused correlation launch of `desc` runs ("k_corr2" / "k_corr_main"), from the library's own predicate."""
+    name = _lib.load().dg_corr_main_kernel_name(ctypes.byref(desc))
+    if name is None:
+        _lib.check(-1, "dg_corr_main_kernel_name")
+    return name.decode()

@@ -161,9 +161,9 @@ class UnsupervisedSegmenter(nn.Module):
         return self.net(x)[1]                                                          # :160-167
 
     def configure_optimizers(self):                                                    # :537-547
+        # as the reference: net_optim steps `self.net.parameters()` only (its decoder is out of scope here, rec_weight = 0) - the
+        # LHP projection head is NOT among them, so it keeps its initial weights there and here
         main_params = list(self.net.parameters())
-        if getattr(self.cfg, "lhp", False):
-            main_params += list(self.lhp_module.parameters())
         net_optim = torch.optim.Adam([p for p in main_params if p.requires_grad], lr=self.cfg.lr)
         linear_probe_optim = torch.optim.Adam(list(self.linear_probe.parameters()), lr=5e-3)
         cluster_probe_optim = torch.optim.Adam(list(self.cluster_probe.parameters()), lr=5e-3)
@@ -175,8 +175,15 @@ class UnsupervisedSegmenter(nn.Module):
         return self._optims
 
     def head_parameters(self):
-        """The parameters net_optim steps (= what a data-parallel run all-reduces: cluster1 + cluster2)."""
+        """The parameters net_optim steps: cluster1 + cluster2."""
         return [p for p in self.net.parameters() if p.requires_grad]
+
+    def all_reduced_parameters(self):
+        """Every parameter one of the three optimisers steps - the head (net_optim), the linear probe and the cluster probe.
+        Under data parallelism ALL of them must be averaged over the ranks before the optimiser steps (build the GradBucket
+        from this list), or the replicas' probes drift apart.  (The LHP head is stepped by no optimiser, as in the reference,
+        src/train_segmentation.py:537-547, so it needs no exchange.)"""
+        return self.head_parameters() + list(self.linear_probe.parameters()) + list(self.cluster_probe.parameters())
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, grad_sync=None):
         """One optimisation step (src/train_segmentation.py:169-462).  `grad_sync`: callable run between backward and the
@@ -205,7 +212,8 @@ class UnsupervisedSegmenter(nn.Module):
                 lhp_out = self.contrastive_corr_loss_fn(feats, feats_pos, salience, salience_pos, lhp_code, lhp_code_pos, *d_args)
             total, logs = correspondence_total(cfg, out, lhp_out)                                    # :303-350
             loss = loss + total
-            legacy_decay_step(cfg, self.contrastive_corr_loss_fn.cfg, self.global_step)              # :356-375 (mutates cfg)
+        # the legacy decays sit at function-body level in the reference: they run every step, whatever correspondence_weight is
+        legacy_decay_step(cfg, self.contrastive_corr_loss_fn.cfg, self.global_step)                  # :356-375 (mutates cfg)
 
         # probes on the detached code (:421-444)
         flat_label = label.reshape(-1)

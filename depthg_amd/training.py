@@ -42,7 +42,8 @@ def correspondence_total(cfg, out: Sequence[torch.Tensor], lhp_out: Optional[Seq
         logs["cd/depth_feat"] = out[7].mean().detach()
         total = (core + cfg.depth_feat_weight * depth_feat) * (cfg.correspondence_weight - _balance(cfg))   # :330-333
         if "lhp_original" in str(getattr(cfg, "experiment_name", "")):                    # :335-337: only the LHP terms train,
-            total = total * 0.0                                                           # and the cfg is rewritten for good
+            total = torch.zeros((), dtype=total.dtype, device=total.device)              # `loss = 0.0` (:336): a nan/inf main term
+                                                                                          # is dropped, not turned into 0 * inf
             cfg.lhp_weight = 1.0
     else:
         total = core * cfg.correspondence_weight                                          # :347-349

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 105   /* 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 106   /* 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -142,6 +142,11 @@ int dg_corr_forward_draw(const dg_corr_desc* desc,
  *                 the cd means carry no gradient
  *                 (DG_OUT_LOSS_INTRA..DG_OUT_LOSS_DEPTH order)
  *  grad_code, grad_code_pos : fp32 (B,D,h,w), overwritten.
+ *  coords1, coords2, perms  : the SAME arrays the forward of this workspace ran on.  With general coordinates the adjoint of
+ *                 sample() gathers through inverse tap records that the FORWARD built from its coords (first launch of a
+ *                 DG_NEED_GRAD forward); the backward does not rebuild them, so coords that differ from the forward's are
+ *                 not detected and give the gradient at the forward's sample positions.  Only valid after a forward with
+ *                 DG_NEED_GRAD on this workspace, before the next forward overwrites it.
  */
 int dg_corr_backward(const dg_corr_desc* desc,
                      const float* grad_scalars,
@@ -292,6 +297,10 @@ int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, int64_t* out,
  * yields new permutations on every replay - the reference draws them with the device generator at the same place,
  * src/modules.py:1184-1188,1336-1339. */
 int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+
+/* Measurement aid: name of the kernel the fused correlation launch of this descriptor runs ("k_corr2": the one-wave-per-SIMD
+ * form of dg_corr2.hip, "k_corr_main": the general form), decided by the same predicate the launch uses; NULL on a bad desc. */
+const char* dg_corr_main_kernel_name(const dg_corr_desc* desc);
 
 /*
  * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a

@@ -103,6 +103,8 @@ def test_segmenter_surface():
     n_net = sum(p.numel() for g in net_optim.param_groups for p in g["params"])
     assert n_net == 384 * 16 + 16 + 384 * 384 + 384 + 384 * 16 + 16        # cluster1 + cluster2 only: the backbone is frozen
     assert n_net == sum(p.numel() for p in m.head_parameters())
+    stepped = {id(p) for o in (net_optim, lin_optim, clu_optim) for g in o.param_groups for p in g["params"]}
+    assert stepped == {id(p) for p in m.all_reduced_parameters()}          # what a data-parallel run must all-reduce
     assert lin_optim.param_groups[0]["lr"] == 5e-3 and clu_optim.param_groups[0]["lr"] == 5e-3
     # ViT-S / dim 70: the 201,740 parameters SURVEY.md section 8(e) sizes the all-reduce by
     m70 = UnsupervisedSegmenter(27, default_segmenter_cfg(dim=70))
@@ -180,8 +182,9 @@ def test_training_steps_across_sample_decay_and_lhp():
     torch.manual_seed(4)
     m = UnsupervisedSegmenter(27, cfg).to(dev)
     m.train()
-    bucket = GradBucket.for_parameters(m.head_parameters())
-    assert bucket.flat.numel() == 201_740
+    # every parameter an optimiser steps is averaged over the ranks: the head + the linear probe + the cluster probe
+    bucket = GradBucket.for_parameters(m.all_reduced_parameters())
+    assert bucket.flat.numel() == 201_740 + (70 * 27 + 27) + 27 * 70
     w0 = m.net.cluster1[0].weight.detach().clone()
     trace = []
     for step in range(3):
