@@ -100,10 +100,9 @@ def algorithmic_gflop(B, P, C, D, n_neg):
     return main + gs, main - dep, gs + dep
 
 
-def _cpu_baseline_at(conf, ncores, seconds_budget):
+def _cpu_baseline_at(conf, ncores, seconds_budget, Bs):
     from oracle import depthg_oracle as O
     H = conf["H"]
-    Bs = conf["cpu_B"]
     torch.set_num_threads(ncores)
     cfg = O.default_cfg(feature_samples=H["S"], neg_samples=H["n_neg"], dim=H["D"], pointwise=conf["pointwise"],
                         depth_sampling=conf["sampling"], **conf["scal"])
@@ -136,22 +135,25 @@ def _cpu_baseline_at(conf, ncores, seconds_budget):
 def cpu_baseline(conf, seconds_budget=20.0):
     """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the SAME workload: same C, D,
     S, pair-sets, sampler and backward, `cpu_B` images of the batch; scaled to steps/s of the full batch.  Timed at two thread
-    counts - every host CPU and 16 threads - and the faster of the two is the reported value; the other
+    counts - 16 threads and every host CPU - and the faster of the two is the reported value; the other
     one rides along in `also`."""
     H = conf["H"]
-    Bs = conf["cpu_B"]
     host = os.cpu_count() or 1
     runs = []
     for ncores in sorted({min(host, 16), host}):
-        t, n = _cpu_baseline_at(conf, ncores, seconds_budget / 2)
-        runs.append({"cores": ncores, "value": (Bs / H["B"]) / t, "seconds": t, "reps": n})
+        # the all-CPU leg thrashes on big hosts (256 threads: 65 x slower than 16 on the same box): an eighth of the sample, a
+        # short budget - it is there to show WHY the reported value uses 16 threads, not to be waited for
+        full = ncores <= 16
+        Bs = conf["cpu_B"] if full else max(1, conf["cpu_B"] // 8)
+        t, n = _cpu_baseline_at(conf, ncores, seconds_budget * (0.75 if full else 0.25), Bs)
+        runs.append({"cores": ncores, "value": (Bs / H["B"]) / t, "seconds": t, "reps": n, "Bs": Bs})
     best = max(runs, key=lambda r: r["value"])
     other = [r for r in runs if r is not best]
     return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "host_cpus": host, "kind": "port",
-            "sample": f"oracle forward+backward at B={Bs} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
+            "sample": f"oracle forward+backward at B={best['Bs']} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
                       f"{H['n_neg']} negatives, sampling={conf['sampling']}, {best['cores']} threads of {host} host CPUs, "
-                      f"min of {best['reps']} timed reps = {best['seconds']:.2f} s; value = ({Bs}/{H['B']}) / t",
-            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s"} for r in other]}
+                      f"min of {best['reps']} timed reps = {best['seconds']:.2f} s; value = ({best['Bs']}/{H['B']}) / t",
+            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other]}
 
 
 def main():

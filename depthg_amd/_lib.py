@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 106                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 107                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID = \
     (1 << i for i in range(8))
 
@@ -16,7 +16,9 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
-           "dg_corr_backward_total", "dg_corr_main_kernel_name"]
+           "dg_corr_backward_total", "dg_corr_main_kernel_name",
+           "dg_head_forward", "dg_head_workspace_bytes", "dg_head_backward", "dg_cluster_lookup_forward",
+           "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -54,6 +56,21 @@ def load():
     lib.dg_corr_forward.argtypes = [cp] + [vp] * 10 + [ctypes.c_size_t, vp]
     lib.dg_corr_forward_draw.restype = ctypes.c_int
     lib.dg_corr_forward_draw.argtypes = [cp] + [vp] * 8 + [ctypes.c_uint64, vp, vp, vp, ctypes.c_size_t, vp]
+    i32, f32 = ctypes.c_int32, ctypes.c_float
+    lib.dg_head_forward.restype = ctypes.c_int
+    lib.dg_head_forward.argtypes = [i32] * 4 + [vp] * 10 + [f32] + [vp] * 4
+    lib.dg_head_workspace_bytes.restype = ctypes.c_size_t
+    lib.dg_head_workspace_bytes.argtypes = [i32] * 4
+    lib.dg_head_backward.restype = ctypes.c_int
+    lib.dg_head_backward.argtypes = [i32] * 4 + [vp] * 3 + [f32] + [vp] * 10 + [ctypes.c_size_t, vp]
+    lib.dg_cluster_lookup_forward.restype = ctypes.c_int
+    lib.dg_cluster_lookup_forward.argtypes = [vp, vp, f32] + [i32] * 4 + [vp] * 6
+    lib.dg_cluster_lookup_backward.restype = ctypes.c_int
+    lib.dg_cluster_lookup_backward.argtypes = [vp, vp, vp, f32, vp] + [i32] * 4 + [vp] * 4
+    lib.dg_probe_ce_forward.restype = ctypes.c_int
+    lib.dg_probe_ce_forward.argtypes = [vp, vp] + [i32] * 6 + [vp] * 3
+    lib.dg_probe_ce_backward.restype = ctypes.c_int
+    lib.dg_probe_ce_backward.argtypes = [vp] * 4 + [i32] * 6 + [vp] * 2
     lib.dg_corr_main_kernel_name.restype = ctypes.c_char_p
     lib.dg_corr_main_kernel_name.argtypes = [cp]
     lib.dg_corr_backward.restype = ctypes.c_int

@@ -737,3 +737,131 @@ extern "C" int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int
     DG_HIP(dg_launch_fps(depth, B, depth_h, depth_w, h, w, S, factor, out_coords, out_inds, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
+
+// ---- the segmentation head and the probes (dg_head.hip, dg_probe.hip)
+static int head_check(int32_t B, int32_t C, int32_t D, int32_t P) {
+    if (B < 1 || C < 1 || D < 1 || P < 1) return fail(DG_ERR_INVALID, "bad head dimensions");
+    if (C > 768 || (C & 7)) return fail(DG_ERR_UNSUPPORTED, "C=%d: the head needs C <= 768 and a multiple of 8", C);
+    if (D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", D);
+    return DG_OK;
+}
+static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
+    int s = (512 + tiles - 1) / tiles;
+    return s < 1 ? 1 : (s > steps ? steps : s);
+}
+struct HeadPlan { size_t dh, p2a, p1, p2b, total; int s2a, s1, s2b; };
+static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
+    HeadPlan h;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
+    h.s2a = head_splits(B, C, C, P); h.s1 = head_splits(B, D, C, P); h.s2b = h.s1;
+    h.dh = take((size_t)B * C * P * 2);
+    h.p2a = take((size_t)h.s2a * C * C * 4);
+    h.p1 = take((size_t)h.s1 * D * C * 4);
+    h.p2b = take((size_t)h.s2b * D * C * 4);
+    h.total = off;
+    return h;
+}
+
+extern "C" int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
+                               const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                               const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                               float* code, float* feats_out, void* hidden, dg_stream_t stream_) {
+    if (int rc = head_check(B, C, D, P)) return rc;
+    if (!feat || !w1 || !b1 || !code) return fail(DG_ERR_INVALID, "null pointer");
+    const bool nonlinear = w2a != nullptr;
+    if (nonlinear && (!b2a || !w2b || !b2b)) return fail(DG_ERR_INVALID, "cluster2 needs all four of its tensors");
+    DgHeadFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = feat; a.w1 = w1; a.b1 = b1; a.w2a = w2a; a.b2a = b2a; a.w2b = w2b; a.b2b = b2b;
+    a.keep1 = keep1; a.keep2 = keep2; a.keep3 = keep3; a.scale = keep_scale;
+    a.code = code; a.feats_out = feats_out; a.hidden = static_cast<__bf16*>(hidden);
+    a.B = B; a.C = C; a.D = D; a.P = P;
+    DG_HIP(dg_launch_head_fwd(a, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32_t P) {
+    if (head_check(B, C, D, P) != DG_OK) return 0;
+    return head_plan(B, C, D, P).total;
+}
+
+extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
+                                float keep_scale, const void* hidden, const float* w2b, const float* grad_code,
+                                float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
+                                void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (int rc = head_check(B, C, D, P)) return rc;
+    if (!feat || !grad_code || !grad_w1 || !grad_b1 || !workspace) return fail(DG_ERR_INVALID, "null pointer");
+    const bool nonlinear = w2b != nullptr;
+    if (nonlinear && (!hidden || !grad_w2a || !grad_b2a || !grad_w2b || !grad_b2b)) return fail(DG_ERR_INVALID, "null cluster2 pointer");
+    const HeadPlan h = head_plan(B, C, D, P);
+    if (workspace_bytes < h.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, h.total);
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    char* ws = static_cast<char*>(workspace);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    // d W1[d][k] = scale * keep1[b][k] * sum_p g[d][p] f[k][p]
+    {
+        DgHeadWgradArgs w{grad_code, feat, keep1, F32(h.p1), B, D, C, P, h.s1};
+        DG_HIP(dg_launch_head_wgrad(w, false, false, s));
+        DG_HIP(dg_launch_head_reduce(F32(h.p1), grad_w1, D * C, h.s1, keep1 ? keep_scale : 1.f, s));
+    }
+    // d b1 (= d b2b) = row sums of d code
+    DG_HIP(dg_launch_head_rowsum(grad_code, false, grad_b1, nonlinear ? grad_b2b : nullptr, B, D, P, s));
+    if (nonlinear) {
+        __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
+        DgHeadDhArgs d{grad_code, w2b, static_cast<const __bf16*>(hidden), dh, B, C, D, P};
+        DG_HIP(dg_launch_head_dh(d, s));
+        DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
+        DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
+        DG_HIP(dg_launch_head_reduce(F32(h.p2b), grad_w2b, D * C, h.s2b, 1.f, s));
+        DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a};
+        DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
+        DG_HIP(dg_launch_head_reduce(F32(h.p2a), grad_w2a, C * C, h.s2a, keep2 ? keep_scale : 1.f, s));
+        DG_HIP(dg_launch_head_rowsum(dh, true, grad_b2a, nullptr, B, C, P, s));
+    }
+    return DG_OK;
+}
+
+extern "C" int dg_cluster_lookup_forward(const float* x, const float* clusters, float alpha, int32_t B, int32_t D, int32_t n, int32_t P,
+                                         float* inner, float* probs, float* logp, float* loss, float* scratch, dg_stream_t stream_) {
+    if (B < 1 || D < 1 || n < 1 || P < 1) return fail(DG_ERR_INVALID, "bad cluster-lookup dimensions");
+    if (D > 128 || (size_t)n * (D + 1) > 16000) return fail(DG_ERR_UNSUPPORTED, "cluster lookup needs D <= 128 and n * (D + 1) <= 16000");
+    if (!x || !clusters || !inner || !loss || !scratch) return fail(DG_ERR_INVALID, "null pointer");
+    DgClusterArgs a{x, clusters, alpha, inner, probs, logp, scratch, B, D, n, P};
+    DG_HIP(dg_launch_cluster_fwd(a, loss, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+extern "C" int dg_cluster_lookup_backward(const float* x, const float* clusters, const float* inner, float alpha, const float* grad_loss,
+                                          int32_t B, int32_t D, int32_t n, int32_t P, float* grad_clusters, float* grad_x, float* scratch,
+                                          dg_stream_t stream_) {
+    if (B < 1 || D < 1 || n < 1 || P < 1) return fail(DG_ERR_INVALID, "bad cluster-lookup dimensions");
+    if (D > 128 || (size_t)n * (D + 1) > 16000 || (size_t)(n + D) * 65 * 4 > 160 * 1024) return fail(DG_ERR_UNSUPPORTED, "cluster lookup needs D <= 128 and n * (D + 1) <= 16000");
+    if (!x || !clusters || !inner || !grad_loss || !grad_clusters || !scratch) return fail(DG_ERR_INVALID, "null pointer");
+    DgClusterBwdArgs a{x, clusters, inner, grad_loss, alpha, scratch, grad_x, scratch + (size_t)B * n * P, grad_clusters, B, D, n, P};
+    DG_HIP(dg_launch_cluster_bwd(a, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
+static int probe_check(int32_t B, int32_t n, int32_t h, int32_t w, int32_t H, int32_t W) {
+    if (B < 1 || n < 1 || h < 1 || w < 1 || H < 1 || W < 1) return fail(DG_ERR_INVALID, "bad probe dimensions");
+    if (n * w > 2048 || (size_t)(2 * n * w + (size_t)n * W) * 4 > 150 * 1024) return fail(DG_ERR_UNSUPPORTED, "probe loss needs n*w <= 2048 and n*(2w+W) floats of LDS");
+    return DG_OK;
+}
+extern "C" int dg_probe_ce_forward(const float* logits, const int64_t* label, int32_t B, int32_t n, int32_t h, int32_t w, int32_t H,
+                                   int32_t W, float* out3, float* scratch, dg_stream_t stream_) {
+    if (int rc = probe_check(B, n, h, w, H, W)) return rc;
+    if (!logits || !label || !out3 || !scratch) return fail(DG_ERR_INVALID, "null pointer");
+    DgProbeCeArgs a{logits, label, scratch, nullptr, nullptr, nullptr, B, n, h, w, H, W};
+    DG_HIP(dg_launch_probe_ce_fwd(a, out3, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+extern "C" int dg_probe_ce_backward(const float* logits, const int64_t* label, const float* out3, const float* grad_loss, int32_t B,
+                                    int32_t n, int32_t h, int32_t w, int32_t H, int32_t W, float* grad_logits, dg_stream_t stream_) {
+    if (int rc = probe_check(B, n, h, w, H, W)) return rc;
+    if (!logits || !label || !out3 || !grad_loss || !grad_logits) return fail(DG_ERR_INVALID, "null pointer");
+    DgProbeCeArgs a{logits, label, nullptr, grad_loss, out3, grad_logits, B, n, h, w, H, W};
+    DG_HIP(dg_launch_probe_ce_bwd(a, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}

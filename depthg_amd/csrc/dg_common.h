@@ -608,3 +608,76 @@ hipError_t dg_launch_lhp_map_bwd(int mode, const float* g, const float* map, con
                                  float* gcode, hipStream_t s);
 hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s);
+
+// ---- the segmentation head (dg_head.hip; DinoFeaturizer's cluster1 / cluster2, src/modules.py:75-88, 122-137)
+struct DgHeadFwdArgs {
+    const float* feat;                     // (B,C,P) fp32
+    const float* w1; const float* b1;      // (D,C), (D)
+    const float* w2a; const float* b2a;    // (C,C), (C)   null: projection_type "linear"
+    const float* w2b; const float* b2b;    // (D,C), (D)
+    const float* keep1; const float* keep2; const float* keep3;   // (B,C): 1 keep / 0 drop; null: no dropout for that use
+    float scale;                           // 1/(1-p) applied where a keep mask is given
+    float* code;                           // (B,D,P)
+    float* feats_out;                      // (B,C,P) = f * keep3 * scale, or null
+    __bf16* hidden;                        // (B,C,P) bf16: ReLU output saved for the backward, or null
+    int32_t B, C, D, P;
+};
+
+struct DgHeadDhArgs {
+    const float* gcode;      // (B,D,P) fp32
+    const float* w2b;        // (D,C)
+    const __bf16* hidden;    // (B,C,P)
+    __bf16* dh;              // (B,C,P) out
+    int32_t B, C, D, P;
+};
+
+struct DgHeadWgradArgs {
+    const void* A; const void* Bm;     // (B, M, P), (B, N, P); fp32 or bf16 (template)
+    const float* keep;                 // (B, N) or null
+    float* part;                       // [splits][M][N]
+    int32_t B, M, N, P, splits;
+};
+
+hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
+hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);
+hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s);
+hipError_t dg_launch_head_reduce(const float* part, float* out, int n, int splits, float scale, hipStream_t s);
+hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s);
+
+// ---- the probes (dg_probe.hip; ClusterLookup src/modules.py:647-675, linear-probe loss src/train_segmentation.py:421-434)
+struct DgClusterArgs {
+    const float* x;          // (B, D, P)
+    const float* clusters;   // (n, D)
+    float alpha;             // NaN: hard assignment (alpha is None)
+    float* inner;            // (B, n, P) out
+    float* probs;            // (B, n, P) out, or null
+    float* logp;             // (B, n, P) out: log_softmax(alpha * inner), or null
+    float* part;             // [blocks] partial sums of sum_n probs * inner
+    int32_t B, D, n, P;
+};
+
+struct DgClusterBwdArgs {
+    const float* x; const float* clusters; const float* inner;   // as the forward
+    const float* gloss;      // [1] upstream gradient of the loss (device)
+    float alpha;
+    float* dinner;           // (B, n, P) scratch out: d loss / d inner
+    float* grad_x;           // (B, D, P) out or null
+    float* part;             // [B * ceil(P/64)][n][D] partial sums of d loss / d normalised centres
+    float* grad_clusters;    // (n, D) out
+    int32_t B, D, n, P;
+};
+
+struct DgProbeCeArgs {
+    const float* logits;     // (B, n, h, w) the probe's output at feature resolution
+    const int64_t* label;    // (B, H, W)
+    float* part;             // [B * H][2]: per label row, sum of -log p[label] over the labelled pixels, their count
+    const float* gloss;      // backward: [1] upstream of the loss
+    const float* total;      // backward: [2] = {loss sum, count} of the forward
+    float* grad_logits;      // backward: (B, n, h, w)
+    int32_t B, n, h, w, H, W;
+};
+
+hipError_t dg_launch_cluster_fwd(const DgClusterArgs& a, float* loss_out, hipStream_t s);
+hipError_t dg_launch_cluster_bwd(const DgClusterBwdArgs& a, hipStream_t s);
+hipError_t dg_launch_probe_ce_fwd(const DgProbeCeArgs& a, float* out3, hipStream_t s);
+hipError_t dg_launch_probe_ce_bwd(const DgProbeCeArgs& a, hipStream_t s);

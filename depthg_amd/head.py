@@ -1,0 +1,227 @@
+"""The segmentation head and the probes around the correlation loss, on the HIP library.
+
+    ProjectionHead      DinoFeaturizer's trainable part (src/modules.py:75-88, 122-132): `cluster1` (1x1 conv C -> dim) and, for
+                        projection_type "nonlinear", `cluster2` (1x1 conv C -> C, ReLU, 1x1 conv C -> dim), each fed by its own
+                        Dropout2d(p=.1) draw of the backbone features, plus the third draw the features themselves get when
+                        cfg.dropout.  One fused launch (dg_head_forward): the fp32 features are read once; parameters keep the
+                        reference's names (`cluster1.0.weight`, `cluster2.2.bias`, ...), so its checkpoints load unchanged.
+    ClusterLookup       src/modules.py:647-675 (dg_cluster_lookup_forward / _backward)
+    probe_cross_entropy the linear probe's loss, src/train_segmentation.py:427-434: resize of the probe's logits to the label
+                        resolution + cross entropy over the labelled pixels in one kernel (dg_probe_ce_forward / _backward)
+All arithmetic runs in the library; CPU tensors raise (there is no eager path).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .ops import _empty, _ptr, _stream
+
+
+def _gpu32(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"depthg_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _HeadFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, keeps, scale, want_feats, w1, b1, w2a, b2a, w2b, b2b):
+        lib = _lib.load()
+        f = _gpu32(feat, "image_feat")
+        B, C, h, w = f.shape
+        D, P, dev = w1.shape[0], h * w, f.device
+        nonlinear = w2a is not None
+        need_grad = any(t is not None and t.requires_grad for t in (w1, b1, w2a, b2a, w2b, b2b))
+        code = _empty((B, D, h, w), torch.float32, dev)
+        feats_out = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
+        hidden = _empty((B, C, P), torch.bfloat16, dev) if (nonlinear and need_grad) else None
+        k1, k2, k3 = keeps if keeps is not None else (None, None, None)
+        W = lambda t: _gpu32(t, "head parameter").reshape(t.shape[0], -1) if t is not None else None
+        w1c, w2ac, w2bc = W(w1), W(w2a), W(w2b)
+        rc = lib.dg_head_forward(B, C, D, P, _ptr(f), _ptr(w1c), _ptr(_gpu32(b1, "bias")), _ptr(w2ac),
+                                 _ptr(_gpu32(b2a, "bias")) if nonlinear else None, _ptr(w2bc),
+                                 _ptr(_gpu32(b2b, "bias")) if nonlinear else None, _ptr(k1), _ptr(k2), _ptr(k3), float(scale),
+                                 _ptr(code), _ptr(feats_out), _ptr(hidden), _stream(dev))
+        _lib.check(rc, "dg_head_forward")
+        ctx.dims, ctx.scale, ctx.nonlinear = (B, C, D, P), float(scale), nonlinear
+        ctx.shapes = tuple(t.shape if t is not None else None for t in (w1, b1, w2a, b2a, w2b, b2b))
+        ctx.save_for_backward(f, k1, k2, hidden, w2bc)
+        if feats_out is not None:
+            ctx.mark_non_differentiable(feats_out)
+        return code, feats_out
+
+    @staticmethod
+    def backward(ctx, gcode, _gfeats):
+        lib = _lib.load()
+        f, k1, k2, hidden, w2bc = ctx.saved_tensors
+        B, C, D, P = ctx.dims
+        dev = f.device
+        if ctx.nonlinear and hidden is None:
+            raise RuntimeError("depthg_amd: head backward without the saved hidden activations")
+        g = _gpu32(gcode, "grad_code")
+        nb = lib.dg_head_workspace_bytes(B, C, D, P)
+        ws = _empty(nb, torch.uint8, dev)
+        gw1, gb1 = _empty((D, C), torch.float32, dev), _empty((D,), torch.float32, dev)
+        gw2a = gb2a = gw2b = gb2b = None
+        if ctx.nonlinear:
+            gw2a, gb2a = _empty((C, C), torch.float32, dev), _empty((C,), torch.float32, dev)
+            gw2b, gb2b = _empty((D, C), torch.float32, dev), _empty((D,), torch.float32, dev)
+        rc = lib.dg_head_backward(B, C, D, P, _ptr(f), _ptr(k1), _ptr(k2), ctx.scale, _ptr(hidden), _ptr(w2bc) if ctx.nonlinear else None,
+                                  _ptr(g), _ptr(gw1), _ptr(gb1), _ptr(gw2a), _ptr(gb2a), _ptr(gw2b), _ptr(gb2b), _ptr(ws), nb,
+                                  _stream(dev))
+        _lib.check(rc, "dg_head_backward")
+        sh = ctx.shapes
+        R = lambda t, i: t.reshape(sh[i]) if t is not None else None
+        return (None, None, None, None, R(gw1, 0), R(gb1, 1), R(gw2a, 2), R(gb2a, 3), R(gw2b, 4), R(gb2b, 5))
+
+
+def draw_keep_masks(B, C, device, p=0.1, count=3):
+    """The Dropout2d draws of one featurizer pass, in the reference's order (cluster1's input, cluster2's input, the returned
+    feats; src/modules.py:123-132): (B, C) keep flags, one bernoulli_(1 - p) each, as F.dropout2d draws its (B, C, 1, 1) noise."""
+    return tuple(torch.empty(B, C, device=device, dtype=torch.float32).bernoulli_(1.0 - p) for _ in range(count))
+
+
+def run_head(cluster1, cluster2, image_feat, training, feats_dropout, p=0.1, keeps=None):
+    """(code, feats) of one featurizer pass (src/modules.py:122-137) from the reference's modules: `cluster1` = Sequential(Conv2d),
+    `cluster2` = Sequential(Conv2d, ReLU, Conv2d) or None (projection_type "linear").  Training: three Dropout2d draws (`keeps`
+    or drawn here), feats = Dropout2d(image_feat) when `feats_dropout` (cfg.dropout); eval: no dropout, feats = image_feat."""
+    B, C = image_feat.shape[:2]
+    nl = cluster2 is not None
+    if training:
+        if keeps is None:
+            keeps = draw_keep_masks(B, C, image_feat.device, p)
+        k1, k2, k3 = keeps
+        keeps = (k1, k2 if nl else None, k3 if feats_dropout else None)
+    else:
+        keeps = None                                                                                  # eval: Dropout2d is the identity
+    c1 = cluster1[0]
+    c2a, c2b = (cluster2[0], cluster2[2]) if nl else (None, None)
+    want_feats = bool(training and feats_dropout)
+    code, feats = _HeadFunction.apply(image_feat, keeps, 1.0 / (1.0 - p), want_feats, c1.weight, c1.bias,
+                                      c2a.weight if nl else None, c2a.bias if nl else None,
+                                      c2b.weight if nl else None, c2b.bias if nl else None)
+    return code, (feats if want_feats else image_feat)
+
+
+class ProjectionHead(nn.Module):
+    """cluster1 / cluster2 of DinoFeaturizer with the reference's module and parameter names; forward(image_feat, feats_dropout,
+    keeps) -> (code, feats): feats = Dropout2d(image_feat) when `feats_dropout` (cfg.dropout) and the module trains, else
+    image_feat itself."""
+
+    def __init__(self, n_feats: int, dim: int, projection_type="nonlinear", p: float = 0.1):
+        super().__init__()
+        self.n_feats, self.dim, self.proj_type, self.p = n_feats, dim, projection_type, p
+        self.cluster1 = nn.Sequential(nn.Conv2d(n_feats, dim, (1, 1)))                                   # make_clusterer, :75-77
+        if projection_type == "nonlinear":                                                                # make_nonlinear_clusterer, :79-83
+            self.cluster2 = nn.Sequential(nn.Conv2d(n_feats, n_feats, (1, 1)), nn.ReLU(), nn.Conv2d(n_feats, dim, (1, 1)))
+
+    def forward(self, image_feat, feats_dropout=True, keeps=None):
+        if self.proj_type is None:                                                                        # :127-128: code = image_feat
+            return image_feat, image_feat
+        return run_head(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
+                        self.training, feats_dropout, self.p, keeps)
+
+
+class _ClusterFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, clusters, alpha, want_logp):
+        lib = _lib.load()
+        xx, cc = _gpu32(x, "x"), _gpu32(clusters, "clusters")
+        B, D, h, w = xx.shape
+        n, P, dev = cc.shape[0], h * w, xx.device
+        inner = _empty((B, n, h, w), torch.float32, dev)
+        probs = _empty((B, n, h, w), torch.float32, dev)
+        logp = _empty((B, n, h, w), torch.float32, dev) if want_logp else None
+        loss = _empty((1,), torch.float32, dev)
+        scratch = _empty((B * ((P + 255) // 256),), torch.float32, dev)
+        a = float("nan") if alpha is None else float(alpha)
+        rc = lib.dg_cluster_lookup_forward(_ptr(xx), _ptr(cc), a, B, D, n, P, _ptr(inner), _ptr(probs), _ptr(logp), _ptr(loss),
+                                           _ptr(scratch), _stream(dev))
+        _lib.check(rc, "dg_cluster_lookup_forward")
+        ctx.alpha, ctx.dims, ctx.x_grad = a, (B, D, n, P), x.requires_grad
+        ctx.save_for_backward(xx, cc, inner)
+        ctx.mark_non_differentiable(probs)
+        if logp is not None:
+            return loss[0], probs, logp
+        return loss[0], probs, None
+
+    @staticmethod
+    def backward(ctx, gloss, _gprobs, glogp):
+        if glogp is not None:
+            raise RuntimeError("depthg_amd: ClusterLookup(log_probs=True) is an evaluation output and carries no gradient")
+        lib = _lib.load()
+        xx, cc, inner = ctx.saved_tensors
+        B, D, n, P = ctx.dims
+        dev = xx.device
+        g = _gpu32(gloss, "grad_loss").reshape(1)
+        gc = _empty((n, D), torch.float32, dev)
+        gx = _empty(tuple(xx.shape), torch.float32, dev) if ctx.x_grad else None
+        scratch = _empty((B * n * P + B * ((P + 63) // 64) * n * D,), torch.float32, dev)
+        rc = lib.dg_cluster_lookup_backward(_ptr(xx), _ptr(cc), _ptr(inner), ctx.alpha, _ptr(g), B, D, n, P, _ptr(gc), _ptr(gx),
+                                            _ptr(scratch), _stream(dev))
+        _lib.check(rc, "dg_cluster_lookup_backward")
+        return gx, gc, None, None
+
+
+class ClusterLookup(nn.Module):
+    """Cosine cluster probe (src/modules.py:647-675): `clusters` (n_classes, dim) centres; forward(x, alpha, log_probs=False)
+    returns (cluster_loss, cluster_probs) - hard one-hot assignment when alpha is None, softmax(alpha * similarity) otherwise -
+    or the log-probabilities alone."""
+
+    def __init__(self, dim: int, n_classes: int):
+        super().__init__()
+        self.n_classes, self.dim = n_classes, dim
+        self.clusters = nn.Parameter(torch.randn(n_classes, dim))
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.clusters.copy_(torch.randn(self.n_classes, self.dim))
+
+    def forward(self, x, alpha, log_probs=False):
+        if log_probs:
+            if alpha is None:
+                raise TypeError("log_probs=True needs alpha (the reference multiplies by it)")
+            return _ClusterFunction.apply(x, self.clusters, alpha, True)[2]
+        loss, probs, _ = _ClusterFunction.apply(x, self.clusters, alpha, False)
+        return loss, probs
+
+
+class _ProbeCeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label):
+        lib = _lib.load()
+        lg = _gpu32(logits, "linear_logits")
+        if not label.is_cuda:
+            raise RuntimeError("depthg_amd: `label` must live on the GPU; there is no CPU path")
+        lab = label.detach().to(torch.int64).contiguous()
+        B, n, h, w = lg.shape
+        H, W = lab.shape[-2:]
+        lab = lab.reshape(B, H, W)
+        dev = lg.device
+        out3 = _empty((3,), torch.float32, dev)
+        scratch = _empty((2 * B * H,), torch.float32, dev)
+        rc = lib.dg_probe_ce_forward(_ptr(lg), _ptr(lab), B, n, h, w, H, W, _ptr(out3), _ptr(scratch), _stream(dev))
+        _lib.check(rc, "dg_probe_ce_forward")
+        ctx.dims = (B, n, h, w, H, W)
+        ctx.save_for_backward(lg, lab, out3)
+        return out3[2]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lib = _lib.load()
+        lg, lab, out3 = ctx.saved_tensors
+        B, n, h, w, H, W = ctx.dims
+        g = _gpu32(gloss, "grad_loss").reshape(1)
+        gl = _empty((B, n, h, w), torch.float32, lg.device)
+        rc = lib.dg_probe_ce_backward(_ptr(lg), _ptr(lab), _ptr(out3), _ptr(g), B, n, h, w, H, W, _ptr(gl), _stream(lg.device))
+        _lib.check(rc, "dg_probe_ce_backward")
+        return gl, None
+
+
+def probe_cross_entropy(linear_logits, label):
+    """`CrossEntropyLoss()(interpolate(linear_logits, label.shape[-2:], 'bilinear', align_corners=False)[mask], label[mask])`
+    with mask = (label >= 0) & (label < n_classes)  (src/train_segmentation.py:421-434), without the label-resolution logits."""
+    return _ProbeCeFunction.apply(linear_logits, label)

@@ -2,57 +2,35 @@
 (SURVEY.md section 8 rows A14, N1 and the step-level caller around A13).
 
 Mirrors, with the reference's names, parameter layout and arithmetic:
-    ProjectionHead          the trainable part of DinoFeaturizer - `cluster1` (1x1 conv C -> dim) and, for
-                            projection_type == "nonlinear", `cluster2` (1x1 conv C -> C, ReLU, 1x1 conv C -> dim), each fed by its
-                            OWN Dropout2d(p=.1) mask of the backbone features (src/modules.py:39,75-88,122-126; quirk Q10)
     StandInFeaturizer       a featurizer with DinoFeaturizer's output contract (src/modules.py:90-137: train -> (feats, code,
                             attn), eval -> (feats, code); feats get a third Dropout2d mask when cfg.dropout).  The frozen DINO
                             ViT itself is out of scope (north_star: "the Python host calls PyTorch-ROCm for the ViT forward") and
                             its weights cannot be fetched here, so the backbone is a frozen random patch embedding of the same
                             geometry (patch size, n_feats, no gradient) - any module returning (B, n_feats, H/p, W/p) can be
-                            passed instead.
-    ClusterLookup           src/modules.py:647-675 (cosine cluster probe, hard assignment when alpha is None)
+                            passed instead.  Its head (`cluster1` / `cluster2`, the three Dropout2d draws) is ONE fused HIP launch
+                            (depthg_amd/head.py run_head -> dg_head_forward / dg_head_backward).
     UnsupervisedSegmenter   LitUnsupervisedSegmenter without Lightning (src/train_segmentation.py:71-158, 169-462): attributes
                             net / train_cluster_probe / cluster_probe / linear_probe / contrastive_corr_loss_fn / cfg /
                             n_classes / use_depth, forward(x) = net(x)[1], configure_optimizers() -> three Adams,
                             training_step(batch, batch_idx) with manual optimisation: two featurizer passes, the HIP correlation
                             loss (and the second LHP call when cfg.lhp), the weighted total, the live legacy decay of the cfg
                             scalars, linear-probe cross entropy and cluster-probe loss on the detached code, backward, three steps.
-The 1x1 convolutions are plain GEMMs and stay library calls (torch on ROCm = rocBLAS / MIOpen); everything the correlation
-loss does runs in the HIP library.  Under data parallelism the head gradients are what `parallel.GradBucket` all-reduces.
+ProjectionHead / ClusterLookup (src/modules.py:647-675) / probe_cross_entropy live in depthg_amd/head.py and are re-exported
+here.  The head, the probes' losses and everything the correlation loss does run in the HIP library; what stays torch is the
+frozen backbone, the 27 x dim linear-probe convolution and the three Adams.  Under data parallelism `all_reduced_parameters()` is
+what `parallel.GradBucket` all-reduces.
 """
 from types import SimpleNamespace
 from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .depth_decay import legacy_decay_step
+from .head import ClusterLookup, ProjectionHead, probe_cross_entropy, run_head
 from .lhp import LocalHiddenPositiveProjection, OriginalLocalHiddenPositiveProjection
 from .loss import ContrastiveCorrelationLoss
 from .training import correspondence_total
-
-
-class ProjectionHead(nn.Module):
-    """cluster1 / cluster2 of DinoFeaturizer (src/modules.py:75-88) with the reference's module and parameter names, so that a
-    reference checkpoint's `net.cluster1.0.weight`, `net.cluster2.0.weight`, ... load unchanged."""
-
-    def __init__(self, n_feats: int, dim: int, projection_type: Optional[str] = "nonlinear"):
-        super().__init__()
-        self.n_feats, self.dim, self.proj_type = n_feats, dim, projection_type
-        self.dropout = nn.Dropout2d(p=.1)
-        self.cluster1 = nn.Sequential(nn.Conv2d(n_feats, dim, (1, 1)))
-        if projection_type == "nonlinear":
-            self.cluster2 = nn.Sequential(nn.Conv2d(n_feats, n_feats, (1, 1)), nn.ReLU(), nn.Conv2d(n_feats, dim, (1, 1)))
-
-    def forward(self, image_feat: torch.Tensor) -> torch.Tensor:
-        if self.proj_type is None:                      # src/modules.py:127-128
-            return image_feat
-        code = self.cluster1(self.dropout(image_feat))  # :123   (own Dropout2d draw)
-        if self.proj_type == "nonlinear":
-            code = code + self.cluster2(self.dropout(image_feat))   # :124-125 (a second, independent draw)
-        return code
 
 
 class StandInFeaturizer(nn.Module):
@@ -70,7 +48,7 @@ class StandInFeaturizer(nn.Module):
         for p in self.model.parameters():                       # frozen, as the DINO ViT (:34-35)
             p.requires_grad = False
         self.dropout = nn.Dropout2d(p=.1)
-        head = ProjectionHead(self.n_feats, dim, getattr(cfg, "projection_type", "nonlinear"))
+        head = ProjectionHead(self.n_feats, dim, getattr(cfg, "projection_type", "nonlinear"))   # (modules only: run_head does the work)
         self.cluster1 = head.cluster1                           # registered under the reference's names
         if hasattr(head, "cluster2"):
             self.cluster2 = head.cluster2
@@ -99,39 +77,13 @@ class StandInFeaturizer(nn.Module):
                 return image_feat.mean((2, 3), keepdim=True)
             attn = self._last_selfattention(img, image_feat)
         if self.proj_type is not None:
-            code = self.cluster1(self.dropout(image_feat))
-            if self.proj_type == "nonlinear":
-                code = code + self.cluster2(self.dropout(image_feat))
+            # one fused HIP launch: code = cluster1(drop(f)) [+ cluster2(drop(f))] and feats = drop(f) (:122-132; three draws)
+            code, feats = run_head(self.cluster1, self.cluster2 if self.proj_type == "nonlinear" else None, image_feat,
+                                   self.training, bool(self.cfg.dropout), float(self.dropout.p))
         else:
             code = image_feat
-        feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
+            feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
         return (feats, code, attn) if self.training else (feats, code)
-
-
-class ClusterLookup(nn.Module):
-    """src/modules.py:647-675."""
-
-    def __init__(self, dim: int, n_classes: int):
-        super().__init__()
-        self.n_classes, self.dim = n_classes, dim
-        self.clusters = nn.Parameter(torch.randn(n_classes, dim))
-
-    def reset_parameters(self):
-        with torch.no_grad():
-            self.clusters.copy_(torch.randn(self.n_classes, self.dim))
-
-    def forward(self, x, alpha, log_probs=False):
-        normed_clusters = F.normalize(self.clusters, dim=1)
-        normed_features = F.normalize(x, dim=1)
-        inner_products = torch.einsum("bchw,nc->bnhw", normed_features, normed_clusters)
-        if alpha is None:
-            cluster_probs = F.one_hot(torch.argmax(inner_products, dim=1), self.clusters.shape[0]).permute(0, 3, 1, 2).to(torch.float32)
-        else:
-            cluster_probs = F.softmax(inner_products * alpha, dim=1)
-        cluster_loss = -(cluster_probs * inner_products).sum(1).mean()
-        if log_probs:
-            return F.log_softmax(inner_products * alpha, dim=1)
-        return cluster_loss, cluster_probs
 
 
 class UnsupervisedSegmenter(nn.Module):
@@ -146,7 +98,7 @@ class UnsupervisedSegmenter(nn.Module):
         self.train_cluster_probe = ClusterLookup(dim, n_classes)                      # :110
         self.cluster_probe = ClusterLookup(dim, n_classes + cfg.extra_clusters)       # :112
         self.linear_probe = nn.Conv2d(dim, n_classes, (1, 1))                         # :113
-        self.linear_probe_loss_fn = nn.CrossEntropyLoss()                             # :127
+        self.linear_probe_loss_fn = nn.CrossEntropyLoss()                             # :127 (kept for the surface; the step uses the fused HIP loss)
         self.contrastive_corr_loss_fn = ContrastiveCorrelationLoss(cfg)               # :131 (shares cfg: the decay below mutates it)
         for p in self.contrastive_corr_loss_fn.parameters():                          # :136
             p.requires_grad = False
@@ -216,13 +168,10 @@ class UnsupervisedSegmenter(nn.Module):
         legacy_decay_step(cfg, self.contrastive_corr_loss_fn.cfg, self.global_step)                  # :356-375 (mutates cfg)
 
         # probes on the detached code (:421-444)
-        flat_label = label.reshape(-1)
-        mask = (flat_label >= 0) & (flat_label < self.n_classes)
         detached_code = code.detach().clone()
-        linear_logits = self.linear_probe(detached_code)
-        linear_logits = F.interpolate(linear_logits, label.shape[-2:], mode="bilinear", align_corners=False)
-        linear_logits = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.n_classes)
-        linear_loss = self.linear_probe_loss_fn(linear_logits[mask], flat_label[mask]).mean()
+        # resize to the label resolution + masked cross entropy in one HIP kernel (the reference materialises the logits at label
+        # resolution and three masks, :427-434); the cluster probe's similarity / arg-max / loss likewise
+        linear_loss = probe_cross_entropy(self.linear_probe(detached_code), label)
         cluster_loss, _ = self.cluster_probe(detached_code, None)
         loss = loss + linear_loss + cluster_loss
         logs.update({"loss/linear": linear_loss.detach(), "loss/cluster": cluster_loss.detach(), "loss/total": loss.detach()})

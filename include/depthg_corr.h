@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 106   /* 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 107   /* 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -297,6 +297,63 @@ int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, int64_t* out,
  * yields new permutations on every replay - the reference draws them with the device generator at the same place,
  * src/modules.py:1184-1188,1336-1339. */
 int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+
+/*
+ * The segmentation head of DinoFeaturizer (replaces `cluster1(dropout(f)) + cluster2(dropout(f))` and the third
+ * `dropout(f)` of src/modules.py:122-132, modules cluster1 / cluster2 of :75-88): 1x1 convolutions as bf16 MFMA products with
+ * fp32 accumulation, Dropout2d and ReLU fused (a dropped channel is a zeroed weight column, 1/(1-p) scales the accumulator),
+ * the fp32 features read once.
+ *  feat                 : fp32 (B,C,P), P = h*w, C <= 768 and a multiple of 8
+ *  w1,b1                : cluster1[0].weight (D,C), .bias (D); D <= 128
+ *  w2a,b2a,w2b,b2b      : cluster2[0] (C,C),(C) and cluster2[2] (D,C),(D); all NULL for projection_type "linear"
+ *  keep1,keep2,keep3    : fp32 (B,C) 1 = keep / 0 = drop: the three Dropout2d draws in the reference's order (cluster1's
+ *                         input, cluster2's input, the returned feats); NULL = no dropout for that use (eval mode)
+ *  keep_scale           : 1/(1-p)
+ *  code                 : fp32 (B,D,P) out
+ *  feats_out            : fp32 (B,C,P) out = feat * keep3 * keep_scale, or NULL
+ *  hidden               : bf16 (B,C,P) out: cluster2's ReLU output, needed by dg_head_backward; may be NULL without one
+ */
+int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
+                    const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                    const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                    float* code, float* feats_out, void* hidden, dg_stream_t stream);
+/* Bytes of scratch dg_head_backward needs (d hidden + the split partial sums of the three weight gradients). */
+size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32_t P);
+/*
+ * Gradients of the six head tensors from grad_code (B,D,P) (the backbone is frozen: nothing flows into feat).  Same feat /
+ * keep1 / keep2 / keep_scale / hidden as the forward.  grad_* : fp32, shapes of the parameters, overwritten; the cluster2
+ * ones are ignored when w2b is NULL.  Bit-reproducible (no floating-point atomics).
+ */
+int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
+                     float keep_scale, const void* hidden, const float* w2b, const float* grad_code,
+                     float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
+                     void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * ClusterLookup.forward (src/modules.py:664-675): inner = <normalize(x), normalize(clusters)>, probs = one-hot(arg-max) when
+ * alpha is NaN (the reference's `alpha is None`) else softmax(alpha * inner), loss = -mean over (B,P) of sum_n probs * inner.
+ *  x : fp32 (B,D,P)   clusters : fp32 (n,D), n * (D + 1) <= 16000   inner : fp32 (B,n,P) out (the backward reads it)
+ *  probs, logp (= log_softmax(alpha * inner)) : fp32 (B,n,P) out or NULL     loss : fp32 [1] out
+ *  scratch : fp32 [B * ceil(P/256)]
+ * dg_cluster_lookup_backward: grad_clusters (n,D) and, when grad_x is not NULL, grad_x (B,D,P) for the upstream grad_loss [1]
+ * (device).  scratch : fp32 [B*n*P + B*ceil(P/64)*n*D].
+ */
+int dg_cluster_lookup_forward(const float* x, const float* clusters, float alpha, int32_t B, int32_t D, int32_t n, int32_t P,
+                              float* inner, float* probs, float* logp, float* loss, float* scratch, dg_stream_t stream);
+int dg_cluster_lookup_backward(const float* x, const float* clusters, const float* inner, float alpha, const float* grad_loss,
+                               int32_t B, int32_t D, int32_t n, int32_t P, float* grad_clusters, float* grad_x, float* scratch,
+                               dg_stream_t stream);
+
+/*
+ * The linear probe's loss (src/train_segmentation.py:427-434): logits (B,n,h,w) resized to the label resolution with
+ * F.interpolate(mode="bilinear", align_corners=False), cross entropy over the pixels with 0 <= label < n, mean.
+ *  label : int64 (B,H,W)    out3 : fp32 [3] = {sum of -log p[label], labelled pixels, loss}    scratch : fp32 [2*B*H]
+ * dg_probe_ce_backward: grad_logits (B,n,h,w) for the upstream grad_loss [1]; out3 as the forward wrote it.  n*w <= 2048.
+ */
+int dg_probe_ce_forward(const float* logits, const int64_t* label, int32_t B, int32_t n, int32_t h, int32_t w, int32_t H, int32_t W,
+                        float* out3, float* scratch, dg_stream_t stream);
+int dg_probe_ce_backward(const float* logits, const int64_t* label, const float* out3, const float* grad_loss, int32_t B, int32_t n,
+                         int32_t h, int32_t w, int32_t H, int32_t W, float* grad_logits, dg_stream_t stream);
 
 /* Measurement aid: name of the kernel the fused correlation launch of this descriptor runs ("k_corr2": the one-wave-per-SIMD
  * form of dg_corr2.hip, "k_corr_main": the general form), decided by the same predicate the launch uses; NULL on a bad desc. */

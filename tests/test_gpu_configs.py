@@ -35,16 +35,20 @@ def _pair(cfg, f, fp, c, cp, d, dp, coords1, coords2, perms, dev, **kw):
     return ref, (cr.grad, cpr.grad), out, (cg.grad.cpu(), cpg.grad.cpu())
 
 
-def _check(ref, rgrads, out, ggrads, rt=2e-3, gt=3e-2):
+def _check(ref, rgrads, out, ggrads, rt=1.5e-4, at=3e-7, gt=2.1e-2, worst=0.16):
+    """Bounds at <= 1.5 x the errors measured at these recipes (profiles/r03_parity.md, scripts/parity_table.py): loss means 1e-4
+    relative at worst (the near-cancelling intra mean of config 2; 1e-5 and below elsewhere) - the north_star tolerance -,
+    gradients 1.0-1.4e-2 relative L2 and 3-10 % of the largest element (clamp-mask flips of the fp16 cd)."""
     n = len(ref)
     for i in range(0, n, 2):
-        _relclose(out[i].mean(), ref[i].mean(), rt, 1e-5, f"tuple[{i}]")
+        _relclose(out[i].mean(), ref[i].mean(), rt, at, f"tuple[{i}]")
     for i in range(1, n, 2):
-        _relclose(out[i].mean(), ref[i].mean(), rt, 1e-5, f"tuple[{i}] mean")
+        _relclose(out[i].mean(), ref[i].mean(), 2e-3, 1e-5, f"tuple[{i}] mean")
     for got, want in zip(ggrads, rgrads):
         assert torch.isfinite(got).all()
-        rel = (got - want).norm() / want.norm()
-        assert rel < gt, float(rel)
+        rel = float((got - want).norm() / want.norm())
+        w = float((got - want).abs().max() / want.abs().max())
+        assert rel < gt and w < worst, (rel, w)
 
 
 def test_config4_shard_shape_fps(dev):
@@ -75,7 +79,7 @@ def test_config3_vitb_no_pointwise(dev):
     depth_sampling=none, pointwise=False (no centering: the rank-1 correction is off, m0 unused)."""
     from oracle import depthg_oracle as O
     g = torch.Generator().manual_seed(303)
-    B, C, D, hw, S, N = 4, 768, 100, 28, 11, 5
+    B, C, D, hw, S, N = 32, 768, 100, 28, 11, 5
     f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
     c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
     d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float()
@@ -93,7 +97,7 @@ def test_config2_potsdam_recipe_fps(dev):
     quantised to {0, 1} as the Potsdam loader leaves it (quirk Q11), so the depth indicators are mixed."""
     from oracle import depthg_oracle as O
     g = torch.Generator().manual_seed(202)
-    B, C, D, hw, S, N = 4, 384, 90, 28, 11, 5
+    B, C, D, hw, S, N = 16, 384, 90, 28, 11, 5
     f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
     c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
     d = (torch.rand(B, 1, 224, 224, generator=g) > 0.3).float()
@@ -121,7 +125,7 @@ def test_config5_hires_56_vs_oracle(dev):
     coords = identity_coords(B, hw, "cpu")
     perms = [O.super_perm(B, g) for _ in range(N)]
     ref, rg, out, gg = _pair(cfg, f, fp, c, cp, d, d, coords, coords, perms, dev, shared_coords=True, identity_grid=True)
-    _check(ref, rg, out, gg, rt=5e-4)
+    _check(ref, rg, out, gg, rt=2e-4, at=5e-6)      # (B = 2 of 32: measured 7.5-8.6e-5 per term)
     # the general gather path on the same coordinates (no identity flag) must agree with the fast path
     _, _, out2, gg2 = _pair(cfg, f, fp, c, cp, d, d, coords, coords, perms, dev)
     for i in (0, 2, 4, 6):
@@ -420,8 +424,9 @@ def test_bench_line_of_the_multi_gpu_schedule():
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29691")
     lines = {}
-    for mode in ("--force-dist", "--graph"):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), mode, "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+    for mode in ("--force-dist", "--graph", "--eager"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), mode, "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                            "--clock-warmup-s", "0.05"],
                            capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         last = r.stdout.strip().splitlines()[-1]
@@ -434,4 +439,9 @@ def test_bench_line_of_the_multi_gpu_schedule():
     assert "side stream" in d["config"]["allreduce"] and "hipGraph" in d["config"]["workload"]
     assert d["roofline"]["kernel"] == "k_corr2" and 0.2 < d["roofline"]["frac"] < 0.6
     assert abs(d["loss_total"] - lines["--graph"]["loss_total"]) < 0.02 * abs(d["loss_total"])
+    assert abs(d["loss_total"] - lines["--eager"]["loss_total"]) < 0.02 * abs(d["loss_total"])
+    # one schedule at every N: the plain single-GPU line is the replayed step too; --eager is the explicit opt-out
+    assert d["config"]["schedule"] == lines["--graph"]["config"]["schedule"] == "hipGraph replay"
+    assert lines["--eager"]["config"]["schedule"] == "eager" and d["config"]["ranks_seen"] == 1
+    assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r03_pmc_per_launch.json")
 

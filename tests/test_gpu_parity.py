@@ -256,6 +256,45 @@ def test_headline_loss_vs_oracle_subset(dev):
         assert rel < 2e-2 and worst < 0.12, (name, float(rel), float(worst))
 
 
+def test_headline_full_batch_vs_oracle(dev):
+    """THE headline, whole: B=32, C=384, D=70, 28x28 dense grid, 5 negatives, depth term - bench.py's workload with its recipe
+    scalars - against the CPU oracle (about two seconds on 16 host threads).  Loss means and the weighted total within the
+    north_star tolerance of 1e-4 relative (measured 0 .. 4.4e-6, profiles/r03_parity.md); gradients at 1.5 x the measurement
+    (1.4e-2 relative L2; largest element error 2.9 % / 8.7 % of the largest element)."""
+    import os
+    import bench
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    conf = bench.CONFIGS["headline"]
+    H = conf["H"]
+    B, hw = H["B"], H["S"]
+    f, fp, c, cp, d, dp = bench.synth_inputs(B, 1234, "cpu", H)
+    g = torch.Generator().manual_seed(1235)
+    perms = [O.super_perm(B, g) for _ in range(H["n_neg"])]
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=H["n_neg"], dim=H["D"], dg_outputs="reduced", **conf["scal"])
+    coords = O.identity_coords(B, hw)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, dp, coords1=coords, coords2=coords, perms=perms)
+    tot_ref = O.total_loss(cfg, ref)
+    tot_ref.backward()
+    T = lambda t: t.to(dev)
+    cg, cpg = T(c).requires_grad_(True), T(cp).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(T(f), T(fp), cg, cpg, T(d), T(coords), T(coords), [T(p) for p in perms],
+                                                       shared_coords=True, identity_grid=True)
+    tot = O.total_loss(cfg, out)
+    tot.backward()
+    for i in (0, 2, 4, 6):
+        _relclose(out[i].mean(), ref[i].mean(), 1e-4, 0.0, f"loss term {i}")
+    _relclose(tot, tot_ref, 1e-4, 0.0, "weighted total")
+    for i in (1, 3, 5):
+        _relclose(out[i].mean(), ref[i].mean(), 1e-3, 1e-7, f"cd mean {i}")
+    for got, want, name in ((cg.grad.cpu(), cr.grad, "code"), (cpg.grad.cpu(), cpr.grad, "code_pos")):
+        rel = (got - want).norm() / want.norm()
+        worst = (got - want).abs().max() / want.abs().max()
+        assert rel < 2.1e-2 and worst < 0.13, (name, float(rel), float(worst))
+
+
 def test_headline_width_without_clamp_gradient(dev):
     """The same width with zero_clamp off (no mask, nothing discontinuous): the kernels' own arithmetic error.  Measured 4e-4
     (code) / 2e-3 (code_pos) relative L2; bounds 3e-3 relative L2 and 5e-3 of the largest element."""
