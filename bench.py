@@ -33,6 +33,12 @@ CONFIGS = {
                                pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
                      what="headline: B=32/GPU, C=384, D=70, 28x28 dense grid (S=28, P=784), 5 negatives, depth term on, pointwise, "
                           "zero_clamp; fwd + bwd to orig_code/orig_code_pos", cpu_B=32),
+    "headline+head": dict(H=HEADLINE, sampling="none", dense=True, pointwise=True, head=True,
+                          scal=dict(pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761, depth_feat_shift=0.03,
+                                    pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
+                          what="headline + the segmentation head: backbone features (B,384,28,28) x 2 -> cluster1 / cluster2 with their "
+                               "three Dropout2d draws (HIP head, bf16 MFMA) -> the headline loss -> backward into the 201,740 head "
+                               "parameters (the all-reduced bucket holds these real gradients)", cpu_B=32),
     "C2": dict(H=dict(B=16, C=384, D=90, h=28, w=28, S=11, n_neg=5, depth_hw=224), sampling="fps", dense=False, pointwise=True,
                scal=dict(pos_intra_shift=0.2, pos_inter_shift=0.09, neg_inter_shift=0.63, depth_feat_shift=0.14,
                          pos_intra_weight=0.61, pos_inter_weight=0.34, neg_inter_weight=0.72, depth_feat_weight=0.13),
@@ -109,6 +115,10 @@ def _cpu_baseline_at(conf, ncores, seconds_budget, Bs):
     f, fp, c, cp, d, dp = synth_inputs(Bs, 4321, "cpu", H)
     g = torch.Generator().manual_seed(7)
     perms = [O.super_perm(Bs, g) for _ in range(H["n_neg"])]
+    if conf.get("head"):
+        C_, D_ = H["C"], H["D"]
+        head_prm = [(torch.randn(sh, generator=g) * 0.05).requires_grad_(True)
+                    for sh in ((D_, C_), (D_,), (C_, C_), (C_,), (D_, C_), (D_,))]
     times = []
     t_start = time.time()
     for rep in range(40):
@@ -123,7 +133,14 @@ def _cpu_baseline_at(conf, ncores, seconds_budget, Bs):
         else:
             coords1 = torch.rand(Bs, H["S"], H["S"], 2, generator=g) * 2 - 1
             coords2 = torch.rand(Bs, H["S"], H["S"], 2, generator=g) * 2 - 1
-        out = O.forward(cfg, f, fp, c1, cp1, d, dp, coords1=coords1, coords2=coords2, perms=perms)
+        if conf.get("head"):               # the head in front of the loss: c / cp play no role, the code comes from the features
+            from oracle import head_oracle as HO
+            keeps = [tuple((torch.rand(Bs, H["C"], generator=g) > 0.1).float() for _ in range(3)) for _ in range(2)]
+            c1, f_in = HO.head_forward(f, *head_prm, keeps=keeps[0])
+            cp1, fp_in = HO.head_forward(fp, *head_prm, keeps=keeps[1])
+        else:
+            f_in, fp_in = f, fp
+        out = O.forward(cfg, f_in, fp_in, c1, cp1, d, dp, coords1=coords1, coords2=coords2, perms=perms)
         O.total_loss(cfg, out).backward()
         times.append(time.time() - t0)
         if time.time() - t_start > seconds_budget and len(times) >= 2:
@@ -213,14 +230,40 @@ def main():
     f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev, H)
     c.requires_grad_(True)
     cp.requires_grad_(True)
-    # stand-in for the head gradients (no head in the loss-only benchmark): a buffer of the head's size filled from this step's
-    # d/d code, averaged over the ranks (RCCL over xGMI).  Two buffers: step i + 1 fills the other one while step i's is in flight
-    buckets = [GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None) for _ in range(2)]
+    # loss-only configurations: a stand-in for the head gradients - a buffer of the head's size filled from this step's d/d code,
+    # averaged over the ranks (RCCL over xGMI); --config headline+head: the real head in front of the loss and its real
+    # gradients in the bucket.  Two buffers: step i + 1 fills the other one while step i's is in flight
+    head, head_params = None, []
+    if conf.get("head"):
+        from depthg_amd.head import ProjectionHead
+        torch.manual_seed(1234 + rank)
+        head = ProjectionHead(H["C"], H["D"], "nonlinear").to(dev).train()
+        head_params = list(head.parameters())
+        c.requires_grad_(False)
+        cp.requires_grad_(False)
+        buckets = [GradBucket.for_parameters(head_params, dist if use_dist else None) for _ in range(2)]
+        assert buckets[0].flat.numel() == HEAD_GRAD_ELEMS
+    else:
+        buckets = [GradBucket(HEAD_GRAD_ELEMS, dev, dist if use_dist else None) for _ in range(2)]
     comm = torch.cuda.Stream() if use_dist else None     # the gradient exchange runs here
     seed_grad = torch.ones((), device=dev)   # d(total)/d(total): the upstream of the step, resident like the other inputs
     counter = [0]
 
+    def compute_with_head(bucket=None):
+        for prm in head_params:
+            prm.grad = None
+        code, feats = head(f)              # f / fp are the frozen backbone's outputs here; three Dropout2d draws per pass
+        code_pos, feats_pos = head(fp)
+        loss_fn(feats, feats_pos, None, None, code, code_pos, d, dp)
+        total = loss_fn.total
+        total.backward(gradient=seed_grad)
+        if bucket is not None:
+            bucket.pack()                  # the real head gradients
+        return total
+
     def compute(bucket=None):
+        if head is not None:
+            return compute_with_head(bucket)
         c.grad = None
         cp.grad = None
         loss_fn(f, fp, None, None, c, cp, d, dp)
@@ -286,8 +329,12 @@ def main():
         def step():
             k = counter[0] & 1
             counter[0] += 1
-            total = compute()
-            buckets[k].exchange_on(comm, c.grad, even_if_alone=args.force_dist)
+            if head is not None:
+                total = compute(buckets[k])
+                buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
+            else:
+                total = compute()
+                buckets[k].exchange_on(comm, c.grad, even_if_alone=args.force_dist)
             return total
 
     def sync():

@@ -17,7 +17,7 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
-           "dg_head_forward", "dg_head_workspace_bytes", "dg_head_backward", "dg_cluster_lookup_forward",
+           "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_cluster_lookup_forward",
            "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward"]
 
 
@@ -58,7 +58,9 @@ def load():
     lib.dg_corr_forward_draw.argtypes = [cp] + [vp] * 8 + [ctypes.c_uint64, vp, vp, vp, ctypes.c_size_t, vp]
     i32, f32 = ctypes.c_int32, ctypes.c_float
     lib.dg_head_forward.restype = ctypes.c_int
-    lib.dg_head_forward.argtypes = [i32] * 4 + [vp] * 10 + [f32] + [vp] * 4
+    lib.dg_head_forward.argtypes = [i32] * 4 + [vp] * 10 + [f32] + [vp] * 5
+    lib.dg_head_weights_bytes.restype = ctypes.c_size_t
+    lib.dg_head_weights_bytes.argtypes = [i32] * 2
     lib.dg_head_workspace_bytes.restype = ctypes.c_size_t
     lib.dg_head_workspace_bytes.argtypes = [i32] * 4
     lib.dg_head_backward.restype = ctypes.c_int

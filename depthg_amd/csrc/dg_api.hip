@@ -747,38 +747,52 @@ static int head_check(int32_t B, int32_t C, int32_t D, int32_t P) {
 }
 static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
-    int s = (512 + tiles - 1) / tiles;
+    int s = (512 + tiles - 1) / tiles;        // about two blocks per CU
     return s < 1 ? 1 : (s > steps ? steps : s);
 }
-struct HeadPlan { size_t dh, p2a, p1, p2b, total; int s2a, s1, s2b; };
+struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, total; int s2a, s1, s2b, tiles; };
 static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     HeadPlan h;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
     h.s2a = head_splits(B, C, C, P); h.s1 = head_splits(B, D, C, P); h.s2b = h.s1;
+    h.tiles = (P + 63) / 64;
     h.dh = take((size_t)B * C * P * 2);
     h.p2a = take((size_t)h.s2a * C * C * 4);
     h.p1 = take((size_t)h.s1 * D * C * 4);
     h.p2b = take((size_t)h.s2b * D * C * 4);
+    h.pbd = take((size_t)B * h.tiles * D * 4);
+    h.pb2a = take((size_t)B * h.tiles * C * 4);
     h.total = off;
     return h;
+}
+static size_t head_weights_bytes(int32_t C, int32_t D) {
+    const size_t DP = (size_t)(D + 31) / 32 * 32;
+    return ((size_t)2 * D * C + (size_t)C * C + (size_t)C * DP) * 2;
+}
+extern "C" size_t dg_head_weights_bytes(int32_t C, int32_t D) {
+    if (head_check(1, C, D, 1) != DG_OK) return 0;
+    return head_weights_bytes(C, D);
 }
 
 extern "C" int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
                                const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
                                const float* keep1, const float* keep2, const float* keep3, float keep_scale,
-                               float* code, float* feats_out, void* hidden, dg_stream_t stream_) {
+                               float* code, float* feats_out, void* hidden, void* wscratch, dg_stream_t stream_) {
     if (int rc = head_check(B, C, D, P)) return rc;
-    if (!feat || !w1 || !b1 || !code) return fail(DG_ERR_INVALID, "null pointer");
+    if (!feat || !w1 || !b1 || !code || !wscratch) return fail(DG_ERR_INVALID, "null pointer");
     const bool nonlinear = w2a != nullptr;
     if (nonlinear && (!b2a || !w2b || !b2b)) return fail(DG_ERR_INVALID, "cluster2 needs all four of its tensors");
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    DG_HIP(dg_launch_head_prep(w1, w2a, w2b, wscratch, C, D, s));
     DgHeadFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.feat = feat; a.w1 = w1; a.b1 = b1; a.w2a = w2a; a.b2a = b2a; a.w2b = w2b; a.b2b = b2b;
+    a.w1_bf = static_cast<const __bf16*>(wscratch); a.w2a_bf = a.w1_bf + (size_t)D * C; a.w2b_bf = a.w2a_bf + (size_t)C * C;
     a.keep1 = keep1; a.keep2 = keep2; a.keep3 = keep3; a.scale = keep_scale;
     a.code = code; a.feats_out = feats_out; a.hidden = static_cast<__bf16*>(hidden);
     a.B = B; a.C = C; a.D = D; a.P = P;
-    DG_HIP(dg_launch_head_fwd(a, static_cast<hipStream_t>(stream_)));
+    DG_HIP(dg_launch_head_fwd(a, s));
     return DG_OK;
 }
 
@@ -788,38 +802,47 @@ extern "C" size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32
 }
 
 extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
-                                float keep_scale, const void* hidden, const float* w2b, const float* grad_code,
+                                float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
                                 float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
                                 void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     if (int rc = head_check(B, C, D, P)) return rc;
     if (!feat || !grad_code || !grad_w1 || !grad_b1 || !workspace) return fail(DG_ERR_INVALID, "null pointer");
-    const bool nonlinear = w2b != nullptr;
-    if (nonlinear && (!hidden || !grad_w2a || !grad_b2a || !grad_w2b || !grad_b2b)) return fail(DG_ERR_INVALID, "null cluster2 pointer");
+    const bool nonlinear = grad_w2a != nullptr;
+    if (nonlinear && (!hidden || !wscratch || !grad_b2a || !grad_w2b || !grad_b2b)) return fail(DG_ERR_INVALID, "null cluster2 pointer");
     const HeadPlan h = head_plan(B, C, D, P);
     if (workspace_bytes < h.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, h.total);
     hipStream_t s = static_cast<hipStream_t>(stream_);
     char* ws = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    DgHeadReduceArgs red;
+    memset(&red, 0, sizeof(red));
+    auto reduce = [&](const float* part, float* out, float* out2, int n, int splits, float scale) {
+        red.jobs[red.njobs++] = DgHeadReduceJob{part, out, out2, n, splits, scale};
+    };
     // d W1[d][k] = scale * keep1[b][k] * sum_p g[d][p] f[k][p]
     {
         DgHeadWgradArgs w{grad_code, feat, keep1, F32(h.p1), B, D, C, P, h.s1};
         DG_HIP(dg_launch_head_wgrad(w, false, false, s));
-        DG_HIP(dg_launch_head_reduce(F32(h.p1), grad_w1, D * C, h.s1, keep1 ? keep_scale : 1.f, s));
+        reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s1, keep1 ? keep_scale : 1.f);
     }
-    // d b1 (= d b2b) = row sums of d code
-    DG_HIP(dg_launch_head_rowsum(grad_code, false, grad_b1, nonlinear ? grad_b2b : nullptr, B, D, P, s));
-    if (nonlinear) {
-        __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
-        DgHeadDhArgs d{grad_code, w2b, static_cast<const __bf16*>(hidden), dh, B, C, D, P};
-        DG_HIP(dg_launch_head_dh(d, s));
-        DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
-        DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
-        DG_HIP(dg_launch_head_reduce(F32(h.p2b), grad_w2b, D * C, h.s2b, 1.f, s));
-        DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a};
-        DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
-        DG_HIP(dg_launch_head_reduce(F32(h.p2a), grad_w2a, C * C, h.s2a, keep2 ? keep_scale : 1.f, s));
-        DG_HIP(dg_launch_head_rowsum(dh, true, grad_b2a, nullptr, B, C, P, s));
+    if (!nonlinear) {        // d b1 = row sums of d code
+        DG_HIP(dg_launch_head_rowsum(grad_code, false, grad_b1, nullptr, B, D, P, s));
+        DG_HIP(dg_launch_head_reduce(red, s));
+        return DG_OK;
     }
+    __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
+    const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + (size_t)2 * D * C + (size_t)C * C;
+    DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P};
+    DG_HIP(dg_launch_head_dh(d, s));
+    reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
+    reduce(F32(h.pb2a), grad_b2a, nullptr, C, B * h.tiles, 1.f);
+    DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
+    DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
+    reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
+    DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a};
+    DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
+    reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
+    DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
 }
 

@@ -615,19 +615,23 @@ struct DgHeadFwdArgs {
     const float* w1; const float* b1;      // (D,C), (D)
     const float* w2a; const float* b2a;    // (C,C), (C)   null: projection_type "linear"
     const float* w2b; const float* b2b;    // (D,C), (D)
+    const __bf16* w1_bf; const __bf16* w2a_bf; const __bf16* w2b_bf;   // bf16 copies of the three weight matrices (k_head_prep)
     const float* keep1; const float* keep2; const float* keep3;   // (B,C): 1 keep / 0 drop; null: no dropout for that use
     float scale;                           // 1/(1-p) applied where a keep mask is given
     float* code;                           // (B,D,P)
     float* feats_out;                      // (B,C,P) = f * keep3 * scale, or null
     __bf16* hidden;                        // (B,C,P) bf16: ReLU output saved for the backward, or null
     int32_t B, C, D, P;
+    unsigned long long* stamps;            // developer timing stamps (null in production)
 };
 
 struct DgHeadDhArgs {
     const float* gcode;      // (B,D,P) fp32
-    const float* w2b;        // (D,C)
+    const __bf16* w2bT;      // (C, DP) bf16: W2b transposed, DP = D rounded up to 32, zero padded (k_head_prep)
     const __bf16* hidden;    // (B,C,P)
     __bf16* dh;              // (B,C,P) out
+    float* part_bd;          // [B * tiles][D] per-block row sums of d code (bias gradients of the output convolutions)
+    float* part_b2a;         // [B * tiles][C] per-block row sums of d hidden_pre
     int32_t B, C, D, P;
 };
 
@@ -639,9 +643,12 @@ struct DgHeadWgradArgs {
 };
 
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
+hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);
 hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s);
-hipError_t dg_launch_head_reduce(const float* part, float* out, int n, int splits, float scale, hipStream_t s);
+struct DgHeadReduceJob { const float* part; float* out; float* out2; int32_t n, splits; float scale; };
+struct DgHeadReduceArgs { DgHeadReduceJob jobs[6]; int32_t njobs; };
+hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s);
 hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s);
 
 // ---- the probes (dg_probe.hip; ClusterLookup src/modules.py:647-675, linear-probe loss src/train_segmentation.py:421-434)

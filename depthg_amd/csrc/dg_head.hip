@@ -10,6 +10,9 @@
 // (the three weight gradients: products over all positions of the batch, split over blocks, partial sums reduced in a fixed order),
 // k_head_rowsum (bias gradients).  No floating-point atomics: results are bit-reproducible.
 #include "dg_common.h"
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -42,116 +45,181 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, const int rowb, const
 // first k of element block u (0: elements 0..3, 1: elements 4..7) of a lane's fragment in the order tr_frag delivers
 __device__ __forceinline__ int frag_k_order(const int lane, const int u) { return 8 * (lane >> 4) + 4 * (u ^ ((lane >> 4) & 1)); }
 
-// eight fp32 weights W[row][k .. k+3], W[row][k' .. k'+3] (k, k' = the lane's two element blocks) times keep flags -> bf16 fragment
-__device__ __forceinline__ bf16x8 weight_frag(const float* __restrict__ W, const int ld, const int row, const int nrows, const int kbase,
-                                              const int K, const float* keep /* LDS [Kpad] or null */, const int lane) {
-    f32x4 v[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int k = kbase + frag_k_order(lane, u);
-        if (row < nrows && k + 3 < K) v[u] = *reinterpret_cast<const f32x4*>(W + (size_t)row * ld + k);
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[u][e] = (row < nrows && k + e < K) ? W[(size_t)row * ld + k + e] : 0.f;
-        }
-        if (keep) {
-            const f32x4 kp = *reinterpret_cast<const f32x4*>(keep + k);
-            v[u] = v[u] * kp;
-        }
-    }
-    return pack8(v[0], v[1]);
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Raw A fragment from bf16 weights W[row][kbase + 8g .. + 7] (one 16-byte load; zero outside the matrix).  K is a multiple of 8.
+__device__ __forceinline__ u32x4 wraw(const __bf16* __restrict__ W, const int ld, const int row, const int nrows, const int kbase,
+                                      const int K, const int lane) {
+    // (always a valid address, the value selected away afterwards: a load under a condition becomes a branch with its own wait,
+    //  and the loads of a k-step would then run one memory latency after the other)
+    const int k = kbase + 8 * (lane >> 4);
+    const bool ok = row < nrows && k < K;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(W + (size_t)(row < nrows ? row : nrows - 1) * ld + (k < K ? k : K - 8));
+    return ok ? v : u32x4{0u, 0u, 0u, 0u};
+}
+// ... masked with the keep bits of its eight k (16-bit all-ones / zero words, natural k order) and brought into tr_frag's k order
+// (odd lane groups hold their two blocks of four in the opposite order)
+__device__ __forceinline__ bf16x8 wfrag(u32x4 v, const u32x4 keep, const int lane) {
+    v &= keep;
+    if ((lane >> 4) & 1) v = u32x4{v[2], v[3], v[0], v[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// fp32 parameters -> bf16 copies for the MFMA kernels: w1 (D,C), w2a (C,C), w2b (D,C) as they are, and w2b transposed (C, DP) with
+// DP = D rounded up to 32 (zero padded) for the backward's d hidden product
+__global__ __launch_bounds__(256) void k_head_prep(const float* __restrict__ w1, const float* __restrict__ w2a, const float* __restrict__ w2b,
+                                                   __bf16* __restrict__ o1, __bf16* __restrict__ o2a, __bf16* __restrict__ o2b,
+                                                   __bf16* __restrict__ o2bT, int C, int D, int DP) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < D * C) { o1[i] = (__bf16)w1[i]; if (w2b) o2b[i] = (__bf16)w2b[i]; }
+    if (w2a && i < C * C) o2a[i] = (__bf16)w2a[i];
+    if (w2b && i < C * DP) { const int m = i / DP, d = i - m * DP; o2bT[i] = d < D ? (__bf16)w2b[(size_t)d * C + m] : (__bf16)0.f; }
+}
+hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s) {
+    const int DP = (D + 31) / 32 * 32;
+    __bf16* o1 = static_cast<__bf16*>(scratch);
+    __bf16* o2a = o1 + (size_t)D * C;
+    __bf16* o2b = o2a + (size_t)C * C;
+    __bf16* o2bT = o2b + (size_t)D * C;
+    const int n = C * (C > DP ? C : DP);
+    hipLaunchKernelGGL(k_head_prep, dim3((n + 255) / 256), dim3(256), 0, s, w1, w2a, w2b, o1, o2a, o2b, o2bT, C, D, DP);
+    return hipGetLastError();
 }
 
 // MB = 16-row blocks of hidden channels per wave (Cpad = 64 MB), NT = positions per block
 template <int MB, int NT>
 __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
-    constexpr int CP = 64 * MB, NB = NT / 16, FROW = NT * 2 + 32, HROW = CP * 2 + 32, DBMAX = 8;
+    constexpr int CP = 64 * MB, NB = NT / 16, FROW = NT * 2 + 32, HROW = CP * 2 + 32, DBMAX = 8, KS = CP / 32;
     extern __shared__ __attribute__((aligned(16))) char hsm[];
     char* const Ft = hsm;                                   // [CP][FROW]  bf16 f tile, channel-major; later Hm [channel][position]
     char* const Ht = hsm + CP * FROW;                       // [NT][HROW]  bf16 hidden tile, position-major
-    float* const km1 = reinterpret_cast<float*>(Ht + NT * HROW);     // [CP] keep flags of cluster1's dropout (1 everywhere without one)
-    float* const km2 = km1 + CP;
+    unsigned short* const km1 = reinterpret_cast<unsigned short*>(Ht + NT * HROW);   // [CP] keep bits of cluster1's dropout (0xffff / 0)
+    unsigned short* const km2 = km1 + CP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y, p0 = blockIdx.x * NT;
     const int C = a.C, D = a.D, P = a.P;
     const bool nonlinear = a.w2a != nullptr;
     const float s1 = a.keep1 ? a.scale : 1.f, s2 = a.keep2 ? a.scale : 1.f, s3 = a.keep3 ? a.scale : 1.f;
+#ifdef DG_DEVTOOLS
+#define HSTAMP(k) if (a.stamps && blockIdx.x == 3 && blockIdx.y == 5 && tid == 0) a.stamps[k] = __builtin_amdgcn_s_memtime();
+#else
+#define HSTAMP(k)
+#endif
+    HSTAMP(0)
 
-    // ---- stage the feature tile: fp32 (C, NT) -> bf16 LDS image, drop3(f) written on the way
+    // ---- stage the feature tile: fp32 (C, NT) -> bf16 LDS image, drop3(f) written on the way.  Eight rows' loads in flight per
+    //      thread (one block per CU: nothing else hides the latency)
     for (int k = tid; k < CP; k += 256) {
-        km1[k] = k < C ? (a.keep1 ? a.keep1[(size_t)b * C + k] : 1.f) : 0.f;
-        km2[k] = k < C ? (a.keep2 ? a.keep2[(size_t)b * C + k] : 1.f) : 0.f;
+        km1[k] = (k < C && (!a.keep1 || a.keep1[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
+        km2[k] = (k < C && (!a.keep2 || a.keep2[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
     }
     {
-        constexpr int Q = NT / 4;
-        const bool vec = (P & 3) == 0;
-        for (int idx = tid; idx < CP * Q; idx += 256) {
-            const int k = idx / Q, q4 = idx - k * Q, p = p0 + 4 * q4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < C) {
-                const float* src = a.feat + ((size_t)b * C + k) * P + p;
-                if (vec && p + 3 < P) v = *reinterpret_cast<const f32x4*>(src);
-                else {
+        constexpr int Q = NT / 4, RPP = 256 / Q, U = (CP / RPP) % 12 == 0 ? 12 : ((CP / RPP) % 8 == 0 ? 8 : 4);     // threads per row, rows per pass, passes batched (loads in flight per thread)
+        const int q4 = tid % Q, kr = tid / Q, p = p0 + 4 * q4;
+        if ((P & 3) == 0) {
+            // fast path: every load unconditional from a clamped address (a load under a condition becomes a branch with its own
+            // wait), values selected afterwards; eight rows in flight per thread
+            const bool pin = p + 3 < P;
+            const int pc = pin ? p : P - 4;
+            for (int kb = 0; kb < CP; kb += RPP * U) {
+                f32x4 v[U];
+                float kf3[U];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (p + e < P) v[e] = src[e];
+                for (int u = 0; u < U; ++u) {
+                    const int k = kb + u * RPP + kr, kc = k < C ? k : C - 1;
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.feat + ((size_t)b * C + kc) * P + pc));
+                    kf3[u] = a.keep3 ? a.keep3[(size_t)b * C + kc] * s3 : 1.f;
                 }
-                if (a.feats_out) {
-                    const float f3 = a.keep3 ? a.keep3[(size_t)b * C + k] * s3 : 1.f;
-                    float* dst = a.feats_out + ((size_t)b * C + k) * P + p;
-                    const f32x4 o = v * f3;
-                    if (vec && p + 3 < P) *reinterpret_cast<f32x4*>(dst) = o;
-                    else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (p + e < P) dst[e] = o[e];
-                    }
+                for (int u = 0; u < U; ++u) {
+                    const int k = kb + u * RPP + kr;
+                    const bool ok = k < C && pin;
+                    const f32x4 vv = ok ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + ((size_t)b * C + k) * P + p) = vv * kf3[u];
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (__bf16)vv[e];
+                    if (k < CP) *reinterpret_cast<bf16x4*>(Ft + k * FROW + q4 * 8) = o4;
                 }
             }
-            bf16x4 o4;
+        } else {
+            // position counts that are not a multiple of 4 (odd maps): element-wise, guarded
+            for (int k = kr; k < CP; k += RPP) {
+                bf16x4 o4;
+                const float f3 = (a.keep3 && k < C) ? a.keep3[(size_t)b * C + k] * s3 : 1.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o4[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4*>(Ft + k * FROW + q4 * 8) = o4;
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (k < C && p + e < P) ? a.feat[((size_t)b * C + k) * P + p + e] : 0.f;
+                    if (a.feats_out && k < C && p + e < P) a.feats_out[((size_t)b * C + k) * P + p + e] = v * f3;
+                    o4[e] = (__bf16)v;
+                }
+                *reinterpret_cast<bf16x4*>(Ft + k * FROW + q4 * 8) = o4;
+            }
         }
     }
     __syncthreads();
+    HSTAMP(1)
 
-    // ---- hidden = relu(s2 * W2a[:, kept] f + b2a): wave `wid` owns hidden channels [16 MB wid, 16 MB (wid + 1))
+    // ---- one k-loop over the input channels for both products that read the feature tile:
+    //        hidden_pre = W2a[:, kept2] f   (wave `wid` owns hidden channels [16 MB wid, 16 MB (wid + 1)), all NB position blocks)
+    //        code1      = W1[:, kept1] f    (wave `wid` owns code-channel blocks wid and wid + 4, all NB position blocks)
+    //      The weight fragments of k-step ks + 1 are in flight while step ks runs.
     f32x4 acc1[MB][NB];
     const int mbase = wid * 16 * MB;
-    if (nonlinear) {
+    // the two output convolutions: wave `wid` owns code-channel blocks wid and wid + 4 (16 channels each, D <= 128) for ALL position
+    // blocks - every weight row is fetched by exactly one wave of the block
+    constexpr int NA = DBMAX / 4;
+    f32x4 acc2a[NA][NB], acc2b[NA][NB];
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < CP / 32; ++ks) {
-            bf16x8 af[MB], bfr[NB];
+        for (int j = 0; j < NB; ++j) { acc2a[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2b[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int i = 0; i < MB; ++i) af[i] = weight_frag(a.w2a, C, mbase + 16 * i + c16, C, 32 * ks, C, km2, lane);
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        u32x4 wn[MB], vn[NA];
+        auto fetch = [&](const int ks) {
+            if (nonlinear) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) wn[i] = wraw(a.w2a_bf, C, mbase + 16 * i + c16, C, 32 * ks, C, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) vn[i] = wraw(a.w1_bf, C, 16 * (wid + 4 * i) + c16, D, 32 * ks, C, lane);
+        };
+        fetch(0);
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 wc[MB], vc[NA];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) wc[i] = wn[i];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) vc[i] = vn[i];
+            if (ks + 1 < KS) fetch(ks + 1);
+            const u32x4 keep2 = *reinterpret_cast<const u32x4*>(km2 + 32 * ks + 8 * g);
+            const u32x4 keep1 = *reinterpret_cast<const u32x4*>(km1 + 32 * ks + 8 * g);
+            bf16x8 bfr[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) bfr[j] = tr_frag(Ft, FROW, 32 * ks, 16 * j, lane);
+            if (nonlinear) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
+                for (int i = 0; i < MB; ++i) {
+                    const bf16x8 af = wfrag(wc[i], keep2, lane);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc1[i][j], 0, 0, 0);
-        }
-    }
-    // ---- cluster1 part of the code: W1[:, kept] f.  Wave -> position block nb, code-channel blocks mb0, mb0 + MSTEP, ...
-    constexpr int MSTEP = 4 / NB;
-    const int nb = wid % NB, mb0 = wid / NB, DB = (D + 15) / 16;
-    f32x4 acc2a[DBMAX / MSTEP], acc2b[DBMAX / MSTEP];
+                    for (int j = 0; j < NB; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc1[i][j], 0, 0, 0);
+                }
+            }
 #pragma unroll
-    for (int i = 0; i < DBMAX / MSTEP; ++i) { acc2a[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2b[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int ks = 0; ks < CP / 32; ++ks) {
-        const bf16x8 bfr = tr_frag(Ft, FROW, 32 * ks, 16 * nb, lane);
+            for (int i = 0; i < NA; ++i) {    // (unconditional: rows beyond D are zero fragments; a condition around an MFMA makes hipcc
+                                              //  shuffle the whole accumulator array through v_accvgpr moves at every branch)
+                const bf16x8 af = wfrag(vc[i], keep1, lane);
 #pragma unroll
-        for (int i = 0; i < DBMAX / MSTEP; ++i) {
-            const int mb = mb0 + i * MSTEP;
-            if (mb < DB) {
-                const bf16x8 af = weight_frag(a.w1, C, 16 * mb + c16, D, 32 * ks, C, km1, lane);
-                acc2a[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc2a[i], 0, 0, 0);
+                for (int j = 0; j < NB; ++j) acc2a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2a[i][j], 0, 0, 0);
             }
         }
     }
+    HSTAMP(2)
     __syncthreads();                                       // every wave is done reading the f tile
+    HSTAMP(3)
     if (nonlinear) {
         // bias + ReLU in the accumulators; hidden tile -> Ht [position][channel] (next operand) and Hm [channel][position] (saved)
 #pragma unroll
@@ -159,7 +227,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             const int m = mbase + 16 * i + 4 * g;
             f32x4 bias;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias[r] = m + r < C ? a.b2a[m + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bias[r] = a.b2a[m + r < C ? m + r : C - 1];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int p = 16 * j + c16;
@@ -174,45 +242,58 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             }
         }
         __syncthreads();
-        // ---- cluster2's output convolution: W2b hidden
-        for (int ks = 0; ks < CP / 32; ++ks) {
-            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Ht + (16 * nb + c16) * HROW + (32 * ks + 8 * g) * 2);
+        HSTAMP(4)
+        // ---- cluster2's output convolution: W2b hidden (natural k order on both sides: element e of group g is k = 32 ks + 8 g + e)
+        static_assert(KS % 2 == 0, "two k-steps per iteration");
+        u32x4 wn[2][NA];
+        auto fetch2 = [&](const int ks) {
 #pragma unroll
-            for (int i = 0; i < DBMAX / MSTEP; ++i) {
-                const int mb = mb0 + i * MSTEP;
-                if (mb < DB) {
-                    // (natural k order on both sides: element e of group g is k = 32 ks + 8 g + e)
-                    const int row = 16 * mb + c16, k = 32 * ks + 8 * g;
-                    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
-                    if (row < D && k + 7 < C) {
-                        lo = *reinterpret_cast<const f32x4*>(a.w2b + (size_t)row * C + k);
-                        hi = *reinterpret_cast<const f32x4*>(a.w2b + (size_t)row * C + k + 4);
-                    } else if (row < D) {
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { lo[e] = k + e < C ? a.w2b[(size_t)row * C + k + e] : 0.f; hi[e] = k + 4 + e < C ? a.w2b[(size_t)row * C + k + 4 + e] : 0.f; }
-                    }
-                    acc2b[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack8(lo, hi), bfr, acc2b[i], 0, 0, 0);
-                }
+                for (int i = 0; i < NA; ++i) wn[h2][i] = wraw(a.w2b_bf, C, 16 * (wid + 4 * i) + c16, D, 32 * (ks + h2), C, lane);
+        };
+        fetch2(0);
+        for (int ks = 0; ks < KS; ks += 2) {
+            u32x4 wc[2][NA];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) wc[h2][i] = wn[h2][i];
+            if (ks + 2 < KS) fetch2(ks + 2);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                bf16x8 bfr[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Ht + (16 * j + c16) * HROW + (32 * (ks + h2) + 8 * g) * 2);
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc2b[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[h2][i]), bfr[j], acc2b[i][j], 0, 0, 0);
             }
         }
     }
+    HSTAMP(5)
     // ---- code = s1 * (W1 f) + (W2b hidden) + b1 + b2b
 #pragma unroll
-    for (int i = 0; i < DBMAX / MSTEP; ++i) {
-        const int mb = mb0 + i * MSTEP;
-        if (mb < DB) {
-            const int p = p0 + 16 * nb + c16;
+    for (int i = 0; i < NA; ++i) {
+        float bb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = 16 * (wid + 4 * i) + 4 * g + r, dc = d < D ? d : D - 1;
+            bb[r] = a.b1[dc] + (nonlinear ? a.b2b[dc] : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int p = p0 + 16 * j + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int d = 16 * mb + 4 * g + r;
-                if (d < D && p < P) {
-                    float v = fmaf(acc2a[i][r], s1, a.b1[d]);
-                    if (nonlinear) v += acc2b[i][r] + a.b2b[d];
-                    a.code[((size_t)b * D + d) * P + p] = v;
-                }
+                const int d = 16 * (wid + 4 * i) + 4 * g + r;
+                if (d < D && p < P) a.code[((size_t)b * D + d) * P + p] = fmaf(acc2a[i][j][r], s1, bb[r]) + (nonlinear ? acc2b[i][j][r] : 0.f);
             }
         }
     }
+    HSTAMP(6)
     // ---- hidden tile -> HBM (B, C, P) bf16, rows copied from the channel-major LDS image
     if (nonlinear && a.hidden) {
         constexpr int Q8 = NT / 8;
@@ -228,15 +309,29 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             }
         }
     }
+    HSTAMP(7)
 }
 
 template <int MB, int NT>
 static hipError_t launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
     constexpr int CP = 64 * MB;
-    const int smem = CP * (NT * 2 + 32) + NT * (CP * 2 + 32) + 2 * CP * 4;
+    const int smem = CP * (NT * 2 + 32) + NT * (CP * 2 + 32) + 2 * CP * 2;
     auto kern = k_head_fwd<MB, NT>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
+#ifdef DG_DEVTOOLS
+    if (const char* f = getenv("DG_HEAD_STAMPS")) {
+        static unsigned long long* buf = nullptr;
+        if (!buf && hipMalloc(&buf, 64) != hipSuccess) return hipErrorOutOfMemory;
+        DgHeadFwdArgs a2 = a;
+        a2.stamps = buf;
+        hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(256), smem, s, a2);
+        unsigned long long h[8];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* fp = fopen(f, "w")) { for (int i = 1; i < 8; ++i) fprintf(fp, "phase %d: %llu cycles\n", i, h[i] - h[i - 1]); fclose(fp); }
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(256), smem, s, a);
     return hipGetLastError();
 }
@@ -245,7 +340,13 @@ hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
     if (a.C <= 64) return launch_head_fwd<1, 64>(a, s);
     if (a.C <= 128) return launch_head_fwd<2, 64>(a, s);
     if (a.C <= 192) return launch_head_fwd<3, 64>(a, s);
+#ifdef HEAD_NT64
     if (a.C <= 384) return launch_head_fwd<6, 64>(a, s);
+#else
+    // 32 positions per block: 64 KB of LDS and < 256 registers -> two blocks per CU, one block's tile load under the other's MFMAs
+    // (with 64 positions - one block per CU - all blocks load, then all blocks multiply: 118 us against .. us)
+    if (a.C <= 384) return launch_head_fwd<6, 32>(a, s);
+#endif
     if (a.C <= 768) return launch_head_fwd<12, 32>(a, s);
     return hipErrorInvalidValue;
 }
@@ -262,12 +363,22 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y, p0 = blockIdx.x * NT;
     const int C = a.C, D = a.D, P = a.P, DP = (D + 31) / 32 * 32;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    // d code tile -> LDS; its row sums over the tile are the block's share of d b1 (= d b2b): 16 consecutive lanes hold one row
     for (int idx = tid; idx < DP * (NT / 4); idx += 256) {
         const int d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
         bf16x4 o;
+        float rs = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)((d < D && p + e < P) ? a.gcode[((size_t)b * D + d) * P + p + e] : 0.f);
+        for (int e = 0; e < 4; ++e) {
+            const float v = (d < D && p + e < P) ? a.gcode[((size_t)b * D + d) * P + p + e] : 0.f;
+            rs += v;
+            o[e] = (__bf16)v;
+        }
         *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
+#pragma unroll
+        for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
+        if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
     }
     __syncthreads();
     f32x4 acc[4][MB];
@@ -276,22 +387,14 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nbase = wid * 16 * MB;
+    const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
     for (int ks = 0; ks < DP / 32; ++ks) {
         bf16x8 af[4], bfr[MB];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = tr_frag(Dt, FROW, 32 * ks, 16 * i, lane);     // A[position][d]: the same transposing read
 #pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            const int m = nbase + 16 * j + c16;                                            // B[d][channel m] = W2b[d][m]
-            f32x4 v[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int d0 = 32 * ks + frag_k_order(lane, u);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[u][e] = (m < C && d0 + e < D) ? a.w2b[(size_t)(d0 + e) * C + m] : 0.f;
-            }
-            bfr[j] = pack8(v[0], v[1]);
-        }
+        for (int j = 0; j < MB; ++j)                                                       // B[d][channel m] = W2b[d][m] = W2bT[m][d]
+            bfr[j] = wfrag(wraw(a.w2bT, DP, nbase + 16 * j + c16, C, 32 * ks, DP, lane), ones, lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -299,26 +402,39 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
     }
     const bool vec = (P & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < MB; ++j) {
+        const int m = nbase + 16 * j + c16;
+        float bs = 0.f;                                     // sum over the tile's positions of d hidden_pre[m]: share of d b2a
 #pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            const int m = nbase + 16 * j + c16, p = p0 + 16 * i + 4 * g;
-            if (m >= C || p >= P) continue;
-            const size_t off = ((size_t)b * C + m) * P + p;
-            bf16x4 h4, o4;
-            if (vec) h4 = *reinterpret_cast<const bf16x4*>(a.hidden + off);
-            else {
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + 16 * i + 4 * g;
+            bf16x4 hpre = {};
+            if (vec) hpre = *reinterpret_cast<const bf16x4*>(a.hidden + ((size_t)b * C + (m < C ? m : C - 1)) * P + (p < P ? p : P - 4));
+            if (m < C && p < P) {
+                const size_t off = ((size_t)b * C + m) * P + p;
+                bf16x4 h4, o4;
+                if (vec) h4 = hpre;
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h4[r] = p + r < P ? a.hidden[off + r] : (__bf16)0.f;
-            }
+                    for (int r = 0; r < 4; ++r) h4[r] = p + r < P ? a.hidden[off + r] : (__bf16)0.f;
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o4[r] = (float)h4[r] > 0.f ? (__bf16)acc[i][j][r] : (__bf16)0.f;
-            if (vec) *reinterpret_cast<bf16x4*>(a.dh + off) = o4;
-            else {
+                for (int r = 0; r < 4; ++r) {
+                    const float v = ((float)h4[r] > 0.f && p + r < P) ? acc[i][j][r] : 0.f;
+                    bs += v;
+                    o4[r] = (__bf16)v;
+                }
+                if (vec) *reinterpret_cast<bf16x4*>(a.dh + off) = o4;
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (p + r < P) a.dh[off + r] = o4[r];
+                    for (int r = 0; r < 4; ++r) if (p + r < P) a.dh[off + r] = o4[r];
+                }
             }
         }
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (g == 0 && m < C) a.part_b2a[(size_t)blk * C + m] = bs;
+    }
 }
 
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s) {
@@ -365,19 +481,59 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const DgHeadWgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool live = m0 < a.M && n0 < a.N;
-    for (int s = s0; s < s1 && live; ++s) {
+    // the fragments of step s + 1 are loaded (raw) while step s multiplies: every step would otherwise wait a full memory latency
+    using RA = typename std::conditional<sizeof(TA) == 2, u32x4, f32x4>::type;
+    using RB = typename std::conditional<sizeof(TB) == 2, u32x4, f32x4>::type;
+    constexpr int WA = sizeof(TA) == 2 ? 1 : 2, WB = sizeof(TB) == 2 ? 1 : 2;
+    RA ra[4][WA];
+    RB rb[4][WB];
+    float kp[4];
+    auto load_raw = [&](auto& dst, const auto* X, const int row, const int nrows, const int p) {
+        using T = typename std::remove_cv<typename std::remove_pointer<decltype(X)>::type>::type;
+        constexpr int W = sizeof(T) == 2 ? 1 : 2;
+        const bool ok = row < nrows && p + 7 < a.P;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            if (ok && vec) dst[w] = *reinterpret_cast<const typename std::remove_reference<decltype(dst[0])>::type*>(X + (size_t)row * a.P + p + 4 * w);
+            else {
+                if constexpr (sizeof(T) == 2) {
+                    bf16x8 t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (row < nrows && p + e < a.P) ? X[(size_t)row * a.P + p + e] : (__bf16)0.f;
+                    dst[w] = __builtin_bit_cast(u32x4, t);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[w][e] = (row < nrows && p + 4 * w + e < a.P) ? X[(size_t)row * a.P + p + 4 * w + e] : 0.f;
+                }
+            }
+        }
+    };
+    auto fetch = [&](const int s) {
         const int b = s / steps_img, p = (s - b * steps_img) * 32 + 8 * g;
         const TA* Ab = static_cast<const TA*>(a.A) + (size_t)b * a.M * a.P;
         const TB* Bb = static_cast<const TB*>(a.Bm) + (size_t)b * a.N * a.P;
-        bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = row_frag<TA>(Ab, m0 + 16 * i + c16, a.M, a.P, p, vec);
+        for (int i = 0; i < 4; ++i) load_raw(ra[i], Ab, m0 + 16 * i + c16, a.M, p);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + 16 * j + c16;
-            bfr[j] = row_frag<TB>(Bb, n, a.N, a.P, p, vec);
-            if (a.keep && n < a.N && a.keep[(size_t)b * a.N + n] == 0.f) bfr[j] = bf16x8{};
+            load_raw(rb[j], Bb, n, a.N, p);
+            kp[j] = (a.keep && n < a.N) ? a.keep[(size_t)b * a.N + n] : 1.f;
         }
+    };
+    auto cook = [&](const auto& r) {
+        if constexpr (sizeof(r[0]) == 16 && std::is_same<typename std::remove_cv<typename std::remove_reference<decltype(r[0])>::type>::type, u32x4>::value)
+            return __builtin_bit_cast(bf16x8, r[0]);
+        else return pack8(r[0], r[1]);
+    };
+    if (live && s0 < s1) fetch(s0);
+    for (int s = s0; s < s1 && live; ++s) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = cook(ra[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bfr[j] = cook(rb[j]); if (kp[j] == 0.f) bfr[j] = bf16x8{}; }
+        if (s + 1 < s1) fetch(s + 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -411,16 +567,27 @@ hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf
     return launch_wgrad<__bf16, __bf16>(a, s);
 }
 
-// out[i] = scale * sum over splits of part[split][i]   (fixed order)
-__global__ void k_head_reduce(const float* __restrict__ part, float* __restrict__ out, int n, int splits, float scale) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// Up to six reductions in one launch: out[i] (and out2[i]) = scale * sum over splits of part[split][i]   (fixed order; four loads
+// in flight per thread).  blockIdx.y = job.
+__global__ void k_head_reduce(const DgHeadReduceArgs a) {
+    const DgHeadReduceJob& J = a.jobs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x, n = J.n;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-    out[i] = s * scale;
+    const float* part = J.part;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < J.splits; k += 4) {
+        s0 += part[(size_t)k * n + i]; s1 += part[(size_t)(k + 1) * n + i]; s2 += part[(size_t)(k + 2) * n + i]; s3 += part[(size_t)(k + 3) * n + i];
+    }
+    for (; k < J.splits; ++k) s0 += part[(size_t)k * n + i];
+    const float v = ((s0 + s1) + (s2 + s3)) * J.scale;
+    J.out[i] = v;
+    if (J.out2) J.out2[i] = v;
 }
-hipError_t dg_launch_head_reduce(const float* part, float* out, int n, int splits, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(k_head_reduce, dim3((n + 255) / 256), dim3(256), 0, s, part, out, n, splits, scale);
+hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s) {
+    int nmax = 0;
+    for (int j = 0; j < a.njobs; ++j) nmax = a.jobs[j].n > nmax ? a.jobs[j].n : nmax;
+    hipLaunchKernelGGL(k_head_reduce, dim3((nmax + 255) / 256, a.njobs), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

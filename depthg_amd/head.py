@@ -41,14 +41,15 @@ class _HeadFunction(torch.autograd.Function):
         k1, k2, k3 = keeps if keeps is not None else (None, None, None)
         W = lambda t: _gpu32(t, "head parameter").reshape(t.shape[0], -1) if t is not None else None
         w1c, w2ac, w2bc = W(w1), W(w2a), W(w2b)
+        wscratch = _empty((lib.dg_head_weights_bytes(C, D),), torch.uint8, dev)     # bf16 copies of the weights (first launch)
         rc = lib.dg_head_forward(B, C, D, P, _ptr(f), _ptr(w1c), _ptr(_gpu32(b1, "bias")), _ptr(w2ac),
                                  _ptr(_gpu32(b2a, "bias")) if nonlinear else None, _ptr(w2bc),
                                  _ptr(_gpu32(b2b, "bias")) if nonlinear else None, _ptr(k1), _ptr(k2), _ptr(k3), float(scale),
-                                 _ptr(code), _ptr(feats_out), _ptr(hidden), _stream(dev))
+                                 _ptr(code), _ptr(feats_out), _ptr(hidden), _ptr(wscratch), _stream(dev))
         _lib.check(rc, "dg_head_forward")
         ctx.dims, ctx.scale, ctx.nonlinear = (B, C, D, P), float(scale), nonlinear
         ctx.shapes = tuple(t.shape if t is not None else None for t in (w1, b1, w2a, b2a, w2b, b2b))
-        ctx.save_for_backward(f, k1, k2, hidden, w2bc)
+        ctx.save_for_backward(f, k1, k2, hidden, wscratch)
         if feats_out is not None:
             ctx.mark_non_differentiable(feats_out)
         return code, feats_out
@@ -56,7 +57,7 @@ class _HeadFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gcode, _gfeats):
         lib = _lib.load()
-        f, k1, k2, hidden, w2bc = ctx.saved_tensors
+        f, k1, k2, hidden, wscratch = ctx.saved_tensors
         B, C, D, P = ctx.dims
         dev = f.device
         if ctx.nonlinear and hidden is None:
@@ -69,7 +70,7 @@ class _HeadFunction(torch.autograd.Function):
         if ctx.nonlinear:
             gw2a, gb2a = _empty((C, C), torch.float32, dev), _empty((C,), torch.float32, dev)
             gw2b, gb2b = _empty((D, C), torch.float32, dev), _empty((D,), torch.float32, dev)
-        rc = lib.dg_head_backward(B, C, D, P, _ptr(f), _ptr(k1), _ptr(k2), ctx.scale, _ptr(hidden), _ptr(w2bc) if ctx.nonlinear else None,
+        rc = lib.dg_head_backward(B, C, D, P, _ptr(f), _ptr(k1), _ptr(k2), ctx.scale, _ptr(hidden), _ptr(wscratch),
                                   _ptr(g), _ptr(gw1), _ptr(gb1), _ptr(gw2a), _ptr(gb2a), _ptr(gw2b), _ptr(gb2b), _ptr(ws), nb,
                                   _stream(dev))
         _lib.check(rc, "dg_head_backward")

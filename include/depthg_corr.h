@@ -312,20 +312,23 @@ int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out
  *  code                 : fp32 (B,D,P) out
  *  feats_out            : fp32 (B,C,P) out = feat * keep3 * keep_scale, or NULL
  *  hidden               : bf16 (B,C,P) out: cluster2's ReLU output, needed by dg_head_backward; may be NULL without one
+ *  wscratch             : dg_head_weights_bytes(C, D) bytes: the forward leaves the bf16 copies of the weight matrices there
+ *                         (its first launch); dg_head_backward reads them - keep the buffer until then
  */
+size_t dg_head_weights_bytes(int32_t C, int32_t D);
 int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
                     const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
                     const float* keep1, const float* keep2, const float* keep3, float keep_scale,
-                    float* code, float* feats_out, void* hidden, dg_stream_t stream);
+                    float* code, float* feats_out, void* hidden, void* wscratch, dg_stream_t stream);
 /* Bytes of scratch dg_head_backward needs (d hidden + the split partial sums of the three weight gradients). */
 size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32_t P);
 /*
  * Gradients of the six head tensors from grad_code (B,D,P) (the backbone is frozen: nothing flows into feat).  Same feat /
- * keep1 / keep2 / keep_scale / hidden as the forward.  grad_* : fp32, shapes of the parameters, overwritten; the cluster2
- * ones are ignored when w2b is NULL.  Bit-reproducible (no floating-point atomics).
+ * keep1 / keep2 / keep_scale / hidden / wscratch as the forward.  grad_* : fp32, shapes of the parameters, overwritten; pass the
+ * four cluster2 ones (and hidden) as NULL for projection_type "linear".  Bit-reproducible (no floating-point atomics).
  */
 int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
-                     float keep_scale, const void* hidden, const float* w2b, const float* grad_code,
+                     float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
                      float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
                      void* workspace, size_t workspace_bytes, dg_stream_t stream);
 

@@ -53,6 +53,7 @@ def test_head_train_forward_backward_vs_oracle(B, C, D, hw, proj, dev):
     from oracle import head_oracle as HO
     g = torch.Generator().manual_seed(100 * C + hw)
     feat = torch.randn(B, C, hw, hw, generator=g) * 2.0
+    torch.manual_seed(C + hw)                               # (the head's initial weights)
     head = ProjectionHead(C, D, proj).to(dev).train()
     keeps = tuple((torch.rand(B, C, generator=g) > 0.1).float() for _ in range(3))
     code, feats = head(feat.to(dev), True, tuple(k.to(dev) for k in keeps))
