@@ -882,13 +882,8 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     const size_t gstride = 128;                             // v4i per R tile step
     auto load_g = [&](int rt, v4i (&g)[2]) {
         const v4i* gp = Gbase + (size_t)((gdbg & 64) ? 0 : rt) * gstride;
-#ifdef GS_G_PLAIN       // (developer A/B: G tiles loaded with the default cache policy)
-        g[0] = *gp;
-        g[1] = *(gp + 64);
-#else
         g[0] = __builtin_nontemporal_load(gp);
         g[1] = __builtin_nontemporal_load(gp + 64);
-#endif
     };
     v4i gring[3][2];
 #pragma unroll

@@ -401,11 +401,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
         v4i_t* g = gbase[f] + (size_t)t * gstep + 64 * sp;
-#ifdef C2_G_PLAIN      // (developer A/B: G tiles with the default cache policy)
-        asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(g), "v"(ga[f][sp]) : "memory");
-#else
+        // (non-temporal: with the default cache policy on these stores / k_gs's loads the step is 1-6 % slower, profiles/r03_SUMMARY.md)
         asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
-#endif
 #endif
     };
 
