@@ -157,20 +157,27 @@ def cpu_baseline(conf, seconds_budget=20.0):
     H = conf["H"]
     host = os.cpu_count() or 1
     runs = []
-    for ncores in sorted({min(host, 16), host}):
-        # the all-CPU leg thrashes on big hosts (256 threads: 65 x slower than 16 on the same box): an eighth of the sample, a
-        # short budget - it is there to show WHY the reported value uses 16 threads, not to be waited for
-        full = ncores <= 16
-        Bs = conf["cpu_B"] if full else max(1, conf["cpu_B"] // 8)
-        t, n = _cpu_baseline_at(conf, ncores, seconds_budget * (0.75 if full else 0.25), Bs)
-        runs.append({"cores": ncores, "value": (Bs / H["B"]) / t, "seconds": t, "reps": n, "Bs": Bs})
+    n16 = min(host, 16)
+    t16, reps16 = _cpu_baseline_at(conf, n16, seconds_budget * 0.75, conf["cpu_B"])
+    runs.append({"cores": n16, "value": (conf["cpu_B"] / H["B"]) / t16, "seconds": t16, "reps": reps16, "Bs": conf["cpu_B"]})
+    skipped = None
+    if host > n16:
+        # The all-CPU leg thrashes on big hosts (256 threads: 65 x slower than 16 on the same box).  It is there to show WHY the
+        # reported value uses 16 threads, not to be waited for: a sample sized for ~0.15 s at the 16-thread rate, and skipped where
+        # even one image would take longer than that (config 5: 22 s per image on 16 threads)
+        Bs = min(conf["cpu_B"], int(conf["cpu_B"] * 0.15 / t16))
+        if Bs >= 1:
+            t, n = _cpu_baseline_at(conf, host, seconds_budget * 0.25, Bs)
+            runs.append({"cores": host, "value": (Bs / H["B"]) / t, "seconds": t, "reps": n, "Bs": Bs})
+        else:
+            skipped = {"cores": host, "skipped": f"one image takes {t16 / conf['cpu_B']:.1f} s on {n16} threads; the all-CPU leg is not waited for"}
     best = max(runs, key=lambda r: r["value"])
     other = [r for r in runs if r is not best]
     return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "host_cpus": host, "kind": "port",
             "sample": f"oracle forward+backward at B={best['Bs']} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
                       f"{H['n_neg']} negatives, sampling={conf['sampling']}, {best['cores']} threads of {host} host CPUs, "
                       f"min of {best['reps']} timed reps = {best['seconds']:.2f} s; value = ({best['Bs']}/{H['B']}) / t",
-            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other]}
+            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other] + ([skipped] if skipped else [])}
 
 
 def main():
@@ -378,18 +385,36 @@ def main():
 
     # ---- roofline of the dominant kernel (the fused correlation launch), measured live with HIP events on the launch stream
     desc, perms_t, ws = loss_fn.last_call
+    # The kernel's launch duration UNDER THE STEP'S CONDITIONS: [step + one extra launch of the fused kernel] minus [step], both
+    # timed with HIP events over `reps` iterations on the launch stream, five interleaved rounds, median.  (A bare loop of
+    # back-to-back re-launches keeps the matrix cores saturated, the chip lowers its clock, and the same kernel measures 5-6 %
+    # slower than rocprofv3's kernel trace shows it inside the step: 160 against 151 us, profiles/r03_SUMMARY.md.  `kernel_ms_loop`
+    # keeps that figure.)
     reps = 20
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps
+
+    def step_plus_kernel():
+        warm()
+        ops.corr_relaunch_main(desc, perms_t, ws)
+
     for _ in range(3):
         ops.corr_relaunch_main(desc, perms_t, ws)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(reps):
-        ops.corr_relaunch_main(desc, perms_t, ws)
-    ev1.record()
-    torch.cuda.synchronize()
-    kern_ms = ev0.elapsed_time(ev1) / reps
+    diffs = []
+    for _ in range(5):
+        t_step = timed(warm)
+        t_both = timed(step_plus_kernel)
+        diffs.append(t_both - t_step)
+    kern_ms = sorted(diffs)[len(diffs) // 2]
+    kern_ms_loop = timed(lambda: ops.corr_relaunch_main(desc, perms_t, ws))
     step_gf, main_gf, gs_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
     achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # which kernel that launch is: the library's own predicate (dg_corr_main_kernel_name), not a copy of it
@@ -408,7 +433,8 @@ def main():
             pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": kname, "kernel_ms": round(kern_ms, 4),
+                "kernel": kname, "kernel_ms": round(kern_ms, 4), "kernel_ms_loop": round(kern_ms_loop, 4),
+                "kernel_ms_method": "HIP events: [step + 1 extra launch] - [step], 5 x 20 iterations, median; kernel_ms_loop: 20 back-to-back launches",
                 "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2)}
 
     if rank == 0:

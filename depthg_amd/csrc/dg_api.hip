@@ -556,6 +556,7 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     j.center_on_lane = 0;
     j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
     a.jobs[0] = j; a.njobs = 1;
+    a.pos_w = p.ident ? p.w : 0;
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, 2, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }

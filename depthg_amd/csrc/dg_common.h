@@ -211,6 +211,8 @@ struct DgCorrArgs {
     float lo, hi;         // clamp bounds
     float inv_BP;         // 1 / (B*P)
     const char* dummy;    // any valid device address (source of DMA lanes that carry nothing)
+    int32_t pos_w;        // > 0: positions are pixel indices y*w + x of a w x w identity grid (DG_IDENTITY_GRID); the un-reduced outputs
+                          //      (materialise) are written at the reference's position x*w + y
     int32_t debug;        // developer ablation bits (0 in production)
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
@@ -352,12 +354,15 @@ __device__ __forceinline__ float depth_nz_at(const float* __restrict__ depth, in
 }
 
 // all positions of image n by one block of 256 threads, plus their sum (mean(dd) = mean_n (sum_p nz)^2 / P^2)
+// `pixel_order` (identity grid): position p is pixel p = y*S + x of the map, whose sample() output index is (i, j) = (x, y), i.e.
+// the reference's position x*S + y - that is where the resized depth is read
 __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, float* __restrict__ nz, float* __restrict__ nzsum,
-                                               int n, int H, int W, int Sh, int S, int Ppad) {
+                                               int n, int H, int W, int Sh, int S, int Ppad, bool pixel_order = false) {
     __shared__ float wred[4];
     float s = 0.f;
     for (int p = threadIdx.x; p < Ppad; p += 256) {
-        const float v = depth_nz_at(depth, n, p, H, W, Sh, S);
+        const int pref = (pixel_order && p < Sh * S) ? (p % S) * S + p / S : p;
+        const float v = depth_nz_at(depth, n, pref, H, W, Sh, S);
         nz[(size_t)n * Ppad + p] = v;
         s += v;
     }

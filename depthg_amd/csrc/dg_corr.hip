@@ -385,7 +385,10 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             if (MAT) {   // R = operand 2 on lanes -> stores contiguous along q
                 const int p = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (act[f] && pr[f] < P && p < P) {
-                    const size_t o = ((size_t)n * P + p) * P + pr[f];
+                    // (identity grid: positions are pixel indices; the reference's tensors are indexed by x*S + y)
+                    const int w_ = args.pos_w;
+                    const int po = w_ ? (p % w_) * w_ + p / w_ : p, qo = w_ ? (pr[f] % w_) * w_ + pr[f] / w_ : pr[f];
+                    const size_t o = ((size_t)n * P + po) * P + qo;
                     if (out_cd) out_cd[o] = KIND == KIND_DEPTH ? nz_lane[f] * vv[i] : Yc[f][i];
                     if (out_loss) out_loss[o] = li;
                 }

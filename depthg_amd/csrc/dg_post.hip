@@ -119,6 +119,147 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
     }
 }
 
+// Identity grid (DG_IDENTITY_GRID; positions = pixel indices): stage 1 and the adjoint of sample() in ONE launch.  The block of
+// k_grad_combine - (tile, image, destination), one wave per 32-channel group - also adds the tiles of the images ROUTED here (the
+// negatives whose batch map points at this image: list built per block by ordered ballot compaction, (source, image) order:
+// bit-reproducible) and writes (B,D,h,w) directly: a tile's 32 positions are 32 consecutive pixels, so each channel row of the
+// tile is one 128-byte run (through a per-wave LDS stage, two channel rows per store instruction).  No combined-tile round trip,
+// no second launch.
+#define COMB_MAXROUTE 512      // (routed source, image) pairs a destination image can collect at worst: routed sources x B
+template <int NDF>
+__global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a) {
+    const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, DP = NDF * 32;
+    const int d = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ __attribute__((aligned(16))) char xs[NDF][DG_XROWS_LDS];
+    __shared__ float part[NDF][32];
+    __shared__ float stage[NDF][32 * 33];
+    __shared__ const float* rl_p[COMB_MAXROUTE];
+    __shared__ float rl_w[COMB_MAXROUTE];
+    __shared__ int rl_cnt, wcnt[NDF], rsrc[DG_MAX_SCATTER];
+    DG_LOAD_GS(a, gs)
+    // ---- routed list of (dest, n): every thread tests one (routed source, image) pair per round
+    int nr = 0;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src[s].dest == dest && a.src[s].route != nullptr) { if (tid == 0) rsrc[nr] = s; ++nr; }
+    if (tid == 0) rl_cnt = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nr * a.B; i0 += 64 * NDF) {
+        const int i = i0 + tid;
+        bool hit = false;
+        int m = 0, s = 0;
+        if (i < nr * a.B) {
+            const int rs = i / a.B;
+            m = i - rs * a.B; s = rsrc[rs];
+            hit = (int)a.src[s].route[m] == n;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[d] = __popcll(bal);
+        __syncthreads();
+        int base = rl_cnt;
+        for (int wv = 0; wv < d; ++wv) base += wcnt[wv];
+        if (hit) {
+            const int o = base + __popcll(bal & ((1ull << lane) - 1));
+            const DgScatterSrc& q = a.src[s];
+            if (o < COMB_MAXROUTE) { rl_p[o] = q.buf + (size_t)m * a.Ppad * a.DP; rl_w[o] = q.factor * dg_pick(gs, q.gidx); }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int c = rl_cnt;
+            for (int wv = 0; wv < NDF; ++wv) c += wcnt[wv];
+            rl_cnt = min(c, COMB_MAXROUTE);
+        }
+        __syncthreads();
+    }
+    const int cnt = rl_cnt;
+    // ---- the direct sources, as k_grad_combine
+    const bool ok = 32 * d + r < a.D;
+    const size_t in_img = (size_t)rt * (32 * DP) + lane * 4 + (ok ? d * 1024 : 0);
+    const size_t tile_off = (size_t)n * a.Ppad * DP + in_img;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    auto add_sources = [&](const int8_t* list, const int nsrc_) __attribute__((always_inline)) {
+        for (int k0 = 0; k0 < nsrc_; k0 += 4) {
+            f32x4 t[4][4];
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool live = k0 + u < nsrc_;
+                const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
+                sc[u] = live ? q.factor * dg_pick(gs, q.gidx) : 0.f;
+                const float* base = q.buf + tile_off;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) t[u][g] = *reinterpret_cast<const f32x4*>(base + (ok ? g * 256 : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool use = ok && k0 + u < nsrc_;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(sc[u], use ? t[u][g][e] : 0.f, v[4 * g + e]);
+            }
+        }
+    };
+    const int nraw = a.ncraw[dest];
+    add_sources(a.craw[dest], nraw);
+    if (nraw > 0) {
+        const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c + d * 2048;
+        _Float16 x[1][16];
+        dg_load_code_rows<1>(xb, xs[d], lane, x);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float t = half_sum((float)x[0][i] * v[i]);
+            if (r == 0) part[d][h * 16 + i] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float t = part[0][h * 16 + i];
+#pragma unroll
+            for (int f = 1; f < NDF; ++f) t += part[f][h * 16 + i];
+            const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float inv = rr < a.P ? a.xinv[(size_t)n * a.Ppad + rr] : 0.f;
+            v[i] = (v[i] - (float)x[0][i] * t) * inv;
+        }
+    }
+    add_sources(a.cfin[dest], a.ncfin[dest]);
+    // ---- the routed images' tiles (k_gs output: final), four at a time
+    for (int e0 = 0; e0 < cnt; e0 += 4) {
+        f32x4 u4[4][4];
+        float sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = min(e0 + k, cnt - 1);
+            sc[k] = e0 + k < cnt ? rl_w[e] : 0.f;
+            const gfloat_p sb = (gfloat_p)rl_p[e] + in_img;       // (pointer out of LDS: name its address space - else FLAT loads)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) u4[k][g] = *(const f32x4 __attribute__((address_space(1)))*)(sb + (ok ? g * 256 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(sc[k], ok ? u4[k][g][e] : 0.f, v[4 * g + e]);
+    }
+    // ---- out[dest][(n, channel, pixel)]: the wave's [32 channels][32 positions] tile through LDS, rows of 128 contiguous bytes
+    float* st = stage[d];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[r * 33 + (i & 3) + 8 * (i >> 2) + 4 * h] = v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int HW = a.h * a.w, p = rt * 32 + r;
+    float* out = a.out[dest] + (size_t)n * a.D * HW + p;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int c = 2 * it + h, ch = 32 * d + c;
+        if (ch < a.D && p < a.P) out[(size_t)ch * HW] = st[c * 33 + r];
+    }
+}
+
 #define SCAT_THREADS 1024
 #define SCAT_DC 4            // channels per block (4 x 256 pixels per pass: the gather keeps 4 sources x 4 passes of loads in flight in 48 registers)
 #define SCAT_PX (SCAT_THREADS / SCAT_DC)
@@ -507,7 +648,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_small(const DgScatterA
 template <int CG, int DENSE_THREADS>
 __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char sd[];
-    const int HW = a.h * a.w, S = a.S, nt = a.Ppad >> 5, NF = a.DP >> 5;
+    const int HW = a.h * a.w, nt = a.Ppad >> 5, NF = a.DP >> 5;
     DG_LOAD_GS(a, gs)
     float* stage = reinterpret_cast<float*>(sd);                       // [CG][HW + 1]
     const float** rl_p = reinterpret_cast<const float**>(stage + CG * (HW + 2));   // routed list: image base (8-byte aligned)
@@ -556,7 +697,6 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
         __syncthreads();
     }
     const int cnt = rl_cnt;
-    const float invS = 1.f / (float)S;
     for (int t0 = wid * TPW; t0 < nt; t0 += NW * TPW) {
         const int t = t0 + ts;
         const bool live = t < nt;
@@ -590,10 +730,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int p = t * 32 + k + 8 * g + 4 * h;
-                if (live && p < a.P) {
-                    const int i = (int)(((float)p + 0.5f) * invS), j = p - i * S;    // p / S without an integer division
-                    stage[idx * (HW + 1) + j * a.w + i] = v[g][k];
-                }
+                if (live && p < a.P) stage[idx * (HW + 1) + p] = v[g][k];      // position = pixel index on the identity grid
             }
     }
     __syncthreads();
@@ -619,6 +756,19 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
             }
         }
         const dim3 cgrid(a.Ppad / 32, a.B, 2);
+#ifndef DG_TWO_STAGE_DENSE      // (developer A/B: the round-2 form, k_grad_combine + k_scatter_dense)
+        {
+            // identity grid: combine + routed negatives + (B,D,h,w) output in one launch
+            int nrouted = 0;
+            for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
+            if (a.dense && a.S == a.h && a.S == a.w && nrouted * a.B <= COMB_MAXROUTE && (a.DP == 96 || a.DP == 128)) {
+                // (the list holds the worst case - every routed image of every routed source pointing at one destination)
+                if (a.DP == 96) hipLaunchKernelGGL(k_combine_out<3>, cgrid, dim3(192), 0, s, ac);
+                else hipLaunchKernelGGL(k_combine_out<4>, cgrid, dim3(256), 0, s, ac);
+                return hipGetLastError();
+            }
+        }
+#endif
         if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid, dim3(192), 0, s, ac);
         else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid, dim3(256), 0, s, ac);
         else return hipErrorInvalidValue;

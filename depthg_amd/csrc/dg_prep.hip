@@ -348,7 +348,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     // and only the NORMALISED bf16 row tile goes to LDS (half the bytes of an fp32 stage -> twice the blocks per CU).
     // maps wider than 32 pixels (56 x 56 at 448 input) are covered by ceil(w / 32) blocks per source row: xb = 32-pixel segment
     const int tid = threadIdx.x, xl = tid & 31, x = xb * 32 + xl, k0 = tid >> 5;
-    const int K = a.K, KF = a.KF, w = a.w, h = a.h, S = a.h;
+    const int K = a.K, KF = a.KF, w = a.w, h = a.h;
     const int wseg = min(32, w - xb * 32);          // pixels of this segment
     const int RS = KF * 2 + 16;                     // LDS row stride in bytes: 16-byte aligned rows (granule reads), 2-way writes at worst
     const DgBlob L(a.KF, a.KD);
@@ -378,12 +378,12 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     }
     __syncthreads();
     if (DG_DBG(a.debug) & 32) return;                       // (ablation: loads + normalisation only)
-    // blob rows: position p = x*S + y (sample() output (i, j) = (x, y)); 8-byte pieces, the lanes of a row run along K
+    // blob rows: position p = y*w + x; the lanes of a row run along K
     const int pieces = KF / 8;                      // granules (16 bytes) per row
     for (int id = tid; id < wseg * pieces; id += 256) {
         const int xx = id / pieces, g = id - xx * pieces;
         const uint4 v = *reinterpret_cast<const uint4*>(tb + xx * RS + g * 16);
-        const int p = (xb * 32 + xx) * S + y;
+        const int p = y * w + xb * 32 + xx;                 // position = pixel index (see "position order" at k_prep_dense)
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
         *reinterpret_cast<uint4*>(blob + L.f(p & 31, g)) = v;
     }
@@ -404,9 +404,8 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     }
 }
 
-// Code operand on the identity grid: one block per DENSE_TPB consecutive tiles (position p = i*S + j <- pixel (y = j, x = i)
-// of the NCHW code map, so a run of positions is a run of source COLUMNS: the block reads, per channel and source row, the
-// run of its 5-6 columns - the more tiles per block, the longer those runs and the fewer line requests of this gather).
+// Code operand on the identity grid: one block per DENSE_TPB consecutive tiles (position = pixel index: a run of positions is a
+// run of pixels of every channel plane).
 // L2-normalise over the D channels (norm(), src/modules.py:789-790; squared norms reduced from registers), keep the
 // NORMALISED fp16 tile in LDS and write from it the C part (K-major granules), the P part (position-major granules in
 // dg_perm32 order), 1/max(||c||, eps) and the per-tile column sums.  Same roundings as k_gather_norm.
@@ -417,11 +416,11 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
 template <int UN>        // channels per thread: D <= 4 * UN
 __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl, int tb, int n, int o) {
     const int tid = threadIdx.x, ps = tid & 63, kg = tid >> 6;
-    const int KD = a.KD, D = a.D, S = a.h, HW = a.h * a.w, nt = a.Ppad / 32;
+    const int KD = a.KD, D = a.D, HW = a.h * a.w, nt = a.Ppad / 32;
     const int RS = (KD + 4) * 2;                       // LDS row stride (bytes): 8-byte aligned rows, odd multiple of 8
     const int t0 = tb * DENSE_TPB, ntile = min(DENSE_TPB, nt - t0);
     const int p0 = t0 * 32, np = ntile * 32, pend = min(p0 + np, a.P);
-    const int xa = p0 / S, NC = (pend - 1) / S - xa + 1, npairs = S * NC;
+
     char* xt = reinterpret_cast<char*>(sl);            // [np][RS] normalised fp16 rows
     float* red = reinterpret_cast<float*>(xt + DENSE_TPB * 32 * RS);      // [4][DENSE_CODE_PAIRS] partial squared norms
     float* inv = red + 4 * DENSE_CODE_PAIRS;                               // [np]
@@ -430,19 +429,16 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
     for (int id = tid; id < np * (RS / 8); id += 256) reinterpret_cast<uint2*>(xt)[id] = make_uint2(0u, 0u);
     for (int pos = tid; pos < np; pos += 256) inv[pos] = 0.f;
     const float* src = a.code[o] + (size_t)n * D * HW;
-    // lanes walk the (source row y, column xl) pairs (xl fastest: runs of NC contiguous pixels), the four waves split the
-    // channels (k = wave + 4u): one integer division per pair, none per load, all loads of a thread in flight at once
+    // lanes walk the positions, the four waves split the channels (k = wave + 4u); all loads of a thread in flight at once
     constexpr int NJ = DENSE_CODE_PAIRS / 64;            // <= 3 pairs per lane, all their channels in one batch
     float t[NJ][UN];
     int pos[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int pair = ps + 64 * j;
-        const int y = pair / NC, xl = pair - y * NC;
-        const int pp = (xa + xl) * S + y;
-        const bool ok = pair < npairs && pp >= p0 && pp < pend;
-        pos[j] = ok ? pp - p0 : -1;
-        const float* sp = src + (ok ? y * a.w + xa + xl : 0);
+        const int pl = ps + 64 * j;                        // position inside the block's tiles = pixel p0 + pl (position = pixel index)
+        const bool ok = pl < np && p0 + pl < pend;
+        pos[j] = ok ? pl : -1;
+        const float* sp = src + (ok ? p0 + pl : 0);
 #pragma unroll
         for (int u = 0; u < UN; ++u) t[j][u] = (ok && kg + 4 * u < D) ? sp[(size_t)(kg + 4 * u) * HW] : 0.f;
     }
@@ -512,7 +508,7 @@ __device__ __forceinline__ void prep_dense_code(const DgDenseArgs& a, float* sl,
 // ((s0 + s1) + s2) + s3; value * inv rounded to fp16; column sums over the 32 positions in order): bit-identical operands.
 template <int UN>
 __device__ __forceinline__ void prep_dense_code_norms(const DgDenseArgs& a, int xb, int n, int o) {
-    const int HW = a.h * a.w, S = a.h, i = xb * 256 + threadIdx.x;
+    const int HW = a.h * a.w, i = xb * 256 + threadIdx.x;
     float* inv = a.inv_norm[o] + (size_t)n * a.Ppad;
     if (xb == 0)
         for (int p = a.P + threadIdx.x; p < a.Ppad; p += 256) inv[p] = 0.f;          // positions of the ragged last tile
@@ -527,12 +523,11 @@ __device__ __forceinline__ void prep_dense_code_norms(const DgDenseArgs& a, int 
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) ss[kg] = fmaf(t[kg + 4 * u], t[kg + 4 * u], ss[kg]);
     const float tot = ss[0] + ss[1] + ss[2] + ss[3];
-    const int y = i / a.w, x = i - y * a.w;
-    inv[x * S + y] = 1.f / fmaxf(sqrtf(tot), DG_EPS_NORM);
+    inv[i] = 1.f / fmaxf(sqrtf(tot), DG_EPS_NORM);          // position = pixel index
 }
 
 __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char* xt, int n, int o, int g) {
-    const int tid = threadIdx.x, HW = a.h * a.w, S = a.h, nt = a.Ppad / 32, KD = a.KD;
+    const int tid = threadIdx.x, HW = a.h * a.w, nt = a.Ppad / 32, KD = a.KD;
     const DgBlob L(a.KF, a.KD);
     const int nch = min(8, a.D - 8 * g);                  // live channels of this group (<= 0: padding group, zeros)
     for (int p = a.P + tid; p < a.Ppad; p += 256) reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
@@ -548,8 +543,7 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
             for (int j = 0; j < 4; ++j) {
                 const int i = i0 + tid + 256 * j;
                 const bool ok = i < HW;
-                const int y = i / a.w, x = i - y * a.w;
-                pp[j] = ok ? x * S + y : -1;
+                pp[j] = ok ? i : -1;                          // position = pixel index
                 iv[j] = ok ? inv[pp[j]] : 0.f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) t[j][c] = (ok && c < nch) ? src[(size_t)c * HW + i] : 0.f;
@@ -618,7 +612,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
             if (x * 256 < a.h * a.w) prep_dense_code_norms<UNC>(a, x, n, z - 2);
         } else if (x * DENSE_TPB < a.Ppad / 32 && !(DG_DBG(a.debug) & 2)) prep_dense_code<UNC>(a, sl, x, n, z - 2);
     } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
-        depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad);
+        depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad, true);
     }
 }
 

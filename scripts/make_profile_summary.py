@@ -2,7 +2,7 @@
 """Copies the round's evidence from gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/
 and writes profiles/<tag>_SUMMARY.md.  usage: scripts/make_profile_summary.py r02"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, f"{tag}_kernel_stats.csv"), dst)
@@ -18,7 +18,7 @@ br = json.loads(open(os.path.join(dst, f"{tag}_bench_under_rocprofv3.json")).rea
 kname = b["roofline"]["kernel"]
 rows = [r for r in st if r["Name"].startswith(("k_", "void k_"))]
 o = [f"# Round profile summary {tag} (MI355X, gfx950)\n",
-     "Command: `python bench.py --steps 50 --warmup 5 --no-cpu-baseline` under `rocprofv3 --kernel-trace --stats` "
+     "Command: `python bench.py --steps 50 --warmup 5 --no-cpu-baseline` (hipGraph replay, 1 s of untimed clock warm-up) under `rocprofv3 --kernel-trace --stats` "
      f"(`scripts/profile_round.sh {tag}`); PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, an SQ set) are separate runs of the "
      f"same command with `--steps 3`. Files: `{tag}_kernel_stats.csv`, `{tag}_pmc_per_launch.json`, `{tag}_bench_under_rocprofv3.json` "
      f"(the bench line printed inside the profiled run), `{tag}_bench.json` (the plain `python bench.py` line, taken BEFORE the counter "
@@ -47,15 +47,19 @@ o += [f"\n(`{kname}` has extra calls: `bench.py`'s roofline leg re-launches it 2
       f"SQ_WAVE_CYCLES {m['SQ_WAVE_CYCLES']:.3g}, SQ_WAIT_INST_ANY {m['SQ_WAIT_INST_ANY']:.3g}.",
       f"\n## Step\n\n{b['value']} steps/s ({b['ms_per_step']} ms per step) on one GPU; CPU restatement on {b['cpu_baseline']['cores']} host threads: "
       f"{b['cpu_baseline']['value']:.2f} steps/s ({b['cpu_baseline']['sample']}).\n",
-      "## BASELINE.json's other configurations (`bench.py --config`)\n",
+      "## Other lines (`bench.py --config`, `--eager`, the driver's arguments)\n",
       "| config | ms per step | steps/s | dominant kernel | µs per launch | fraction of MFMA peak | CPU restatement steps/s |\n|---|---|---|---|---|---|---|"]
 for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
     l = last_json(f)
     shutil.copy(f, dst) if False else open(os.path.join(dst, os.path.basename(f)), "w").write(l)
     c = json.loads(l)
     name = c['config']['name'] + (" (`--force-dist`: the N > 1 schedule with one rank)" if c['config'].get('allreduce', 'none') != 'none'
-                                  else " (`--graph`)" if "hipGraph" in c['config']['workload'] else "")
+                                  else " (`--eager`)" if c['config'].get('schedule') == "eager" else "")
+    if "driver_args" in f:
+        name += " (`--steps 20 --warmup 5`, the driver's command line)"
     o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
              f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
+if os.path.exists(os.path.join(src, f"{tag}_parity.md")):
+    shutil.copy(os.path.join(src, f"{tag}_parity.md"), dst)
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))

@@ -1,23 +1,26 @@
 #!/bin/bash
 # Produces the per-round evidence kept under profiles/: kernel-trace stats of the bench command and the HBM-traffic
 # PMC passes of the fused kernel (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM").
-# usage (on the GPU box): scripts/profile_round.sh r02   (then, here: scripts/make_profile_summary.py r02)
-tag=${1:-r02}
+# usage (on the GPU box): scripts/profile_round.sh r03   (then, here: scripts/make_profile_summary.py r03)
+tag=${1:-r03}
 export TMPDIR=/tmp
 out=/root/repo/gpurun_out/$tag
 rm -rf $out
 mkdir -p $out
-# plain bench lines first (counter collection leaves the GPU in the profiling power state)
+# plain bench lines first (counter collection leaves the GPU in the profiling power state).  Since round 3 the default schedule is
+# the step replayed from a hipGraph at every N; --eager lines ride along for the host-launched step
 python3 /root/repo/bench.py > $out/${tag}_bench.json 2>/dev/null
-for c in C2 C3 C4shard C5; do python3 /root/repo/bench.py --config $c > $out/${tag}_bench_$c.json 2>/dev/null; done
-for c in C2 C3 C4shard; do python3 /root/repo/bench.py --config $c --graph --no-cpu-baseline > $out/${tag}_bench_${c}_graph.json 2>/dev/null; done
+python3 /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_driver_args.json 2>/dev/null     # the driver's command line
+for c in C2 C3 C4shard C5 headline+head; do python3 /root/repo/bench.py --config $c > $out/${tag}_bench_$c.json 2>/dev/null; done
+for c in headline C2 C3 C4shard; do python3 /root/repo/bench.py --config $c --eager --no-cpu-baseline > $out/${tag}_bench_${c}_eager.json 2>/dev/null; done
 # the N > 1 schedule with one rank (RCCL initialised, step replayed from two hipGraphs, collective on the side stream)
 python3 /root/repo/bench.py --force-dist --no-cpu-baseline 2>/dev/null | grep "^{" > $out/${tag}_bench_force_dist.json
+python3 /root/repo/scripts/parity_table.py $out/${tag}_parity.md > /dev/null 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
 cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
-( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
-( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
-( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
 python3 - <<PY
 import csv, glob, collections, json
 res = {}
