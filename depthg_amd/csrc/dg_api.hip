@@ -392,7 +392,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         for (int o = 0; o < p.nops; ++o) {
             c.colpart[o] = p.pointwise ? F32(p.colpart[o]) : nullptr; c.bbar[o] = F32(p.bbar[o]);
             c.bsplit[o] = reinterpret_cast<__bf16*>(ws + p.bsplit[o]);
-            c.ngroups[o] = p.ident ? p.h * ((p.w + 31) / 32) : p.Ppad / 32;
+            c.ngroups[o] = p.Ppad / 32;              // feats partial column sums: one group per tile on both paths
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
         c.zero_word = (p.grad && p.depth) ? reinterpret_cast<unsigned int*>(ws + p.ticket) : nullptr;

@@ -338,22 +338,25 @@ hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // Dense identity grid (S == h == w, coords = the pixel centres): sample() is an exact spatial transpose
 // (out[b,:,i,j] = t[b,:,j,i], reference quirk Q3), so the feats operand is built straight from the NCHW map: no
-// channel-last copy, no bilinear taps.  One block per (source row y, image): reads the K x w slab of that row
-// (w-float segments), normalises the w positions p = x*S + y and writes their swizzled bf16 rows into the tile blobs.
-// grid (h, B, nops), block 256, dynamic LDS w * (KF + 1) floats.
+// channel-last copy, no bilinear taps.  POSITION ORDER on this grid: position p = pixel index y*w + x (the reference numbers the
+// same sample x*S + y; the loss only ever sums over positions, and the order is the same for every operand, the depth indicators
+// and the adjoint - the un-reduced outputs of dg_corr_materialize are written at the reference's index).  One block per (tile of
+// 32 positions, image): per channel the tile is 128 contiguous, 128-byte aligned bytes of the plane; the block normalises its 32
+// positions and writes the tile's whole F part (24 KB at C = 384, contiguous).
+// (Round 2 kept the reference's order: one block per source row, 112-byte segments in, rows of 28 different tiles out.)
 template <int MAXU>      // channels per thread = KF / 8 <= MAXU
-__device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int y, int xb, int n, int o) {
-    // thread (x = tid & 31, k0 = tid >> 5) owns pixel x of the row and the channels k0 + 8u: all of them are loaded in one
-    // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a pixel through LDS,
+__device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int tile, int n, int o) {
+    // thread (xl = tid & 31, k0 = tid >> 5) owns position xl of the tile and the channels k0 + 8u: all of them are loaded in one
+    // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a position through LDS,
     // and only the NORMALISED bf16 row tile goes to LDS (half the bytes of an fp32 stage -> twice the blocks per CU).
-    // maps wider than 32 pixels (56 x 56 at 448 input) are covered by ceil(w / 32) blocks per source row: xb = 32-pixel segment
-    const int tid = threadIdx.x, xl = tid & 31, x = xb * 32 + xl, k0 = tid >> 5;
-    const int K = a.K, KF = a.KF, w = a.w, h = a.h;
-    const int wseg = min(32, w - xb * 32);          // pixels of this segment
+    const int tid = threadIdx.x, xl = tid & 31, x = tile * 32 + xl, k0 = tid >> 5;
+    const int K = a.K, KF = a.KF, w = a.P;           // (the tile walks the flattened plane: a "row" of P pixels)
+    const int xb = tile;
+    const int wseg = min(32, a.P - tile * 32);      // positions of this tile
     const int RS = KF * 2 + 16;                     // LDS row stride in bytes: 16-byte aligned rows (granule reads), 2-way writes at worst
     const DgBlob L(a.KF, a.KD);
-    const float* src = a.src[o] + (size_t)n * K * h * w + (size_t)y * w + x;
-    char* tb = reinterpret_cast<char*>(sl);         // [w][RS] bf16 rows
+    const float* src = a.src[o] + (size_t)n * K * a.h * a.w + x;
+    char* tb = reinterpret_cast<char*>(sl);         // [32][RS] bf16 rows
     float* red = reinterpret_cast<float*>(tb + 32 * RS);   // [8][32] partial squared norms
     const int nu = KF >> 3;
     float t[MAXU];
@@ -361,7 +364,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
         const int k = k0 + 8 * u;
-        t[u] = (u < nu && x < w && k < K) ? src[(size_t)k * h * w] : 0.f;
+        t[u] = (u < nu && x < w && k < K) ? src[(size_t)k * a.h * a.w] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) ss = fmaf(t[u], t[u], ss);
@@ -383,7 +386,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     for (int id = tid; id < wseg * pieces; id += 256) {
         const int xx = id / pieces, g = id - xx * pieces;
         const uint4 v = *reinterpret_cast<const uint4*>(tb + xx * RS + g * 16);
-        const int p = y * w + xb * 32 + xx;                 // position = pixel index (see "position order" at k_prep_dense)
+        const int p = xb * 32 + xx;                         // position = pixel index
         char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
         *reinterpret_cast<uint4*>(blob + L.f(p & 31, g)) = v;
     }
@@ -392,10 +395,10 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     for (int k = tid; k < KF; k += 256) {
         float cs = 0.f;
         for (int xx = 0; xx < wseg; ++xx) cs += (float)*reinterpret_cast<const __bf16*>(tb + xx * RS + k * 2);
-        a.colpart[o][((size_t)n * (h * ((w + 31) / 32)) + xb * h + y) * KF + k] = cs;      // one partial per (segment, source row)
+        a.colpart[o][((size_t)n * (a.Ppad / 32) + tile) * KF + k] = cs;      // one partial per tile
     }
     // zero rows of the ragged last tile (positions P .. Ppad-1), once per image
-    if (y == 0 && xb == 0) {
+    if (tile == a.Ppad / 32 - 1) {
         for (int idx = tid; idx < (a.Ppad - a.P) * (KF / 4); idx += 256) {
             const int p = a.P + idx / (KF / 4), k = (idx % (KF / 4)) * 4;
             char* blob = a.blob[o] + ((size_t)n * (a.Ppad / 32) + (p >> 5)) * L.bytes;
@@ -585,8 +588,8 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
 
 
 // One launch prepares everything the fused kernel needs on the identity grid:
-//   z = 0,1: feats operands (one block per source row), z = 2,3: code operands (one block per tile), z = 4: depth indicators.
-// grid h * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
+//   z = 0,1: feats operands (one block per tile), z = 2,3: code operands / norms, z = 4: depth indicators.
+// grid tiles * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
 template <int MAXU, int UNC>
 __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     extern __shared__ float sl[];
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    const int gx = a.h * ((a.w + 31) / 32);              // (>= the code role's ceil(tiles / DENSE_TPB) blocks: launcher)
+    const int gx = a.Ppad / 32;                          // blocks per (image, role): one per tile (>= what the code roles need: launcher)
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
     if (n >= a.B) {                                      // the trailing blocks: the negatives' batch maps of this step
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
         return;
     }
     if (z < 2) {
-        if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x % a.h, x / a.h, n, z);
+        if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
     } else if (z < 4) {
         if (a.code_split) {
             if (x * 256 < a.h * a.w) prep_dense_code_norms<UNC>(a, x, n, z - 2);
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
     if (a.KF > 768 || a.D > 128) return hipErrorInvalidValue;
-    const int nt = a.Ppad / 32, gx = a.h * ((a.w + 31) / 32);
+    const int nt = a.Ppad / 32, gx = nt;
     if ((nt + DENSE_TPB - 1) / DENSE_TPB > gx || (a.h * a.w + 255) / 256 > gx) return hipErrorInvalidValue;
     const int smem = max(max(32 * (a.KF * 2 + 16) + 8 * 32 * 4,
                              DENSE_TPB * 32 * (a.KD + 4) * 2 + 4 * DENSE_CODE_PAIRS * 4 + DENSE_TPB * 32 * 4), a.draw_count > 0 ? a.B * 4 : 0);
