@@ -40,6 +40,8 @@ struct Plan {
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
     size_t ticket;                          // the depth blocks' ticket of the k_gs launch
+    size_t maskbits[DG_MAX_NEG + 2];        // exact clamp masks of the pair-sets (k_cd_mask; small sample grids), xmask: in use
+    bool xmask;
     size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
     size_t total;
 };
@@ -99,6 +101,13 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
     p.ticket = take(256);
+    // exact clamp masks: gradient passes of the zero_clamp recipe on small sample grids (fp32 sampled rows exist, <= 8 tiles, the
+    // one-wave-per-SIMD form of k_corr_main)
+    p.xmask = p.rows && p.grad && (d->flags & DG_ZERO_CLAMP) && !(d->flags & DG_STABALIZE) && p.Ppad <= 256 && p.rf == 4;
+#ifdef DG_NO_XMASK      // developer A/B: the fp16 masks everywhere
+    p.xmask = false;
+#endif
+    for (int t = 0; t < p.T; ++t) p.maskbits[t] = take(p.xmask ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
     p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
     p.gr_rank = take((size_t)DG_MAX_JOBS * B * 2);
@@ -198,6 +207,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
         j.Gout = p.grad ? reinterpret_cast<uint16_t*>(ws + p.gbuf[t]) : nullptr;
+        j.maskbits = p.xmask ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[t]) : nullptr;
         j.slot_loss = t < 2 ? t : DG_OUT_LOSS_NEG;
         j.slot_cd = t < 2 ? DG_OUT_CD_INTRA + t : DG_OUT_CD_NEG;
         j.fin_scale = (float)(1.0 / (t < 2 ? numel : numel * p.N));
@@ -375,6 +385,17 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.njobs = nj;
         g.direct = p.rows ? 1 : 0;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
+        if (p.xmask) {
+            DgCdMaskArgs m;
+            memset(&m, 0, sizeof(m));
+            m.rowsR = F32(p.rows_c[0]);
+            for (int t = 0; t < p.T; ++t) {
+                m.rowsS[t] = F32(p.rows_c[op_of(p, t)]); m.sidx[t] = map_of(p, t, perms);
+                m.bits[t] = reinterpret_cast<uint32_t*>(ws + p.maskbits[t]);
+            }
+            m.T = p.T; m.B = p.B; m.P = p.P; m.Ppad = p.Ppad; m.D = p.D; m.D4 = p.D4;
+            DG_HIP(dg_launch_cd_mask(m, stream));
+        }
     }
 
     // (the launch plan of step 4 is needed here already: the consumer lists of k_corr2's grouped ragged blocks are written by
@@ -449,15 +470,17 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
     f.wtot[0] = desc->w_intra; f.wtot[1] = desc->w_inter; f.wtot[2] = desc->w_neg; f.wtot[3] = desc->w_depth;
     if (p.grad) {
         DgGsArgs g;
+        const uint32_t* dep_maskbits = nullptr;
         build_gs_jobs(p, ws, perms, g);
         g.fin = f;
         if (p.depth) {
             g.dep_op = ws + p.op[0]; g.dep_nz = F32(p.nz); g.dep_dR = F32(p.dRA[p.T]); g.dep_part = F32(p.part[p.T]);
             g.dep_ticket = reinterpret_cast<unsigned int*>(ws + p.ticket);
+            dep_maskbits = p.xmask ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[0]) : nullptr;   // cd of the depth term = intra's cd
             g.dep_shift = desc->shift_depth; g.dep_nrb = dep_nrb; g.dep_blocks = p.B * dep_nrb;
             clamp_bounds(desc, g.dep_lo, g.dep_hi);
         }
-        DG_HIP(dg_launch_gs(g, stream));
+        DG_HIP(dg_launch_gs(g, dep_maskbits, stream));
     } else {
         DG_HIP(dg_launch_finish(f, stream));
     }

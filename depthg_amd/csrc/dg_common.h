@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
@@ -179,6 +180,8 @@ struct DgJob {
     const char* Sop;      // ... of the streamed operand
     const float* rvec;    // fp32 [B][Ppad] row means a_p . bbar (indexed by operand-1 position) or null
     const float* rimg;    // fp32 [B] per-image sums of rvec: m0 = sum / (B*P) = old_mean of the reference (modules.py:1237) or null
+    const uint32_t* maskbits;   // [B][Ppad/32 (S tile)][Ppad (R position)]: bit i = 1[cd >= 0] of (S position 32 tile + i, R position), from
+                                // the fp32 sampled code rows (k_cd_mask; small sample grids) - or null: the sign of the fp16-operand cd
     const float* nzR;     // fp32 [B][Ppad] depth indicators (DG_JOB_DEPTH)
     const float* nzS;
     const float* RcInv;   // fp32 [B][Ppad] 1/max(||c||,eps) of the R code operand (normalisation backward)
@@ -585,10 +588,20 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
 bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD);
-hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream);
+hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream);   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
+// Exact clamp masks of the pair-sets on small sample grids: 1[<c1_p, c2_q> >= 0] from the fp32 sampled code rows (the sign of cd
+// does not depend on the normalisation), packed as one word per (S tile, R position).
+struct DgCdMaskArgs {
+    const float* rowsR;                      // sampled code rows of operand 1: (B, P, D4) fp32
+    const float* rowsS[DG_MAX_NEG + 2];      // ... of the streamed operand of pair-set t
+    const int64_t* sidx[DG_MAX_NEG + 2];     // batch map of the streamed operand (null: identity)
+    uint32_t* bits[DG_MAX_NEG + 2];          // [B][Ppad/32][Ppad] out
+    int32_t T, B, P, Ppad, D, D4;
+};
+hipError_t dg_launch_cd_mask(const DgCdMaskArgs& a, hipStream_t s);
 hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);

@@ -229,6 +229,18 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
             for (int c = 0; c < RCB / 1024; ++c)
                 dma16(Rblob[f] + BL::OFF_C + c * 1024 + lane * 16, smem_a + NBUF * BUF + (wid * RF + f) * RCB + c * 1024);
     }
+    // exact clamp masks (k_cd_mask; small sample grids, one wave per SIMD: the words of this lane's R position for all <= 8 S tiles)
+    constexpr bool XMASK = GRAD && SIMPLE && !MAT && KIND == KIND_LANE && NWAVES == 4 && RF == 1;
+    uint32_t mw[XMASK ? 8 : 1];
+    const bool xmask = XMASK && job.maskbits != nullptr && ntiles_all <= 8;
+    if constexpr (XMASK) {
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) mw[t8] = 0u;
+        if (xmask) {            // (one uniform branch, clamped tile indices: guarded loads are issued and waited for one by one)
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) mw[t8] = job.maskbits[((size_t)n * ntiles_all + min(t8, ntiles_all - 1)) * Ppad + pr[0]];
+        }
+    }
     bf16x8 Rf[RF][NSF > 0 ? NSF : 1];
     if (KIND != KIND_DEPTH && !(dbg & 2048)) {
 #pragma unroll
@@ -241,6 +253,10 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
     // latencies overlap): its counted vmcnt waits at their first use inside the tile loop would otherwise also count
     // (and drain) the tile DMAs it does not know about.
     auto settle_R = [&]() {
+        if constexpr (XMASK) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) asm volatile("" : "+v"(mw[t8]));
+        }
         if (KIND != KIND_DEPTH && !(dbg & 1024)) {
 #pragma unroll
             for (int f = 0; f < RF; ++f)
@@ -381,7 +397,16 @@ __device__ __forceinline__ void corr_body(const DgCorrArgs& args, const DgJob& j
         f16x8 ga[RF][2];                   // G as the A operand of the gradient product: k-step sp holds elements 8sp..8sp+7
         auto epi = [&](int f, int i) {     // accumulator element i = (tile row (i&3)+8*(i>>2)+4*h, lane column r)
             float li;
-            ga[f][i >> 3][i & 7] = (_Float16)epi_elem<KIND, SIMPLE, FOLD>(Yf[f][i], Yc[f][i], vv[i], c0, nz_lane[f], lo, hi, lsum, csum, li);
+            float cdm = Yc[f][i];
+            if constexpr (XMASK) {
+                // the exact sign of cd instead of the fp16-operand one (same magnitude: the value only enters the loss sums)
+                uint32_t w8 = mw[0];
+#pragma unroll
+                for (int t8 = 1; t8 < 8; ++t8) w8 = t == t8 ? mw[t8] : w8;
+                const bool on = (w8 >> ((i & 3) + 8 * (i >> 2) + 4 * h)) & 1u;
+                if (xmask) cdm = on ? fabsf(cdm) : -fabsf(cdm) - 1e-30f;
+            }
+            ga[f][i >> 3][i & 7] = (_Float16)epi_elem<KIND, SIMPLE, FOLD>(Yf[f][i], cdm, vv[i], c0, nz_lane[f], lo, hi, lsum, csum, li);
             if (MAT) {   // R = operand 2 on lanes -> stores contiguous along q
                 const int p = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (act[f] && pr[f] < P && p < P) {
@@ -704,8 +729,8 @@ __device__ __forceinline__ void gs_wait_tiles(int k) {   // at most k tiles (CH 
 // the streamed tile's C and P parts + its 32 indicators come through two LDS buffers, register-staged one tile ahead (plain
 // loads: with eight waves per block and other blocks on the CU there is enough in flight); per tile NKD cd MFMAs, the epilogue
 // with per-element sums (G takes two or three distinct values: the fold of the helper jobs would bias), 6 gradient MFMAs.
-template <int NKF, int NKD>
-__device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid, char* smem) {
+template <int NKF, int NKD, bool XM>      // XM: exact clamp masks of the intra pair-set (k_cd_mask), dep_maskbits
+__device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t* dep_maskbits, const int dbid, char* smem) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, NDF = KD / 32, NTH = (GS_CW + 1) * 64;
     constexpr int TILE = 256 + (BL::BYTES - BL::OFF_C);       // [32 indicators, padded][C part][P part]
@@ -732,6 +757,16 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid
     // tile staging: thread t owns pieces t and t + NTH of the C/P parts, threads 0..7 also four indicators each
     v4i st0, st1 = v4i{0, 0, 0, 0};
     f32x4 stz = f32x4{0.f, 0.f, 0.f, 0.f};
+    // XM - exact clamp masks of the intra pair-set (zero_clamp, no upper bound; <= 8 tiles): the words of this lane's R position
+    // against every S tile, loaded up front and waited for once.  The block without them sits at k_gs's 128 registers (9 spilled);
+    // eight more spill 80 (KD = 96) / 454 (KD = 128) and cost 11 - 27 us at C3's shape, so the masked form is its own
+    // instantiation of k_gs with 256 registers per wave (one block per CU: small sample grids have few blocks).
+    uint32_t mw[XM ? 8 : 1];
+    if constexpr (XM) {
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8)       // (clamped tile indices, no guards: guarded loads are issued and waited for one by one)
+            mw[t8] = dep_maskbits[((size_t)n * ntiles + min(t8, ntiles - 1)) * a.Ppad + (act ? rtile : 0) * 32 + r];
+    }
     auto fetch = [&](int t) {
         const char* src = img + (size_t)t * BL::BYTES + BL::OFF_C;
         st0 = *reinterpret_cast<const v4i*>(src + tid * 16);
@@ -745,9 +780,19 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid
         if (tid < 8) *reinterpret_cast<f32x4*>(tile + tid * 16) = stz;
     };
     fetch(0);
+    if constexpr (XM) {
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) asm volatile("" : "+v"(mw[t8]));
+    }
     stash(0);
     const int crow = (h * 32 + r) * 16;
     for (int t = 0; t < ntiles; ++t) {
+        uint32_t mwd = 0u;
+        if constexpr (XM) {
+            mwd = mw[0];
+#pragma unroll
+            for (int t8 = 1; t8 < 8; ++t8) mwd = t == t8 ? mw[t8] : mwd;
+        }
         if (t + 1 < ntiles) fetch(t + 1);                 // in flight during this tile's arithmetic
         __syncthreads();                                   // tile t is in buffer t & 1; everybody is done with the other one
         const char* tile = smem + (t & 1) * TILE;
@@ -766,7 +811,8 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * i4 + e;
                     const float fdv = fmaf(nz_lane, v4[e], c0);
-                    const float g = (yc[i] >= a.dep_lo && yc[i] <= a.dep_hi) ? fdv : 0.f;      // d clamp(cd) / d cd
+                    const bool on = XM ? ((mwd >> ((i & 3) + 8 * (i >> 2) + 4 * h)) & 1u) != 0u : (yc[i] >= a.dep_lo && yc[i] <= a.dep_hi);
+                    const float g = on ? fdv : 0.f;      // d clamp(cd) / d cd
                     lsum = fmaf(fdv, fminf(fmaxf(yc[i], a.dep_lo), a.dep_hi), lsum);           // clamp(cd) (dd - shift)
                     g8[i >> 3][i & 7] = (_Float16)g;
                 }
@@ -816,8 +862,8 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const int dbid
     }
 }
 
-template <int NKF, int NKD>
-__global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
+template <int NKF, int NKD, bool XM>
+__device__ __forceinline__ void gs_body(const DgGsArgs& a, const uint32_t* dep_maskbits) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, NDF = KD / 32, TS = GS_TS;
     constexpr int PB = BL::BYTES - BL::OFF_P, CH = PB / 1024;     // bytes / DMA instructions of a P part
@@ -830,7 +876,7 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
     // operand - get consecutive logical ids on one XCD, so its P parts are fetched into one L2 once
     // the depth term's blocks FIRST (they are long latency chains: started last they would be this launch's tail), then the
     // G-stream blocks
-    if ((int)blockIdx.x < a.dep_blocks) { gs_depth_block<NKF, NKD>(a, (int)blockIdx.x, gs_smem); return; }
+    if ((int)blockIdx.x < a.dep_blocks) { gs_depth_block<NKF, NKD, XM>(a, dep_maskbits, (int)blockIdx.x, gs_smem); return; }
     int bid;
     {
         const int nwg = (int)gridDim.x - a.dep_blocks, orig = (int)blockIdx.x - a.dep_blocks;
@@ -972,7 +1018,17 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) {
         }
 }
 
-hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
+template <int NKF, int NKD>
+__global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) { gs_body<NKF, NKD, false>(a, nullptr); }
+// the same launch with the exact clamp masks of the intra pair-set in the depth term's blocks (small sample grids: k_cd_mask;
+// 256 registers per wave - see gs_depth_block).  Its own kernel and argument list: the plain one is at a register cliff where an
+// eight-byte longer argument block alone cost 9 us at the headline (13 instead of 9 spilled registers).
+template <int NKF, int NKD>
+__global__ __launch_bounds__((GS_CW + 1) * 64, 2) void k_gs_xm(const DgGsArgs a, const uint32_t* dep_maskbits) {
+    gs_body<NKF, NKD, true>(a, dep_maskbits);
+}
+
+hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream) {
     dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B + a.dep_blocks), block((GS_CW + 1) * 64);
     DgGsArgs a2 = a;
 #ifdef DG_DEVTOOLS
@@ -981,9 +1037,12 @@ hipError_t dg_launch_gs(const DgGsArgs& a, hipStream_t stream) {
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;
 #define DG_GS(NKF_, NKD_)                                                                                               \
     if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) {                                                                        \
-        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_gs<NKF_, NKD_>), smem); \
+        const void* kern = dep_maskbits ? reinterpret_cast<const void*>(k_gs_xm<NKF_, NKD_>)                             \
+                                        : reinterpret_cast<const void*>(k_gs<NKF_, NKD_>);                               \
+        hipError_t e = dg_set_max_smem(kern, smem);                                                                      \
         if (e != hipSuccess) return e;                                                                                   \
-        hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, smem, stream, a2);                                           \
+        if (dep_maskbits) hipLaunchKernelGGL((k_gs_xm<NKF_, NKD_>), grid, block, smem, stream, a2, dep_maskbits);        \
+        else hipLaunchKernelGGL((k_gs<NKF_, NKD_>), grid, block, smem, stream, a2);                                      \
         return hipGetLastError();                                                                                        \
     }
     DG_GS(8, 6) DG_GS(8, 8) DG_GS(24, 6) DG_GS(24, 8) DG_GS(48, 6) DG_GS(48, 8)

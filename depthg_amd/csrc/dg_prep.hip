@@ -318,6 +318,70 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArg
     }
 }
 
+// Exact clamp masks on small sample grids (the S = 11 / 12 recipes).  The gradient of the loss is discontinuous in cd (the
+// factor 1[cd >= 0] of zero_clamp); with fp16 code operands a fraction ~5e-4 of the elements has |cd| below the operand rounding
+// and gets the other sign - an incoherent 1.2e-2 relative error of the code gradients.  The sign of cd is the sign of the RAW
+// dot product of the two sampled fp32 code rows (norm() divides by positive numbers), and at P = 121 / 144 positions that is half
+// a GFLOP of fp32 for the whole batch: one block per (S tile, image, pair-set) forms the 32 x P dot products in fp32 and packs
+// them as one word per (S tile, R position) - bit i = position 32 tile + i - which the fused kernel reads instead of comparing.
+template <int NC>      // 16-byte chunks of a code row per lane: D4 <= 8 NC
+__global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
+    // One wave per (S tile, R tile) pair: the 32 x 32 raw dot products on the fp32 MFMA (v_mfma_f32_32x32x2_f32: fp32 products,
+    // fp32 accumulation - the sign of the reference's fp32 cd, which the fp16 MFMA of k_corr_main flips for |cd| < ~1e-3).
+    // Lane (j = lane & 31, h = lane >> 5) holds the 16-byte chunks 2m + h of S row j (A) and of R row j (B); k-step (m, e) of the
+    // MFMA pairs element e of chunk 2m (lanes h = 0) with element e of chunk 2m + 1 (h = 1) - the MFMA does not care which two
+    // elements of the rows share a step.  A chunk past the row (odd chunk counts, NC larger than the row) is read at a clamped
+    // address and zeroed.  The lane ends with column j of the tile: the bits of R position j for 16 of the 32 S positions
+    // (rows (reg & 3) + 8 (reg >> 2) + 4 h - the bit order k_corr_main's epilogue reads); the halves are OR-ed across lane ^ 32.
+    // (Measured at C3's shape, 3584 tile pairs: an LDS-staged fp32 FMA form 50 us, LDS-bound; rows through the scalar cache as
+    // SGPR operands of v_pk_fma_f32 27 us, bound by the scalar-cache misses of each row; this form with 8-byte loads 19 us.)
+    const int nt = a.Ppad >> 5, D4 = a.D4, nq = D4 >> 2;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y, t = blockIdx.z;
+    if (w >= nt * nt) return;
+    const int st = w / nt, rt = w - st * nt;
+    const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int ps = st * 32 + j, pr = rt * 32 + j;
+    const float* srow = a.rowsS[t] + ((size_t)nS * a.P + min(ps, a.P - 1)) * D4;
+    const float* rrow = a.rowsR + ((size_t)n * a.P + min(pr, a.P - 1)) * D4;
+    f32x4 av[NC], bv[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int c = min(2 * m + h, nq - 1);
+        av[m] = *reinterpret_cast<const f32x4*>(srow + 4 * c);
+        bv[m] = *reinterpret_cast<const f32x4*>(rrow + 4 * c);
+    }
+#pragma unroll
+    for (int m = 0; m < NC; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[m][e] = 2 * m + h < nq ? av[m][e] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[m][e], acc, 0, 0, 0);
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) word |= (acc[i] >= 0.f ? 1u : 0u) << ((i & 3) + 8 * (i >> 2) + 4 * h);
+    word |= (uint32_t)__shfl_xor((int)word, 32);
+    // padding: cd = 0 there, inside the clamp (what the fp16 path sees)
+    const int nvalid = a.P - st * 32;
+    if (nvalid < 32) word |= ~0u << max(nvalid, 0);
+    if (pr >= a.P) word = ~0u;
+    if (h == 0) a.bits[t][((size_t)n * nt + st) * a.Ppad + pr] = word;
+}
+hipError_t dg_launch_cd_mask(const DgCdMaskArgs& a, hipStream_t s) {
+    if (a.D4 > 128) return hipErrorInvalidValue;
+    const int nt = a.Ppad / 32;
+    const dim3 grid((nt * nt + 3) / 4, a.B, a.T);     // one wave per (S tile, R tile)
+    if (a.D4 <= 72)       hipLaunchKernelGGL(k_cd_mask<9>, grid, dim3(256), 0, s, a);       // D = 70 (the headline width)
+    else if (a.D4 <= 104) hipLaunchKernelGGL(k_cd_mask<13>, grid, dim3(256), 0, s, a);      // D = 90, 100
+    else                  hipLaunchKernelGGL(k_cd_mask<16>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s) {
     constexpr int CH = 32;
     int gx = 0;

@@ -38,7 +38,9 @@ def _pair(cfg, f, fp, c, cp, d, dp, coords1, coords2, perms, dev, **kw):
 def _check(ref, rgrads, out, ggrads, rt=1.5e-4, at=3e-7, gt=2.1e-2, worst=0.16):
     """Bounds at <= 1.5 x the errors measured at these recipes (profiles/r03_parity.md, scripts/parity_table.py): loss means 1e-4
     relative at worst (the near-cancelling intra mean of config 2; 1e-5 and below elsewhere) - the north_star tolerance -,
-    gradients 1.0-1.4e-2 relative L2 and 3-10 % of the largest element (clamp-mask flips of the fp16 cd)."""
+    gradients 1.0-1.4e-2 relative L2 and 3-10 % of the largest element on the dense grids (clamp-mask flips of the fp16 cd, DESIGN.md
+    section 6).  The small sample grids of configs 2-4 take their clamp masks from fp32 dot products (k_cd_mask): 4e-4 - 1.1e-3
+    there, and the callers below pass those bounds."""
     n = len(ref)
     for i in range(0, n, 2):
         _relclose(out[i].mean(), ref[i].mean(), rt, at, f"tuple[{i}]")
@@ -71,7 +73,7 @@ def test_config4_shard_shape_fps(dev):
     g2 = ops.fps_coords(dp.to(dev), (hw, hw), S).cpu()
     assert torch.equal(g1, c1) and torch.equal(g2, c2), "FPS coordinates must be bit-identical"
     perms = [O.super_perm(B, g) for _ in range(N)]
-    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev))
+    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev), gt=7.5e-4, worst=7e-4)     # measured 4.7e-4 / 4.4e-4 (exact masks)
 
 
 def test_config3_vitb_no_pointwise(dev):
@@ -89,7 +91,7 @@ def test_config3_vitb_no_pointwise(dev):
     c1 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
     c2 = torch.rand(B, S, S, 2, generator=g) * 2 - 1
     perms = [O.super_perm(B, g) for _ in range(N)]
-    _check(*_pair(cfg, f, fp, c, cp, d, d, c1, c2, perms, dev))
+    _check(*_pair(cfg, f, fp, c, cp, d, d, c1, c2, perms, dev), gt=6e-4, worst=5e-4)        # measured 4.0e-4 / 3.0e-4 (exact masks)
 
 
 def test_config2_potsdam_recipe_fps(dev):
@@ -108,7 +110,7 @@ def test_config2_potsdam_recipe_fps(dev):
     c1 = O.farthest_point_sampling_depth((hw, hw), d, S) * 2 - 1
     c2 = O.farthest_point_sampling_depth((hw, hw), dp, S) * 2 - 1
     perms = [O.super_perm(B, g) for _ in range(N)]
-    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev))
+    _check(*_pair(cfg, f, fp, c, cp, d, dp, c1, c2, perms, dev), gt=1.7e-3, worst=1.6e-3)   # measured 1.1e-3 / 1.0e-3 (exact masks)
 
 
 def test_config5_hires_56_vs_oracle(dev):
