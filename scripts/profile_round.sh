@@ -44,3 +44,5 @@ print(main, json.dumps(m, indent=1))
 PY
 head -14 $out/${tag}_kernel_stats.csv | cut -c1-150
 cat $out/bench_under_rocprof.json
+# (the raw traces are tens of MB: only the summaries travel back)
+find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete
