@@ -326,3 +326,16 @@ def test_byte_movers_use_no_scratch_and_no_flat_loads(unit, tmp_path):
     assert scratch, "no kernels found in the generated code"
     bad = {k: v for k, v in scratch.items() if v > 0}
     assert not bad, f"{unit}: kernels with scratch (bytes per thread): {bad}"
+
+
+def test_bench_cpu_baseline_reports_both_thread_counts(monkeypatch):
+    """bench.py's cpu_baseline: the oracle timed at 16 threads and at every host CPU; the second leg runs in a child process
+    with a wall-clock limit and is either reported or said to be skipped - it can never hold the bench line up."""
+    import os
+    import bench
+    monkeypatch.setattr(os, "cpu_count", lambda: 24)
+    r = bench.cpu_baseline(bench.CONFIGS["C2"], seconds_budget=2.0)
+    assert r["kind"] == "port" and r["unit"] == "steps/s" and r["value"] > 0 and r["host_cpus"] == 24
+    assert r["cores"] in (16, 24) and "threads" in r["sample"]
+    assert len(r["also"]) == 1 and r["also"][0]["cores"] in (16, 24) and r["also"][0]["cores"] != r["cores"]
+    assert "value" in r["also"][0] or "skipped" in r["also"][0]
