@@ -769,21 +769,26 @@ static int head_check(int32_t B, int32_t C, int32_t D, int32_t P) {
     if (D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", D);
     return DG_OK;
 }
-static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P) {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
-    int s = (512 + tiles - 1) / tiles;        // about two blocks per CU
-    return s < 1 ? 1 : (s > steps ? steps : s);
+static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P, int32_t M2 = 0) {     // (M2: a second product in the same launch)
+    const int tiles = ((M + 127) / 128 + (M2 + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
+#ifndef HEAD_SPLIT_TARGET
+#define HEAD_SPLIT_TARGET 512
+#endif
+    int s = (HEAD_SPLIT_TARGET + tiles - 1) / tiles;        // about two blocks per CU
+    s = (s + 7) & ~7;                                       // a multiple of 8: k_head_wgrad2 keeps the tiles of a split on one XCD
+    return s > steps ? steps : s;
 }
 struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, total; int s2a, s1, s2b, tiles; };
 static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     HeadPlan h;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
-    h.s2a = head_splits(B, C, C, P); h.s1 = head_splits(B, D, C, P); h.s2b = h.s1;
+    // cluster2: d W2a and d W1 share the feature operand and one launch (same splits); cluster1 alone (linear head): d W1 by itself
+    h.s2a = head_splits(B, C, C, P, D); h.s1 = head_splits(B, D, C, P); h.s2b = h.s1;
     h.tiles = (P + 63) / 64;
     h.dh = take((size_t)B * C * P * 2);
     h.p2a = take((size_t)h.s2a * C * C * 4);
-    h.p1 = take((size_t)h.s1 * D * C * 4);
+    h.p1 = take((size_t)(h.s1 > h.s2a ? h.s1 : h.s2a) * D * C * 4);
     h.p2b = take((size_t)h.s2b * D * C * 4);
     h.pbd = take((size_t)B * h.tiles * D * 4);
     h.pb2a = take((size_t)B * h.tiles * C * 4);
@@ -843,8 +848,8 @@ extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, cons
     auto reduce = [&](const float* part, float* out, float* out2, int n, int splits, float scale) {
         red.jobs[red.njobs++] = DgHeadReduceJob{part, out, out2, n, splits, scale};
     };
-    // d W1[d][k] = scale * keep1[b][k] * sum_p g[d][p] f[k][p]
-    {
+    // d W1[d][k] = scale * keep1[b][k] * sum_p g[d][p] f[k][p]      (with cluster2: in the launch of d W2a below, which reads the same f)
+    if (!nonlinear) {
         DgHeadWgradArgs w{grad_code, feat, keep1, F32(h.p1), B, D, C, P, h.s1};
         DG_HIP(dg_launch_head_wgrad(w, false, false, s));
         reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s1, keep1 ? keep_scale : 1.f);
@@ -863,9 +868,10 @@ extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, cons
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
     DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
     reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
-    DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a};
+    DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
+    reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);
     DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
 }

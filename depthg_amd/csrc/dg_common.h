@@ -658,6 +658,8 @@ struct DgHeadWgradArgs {
     const float* keep;                 // (B, N) or null
     float* part;                       // [splits][M][N]
     int32_t B, M, N, P, splits;
+    // optional second product with the same Bm in the same launch (M2 > 0): A2 (B, M2, P) fp32, its keep mask and partial sums
+    const void* A2; const float* keep_2; float* part2; int32_t M2;
 };
 
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);

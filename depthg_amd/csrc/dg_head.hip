@@ -85,14 +85,16 @@ hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w
     return hipGetLastError();
 }
 
-// MB = 16-row blocks of hidden channels per wave (Cpad = 64 MB), NT = positions per block
-template <int MB, int NT>
-__global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
-    constexpr int CP = 64 * MB, NB = NT / 16, FROW = NT * 2 + 32, HROW = CP * 2 + 32, DBMAX = 8, KS = CP / 32;
+// MB = 16-row blocks of hidden channels per wave, NW = waves per block (Cpad = 16 MB NW), NT = positions per block
+// (head_frow(NT): an odd number of 32-byte pieces per row, what tr_frag's bank pattern needs)
+__host__ __device__ constexpr int head_frow(int NT) { return ((NT * 2 / 32) & 1) ? NT * 2 : NT * 2 + 32; }
+template <int MB, int NT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
+    constexpr int NTH = 64 * NW, CP = 16 * MB * NW, NB = NT / 16, FROW = head_frow(NT), DBMAX = 8, KS = CP / 32;
+    static_assert(NT % 16 == 0 && DBMAX % NW == 0 && CP % 32 == 0, "blocking");
     extern __shared__ __attribute__((aligned(16))) char hsm[];
-    char* const Ft = hsm;                                   // [CP][FROW]  bf16 f tile, channel-major; later Hm [channel][position]
-    char* const Ht = hsm + CP * FROW;                       // [NT][HROW]  bf16 hidden tile, position-major
-    unsigned short* const km1 = reinterpret_cast<unsigned short*>(Ht + NT * HROW);   // [CP] keep bits of cluster1's dropout (0xffff / 0)
+    char* const Ft = hsm;                                   // [CP][FROW]  bf16 f tile, channel-major; later the hidden tile, same layout
+    unsigned short* const km1 = reinterpret_cast<unsigned short*>(Ft + CP * FROW);   // [CP] keep bits of cluster1's dropout (0xffff / 0)
     unsigned short* const km2 = km1 + CP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
     const int b = blockIdx.y, p0 = blockIdx.x * NT;
@@ -108,31 +110,30 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
 
     // ---- stage the feature tile: fp32 (C, NT) -> bf16 LDS image, drop3(f) written on the way.  Eight rows' loads in flight per
     //      thread (one block per CU: nothing else hides the latency)
-    for (int k = tid; k < CP; k += 256) {
+    for (int k = tid; k < CP; k += NTH) {
         km1[k] = (k < C && (!a.keep1 || a.keep1[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
         km2[k] = (k < C && (!a.keep2 || a.keep2[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
     }
     {
-        constexpr int Q = NT / 4, RPP = 256 / Q, U = (CP / RPP) % 12 == 0 ? 12 : ((CP / RPP) % 8 == 0 ? 8 : 4);     // threads per row, rows per pass, passes batched (loads in flight per thread)
-        const int q4 = tid % Q, kr = tid / Q, p = p0 + 4 * q4;
+        constexpr int Q = NT / 4, NIT = (CP * Q + NTH - 1) / NTH;        // 16-byte pieces per row; pieces per thread
+        constexpr int U = NIT % 7 == 0 ? 7 : (NIT % 6 == 0 ? 6 : (NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : 1)));   // loads in flight per thread
         if ((P & 3) == 0) {
             // fast path: every load unconditional from a clamped address (a load under a condition becomes a branch with its own
-            // wait), values selected afterwards; eight rows in flight per thread
-            const bool pin = p + 3 < P;
-            const int pc = pin ? p : P - 4;
-            for (int kb = 0; kb < CP; kb += RPP * U) {
+            // wait), values selected afterwards; U pieces in flight per thread
+            for (int it = 0; it < NIT; it += U) {
                 f32x4 v[U];
                 float kf3[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int k = kb + u * RPP + kr, kc = k < C ? k : C - 1;
+                    const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
+                    const int kc = k < C ? k : C - 1, pc = p + 3 < P ? p : P - 4;
                     v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.feat + ((size_t)b * C + kc) * P + pc));
                     kf3[u] = a.keep3 ? a.keep3[(size_t)b * C + kc] * s3 : 1.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int k = kb + u * RPP + kr;
-                    const bool ok = k < C && pin;
+                    const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
+                    const bool ok = k < C && p + 3 < P;
                     const f32x4 vv = ok ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
                     if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + ((size_t)b * C + k) * P + p) = vv * kf3[u];
                     bf16x4 o4;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             }
         } else {
             // position counts that are not a multiple of 4 (odd maps): element-wise, guarded
-            for (int k = kr; k < CP; k += RPP) {
+            for (int i = tid; i < CP * Q; i += NTH) {
+                const int k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
                 bf16x4 o4;
                 const float f3 = (a.keep3 && k < C) ? a.keep3[(size_t)b * C + k] * s3 : 1.f;
 #pragma unroll
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
     //      The weight fragments of k-step ks + 1 are in flight while step ks runs.
     f32x4 acc1[MB][NB];
     const int mbase = wid * 16 * MB;
-    // the two output convolutions: wave `wid` owns code-channel blocks wid and wid + 4 (16 channels each, D <= 128) for ALL position
+    // the two output convolutions: wave `wid` owns code-channel blocks wid + NW i (16 channels each, D <= 128) for ALL position
     // blocks - every weight row is fetched by exactly one wave of the block
-    constexpr int NA = DBMAX / 4;
+    constexpr int NA = DBMAX / NW;
     f32x4 acc2a[NA][NB], acc2b[NA][NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i)
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
                 for (int i = 0; i < MB; ++i) wn[i] = wraw(a.w2a_bf, C, mbase + 16 * i + c16, C, 32 * ks, C, lane);
             }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) vn[i] = wraw(a.w1_bf, C, 16 * (wid + 4 * i) + c16, D, 32 * ks, C, lane);
+            for (int i = 0; i < NA; ++i) vn[i] = wraw(a.w1_bf, C, 16 * (wid + NW * i) + c16, D, 32 * ks, C, lane);
         };
         fetch(0);
         for (int ks = 0; ks < KS; ++ks) {
@@ -221,7 +223,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
     __syncthreads();                                       // every wave is done reading the f tile
     HSTAMP(3)
     if (nonlinear) {
-        // bias + ReLU in the accumulators; hidden tile -> Ht [position][channel] (next operand) and Hm [channel][position] (saved)
+        // bias + ReLU in the accumulators; hidden tile -> the channel-major image the f tile occupied (the next product reads it
+        // with the same transposing fragment reads; it is also what goes to HBM)
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             const int m = mbase + 16 * i + 4 * g;
@@ -231,26 +234,24 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int p = 16 * j + c16;
-                bf16x4 h4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float h = m + r < C ? fmaxf(fmaf(acc1[i][j][r], s2, bias[r]), 0.f) : 0.f;
-                    h4[r] = (__bf16)h;
-                    *reinterpret_cast<__bf16*>(Ft + (m + r) * FROW + p * 2) = h4[r];
+                    *reinterpret_cast<__bf16*>(Ft + (m + r) * FROW + p * 2) = (__bf16)h;
                 }
-                *reinterpret_cast<bf16x4*>(Ht + p * HROW + m * 2) = h4;
             }
         }
         __syncthreads();
         HSTAMP(4)
-        // ---- cluster2's output convolution: W2b hidden (natural k order on both sides: element e of group g is k = 32 ks + 8 g + e)
+        // ---- cluster2's output convolution: W2b hidden
         static_assert(KS % 2 == 0, "two k-steps per iteration");
+        const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         u32x4 wn[2][NA];
         auto fetch2 = [&](const int ks) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int i = 0; i < NA; ++i) wn[h2][i] = wraw(a.w2b_bf, C, 16 * (wid + 4 * i) + c16, D, 32 * (ks + h2), C, lane);
+                for (int i = 0; i < NA; ++i) wn[h2][i] = wraw(a.w2b_bf, C, 16 * (wid + NW * i) + c16, D, 32 * (ks + h2), C, lane);
         };
         fetch2(0);
         for (int ks = 0; ks < KS; ks += 2) {
@@ -264,12 +265,13 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             for (int h2 = 0; h2 < 2; ++h2) {
                 bf16x8 bfr[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Ht + (16 * j + c16) * HROW + (32 * (ks + h2) + 8 * g) * 2);
+                for (int j = 0; j < NB; ++j) bfr[j] = tr_frag(Ft, FROW, 32 * (ks + h2), 16 * j, lane);
 #pragma unroll
-                for (int i = 0; i < NA; ++i)
+                for (int i = 0; i < NA; ++i) {
+                    const bf16x8 af = wfrag(wc[h2][i], ones, lane);
 #pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        acc2b[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[h2][i]), bfr[j], acc2b[i][j], 0, 0, 0);
+                    for (int j = 0; j < NB; ++j) acc2b[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2b[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
         float bb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int d = 16 * (wid + 4 * i) + 4 * g + r, dc = d < D ? d : D - 1;
+            const int d = 16 * (wid + NW * i) + 4 * g + r, dc = d < D ? d : D - 1;
             bb[r] = a.b1[dc] + (nonlinear ? a.b2b[dc] : 0.f);
         }
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
             const int p = p0 + 16 * j + c16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int d = 16 * (wid + 4 * i) + 4 * g + r;
+                const int d = 16 * (wid + NW * i) + 4 * g + r;
                 if (d < D && p < P) a.code[((size_t)b * D + d) * P + p] = fmaf(acc2a[i][j][r], s1, bb[r]) + (nonlinear ? acc2b[i][j][r] : 0.f);
             }
         }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
     if (nonlinear && a.hidden) {
         constexpr int Q8 = NT / 8;
         const bool vec = (P & 7) == 0;
-        for (int idx = tid; idx < C * Q8; idx += 256) {
+        for (int idx = tid; idx < C * Q8; idx += NTH) {
             const int m = idx / Q8, c = idx - m * Q8, p = p0 + 8 * c;
             __bf16* dst = a.hidden + ((size_t)b * C + m) * P + p;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ft + m * FROW + c * 16);
@@ -312,11 +314,11 @@ __global__ __launch_bounds__(256) void k_head_fwd(const DgHeadFwdArgs a) {
     HSTAMP(7)
 }
 
-template <int MB, int NT>
+template <int MB, int NT, int NW = 4>
 static hipError_t launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
-    constexpr int CP = 64 * MB;
-    const int smem = CP * (NT * 2 + 32) + NT * (CP * 2 + 32) + 2 * CP * 2;
-    auto kern = k_head_fwd<MB, NT>;
+    constexpr int CP = 16 * MB * NW;
+    const int smem = CP * head_frow(NT) + 2 * CP * 2;
+    auto kern = k_head_fwd<MB, NT, NW>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
 #ifdef DG_DEVTOOLS
@@ -325,14 +327,14 @@ static hipError_t launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
         if (!buf && hipMalloc(&buf, 64) != hipSuccess) return hipErrorOutOfMemory;
         DgHeadFwdArgs a2 = a;
         a2.stamps = buf;
-        hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(256), smem, s, a2);
+        hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(64 * NW), smem, s, a2);
         unsigned long long h[8];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* fp = fopen(f, "w")) { for (int i = 1; i < 8; ++i) fprintf(fp, "phase %d: %llu cycles\n", i, h[i] - h[i - 1]); fclose(fp); }
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.P + NT - 1) / NT, a.B), dim3(64 * NW), smem, s, a);
     return hipGetLastError();
 }
 
@@ -340,13 +342,14 @@ hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
     if (a.C <= 64) return launch_head_fwd<1, 64>(a, s);
     if (a.C <= 128) return launch_head_fwd<2, 64>(a, s);
     if (a.C <= 192) return launch_head_fwd<3, 64>(a, s);
-#ifdef HEAD_NT64
-    if (a.C <= 384) return launch_head_fwd<6, 64>(a, s);
-#else
-    // 32 positions per block: 64 KB of LDS and < 256 registers -> two blocks per CU, one block's tile load under the other's MFMAs
-    // (with 64 positions - one block per CU - all blocks load, then all blocks multiply: 118 us against .. us)
-    if (a.C <= 384) return launch_head_fwd<6, 32>(a, s);
+    // C <= 384 on maps whose positions split into tiles of 112 (28 x 28, 56 x 56, ...): eight waves and 112 positions per block -
+    // every block streams the 0.4 MB of bf16 weights once per 112 positions instead of once per 32 (the 32-position form re-reads
+    // them 784 times at the headline: 316 MB through L2 for 10 GFLOP)
+#ifndef HEAD_NT32
+    if (a.C <= 384 && a.P % 112 == 0) return launch_head_fwd<3, 112, 8>(a, s);
 #endif
+    // 32 positions per block: 40 KB of LDS and < 256 registers -> two blocks per CU, one block's tile load under the other's MFMAs
+    if (a.C <= 384) return launch_head_fwd<6, 32>(a, s);
     if (a.C <= 768) return launch_head_fwd<12, 32>(a, s);
     return hipErrorInvalidValue;
 }
@@ -554,40 +557,183 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const DgHeadWgradArgs a) {
         }
 }
 
+// The same product staged through LDS (P a multiple of 8: every 16-byte piece of a row is whole): block = 128 x 128 output tile,
+// k-step = 32 positions.  Two threads per operand row load its 64 (bf16) / 128 (fp32) contiguous bytes of the step -
+// whole lines, where the direct form above reads 16 bytes per lane from 64 different rows per instruction and is bound by the
+// address path -, convert to bf16 and store [row][32 positions] images (80-byte rows: eight consecutive lanes of a 16-byte
+// fragment read fall into eight different bank groups); each wave owns a 64 x 64 sub-tile = 2 x 2 MFMAs of 32x32x16 per 16
+// positions.  The loads of step s + 1 are in flight while step s multiplies; one barrier per step.
 template <typename TA, typename TB>
+__device__ __forceinline__ void wgrad2_body(const DgHeadWgradArgs& a, const void* Aop, const float* keep, float* part, const int M,
+                                            const int m0, const int n0, const int split) {
+    constexpr int PS = 32, RS = PS * 2 + 16, TILE = 128 * RS;     // positions per step; row stride (80 bytes)
+    extern __shared__ __attribute__((aligned(16))) char wsm[];     // [2 stages][A, B][TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int steps_img = (a.P + PS - 1) / PS, total = a.B * steps_img;
+    const int s0 = (int)((long long)total * split / a.splits), s1 = (int)((long long)total * (split + 1) / a.splits);
+    // loader: two threads per operand row, each with 16 consecutive positions of the step.  (Dealing the 16-byte pieces to the
+    // threads in row-major order - 8 / 16 lines per wave instruction instead of 32 - was slower: 36 / 27 / 17 -> 40 / 39 / 15 us for
+    // the three products, its per-piece index arithmetic costs 40 registers; 64 positions per step: 50 / 30 / 20 us.)
+    constexpr int WA = sizeof(TA) == 2 ? 2 : 4, WB = sizeof(TB) == 2 ? 2 : 4;      // 16-byte loads per thread and step
+    using RA = typename std::conditional<sizeof(TA) == 2, u32x4, f32x4>::type;
+    using RB = typename std::conditional<sizeof(TB) == 2, u32x4, f32x4>::type;
+    RA ra[WA];
+    RB rb[WB];
+    bool oka[2], okb[2];                  // the two 8-position chunks of this thread: inside the matrix and the image
+    const int lrow = tid >> 1, half = tid & 1;
+    auto fetch = [&](const int s) {
+        const int b = s / steps_img, p = (s - b * steps_img) * PS + 16 * half;
+        const int m = m0 + lrow, n = n0 + lrow;
+        const TA* Ar = static_cast<const TA*>(Aop) + ((size_t)b * M + (m < M ? m : 0)) * a.P;
+        const TB* Br = static_cast<const TB*>(a.Bm) + ((size_t)b * a.N + (n < a.N ? n : 0)) * a.P;
+        const float kp = (keep && n < a.N) ? keep[(size_t)b * a.N + n] : 1.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bool in = p + 8 * c + 7 < a.P;
+            const int pc = in ? p + 8 * c : 0;                     // (always a valid address; the value is selected away)
+            oka[c] = in && m < M;
+            okb[c] = in && n < a.N && kp != 0.f;
+            if constexpr (sizeof(TA) == 2) ra[c] = *reinterpret_cast<const u32x4*>(Ar + pc);
+            else { ra[2 * c] = *reinterpret_cast<const f32x4*>(Ar + pc); ra[2 * c + 1] = *reinterpret_cast<const f32x4*>(Ar + pc + 4); }
+            if constexpr (sizeof(TB) == 2) rb[c] = *reinterpret_cast<const u32x4*>(Br + pc);
+            else { rb[2 * c] = *reinterpret_cast<const f32x4*>(Br + pc); rb[2 * c + 1] = *reinterpret_cast<const f32x4*>(Br + pc + 4); }
+        }
+    };
+    auto stash = [&](const int buf) {
+        char* At = wsm + buf * 2 * TILE + lrow * RS + half * 32;
+        char* Bt = At + TILE;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            u32x4 va, vb;
+            if constexpr (sizeof(TA) == 2) va = ra[c]; else va = __builtin_bit_cast(u32x4, pack8(ra[2 * c], ra[2 * c + 1]));
+            if constexpr (sizeof(TB) == 2) vb = rb[c]; else vb = __builtin_bit_cast(u32x4, pack8(rb[2 * c], rb[2 * c + 1]));
+            *reinterpret_cast<u32x4*>(At + 16 * c) = oka[c] ? va : u32x4{0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(Bt + 16 * c) = okb[c] ? vb : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int wm = wid >> 1, wn = wid & 1, r32 = lane & 31, kg = lane >> 5;
+    if (s0 < s1) { fetch(s0); stash(0); }
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        if (s + 1 < s1) fetch(s + 1);
+        const char* At = wsm + buf * 2 * TILE + (wm * 64 + r32) * RS + kg * 16;
+        const char* Bt = wsm + buf * 2 * TILE + TILE + (wn * 64 + r32) * RS + kg * 16;
+        constexpr int KSN = PS / 16;
+        bf16x8 af[2][KSN], bfr[2][KSN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) {
+                af[i][ks] = *reinterpret_cast<const bf16x8*>(At + i * 32 * RS + ks * 32);
+                bfr[i][ks] = *reinterpret_cast<const bf16x8*>(Bt + i * 32 * RS + ks * 32);
+            }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+        if (s + 1 < s1) stash(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = part + (size_t)split * M * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                if (m < M && n < a.N) out[(size_t)m * a.N + n] = acc[i][j][e];
+            }
+        }
+}
+
+// One launch, one or two products that share the operand Bm (the weight gradients of cluster1 and of cluster2's first convolution
+// both multiply the feature tile): tiles of A (M rows) first, then tiles of A2 (M2 rows, its own keep mask and output).
+// XCD-aware order: blocks are dealt round-robin over the 8 XCDs, each with its own L2.  All output tiles of one split read the same
+// position range of the operands: they get consecutive slots on ONE XCD, so the range comes from HBM once and its re-reads are
+// L2 hits (50 -> 36 us for the 384 x 384 product).  (splits is a multiple of 8; grid = tiles x splits, one dimension)
+template <typename TA, typename TB, typename TA2>
+__global__ __launch_bounds__(256, 2) void k_head_wgrad2(const DgHeadWgradArgs a) {
+    const int tn = (a.N + 127) / 128, tm1 = (a.M + 127) / 128, tm2 = (a.M2 + 127) / 128, ntile = tn * (tm1 + tm2);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = xcd + 8 * (slot / ntile), tile = slot % ntile;
+    const int tm = tile / tn, n0 = (tile - tm * tn) * 128;
+    if (tm < tm1) wgrad2_body<TA, TB>(a, a.A, a.keep, a.part, a.M, tm * 128, n0, split);
+    else wgrad2_body<TA2, TB>(a, a.A2, a.keep_2, a.part2, a.M2, (tm - tm1) * 128, n0, split);
+}
+
+template <typename TA, typename TB, typename TA2 = TA>
 static hipError_t launch_wgrad(const DgHeadWgradArgs& a, hipStream_t s) {
+    const int tiles = ((a.N + 127) / 128) * ((a.M + 127) / 128 + (a.M2 + 127) / 128);
+    if ((a.P & 7) == 0 && (a.splits & 7) == 0) {
+        const int smem = 4 * 128 * (32 * 2 + 16);
+        hipLaunchKernelGGL((k_head_wgrad2<TA, TB, TA2>), dim3(tiles * a.splits), dim3(256), smem, s, a);
+        return hipGetLastError();
+    }
+    // (odd position counts, or fewer steps than eight splits: the direct form, one product per launch)
     dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, a.splits);
     hipLaunchKernelGGL((k_head_wgrad<TA, TB>), grid, dim3(256), 0, s, a);
+    if (a.M2 > 0) {
+        DgHeadWgradArgs b = a;
+        b.A = a.A2; b.M = a.M2; b.keep = a.keep_2; b.part = a.part2; b.M2 = 0;
+        hipLaunchKernelGGL((k_head_wgrad<TA2, TB>), dim3((a.N + 127) / 128, (b.M + 127) / 128, a.splits), dim3(256), 0, s, b);
+    }
     return hipGetLastError();
 }
+// a_bf16 / b_bf16: element types of A and Bm; a second product (A2: fp32) rides in the same launch when a.M2 > 0
 hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s) {
+    if (a.M2 > 0) {
+        if (a_bf16 && !b_bf16) return launch_wgrad<__bf16, float, float>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (a_bf16 && !b_bf16) return launch_wgrad<__bf16, float>(a, s);
     if (!a_bf16 && !b_bf16) return launch_wgrad<float, float>(a, s);
     if (!a_bf16 && b_bf16) return launch_wgrad<float, __bf16>(a, s);
     return launch_wgrad<__bf16, __bf16>(a, s);
 }
 
-// Up to six reductions in one launch: out[i] (and out2[i]) = scale * sum over splits of part[split][i]   (fixed order; four loads
-// in flight per thread).  blockIdx.y = job.
-__global__ void k_head_reduce(const DgHeadReduceArgs a) {
+// Up to six reductions in one launch: out[i] (and out2[i]) = scale * sum over splits of part[split][i], in a fixed order.
+// blockIdx.y = job; a block owns 64 consecutive outputs, its four waves take the splits k = wave, wave + 4, ... with eight loads
+// in flight each and meet in LDS (one thread per output walking all the splits was a chain of splits / 4 memory latencies: 33 us
+// for 70 MB).
+__global__ __launch_bounds__(256) void k_head_reduce(const DgHeadReduceArgs a) {
+    __shared__ float red[4][64];
     const DgHeadReduceJob& J = a.jobs[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x, n = J.n;
-    if (i >= n) return;
-    const float* part = J.part;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < J.splits; k += 4) {
-        s0 += part[(size_t)k * n + i]; s1 += part[(size_t)(k + 1) * n + i]; s2 += part[(size_t)(k + 2) * n + i]; s3 += part[(size_t)(k + 3) * n + i];
+    const int o = threadIdx.x & 63, w = threadIdx.x >> 6, i = blockIdx.x * 64 + o, n = J.n;
+    if (blockIdx.x * 64 >= n) return;
+    const float* part = J.part + (i < n ? i : 0);
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int k = w;
+    for (; k + 28 < J.splits; k += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(k + 4 * u) * n];
     }
-    for (; k < J.splits; ++k) s0 += part[(size_t)k * n + i];
-    const float v = ((s0 + s1) + (s2 + s3)) * J.scale;
-    J.out[i] = v;
-    if (J.out2) J.out2[i] = v;
+    for (; k < J.splits; k += 4) acc[0] += part[(size_t)k * n];
+    red[w][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && i < n) {
+        const float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) * J.scale;
+        J.out[i] = v;
+        if (J.out2) J.out2[i] = v;
+    }
 }
 hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s) {
     int nmax = 0;
     for (int j = 0; j < a.njobs; ++j) nmax = a.jobs[j].n > nmax ? a.jobs[j].n : nmax;
-    hipLaunchKernelGGL(k_head_reduce, dim3((nmax + 255) / 256, a.njobs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_head_reduce, dim3((nmax + 63) / 64, a.njobs), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
