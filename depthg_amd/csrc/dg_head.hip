@@ -46,15 +46,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, const int rowb, const
 __device__ __forceinline__ int frag_k_order(const int lane, const int u) { return 8 * (lane >> 4) + 4 * (u ^ ((lane >> 4) & 1)); }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// Raw A fragment from bf16 weights W[row][kbase + 8g .. + 7] (one 16-byte load; zero outside the matrix).  K is a multiple of 8.
+// Raw A fragment from bf16 weights W[row][kbase + 8g .. + 7]: one 16-byte load from a clamped (always valid) address.  K is a
+// multiple of 8.  NO select on the loaded value: a VALU operation on it right behind the load makes hipcc wait for the load where it
+// is issued - the k-step-ahead prefetch of the GEMM loops then overlaps nothing (2.0 k cycles per k-step against 0.9 k of MFMAs).
+// Rows beyond the matrix and k beyond K therefore deliver (finite) values of other rows / columns: k >= K meets zero keep bits or a
+// zero operand, rows >= nrows produce accumulator rows that are never stored.
 __device__ __forceinline__ u32x4 wraw(const __bf16* __restrict__ W, const int ld, const int row, const int nrows, const int kbase,
                                       const int K, const int lane) {
-    // (always a valid address, the value selected away afterwards: a load under a condition becomes a branch with its own wait,
-    //  and the loads of a k-step would then run one memory latency after the other)
     const int k = kbase + 8 * (lane >> 4);
-    const bool ok = row < nrows && k < K;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(W + (size_t)(row < nrows ? row : nrows - 1) * ld + (k < K ? k : K - 8));
-    return ok ? v : u32x4{0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const u32x4*>(W + (size_t)(row < nrows ? row : nrows - 1) * ld + (k < K ? k : K - 8));
 }
 // ... masked with the keep bits of its eight k (16-bit all-ones / zero words, natural k order) and brought into tr_frag's k order
 // (odd lane groups hold their two blocks of four in the opposite order)
@@ -116,10 +116,12 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
     }
     {
         constexpr int Q = NT / 4, NIT = (CP * Q + NTH - 1) / NTH;        // 16-byte pieces per row; pieces per thread
-        constexpr int U = NIT % 7 == 0 ? 7 : (NIT % 6 == 0 ? 6 : (NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : 1)));   // loads in flight per thread
+        // loads in flight per thread: all of a thread's pieces where they fit the registers (the accumulators are not live yet)
+        constexpr int U = NIT <= 24 ? NIT : (NIT % 8 == 0 ? 8 : (NIT % 6 == 0 ? 6 : (NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : 1))));
         if ((P & 3) == 0) {
             // fast path: every load unconditional from a clamped address (a load under a condition becomes a branch with its own
             // wait), values selected afterwards; U pieces in flight per thread
+            const float* const k3p = a.keep3 ? a.keep3 : a.feat;       // (no dropout of the features: any valid address, value unused)
             for (int it = 0; it < NIT; it += U) {
                 f32x4 v[U];
                 float kf3[U];
@@ -128,14 +130,14 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                     const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
                     const int kc = k < C ? k : C - 1, pc = p + 3 < P ? p : P - 4;
                     v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.feat + ((size_t)b * C + kc) * P + pc));
-                    kf3[u] = a.keep3 ? a.keep3[(size_t)b * C + kc] * s3 : 1.f;
+                    kf3[u] = k3p[(size_t)b * C + kc];        // (raw: an operation on a loaded value here makes hipcc wait for ALL loads issued so far)
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
                     const bool ok = k < C && p + 3 < P;
                     const f32x4 vv = ok ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + ((size_t)b * C + k) * P + p) = vv * kf3[u];
+                    if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + ((size_t)b * C + k) * P + p) = vv * (a.keep3 ? kf3[u] * s3 : 1.f);
                     bf16x4 o4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o4[e] = (__bf16)vv[e];
@@ -180,42 +182,49 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        u32x4 wn[MB], vn[NA];
-        auto fetch = [&](const int ks) {
+        // weight fragments two k-steps ahead: one step of 28 MFMAs (0.2 us) does not cover an L2 round trip
+        static_assert(KS % 2 == 0, "two k-steps per iteration");
+        u32x4 wn[2][MB], vn[2][NA];
+        auto fetch = [&](const int ks, const int q) {
             if (nonlinear) {
 #pragma unroll
-                for (int i = 0; i < MB; ++i) wn[i] = wraw(a.w2a_bf, C, mbase + 16 * i + c16, C, 32 * ks, C, lane);
+                for (int i = 0; i < MB; ++i) wn[q][i] = wraw(a.w2a_bf, C, mbase + 16 * i + c16, C, 32 * ks, C, lane);
             }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) vn[i] = wraw(a.w1_bf, C, 16 * (wid + NW * i) + c16, D, 32 * ks, C, lane);
+            for (int i = 0; i < NA; ++i) vn[q][i] = wraw(a.w1_bf, C, 16 * (wid + NW * i) + c16, D, 32 * ks, C, lane);
         };
-        fetch(0);
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 wc[MB], vc[NA];
+        fetch(0, 0);
+        fetch(1, 1);
+        for (int ks0 = 0; ks0 < KS; ks0 += 2) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) wc[i] = wn[i];
+            for (int q = 0; q < 2; ++q) {
+                const int ks = ks0 + q;
+                u32x4 wc[MB], vc[NA];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) vc[i] = vn[i];
-            if (ks + 1 < KS) fetch(ks + 1);
-            const u32x4 keep2 = *reinterpret_cast<const u32x4*>(km2 + 32 * ks + 8 * g);
-            const u32x4 keep1 = *reinterpret_cast<const u32x4*>(km1 + 32 * ks + 8 * g);
-            bf16x8 bfr[NB];
+                for (int i = 0; i < MB; ++i) wc[i] = wn[q][i];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bfr[j] = tr_frag(Ft, FROW, 32 * ks, 16 * j, lane);
-            if (nonlinear) {
+                for (int i = 0; i < NA; ++i) vc[i] = vn[q][i];
+                if (ks + 2 < KS) fetch(ks + 2, q);
+                const u32x4 keep2 = *reinterpret_cast<const u32x4*>(km2 + 32 * ks + 8 * g);
+                const u32x4 keep1 = *reinterpret_cast<const u32x4*>(km1 + 32 * ks + 8 * g);
+                bf16x8 bfr[NB];
 #pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    const bf16x8 af = wfrag(wc[i], keep2, lane);
+                for (int j = 0; j < NB; ++j) bfr[j] = tr_frag(Ft, FROW, 32 * ks, 16 * j, lane);
+                if (nonlinear) {
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc1[i][j], 0, 0, 0);
+                    for (int i = 0; i < MB; ++i) {
+                        const bf16x8 af = wfrag(wc[i], keep2, lane);
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc1[i][j], 0, 0, 0);
+                    }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {    // (unconditional: rows beyond D are zero fragments; a condition around an MFMA makes hipcc
-                                              //  shuffle the whole accumulator array through v_accvgpr moves at every branch)
-                const bf16x8 af = wfrag(vc[i], keep1, lane);
+                for (int i = 0; i < NA; ++i) {    // (unconditional: rows beyond D are zero fragments; a condition around an MFMA makes hipcc
+                                                  //  shuffle the whole accumulator array through v_accvgpr moves at every branch)
+                    const bf16x8 af = wfrag(vc[i], keep1, lane);
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc2a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2a[i][j], 0, 0, 0);
+                    for (int j = 0; j < NB; ++j) acc2a[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2a[i][j], 0, 0, 0);
+                }
             }
         }
     }
