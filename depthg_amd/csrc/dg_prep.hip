@@ -66,21 +66,37 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) colacc[m][0] = colacc[m][1] = colacc[m][2] = colacc[m][3] = 0.f;
 
-    for (int pi = wid; pi < 32; pi += 4) {
+    // sampled rows (k_plane_sample): the wave's eight rows are loaded up front from clamped addresses - loads under `if (k < K4)`
+    // are issued and waited for one by one, 24 memory round trips per wave at K = 768 (38 us at C3's shape)
+    float4 pre[8][MAXM];
+    if (a.direct) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = pt * 32 + wid + 4 * q;
+            const float* p00 = img + (size_t)(p < a.P ? p : a.P - 1) * K4;
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) {
+                const int k = 4 * lane + 256 * m;
+                pre[q][m] = *reinterpret_cast<const float4*>(p00 + (k < K4 ? k : K4 - 4));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int pi = wid + 4 * q;
         const int p = pt * 32 + pi;
         float4 v[MAXM];
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) v[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         float inv = 0.f;
         if (p < a.P && a.direct) {
-            // the rows are sampled already (k_plane_sample): row p of this image
-            const float* p00 = img + (size_t)p * K4;
             float ss = 0.f;
 #pragma unroll
             for (int m = 0; m < MAXM; ++m) {
                 const int k = 4 * lane + 256 * m;
                 if (k < K4) {
-                    const float4 acc = *reinterpret_cast<const float4*>(p00 + k);
+                    const float4 acc = pre[q][m];
                     v[m] = acc;
                     ss += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
                 }
@@ -351,6 +367,9 @@ __global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
         av[m] = *reinterpret_cast<const f32x4*>(srow + 4 * c);
         bv[m] = *reinterpret_cast<const f32x4*>(rrow + 4 * c);
     }
+    // (hipcc's scheduler otherwise sinks every load next to the MFMA that consumes it - the accumulator chain is serial, so it
+    //  sees nothing to gain - and the wave walks 2 NC memory round trips one after the other: 14 us instead of .. at C3's shape)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NC; ++m)
 #pragma unroll
