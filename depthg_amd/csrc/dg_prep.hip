@@ -208,6 +208,7 @@ hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
 // leaves no launch whose time scales with B*h*w*C twice.
 // grid (sum over maps of ceil(K4 / 32), B), block 1024, dynamic LDS 32 * (h*w + 1) floats.
 #define PLANE_THREADS 1024
+typedef int v4i_pl __attribute__((ext_vector_type(4)));
 template <int CH>         // channels per block (32 or 16: smaller planes, more blocks per CU, their load and blend phases overlap)
 __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pl[];          // [CH][HW + 1], then the tap table [consumers][P][8]
@@ -220,20 +221,27 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArg
     // planes -> LDS (rows of h*w contiguous floats; channels past K are zero)
     // (all loads of a thread are issued before the first LDS store: one memory latency per block, not one per element)
     if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // (piece i = channel i / hw4, pixel quad i % hw4: ONE division per thread and batch, then carried - a division by a run-time
+        //  value is ~20 VALU instructions, and sixteen of them per thread were the largest part of this launch's instruction count)
         const int n4 = CH * HW / 4, hw4 = HW / 4;
+        const int dstep = PLANE_THREADS / hw4, rstep = PLANE_THREADS - dstep * hw4;
         for (int i0 = tid; i0 < n4; i0 += PLANE_THREADS * 8) {
             f32x4 t[8];
+            int ccs[8], qs[8];
+            int cc = i0 / hw4, q = i0 - cc * hw4;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * PLANE_THREADS, cc = i / hw4;
+                const int i = i0 + u * PLANE_THREADS;
+                ccs[u] = cc; qs[u] = q;
                 t[u] = i < n4 && k0 + cc < K ? *(reinterpret_cast<const f32x4*>(src) + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                cc += dstep; q += rstep;
+                if (q >= hw4) { q -= hw4; ++cc; }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * PLANE_THREADS;
                 if (i < n4) {
-                    const int cc = i / hw4, q = (i - cc * hw4) * 4;
-                    float* o = pl + cc * (HW + 1) + q;
+                    float* o = pl + ccs[u] * (HW + 1) + qs[u] * 4;
                     o[0] = t[u][0]; o[1] = t[u][1]; o[2] = t[u][2]; o[3] = t[u][3];
                 }
             }
@@ -309,24 +317,34 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArg
                 tt[1] = inx ? wy0 * wx1 : 0.f;
                 tt[2] = iny ? wy1 * wx0 : 0.f;
                 tt[3] = inx && iny ? wy1 * wx1 : 0.f;
-                reinterpret_cast<int*>(tt)[4] = y0 * a.w + x0;
-                reinterpret_cast<int*>(tt)[5] = inx ? 1 : 0;
-                reinterpret_cast<int*>(tt)[6] = iny ? a.w : 0;
+                const int pix = y0 * a.w + x0, dx = inx ? 1 : 0, dy = iny ? a.w : 0;
+                reinterpret_cast<int*>(tt)[4] = pix;                 // the four taps' pixel indices (one 16-byte read in the blend)
+                reinterpret_cast<int*>(tt)[5] = pix + dx;
+                reinterpret_cast<int*>(tt)[6] = pix + dy;
+                reinterpret_cast<int*>(tt)[7] = pix + dy + dx;
             }
             __syncthreads();
+            // the blend: the launch is bound by its INSTRUCTION count (SQ counters at config 3's shape: 55 VALU + 37 SALU wave
+            // instructions per 64 outputs - 44 us of VALU issue alone), so the loop carries its pointers instead of recomputing
+            // them and reads all four taps unconditionally (a tap border padding never reads has weight 0 and the first tap's
+            // address; three branches on the weights cost more than the LDS reads they saved)
             for (int e = 0; e < ne; ++e) {
                 const int o = l_o[e0 + e], n = l_n[e0 + e];
-                float* rows = a.rows[o][kind] + (size_t)n * a.P * K4 + k0 + c;
-                for (int p = ps; p < a.P; p += PLANE_THREADS / CH) {
-                    const float* tt = taps + ((size_t)e * a.P + p) * 8;
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(tt);
-                    const int pix = reinterpret_cast<const int*>(tt)[4], dx = reinterpret_cast<const int*>(tt)[5], dy = reinterpret_cast<const int*>(tt)[6];
-                    const float* t = plane + pix;
-                    float acc = t[0] * w[0];
-                    if (w[1] != 0.f) acc += t[dx] * w[1];
-                    if (w[2] != 0.f) acc += t[dy] * w[2];
-                    if (w[3] != 0.f) acc += t[dy + dx] * w[3];
-                    if (chan) rows[(size_t)p * K4] = acc;
+                constexpr int PSTEP = PLANE_THREADS / CH;
+                float* rows = a.rows[o][kind] + ((size_t)n * a.P + ps) * K4 + k0 + c;
+                const float* tt = taps + ((size_t)e * a.P + ps) * 8;
+                const int rstep = PSTEP * K4;
+                if (chan) {
+#pragma unroll 2
+                    for (int p = ps; p < a.P; p += PSTEP, tt += PSTEP * 8, rows += rstep) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(tt);
+                        const v4i_pl ix = *reinterpret_cast<const v4i_pl*>(tt + 4);
+                        float acc = plane[ix[0]] * w[0];
+                        acc = fmaf(plane[ix[1]], w[1], acc);
+                        acc = fmaf(plane[ix[2]], w[2], acc);
+                        acc = fmaf(plane[ix[3]], w[3], acc);
+                        *rows = acc;
+                    }
                 }
             }
             __syncthreads();

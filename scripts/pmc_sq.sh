@@ -9,7 +9,7 @@ for set in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_
            "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
-  ( cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 )
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -- python3 /root/repo/bench.py --steps 2 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline ${BENCH_ARGS} > /dev/null 2>&1 )
 done
 python3 - <<PY
 import csv, glob, collections
