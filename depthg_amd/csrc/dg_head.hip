@@ -377,20 +377,47 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
     const int C = a.C, D = a.D, P = a.P, DP = (D + 31) / 32 * 32;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     // d code tile -> LDS; its row sums over the tile are the block's share of d b1 (= d b2b): 16 consecutive lanes hold one row
-    for (int idx = tid; idx < DP * (NT / 4); idx += 256) {
-        const int d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
-        bf16x4 o;
-        float rs = 0.f;
+    if ((P & 3) == 0) {
+        // all of a thread's pieces requested first (clamped addresses), then used: one memory round trip for the tile instead of
+        // one per piece (each piece's row sum was formed right behind its loads)
+        constexpr int NP = DPMAX * (NT / 4) / 256;             // 8 pieces per thread at most
+        f32x4 v[NP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = (d < D && p + e < P) ? a.gcode[((size_t)b * D + d) * P + p + e] : 0.f;
-            rs += v;
-            o[e] = (__bf16)v;
+        for (int u = 0; u < NP; ++u) {
+            const int idx = tid + 256 * u, d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
+            v[u] = *reinterpret_cast<const f32x4*>(a.gcode + ((size_t)b * D + (d < D ? d : D - 1)) * P + (p < P ? p : P - 4));
         }
-        *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
 #pragma unroll
-        for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
-        if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
+        for (int u = 0; u < NP; ++u) {
+            const int idx = tid + 256 * u, d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
+            if (idx < DP * (NT / 4)) {                        // (uniform per wave: 16 consecutive lanes hold one row)
+                const bool ok = d < D && p < P;
+                bf16x4 o;
+                float rs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = ok ? v[u][e] : 0.f; rs += x; o[e] = (__bf16)x; }
+                *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
+#pragma unroll
+                for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
+                if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < DP * (NT / 4); idx += 256) {
+            const int d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
+            bf16x4 o;
+            float rs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = (d < D && p + e < P) ? a.gcode[((size_t)b * D + d) * P + p + e] : 0.f;
+                rs += v;
+                o[e] = (__bf16)v;
+            }
+            *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
+#pragma unroll
+            for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
+            if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
+        }
     }
     __syncthreads();
     f32x4 acc[4][MB];
