@@ -215,6 +215,7 @@ def main():
                     help="untimed steps are run for this many seconds BEFORE the --warmup steps, so that the GPU has left its idle "
                          "power state when the timed region starts (an idle MI355X needs tens of ms of load to reach its "
                          "sustained clock; reported as `clock_warmup_steps`)")
+    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph"], default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -336,12 +337,17 @@ def main():
                          "the timed region; the step (with the fill of its bucket) is replayed from one of two hipGraphs")
         graphs = [capture_or_die(lambda k=k: compute(buckets[k])) for k in range(2)]
 
+        # (an external event node at the end of each graph would keep the compute stream's queue free of event records - torch
+        #  refuses them on ROCm: "External events are disallowed in rocm")
         def step():
             k = counter[0] & 1
             counter[0] += 1
+            if args.ablate == "onegraph":          # (timing experiments only: where the N > 1 schedule's extra time goes)
+                k = 0
             buckets[k].wait_exchange()     # (the collective that read this bucket two steps ago: long done, keeps the order explicit)
             graphs[k][0].replay()
-            buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
+            if args.ablate != "noexchange":
+                buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
             return graphs[k][1]
     if use_dist and not args.sync_allreduce and not graph_mode:
         exchange_mode = "every step, on a side stream: overlaps the next step's kernels, completes inside the timed region (eager step)"
