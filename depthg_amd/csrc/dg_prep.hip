@@ -50,7 +50,11 @@ hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s) {
 // and P part (fp16, P-major, dg_perm32 order; transposed through LDS).
 template <int MAXM>
 __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
-    __shared__ __attribute__((aligned(16))) uint16_t ptile[128 * 32];   // [KD<=128][32] for the P part
+    // [KD<=128][32 positions] for the P part, rows of 40 halves (80 bytes) with the four 16-byte granules of a row XOR-ed by
+    // (channel >> 4) & 3: a wave writes one position column of up to 32 channels 4 apart at a time - with rows of 64 bytes all
+    // of them fell into ONE bank (3.6 M conflict cycles per launch at config 3's shape, a fifth of the kernel)
+    constexpr int PTS = 40;
+    __shared__ __attribute__((aligned(16))) uint16_t ptile[128 * PTS];
     __shared__ float colred[4][MAXM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
                     const int pp = dg_perm32(pi);
                     const uint16_t* ob = reinterpret_cast<const uint16_t*>(&o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ptile[(k + e) * 32 + pp] = ob[e];
+                    for (int e = 0; e < 4; ++e) ptile[(k + e) * PTS + ((((pp >> 3) ^ (k >> 4)) & 3) << 3) + (pp & 7)] = ob[e];
                 } else {
                     bf16x4 t; t[0] = (__bf16)u.x; t[1] = (__bf16)u.y; t[2] = (__bf16)u.z; t[3] = (__bf16)u.w;
                     colacc[m][0] += (float)t[0]; colacc[m][1] += (float)t[1]; colacc[m][2] += (float)t[2]; colacc[m][3] += (float)t[3];
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
         // P part: channel d, granule cc = 8 permuted positions = 16 bytes
         for (int id = tid; id < Kpad * 4; id += 256) {
             const int d = id >> 2, cc = id & 3;
-            uint4 val = *reinterpret_cast<const uint4*>(&ptile[d * 32 + cc * 8]);
+            uint4 val = *reinterpret_cast<const uint4*>(&ptile[d * PTS + (((cc ^ (d >> 4)) & 3) << 3)]);
             *reinterpret_cast<uint4*>(blob + L.p(d, cc)) = val;
         }
     }
