@@ -152,45 +152,48 @@ def _cpu_baseline_at(conf, ncores, seconds_budget, Bs):
 
 def cpu_baseline(conf, seconds_budget=20.0):
     """The CPU restatement (oracle/, kind "port") timed on the host cores on a bounded sample of the SAME workload: same C, D,
-    S, pair-sets, sampler and backward, `cpu_B` images of the batch; scaled to steps/s of the full batch.  Timed at two thread
-    counts - 16 threads and every host CPU - and the faster of the two is the reported value; the other
-    one rides along in `also`."""
+    S, pair-sets, sampler and backward, `cpu_B` images of the batch; scaled to steps/s of the full batch.  Timed at 16 threads
+    in this process and at 32 / 64 / 128 threads and every host CPU in child processes with a wall-clock limit each (torch's
+    intra-op pool thrashes on the pool's 256-CPU hosts: 600 x slower at 256 threads than at 16); the fastest leg is the reported
+    value, the others ride along in `also`."""
     H = conf["H"]
     host = os.cpu_count() or 1
-    runs = []
+    runs, skipped = [], []
     n16 = min(host, 16)
-    t16, reps16 = _cpu_baseline_at(conf, n16, seconds_budget * 0.75, conf["cpu_B"])
+    t16, reps16 = _cpu_baseline_at(conf, n16, seconds_budget * 0.5, conf["cpu_B"])
     runs.append({"cores": n16, "value": (conf["cpu_B"] / H["B"]) / t16, "seconds": t16, "reps": reps16, "Bs": conf["cpu_B"]})
-    skipped = None
-    if host > n16:
-        # The all-CPU leg thrashes on big hosts (256 threads: 65 x slower than 16 on the same box).  It is there to show WHY the
-        # reported value uses 16 threads, not to be waited for: a sample sized for ~0.15 s at the 16-thread rate, and skipped where
-        # even one image would take longer than that (config 5: 22 s per image on 16 threads)
-        Bs = min(conf["cpu_B"], int(conf["cpu_B"] * 0.15 / t16))
-        if Bs >= 1:
-            # ... in a child process with a wall-clock limit (subprocess.run ends exactly that child when the limit passes):
-            # at 256 threads one repetition of TWO headline images took 93 s on a pool box, 600 x the 16-thread rate
-            limit = 20.0
-            name = [k for k, v in CONFIGS.items() if v is conf][0]
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{name},{host},{Bs},{seconds_budget * 0.25}"],
-                                   capture_output=True, text=True, timeout=limit)
-                t, n = json.loads(r.stdout.strip().splitlines()[-1])
-                runs.append({"cores": host, "value": (Bs / H["B"]) / t, "seconds": t, "reps": n, "Bs": Bs})
-            except subprocess.TimeoutExpired:
-                skipped = {"cores": host, "skipped": f"two repetitions at B={Bs} did not finish in {limit:.0f} s on {host} threads "
-                                                     f"(16 threads: {t16 * Bs / conf['cpu_B']:.2f} s each)"}
-            except Exception as e:      # the 16-thread leg is the reported one; say what happened to the other
-                skipped = {"cores": host, "skipped": f"child failed: {type(e).__name__}"}
-        else:
-            skipped = {"cores": host, "skipped": f"one image takes {t16 / conf['cpu_B']:.1f} s on {n16} threads; the all-CPU leg is not waited for"}
+    name = [k for k, v in CONFIGS.items() if v is conf][0]
+    for n in [n for n in (32, 64, 128) if n < host] + ([host] if host > n16 else []):
+        # a child process per thread count, ended by subprocess.run when its limit passes.  The sample shrinks to what would
+        # take ~1 s per repetition at the 16-thread rate for the all-CPU leg (known to thrash); the others keep the full sample
+        # unless one repetition at the 16-thread rate would not fit the limit twice
+        limit = 14.0
+        Bs = conf["cpu_B"]
+        if n == host:
+            Bs = min(Bs, int(conf["cpu_B"] * 0.15 / t16))
+        elif t16 * 2.5 > limit:
+            Bs = int(conf["cpu_B"] * limit / (t16 * 2.5))
+        if Bs < 1:
+            skipped.append({"cores": n, "skipped": f"one image takes {t16 / conf['cpu_B']:.1f} s on {n16} threads; this leg is not waited for"})
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{name},{n},{Bs},{limit * 0.4}"],
+                               capture_output=True, text=True, timeout=limit)
+            t, reps = json.loads(r.stdout.strip().splitlines()[-1])
+            runs.append({"cores": n, "value": (Bs / H["B"]) / t, "seconds": t, "reps": reps, "Bs": Bs})
+        except subprocess.TimeoutExpired:
+            skipped.append({"cores": n, "skipped": f"two repetitions at B={Bs} did not finish in {limit:.0f} s on {n} threads "
+                                                   f"(16 threads: {t16 * Bs / conf['cpu_B']:.2f} s each)"})
+        except Exception as e:      # the legs that ran are reported; say what happened to this one
+            skipped.append({"cores": n, "skipped": f"child failed: {type(e).__name__}"})
     best = max(runs, key=lambda r: r["value"])
     other = [r for r in runs if r is not best]
     return {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "host_cpus": host, "kind": "port",
             "sample": f"oracle forward+backward at B={best['Bs']} (of {H['B']}), C={H['C']}, D={H['D']}, S={H['S']}, "
                       f"{H['n_neg']} negatives, sampling={conf['sampling']}, {best['cores']} threads of {host} host CPUs, "
-                      f"min of {best['reps']} timed reps = {best['seconds']:.2f} s; value = ({best['Bs']}/{H['B']}) / t",
-            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other] + ([skipped] if skipped else [])}
+                      f"min of {best['reps']} timed reps = {best['seconds']:.2f} s; value = ({best['Bs']}/{H['B']}) / t; "
+                      f"thread counts tried: {sorted(r['cores'] for r in runs)}",
+            "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other] + skipped}
 
 
 def main():
@@ -332,41 +335,39 @@ def main():
             total = compute(buckets[0])
             buckets[0].allreduce_mean_(even_if_alone=args.force_dist)
             return total
-    elif graph_mode:
-        exchange_mode = ("every step, on a side stream behind the step's graph: overlaps the next step's kernels, completes inside "
-                         "the timed region; the step (with the fill of its bucket) is replayed from one of two hipGraphs")
-        graphs = [capture_or_die(lambda k=k: compute(buckets[k])) for k in range(2)]
+    else:
+        # The N > 1 schedule proper (depthg_amd.parallel.DoubleBufferedExchange; tests/test_dp_gloo.py drives the same class over
+        # gloo with a stub compute): wait for the collective that read bucket k two steps ago -> the step's kernels, which end by
+        # filling bucket k -> the all-reduce of bucket k on the side stream.
+        from depthg_amd.parallel import DoubleBufferedExchange
+        if graph_mode:
+            exchange_mode = ("every step, on a side stream behind the step's graph: overlaps the next step's kernels, completes inside "
+                             "the timed region; the step (with the fill of its bucket) is replayed from one of two hipGraphs")
+            graphs = [capture_or_die(lambda k=k: compute(buckets[k])) for k in range(2)]
 
-        # (an external event node at the end of each graph would keep the compute stream's queue free of event records - torch
-        #  refuses them on ROCm: "External events are disallowed in rocm")
-        def step():
-            k = counter[0] & 1
-            counter[0] += 1
-            if args.ablate == "onegraph":          # (timing experiments only: where the N > 1 schedule's extra time goes)
-                k = 0
-            buckets[k].wait_exchange()     # (the collective that read this bucket two steps ago: long done, keeps the order explicit)
-            graphs[k][0].replay()
-            if args.ablate != "noexchange":
-                buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
-            return graphs[k][1]
-    if use_dist and not args.sync_allreduce and not graph_mode:
-        exchange_mode = "every step, on a side stream: overlaps the next step's kernels, completes inside the timed region (eager step)"
+            # (an external event node at the end of each graph would keep the compute stream's queue free of event records -
+            #  torch refuses them on ROCm: "External events are disallowed in rocm")
+            def run_kernels(k):
+                graphs[k][0].replay()
+                return graphs[k][1]
+        else:
+            exchange_mode = ("every step, on a side stream: overlaps the next step's kernels, completes inside the timed region "
+                             "(eager step)")
 
-        def step():
-            k = counter[0] & 1
-            counter[0] += 1
-            if head is not None:
-                total = compute(buckets[k])
-                buckets[k].exchange_on(comm, even_if_alone=args.force_dist)
-            else:
-                total = compute()
-                buckets[k].exchange_on(comm, c.grad, even_if_alone=args.force_dist)
-            return total
+            def run_kernels(k):
+                return compute(buckets[k])
+        # (--ablate: timing experiments only - where the N > 1 schedule's extra time goes)
+        sched = DoubleBufferedExchange(buckets, run_kernels, comm, even_if_alone=args.force_dist,
+                                       exchange=args.ablate != "noexchange", alternate=args.ablate != "onegraph")
+        step = sched.step
 
     def sync():
         if use_dist:
             for b in buckets:
                 b.wait_exchange()          # every all-reduce of the timed steps completes inside the timed region
+            # (the host must not enter the barrier before its own collectives are done being ENQUEUED-and-complete: the barrier
+            #  is a collective on the same communicator)
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -374,10 +375,10 @@ def main():
     # running different counts cannot mis-order RCCL calls), then the W warm-up steps, then EXACTLY K timed steps
     if not use_dist:
         warm = step
-    elif graph_mode:
-        warm = graphs[0][0].replay
-    else:
+    elif args.sync_allreduce:
         warm = compute
+    else:
+        warm = sched.warm
     clock_warmup_steps = 0
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < args.clock_warmup_s:
@@ -395,10 +396,35 @@ def main():
     host_elapsed = time.perf_counter() - t0     # the Python loop alone (enqueue side); equals `elapsed` when the host is the limit
     sync()
     elapsed = time.perf_counter() - t0
+    dist_diag = None
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # what a first real N > 1 run needs to be read: every rank's own time (a slow rank, a straggling collective), how long the
+        # compute stream actually stalls on the exchange, and the world size RCCL reports
+        mine = torch.tensor([elapsed, host_elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t[0]) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t[0]) for t in every)
+        dist_diag = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                     "ms_per_step_min_rank": round(min(per_rank), 4), "ms_per_step_max_rank": round(max(per_rank), 4),
+                     "ms_per_step_by_rank": [round(v, 4) for v in per_rank],
+                     "host_ms_per_step_max_rank": round(max(float(t[1]) for t in every) / args.steps * 1e3, 4)}
+        if not args.sync_allreduce:
+            # device-side stall of the compute stream on `wait_exchange` (the collective of two steps ago), measured on extra,
+            # untimed steps: events around the wait itself (every rank runs the same count: the collectives stay paired)
+            nprobe, stall = 20, 0.0
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nprobe)]
+            for i in range(nprobe):
+                k = sched.count & 1 if sched.alternate else 0
+                evs[i][0].record()
+                buckets[k].wait_exchange()
+                evs[i][1].record()
+                step()
+            t_d = time.perf_counter()
+            sync()
+            dist_diag["drain_ms"] = round((time.perf_counter() - t_d) * 1e3, 4)      # host wait for the tail: last collectives + barrier
+            stall = sum(a.elapsed_time(b) for a, b in evs) / nprobe
+            dist_diag["exchange_wait_ms"] = round(stall, 5)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed   # every rank completes `steps` steps of its own B=32 shard
 
@@ -466,13 +492,15 @@ def main():
             "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if graph_mode else " [eager step]"),
                        "name": args.config, "schedule": "hipGraph replay" if graph_mode else "eager",
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
-                       "ranks_seen": dist.get_world_size() if use_dist else 1,
+                       "ranks_seen": dist_diag["ranks_seen"] if dist_diag else 1,
                        "clock_warmup_steps": clock_warmup_steps,
                        "allreduce_elems": HEAD_GRAD_ELEMS if use_dist else 0,
                        "allreduce": exchange_mode},
             "loss_total": float(total.detach()),
             "roofline": roofline,
         }
+        if dist_diag:
+            line["dist"] = dist_diag
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(conf)
     if use_dist:

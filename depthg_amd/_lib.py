@@ -8,9 +8,9 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 107                     # must match include/depthg_corr.h: a stale library is refused
-DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID = \
-    (1 << i for i in range(8))
+DG_VERSION = 108                     # must match include/depthg_corr.h: a stale library is refused
+DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
+    DG_EXACT_MASKS = (1 << i for i in range(9))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_super_perms",
@@ -29,7 +29,7 @@ class CorrDesc(ctypes.Structure):
                 ("shift_intra", ctypes.c_float), ("shift_inter", ctypes.c_float), ("shift_neg", ctypes.c_float),
                 ("shift_depth", ctypes.c_float),
                 ("w_intra", ctypes.c_float), ("w_inter", ctypes.c_float), ("w_neg", ctypes.c_float),
-                ("w_depth", ctypes.c_float)]
+                ("w_depth", ctypes.c_float), ("code_h", ctypes.c_int32), ("code_w", ctypes.c_int32)]
 
 
 _lib = None

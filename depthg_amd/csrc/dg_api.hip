@@ -28,7 +28,7 @@ extern "C" const char* dg_last_error(void) { return g_err; }
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Plan {
-    int B, C, D, h, w, S, Sh, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;
+    int B, C, D, h, w, hc, wc, S, Sh, P, Ppad, KF, KD, C4, D4, N, T, nops, rf, nrb, blob;     // (hc, wc): size of the code maps
     bool shared, depth, grad, pointwise, ident, rows;
     size_t nhwc_f[2], nhwc_c[2];
     size_t rows_f[DG_MAX_NEG + 2], rows_c[DG_MAX_NEG + 2];     // sampled fp32 rows per operand (small sample grids)
@@ -54,7 +54,12 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (d->C > 768) return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels not supported", d->C);
     if (d->D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", d->D);
     if ((size_t)d->h * d->w > 16384) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large", d->h, d->w);
+    if (d->code_h < 0 || d->code_w < 0 || (d->code_h == 0) != (d->code_w == 0))
+        return fail(DG_ERR_INVALID, "code_h=%d, code_w=%d: both zero (code maps of the feature maps' size) or both positive", d->code_h, d->code_w);
     p.B = d->B; p.C = d->C; p.D = d->D; p.h = d->h; p.w = d->w; p.S = d->S; p.N = d->n_neg;
+    p.hc = d->code_h ? d->code_h : d->h; p.wc = d->code_w ? d->code_w : d->w;
+    if ((size_t)p.hc * p.wc > 16384) return fail(DG_ERR_UNSUPPORTED, "code map %dx%d too large", p.hc, p.wc);
+    const bool same_maps = p.hc == p.h && p.wc == p.w;
     p.Sh = (d->flags & DG_LINE_GRID) ? 1 : d->S;      // sample grid: Sh rows x S columns
     p.P = p.Sh * d->S;
     p.Ppad = (int)up(p.P, 32);
@@ -69,18 +74,21 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.ident = (d->flags & DG_IDENTITY_GRID) != 0;
     if (p.ident && (p.Sh != p.S || !p.shared || d->S != d->h || d->S != d->w || d->w > 64))
         return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs DG_SHARED_COORDS and S == h == w <= 64");
+    if (p.ident && !same_maps)
+        return fail(DG_ERR_INVALID, "DG_IDENTITY_GRID needs code maps of the feature maps' size (got %dx%d against %dx%d)", p.hc, p.wc, p.h, p.w);
     p.nops = p.shared ? 2 : p.T;
     p.rf = (p.KF == 384 && p.KD == 96 && p.Ppad > 128) ? 8 : 4;    // waves per block (32 stationary rows each)
     p.nrb = (p.Ppad + p.rf * 32 - 1) / (p.rf * 32);
     p.blob = DgBlob(p.KF, p.KD).bytes;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
-    const size_t HW = (size_t)p.h * p.w, B = p.B;
+    const size_t HW = (size_t)p.h * p.w, HWc = (size_t)p.hc * p.wc, B = p.B;
     // small sample grids (all operands together sample fewer positions than the two maps have pixels; planes of 32 channels
     // fit the LDS; batch indices fit the 16-bit consumer lists): sample() straight from NCHW (k_plane_sample) instead of
     // channel-last copies of the whole maps
-    p.rows = !p.ident && (size_t)p.nops * p.P <= 2 * HW && HW <= 1024 && B <= 32767;
-    for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(p.rows ? 0 : B * HW * p.C4 * 4); p.nhwc_c[i] = take(p.rows ? 0 : B * HW * p.D4 * 4); }
+    // (code maps of another size than the feature maps - the FeaturePyramidNet contract - take the channel-last gather path)
+    p.rows = !p.ident && same_maps && (size_t)p.nops * p.P <= 2 * HW && HW <= 1024 && B <= 32767;
+    for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(p.rows ? 0 : B * HW * p.C4 * 4); p.nhwc_c[i] = take(p.rows ? 0 : B * HWc * p.D4 * 4); }
     for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(p.rows ? B * p.P * p.C4 * 4 : 0); p.rows_c[i] = take(p.rows ? B * p.P * p.D4 * 4 : 0); }
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
@@ -98,7 +106,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int t = 0; t < p.T; ++t) p.dRB[t] = take(B * p.Ppad * p.KD * 4);
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
     p.scratch_out = take(DG_OUT_COUNT * 4);
-    p.taps = take(2 * B * dg_taps_record_bytes(p.h * p.w, p.P));
+    p.taps = take(2 * B * dg_taps_record_bytes(p.hc * p.wc, p.P));     // the adjoint of sample() scatters into the CODE maps
     for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
     p.ticket = take(256);
     // exact clamp masks: gradient passes of the zero_clamp recipe on small sample grids (fp32 sampled rows exist, <= 8 tiles, the
@@ -316,7 +324,6 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char* ws = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-    const int HW = p.h * p.w;
 
     // 1.+2. operands.  Identity grid: one launch builds both feats and both code operands straight from NCHW (+ the
     //       depth indicators).  General coords: channel-last copies (the gather reads whole channel vectors per tap), then
@@ -341,8 +348,8 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             memset(&q, 0, sizeof(q));
             if (draw && p.N > 0) { q.seed = draw->seed; q.state = draw->state; q.perms = draw->out; q.count = p.N; }
             if (p.depth) { q.depth = depth; q.nz = F32(p.nz); q.nzsum = F32(p.nzsum); q.dH = desc->depth_h; q.dW = desc->depth_w; }
-            if (p.grad && (size_t)p.h * p.w <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
-            q.B = p.B; q.h = p.h; q.w = p.w; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;
+            if (p.grad && (size_t)p.hc * p.wc <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
+            q.B = p.B; q.h = p.hc; q.w = p.wc; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;      // (h, w): the maps the tap records index = the code maps
             if (p.B > 8192 && q.count > 0) return fail(DG_ERR_UNSUPPORTED, "B=%d too large for the in-call draw", p.B);
             DG_HIP(dg_launch_pre_general(q, stream));
         }
@@ -358,16 +365,16 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         } else {
             DgTransposeArgs t;
             memset(&t, 0, sizeof(t));
-            t.nmaps = 4; t.HW = HW;
-            t.src[0] = orig_feats; t.dst[0] = F32(p.nhwc_f[0]); t.K[0] = p.C; t.K4[0] = p.C4;
-            t.src[1] = orig_feats_pos; t.dst[1] = F32(p.nhwc_f[1]); t.K[1] = p.C; t.K4[1] = p.C4;
-            t.src[2] = orig_code; t.dst[2] = F32(p.nhwc_c[0]); t.K[2] = p.D; t.K4[2] = p.D4;
-            t.src[3] = orig_code_pos; t.dst[3] = F32(p.nhwc_c[1]); t.K[3] = p.D; t.K4[3] = p.D4;
+            t.nmaps = 4;
+            t.src[0] = orig_feats; t.dst[0] = F32(p.nhwc_f[0]); t.K[0] = p.C; t.K4[0] = p.C4; t.HW[0] = p.h * p.w;
+            t.src[1] = orig_feats_pos; t.dst[1] = F32(p.nhwc_f[1]); t.K[1] = p.C; t.K4[1] = p.C4; t.HW[1] = p.h * p.w;
+            t.src[2] = orig_code; t.dst[2] = F32(p.nhwc_c[0]); t.K[2] = p.D; t.K4[2] = p.D4; t.HW[2] = p.hc * p.wc;
+            t.src[3] = orig_code_pos; t.dst[3] = F32(p.nhwc_c[1]); t.K[3] = p.D; t.K4[3] = p.D4; t.HW[3] = p.hc * p.wc;
             DG_HIP(dg_launch_transpose(t, p.B, stream));
         }
         DgGatherArgs g;
         memset(&g, 0, sizeof(g));
-        g.B = p.B; g.h = p.h; g.w = p.w; g.S = p.S; g.Sh = p.Sh; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
+        g.B = p.B; g.S = p.S; g.Sh = p.Sh; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD;
         int nj = 0;
         for (int o = 0; o < p.nops; ++o) {
             const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats/orig_code
@@ -376,11 +383,11 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             DgGatherJob& f = g.jobs[nj++];
             f.src = p.rows ? F32(p.rows_f[o]) : F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = p.rows ? nullptr : idx;
             f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
-            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0;
+            f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0; f.h = p.h; f.w = p.w;
             DgGatherJob& c = g.jobs[nj++];
             c.src = p.rows ? F32(p.rows_c[o]) : F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = p.rows ? nullptr : idx;
             c.blob = ws + p.op[o]; c.inv_norm = F32(p.inv[o]); c.colpart = F32(p.ccolpart[o]);
-            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1;
+            c.K = p.D; c.K4 = p.D4; c.Kpad = p.KD; c.is_code = 1; c.h = p.hc; c.w = p.wc;
         }
         g.njobs = nj;
         g.direct = p.rows ? 1 : 0;
@@ -551,8 +558,8 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
         s.xop = ws + p.op[0]; s.xinv = F32(p.inv[0]); s.blob_bytes = bl.bytes; s.blob_off_c = bl.off_c;
     }
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
-    s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.h; s.w = p.w; s.S = p.S; s.Sh = p.Sh; s.P = p.P; s.Ppad = p.Ppad;
-    if ((size_t)p.h * p.w > 4096) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large for the gradient gather (max 4096 pixels)", p.h, p.w);
+    s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.hc; s.w = p.wc; s.S = p.S; s.Sh = p.Sh; s.P = p.P; s.Ppad = p.Ppad;     // (h, w): the code maps
+    if ((size_t)p.hc * p.wc > 4096) return fail(DG_ERR_UNSUPPORTED, "code map %dx%d too large for the gradient gather (max 4096 pixels)", p.hc, p.wc);
     s.DC = 8;
     s.dense = p.ident ? 1 : 0;
     s.taps_ready = p.ident ? 0 : 1;            // (general coordinates: built by the forward's first launch, dg_launch_pre_general)

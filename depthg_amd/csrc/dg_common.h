@@ -250,8 +250,8 @@ struct DgFinishArgs {
 struct DgTransposeArgs {    // NCHW (B,K,h,w) fp32 -> NHWC (B,h*w,K4) fp32 for up to four maps in one launch
     const float* src[4];
     float* dst[4];
-    int32_t K[4], K4[4];
-    int32_t nmaps, HW;
+    int32_t K[4], K4[4], HW[4];      // per map: channels, padded channels, pixels (the code maps may differ in size from the feature maps)
+    int32_t nmaps;
 };
 
 struct DgGatherJob {
@@ -263,11 +263,12 @@ struct DgGatherJob {
     float* colpart;          // [B][Ppad/32][Kpad] per-tile column sums of the normalised rows or null (feats)
     int32_t K, K4, Kpad;
     int32_t is_code;         // 1: fp16 code (C and P parts), 0: bf16 feats (F part)
+    int32_t h, w;            // size of the map `src` holds (not read in direct mode)
 };
 #define DG_MAX_GATHER 20
 struct DgGatherArgs {
     DgGatherJob jobs[DG_MAX_GATHER];
-    int32_t njobs, B, h, w, S, Sh, P, Ppad, KF, KD;   // sample grid: Sh rows x S columns (Sh == S, or 1 with DG_LINE_GRID)
+    int32_t njobs, B, S, Sh, P, Ppad, KF, KD;   // sample grid: Sh rows x S columns (Sh == S, or 1 with DG_LINE_GRID)
     int32_t direct;          // 1: src holds the SAMPLED rows already, [B][P][K4] per job (k_plane_sample): no taps, no batch map
 };
 

@@ -111,6 +111,12 @@ template <int N> __device__ __forceinline__ void wait_lgkm(void) { asm volatile(
 template <int I> __device__ __forceinline__ void mfma_fd8(acc_t& acc, const v4i_t& a) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "n"(4 * I), "n"(4 * I + 3));
 }
+// first MFMA of an fd chain: the accumulator STARTS at c (sixteen copies of the lane's c0, kept in registers for the whole block) -
+// no per-tile re-initialisation of the accumulator by sixteen 64-bit moves (round 4: hipcc gathered them into bursts of eight in
+// one MFMA gap)
+template <int I> __device__ __forceinline__ void mfma_fd8_from(acc_t& acc, const v4i_t& a, const acc_t& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(acc) : "v"(a), "v"(c), "n"(4 * I), "n"(4 * I + 3));
+}
 __device__ __forceinline__ void mfma_h8(acc_t& acc, const v4i_t& a, const v4i_t& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
@@ -373,10 +379,13 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             asm volatile("" : "+v"(c0pair[f]));
         }
     }
+    acc_t c0splat[RF];                                    // C operand of the first MFMA of every fd chain
 #pragma unroll
-    for (int f = 0; f < RF; ++f)
+    for (int f = 0; f < RF; ++f) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Yf[f][i] = c0pair[f];
+        for (int i = 0; i < 8; ++i) { Yf[f][i] = c0pair[f]; c0splat[f][i] = c0pair[f]; }
+        asm volatile("" : "+v"(c0splat[f]));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     sfor<PF>([&](auto I) { rd_step(I, ra[I.value]); });
 
@@ -396,11 +405,15 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     for (int f = 0; f < RF; ++f)
         gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + ((size_t)fn[f] * ntiles * ntiles + (act[f] ? ft[f] : 0)) * 128 + lane;
     const size_t gstep = (size_t)ntiles * 128;
+    // running store pointers (the tile index times the tile stride as 64-bit scalar multiplies in front of every store cost three
+    // s_mul and two adds each): gp[0] points at S tile t, gp[1] at S tile t - 1 (fragment 1 runs one phase behind)
+    uintptr_t gp[RF] = {reinterpret_cast<uintptr_t>(gbase[0]), reinterpret_cast<uintptr_t>(gbase[1]) - gstep * sizeof(v4i_t)};
     auto g_store = [&](const int f, const int sp, int t) {
 #ifndef C2_NOGST
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
-        v4i_t* g = gbase[f] + (size_t)t * gstep + 64 * sp;
+        (void)t;
+        v4i_t* g = reinterpret_cast<v4i_t*>(gp[f]) + 64 * sp;
         // (non-temporal: with the default cache policy on these stores / k_gs's loads the step is 1-6 % slower, profiles/r03_SUMMARY.md)
         asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
 #endif
@@ -469,7 +482,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                     wait_lgkm<issued - (need + 1)>();
 #endif
                 }
-                if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
+                if constexpr (st == 0) mfma_fd8_from<f * NKF>(Yf[f], ra[idx % PF], c0splat[f]);
+                else if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
                 else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
                 else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
 #ifndef C2_NOARD           // (timing ablation: no fragment refills)
@@ -502,10 +516,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                     constexpr int q = Q.value;
                     dr1(Q);
                     if constexpr (q == 0) { if (t > 0) g_store(1, 1, t - 1); }
-                    if constexpr (q >= 1 && q < 5) {                         // fd accumulator of fragment 1 starts at c0_lane
-                        Yf[1][2 * (q - 1)] = c0pair[1]; Yf[1][2 * (q - 1) + 1] = c0pair[1];
-                        if constexpr (q == 4) asm volatile("" : "+v"(Yf[1]));
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
@@ -541,9 +551,16 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #else
                 constexpr int PL = PIECES;
 #endif
-                // two tiles' pieces and up to three tiles' G stores are younger than the last piece of tile t+1
-                const int tc0 = t < 2 ? t + 1 : 3, tc1 = t < 3 ? t : 3;
-                wait_vm_lgkm_barrier(2 * PL + S0 * tc0 + S1 * tc1);
+                // two tiles' pieces and up to three tiles' G stores are younger than the last piece of tile t+1.  From tile 3 on
+                // the count is a constant: that path must not pass through the switch below - hipcc lowers it to a chain of
+                // compare-and-branch blocks of which the steady state took three TAKEN branches per tile, 40-80 cycles each on one
+                // wave per SIMD (round-4 stamps: a fixed 240-cycle "wait" in front of a barrier all four waves reach within 50)
+                if (__builtin_expect(t >= 3, 1)) {
+                    asm volatile("s_waitcnt vmcnt(%c0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" :: "n"(2 * PL + 3 * S0 + 3 * S1) : "memory");
+                } else {
+                    const int tc0 = t < 2 ? t + 1 : 3, tc1 = t;
+                    wait_vm_lgkm_barrier(2 * PL + S0 * tc0 + S1 * tc1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(t, 3);
@@ -560,16 +577,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                     // first PF fragments of tile t+1 (valid after the barrier), issued in index order (the counted waits rely on it)
                     if constexpr (q < 2) { rd_step(std::integral_constant<int, 2 * q>{}, ra[2 * q]); rd_step(std::integral_constant<int, 2 * q + 1>{}, ra[2 * q + 1]); }
                     else rd_step(std::integral_constant<int, q + 2>{}, ra[q + 2]);
-                    if constexpr (q >= 2) {                                  // fd accumulator of fragment 0 for the next tile
-                        Yf[0][2 * (q - 2)] = c0pair[0]; Yf[0][2 * (q - 2) + 1] = c0pair[0];
-                        if constexpr (q == 5) asm volatile("" : "+v"(Yf[0]));
-                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
             STAMP(t, 4);
             STAMP(t, 5);
             bcur = bnext;
+#pragma unroll
+            for (int f = 0; f < RF; ++f) { gp[f] += gstep * sizeof(v4i_t); asm volatile("" : "+v"(gp[f])); }
         }
         // ---- tail: fragment 1 of the last tile (epilogue, G store, gradient product)
         if constexpr (ACT1) {

@@ -20,8 +20,9 @@ __global__ void k_nchw_to_nhwc(const DgTransposeArgs a) {
     while (m < a.nmaps - 1 && gy >= (a.K4[m] + 31) / 32) { gy -= (a.K4[m] + 31) / 32; ++m; }
     const float* __restrict__ src = a.src[m];
     float* __restrict__ dst = a.dst[m];
-    const int K = a.K[m], K4 = a.K4[m], HW = a.HW;
+    const int K = a.K[m], K4 = a.K4[m], HW = a.HW[m];
     const int k0 = gy * 32, p0 = blockIdx.x * 32;
+    if (p0 >= HW) return;                            // (the grid spans the largest map)
     const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         int k = k0 + i, p = p0 + tx;
@@ -35,9 +36,9 @@ __global__ void k_nchw_to_nhwc(const DgTransposeArgs a) {
 }
 
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s) {
-    int gy = 0;
-    for (int m = 0; m < a.nmaps; ++m) gy += (a.K4[m] + 31) / 32;
-    dim3 grid((a.HW + 31) / 32, gy, B), block(32, 8);
+    int gy = 0, hw = 0;
+    for (int m = 0; m < a.nmaps; ++m) { gy += (a.K4[m] + 31) / 32; hw = a.HW[m] > hw ? a.HW[m] : hw; }
+    dim3 grid((hw + 31) / 32, gy, B), block(32, 8);
     hipLaunchKernelGGL(k_nchw_to_nhwc, grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     const DgGatherJob& J = a.jobs[blockIdx.z];
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
-    const float* img = a.direct ? J.src + (size_t)n * a.P * K4 : J.src + (size_t)ns * a.h * a.w * K4;
+    const int mh = J.h, mw = J.w;                  // the map this job samples (feature and code maps may differ in size)
+    const float* img = a.direct ? J.src + (size_t)n * a.P * K4 : J.src + (size_t)ns * mh * mw * K4;
     const int S = a.S, Sh = a.Sh;
     const DgBlob L(a.KF, a.KD);
     char* blob = J.blob + ((size_t)n * (a.Ppad / 32) + pt) * L.bytes;
@@ -112,18 +114,18 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             // output position (i, j) = (p / S, p % S) reads x = coords[n][j][i][0], y = coords[n][j][i][1]
             const int i = p / S, j = p - i * S;
             const float* c = J.coords + (((size_t)n * S + j) * Sh + i) * 2;
-            float x = ((c[0] + 1.f) / 2.f) * (float)(a.w - 1);
-            float y = ((c[1] + 1.f) / 2.f) * (float)(a.h - 1);
-            x = fminf(fmaxf(x, 0.f), (float)(a.w - 1));
-            y = fminf(fmaxf(y, 0.f), (float)(a.h - 1));
+            float x = ((c[0] + 1.f) / 2.f) * (float)(mw - 1);
+            float y = ((c[1] + 1.f) / 2.f) * (float)(mh - 1);
+            x = fminf(fmaxf(x, 0.f), (float)(mw - 1));
+            y = fminf(fmaxf(y, 0.f), (float)(mh - 1));
             const float x0f = floorf(x), y0f = floorf(y);
             const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const int x0 = (int)x0f, y0 = (int)y0f;
-            const bool inx = x0 + 1 <= a.w - 1, iny = y0 + 1 <= a.h - 1;
+            const bool inx = x0 + 1 <= mw - 1, iny = y0 + 1 <= mh - 1;
             const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-            const float* p00 = img + ((size_t)y0 * a.w + x0) * K4;
+            const float* p00 = img + ((size_t)y0 * mw + x0) * K4;
             const float* p01 = p00 + K4;
-            const float* p10 = p00 + (size_t)a.w * K4;
+            const float* p10 = p00 + (size_t)mw * K4;
             const float* p11 = p10 + K4;
             float ss = 0.f;
 #pragma unroll

@@ -34,7 +34,14 @@ class _HeadFunction(torch.autograd.Function):
         B, C, h, w = f.shape
         D, P, dev = w1.shape[0], h * w, f.device
         nonlinear = w2a is not None
-        need_grad = any(t is not None and t.requires_grad for t in (w1, b1, w2a, b2a, w2b, b2b))
+        if ctx.needs_input_grad[0]:
+            # (the backbone is frozen in the reference - DinoFeaturizer runs it under no_grad, src/modules.py:96 - and no
+            #  d/d image_feat kernel exists: refuse rather than drop that gradient silently)
+            raise RuntimeError("depthg_amd: ProjectionHead received features that require grad; the head has no gradient with "
+                               "respect to its input (frozen backbone) - detach them")
+        # grad mode and requires_grad of the six parameters, as autograd sees them: under torch.no_grad() / eval inference the
+        # bf16 hidden tile (19 MB at the headline shape) is neither written nor kept
+        need_grad = any(ctx.needs_input_grad[4:])
         code = _empty((B, D, h, w), torch.float32, dev)
         feats_out = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
         hidden = _empty((B, C, P), torch.bfloat16, dev) if (nonlinear and need_grad) else None
@@ -79,10 +86,12 @@ class _HeadFunction(torch.autograd.Function):
         return (None, None, None, None, R(gw1, 0), R(gb1, 1), R(gw2a, 2), R(gb2a, 3), R(gw2b, 4), R(gb2b, 5))
 
 
-def draw_keep_masks(B, C, device, p=0.1, count=3):
+def draw_keep_masks(B, C, device, p=0.1, use=(True, True, True)):
     """The Dropout2d draws of one featurizer pass, in the reference's order (cluster1's input, cluster2's input, the returned
-    feats; src/modules.py:123-132): (B, C) keep flags, one bernoulli_(1 - p) each, as F.dropout2d draws its (B, C, 1, 1) noise."""
-    return tuple(torch.empty(B, C, device=device, dtype=torch.float32).bernoulli_(1.0 - p) for _ in range(count))
+    feats; src/modules.py:122-132): (B, C) keep flags, one bernoulli_(1 - p) each, as F.dropout2d draws its (B, C, 1, 1) noise.
+    Only the uses that exist draw (`use`: cluster1, cluster2 = projection_type "nonlinear", feats = cfg.dropout) - the reference
+    calls Dropout2d exactly there, so the torch generator advances as it does there; the others are None."""
+    return tuple(torch.empty(B, C, device=device, dtype=torch.float32).bernoulli_(1.0 - p) if u else None for u in use)
 
 
 def run_head(cluster1, cluster2, image_feat, training, feats_dropout, p=0.1, keeps=None):
@@ -93,7 +102,7 @@ def run_head(cluster1, cluster2, image_feat, training, feats_dropout, p=0.1, kee
     nl = cluster2 is not None
     if training:
         if keeps is None:
-            keeps = draw_keep_masks(B, C, image_feat.device, p)
+            keeps = draw_keep_masks(B, C, image_feat.device, p, use=(True, nl, bool(feats_dropout)))
         k1, k2, k3 = keeps
         keeps = (k1, k2 if nl else None, k3 if feats_dropout else None)
     else:
@@ -120,8 +129,13 @@ class ProjectionHead(nn.Module):
             self.cluster2 = nn.Sequential(nn.Conv2d(n_feats, n_feats, (1, 1)), nn.ReLU(), nn.Conv2d(n_feats, dim, (1, 1)))
 
     def forward(self, image_feat, feats_dropout=True, keeps=None):
-        if self.proj_type is None:                                                                        # :127-128: code = image_feat
-            return image_feat, image_feat
+        if self.proj_type is None:                                                                        # :125-126: code = image_feat
+            feats = image_feat
+            if self.training and feats_dropout:                                                           # :127-129: feats = Dropout2d(image_feat)
+                k3 = keeps[2] if keeps is not None else draw_keep_masks(image_feat.shape[0], image_feat.shape[1], image_feat.device,
+                                                                         self.p, use=(False, False, True))[2]
+                feats = image_feat * (k3 * (1.0 / (1.0 - self.p)))[:, :, None, None]
+            return image_feat, feats
         return run_head(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
                         self.training, feats_dropout, self.p, keeps)
 

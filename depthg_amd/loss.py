@@ -115,7 +115,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                 g("depth_feat_weight") * scale if depth_term else 0.0)
 
     # -- coordinate selection, src/modules.py:1287-1321 -------------------------------------------
-    def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos):
+    def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos, same_maps=True):
         cfg = self.cfg
         B, S = orig_feats.shape[0], int(cfg.feature_samples)
         dev = orig_feats.device
@@ -147,7 +147,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                 c2 = ops.fps_coords(depth_pos, orig_feats_pos.shape[-2:], S)
             assert tuple(c1.shape) == tuple(c2.shape) == tuple(coord_shape), f"{c1.shape} != {c2.shape} != {coord_shape}"
             return c1, c2, False
-        if getattr(cfg, "dg_dense_grid", False) and S == orig_feats.shape[-2] == orig_feats.shape[-1]:
+        if getattr(cfg, "dg_dense_grid", False) and same_maps and S == orig_feats.shape[-2] == orig_feats.shape[-1]:
             key = (B, S, str(dev))
             if self._ident_cache[0] != key:          # constant tensor: built once per (B, S, device)
                 self._ident_cache = (key, identity_coords(B, S, dev))
@@ -157,10 +157,46 @@ class ContrastiveCorrelationLoss(nn.Module):
         c2 = _rand_coords(coord_shape, dev)
         return c1, c2, False
 
+    @staticmethod
+    def _check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth):
+        """The C side receives raw pointers: everything it assumes about the four maps is checked here.  The reference's
+        `sample()` (src/modules.py:822-825) takes normalised coordinates, so the code maps may have another resolution than the
+        feature maps (FeaturePyramidNet: low_res_feats (B,2048,7,7), code (B,dim,56,56), src/modules.py:732-766); what torch
+        itself would refuse there - another batch size (grid_sample), another channel count between the two operands of a
+        correlation (einsum), tensors on different devices - raises RuntimeError here as well."""
+        maps = (("orig_feats", orig_feats), ("orig_feats_pos", orig_feats_pos), ("orig_code", orig_code),
+                ("orig_code_pos", orig_code_pos))
+        for name, t in maps:
+            if not isinstance(t, torch.Tensor) or t.dim() != 4:
+                raise ValueError(f"depthg_amd: `{name}` must be a 4-D (B,K,h,w) tensor, got "
+                                 f"{tuple(t.shape) if isinstance(t, torch.Tensor) else type(t).__name__}")
+            if not t.is_floating_point():
+                raise ValueError(f"depthg_amd: `{name}` must be a floating-point tensor, got {t.dtype}")
+        dev, B = orig_feats.device, orig_feats.shape[0]
+        for name, t in maps[1:] + ((("depth", depth),) if depth is not None else ()):
+            if t.device != dev:
+                raise RuntimeError(f"depthg_amd: `{name}` lives on {t.device}, `orig_feats` on {dev}: all inputs of one call must "
+                                   f"share a device")
+            if t.shape[0] != B:
+                raise RuntimeError(f"depthg_amd: `{name}` has batch size {t.shape[0]}, `orig_feats` has {B} (the reference's "
+                                   f"grid_sample / einsum refuse that too)")
+        if tuple(orig_feats_pos.shape) != tuple(orig_feats.shape):
+            raise RuntimeError(f"depthg_amd: orig_feats_pos {tuple(orig_feats_pos.shape)} must have the shape of orig_feats "
+                               f"{tuple(orig_feats.shape)} (one featurizer produces both)")
+        if tuple(orig_code_pos.shape) != tuple(orig_code.shape):
+            raise RuntimeError(f"depthg_amd: orig_code_pos {tuple(orig_code_pos.shape)} must have the shape of orig_code "
+                               f"{tuple(orig_code.shape)} (one head produces both)")
+        if depth is not None and (depth.dim() != 4 or depth.shape[1] != 1):
+            raise ValueError(f"depthg_amd: `depth` must be (B,1,H,W), got {tuple(depth.shape)}")
+
     def forward(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos,
                 depth=None, depth_pos=None):
+        self._check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth)
+        if depth_pos is not None and depth is not None and (depth_pos.device != depth.device or depth_pos.shape[0] != depth.shape[0]):
+            raise RuntimeError(f"depthg_amd: depth_pos {tuple(depth_pos.shape)} on {depth_pos.device} does not match depth "
+                               f"{tuple(depth.shape)} on {depth.device}")
         coords1, coords2, shared = self._draw_coords(orig_feats, orig_feats_pos, orig_salience, orig_salience_pos,
-                                                     depth, depth_pos)
+                                                     depth, depth_pos, same_maps=orig_code.shape[-2:] == orig_feats.shape[-2:])
         state = None
         if getattr(self.cfg, "dg_graph_safe", False):
             # generator state on the device (hipGraph-capturable step: nothing about the draw is baked into the launch)
@@ -171,15 +207,23 @@ class ContrastiveCorrelationLoss(nn.Module):
         # (seed from torch's CPU generator unless the device generator is in use); `shared` is only ever set together with the
         # identity grid drawn above
         return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, None,
-                                 shared_coords=shared, identity_grid=shared, draw_state=state)
+                                 shared_coords=shared, identity_grid=shared, draw_state=state, _checked=True)
 
     # -- everything after the RNG draws (explicit coords / perms: parity tests, DP shards) ----------
     def forward_with(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                     shared_coords=False, identity_grid=False, draw_state=None):
+                     shared_coords=False, identity_grid=False, draw_state=None, _checked=False):
         cfg = self.cfg
+        if not _checked:
+            self._check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth)
         B, C, h, w = orig_feats.shape
-        D = orig_code.shape[1]
+        D, hc, wc = orig_code.shape[1:]
+        same_maps = (hc, wc) == (h, w)
+        if identity_grid and not same_maps:
+            raise ValueError(f"depthg_amd: the identity grid needs code maps of the feature maps' size, got {hc}x{wc} against {h}x{w}")
         S, N = int(cfg.feature_samples), int(cfg.neg_samples)
+        if tuple(coords1.shape) != tuple(coords2.shape) or tuple(coords1.shape) not in ((B, S, S, 2), (B, S, 1, 2)):
+            raise ValueError(f"depthg_amd: coords must both be (B,S,S,2) or (B,S,1,2) with B={B}, S={S}; got "
+                             f"{tuple(coords1.shape)} and {tuple(coords2.shape)}")
         depth_term = bool(cfg.depth_feat_correlation_loss)
         if depth_term and depth is None:
             raise AttributeError("depth_feat_correlation_loss=True needs `depth` (reference: interpolate(None) raises)")
@@ -189,9 +233,8 @@ class ContrastiveCorrelationLoss(nn.Module):
         depth_c = ops._f32c(depth, "depth") if depth_term else None
         coords1 = ops._f32c(coords1, "coords1")
         coords2 = ops._f32c(coords2, "coords2")
-        if tuple(coords1.shape) != tuple(coords2.shape) or tuple(coords1.shape) not in ((B, S, S, 2), (B, S, 1, 2)):
-            raise ValueError(f"depthg_amd: coords must both be (B,S,S,2) or (B,S,1,2) with B={B}, S={S}; got "
-                             f"{tuple(coords1.shape)} and {tuple(coords2.shape)}")
+        if coords1.device != dev or coords2.device != dev:
+            raise RuntimeError(f"depthg_amd: coords live on {coords1.device} / {coords2.device}, the maps on {dev}")
         line_grid = coords1.shape[2] == 1 and S != 1       # S x 1 grid of depth_sampling='simple'
         if perms is None:
             perms_t = None                 # drawn inside the forward (dg_corr_forward_draw)
@@ -211,7 +254,8 @@ class ContrastiveCorrelationLoss(nn.Module):
                                      cfg.depth_feat_shift if depth_term else 0.0),
                              depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
                              identity_grid=bool(identity_grid), weights=self._total_weights(depth_term),
-                             line_grid=line_grid)
+                             line_grid=line_grid, code_hw=None if same_maps else (hc, wc),
+                             exact_masks=bool(getattr(cfg, "dg_exact_masks", False)))
         holder = {"draw_state": draw_state}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()

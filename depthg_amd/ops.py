@@ -48,7 +48,9 @@ def _f32c(t, name):
 
 
 def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
-              shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0), line_grid=False):
+              shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0), line_grid=False, code_hw=None,
+              exact_masks=False):
+    """dg_corr_desc.  (h, w): the feature maps; code_hw: the code maps' size when it differs (None: the same)."""
     flags = 0
     flags |= _lib.DG_POINTWISE if pointwise else 0
     flags |= _lib.DG_ZERO_CLAMP if zero_clamp else 0
@@ -58,9 +60,11 @@ def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, dept
     flags |= _lib.DG_SHARED_COORDS if shared_coords else 0
     flags |= _lib.DG_IDENTITY_GRID if identity_grid else 0
     flags |= _lib.DG_LINE_GRID if line_grid else 0
+    flags |= _lib.DG_EXACT_MASKS if exact_masks else 0
+    ch, cw = (int(code_hw[0]), int(code_hw[1])) if code_hw is not None and tuple(code_hw) != (h, w) else (0, 0)
     return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
                     float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]),
-                    float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]))
+                    float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]), ch, cw)
 
 
 def workspace_bytes(desc):

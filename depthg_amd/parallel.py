@@ -80,6 +80,12 @@ class GradBucket:
         the bucket from `source` and) all-reduces it there.  The compute stream is never made to wait - no barrier packet in
         its queue; successive exchanges are ordered by `stream` itself, so the buffer is not refilled before the previous
         collective has read it.  Whoever consumes the averaged gradients (the optimiser step) calls `wait_exchange()` first."""
+        if not self.flat.is_cuda:
+            # CPU buckets (gloo: the tests of the step schedule): there are no streams, the exchange completes right here
+            if source is not None:
+                self.fill_from(source)
+            self.allreduce_mean_(even_if_alone=even_if_alone)
+            return
         cur = torch.cuda.current_stream()
         done = cur.record_event()
         if source is not None:
@@ -103,3 +109,52 @@ class GradBucket:
         if w is not None:
             w.wait()
             self._work = None
+
+
+class DoubleBufferedExchange:
+    """The N > 1 step schedule (bench.py, and what a trainer around `UnsupervisedSegmenter.training_step(grad_sync=...)` does):
+    two gradient buckets used alternately, so that step i + 1 fills the other buffer while step i's all-reduce is in flight on
+    the side stream.  Per step, in this order:
+
+        1. `wait_exchange` of bucket k = i mod 2  - the collective that read this buffer two steps ago (long done; it keeps the
+                                                    order between that collective and the refill explicit on the compute stream)
+        2. `compute(k)`                           - the step's kernels; they end by filling bucket k (a hipGraph replay in bench.py)
+        3. `exchange_on(comm)` of bucket k        - the all-reduce on the side stream, behind everything enqueued so far
+
+    `warm()` runs the step's kernels WITHOUT the collective (clock warm-up: ranks may run different counts of it, and a
+    collective there would pair up steps of different ranks); `drain()` makes every outstanding collective complete before the
+    timed region ends.  Every rank must call `step()` the same number of times.  `trace` (when given a list) records the calls -
+    the CPU tests drive this class over gloo with a stub `compute`."""
+
+    def __init__(self, buckets, compute, comm_stream=None, even_if_alone=False, exchange=True, alternate=True, trace=None):
+        assert len(buckets) == 2
+        self.buckets, self.compute, self.comm = buckets, compute, comm_stream
+        self.even_if_alone, self.exchange, self.alternate = even_if_alone, exchange, alternate
+        self.count, self.trace = 0, trace
+
+    def _note(self, what, k):
+        if self.trace is not None:
+            self.trace.append((what, k, self.count))
+
+    def step(self):
+        k = (self.count & 1) if self.alternate else 0
+        self._note("wait", k)
+        self.buckets[k].wait_exchange()
+        self._note("compute", k)
+        out = self.compute(k)
+        if self.exchange:
+            self._note("exchange", k)
+            self.buckets[k].exchange_on(self.comm, even_if_alone=self.even_if_alone)
+        self.count += 1
+        return out
+
+    def warm(self):
+        """The step's kernels alone (bucket 0's buffer is overwritten; nothing is exchanged)."""
+        self._note("warm", 0)
+        self.buckets[0].wait_exchange()
+        return self.compute(0)
+
+    def drain(self):
+        for k, b in enumerate(self.buckets):
+            self._note("drain", k)
+            b.wait_exchange()

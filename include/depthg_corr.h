@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 107   /* 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 108   /* 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -46,6 +46,11 @@ extern "C" {
                                         (simple_depth_informed_sampling returns (B,n,1,2), src/modules.py:828-883,1299-1302);
                                         the depth term resizes depth to (1,S) (modules.py:1261-1262 with c1.shape[2:] = (1,S)) */
 
+#define DG_EXACT_MASKS    (1u << 8)  /* cfg.dg_exact_masks (build-side key): on a gradient pass of the zero_clamp recipe the clamp mask
+                                        1[cd >= 0] (modules.py:1250-1252) is decided by an fp32 cd wherever the fp16 cd the MFMAs
+                                        compute is too close to zero to be trusted; without the flag the fp16 cd decides on the
+                                        dense grids (the small sample grids always take exact masks) */
+
 #define DG_MAX_NEG 8
 
 /* error codes */
@@ -62,7 +67,7 @@ typedef struct dg_corr_desc {
     int32_t B;        /* batch (per rank) */
     int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 */
     int32_t D;        /* code channels = cfg.dim; <= 128 */
-    int32_t h, w;     /* feature-map size of orig_feats / orig_code */
+    int32_t h, w;     /* feature-map size of orig_feats / orig_feats_pos (and of the code maps unless code_h / code_w say otherwise) */
     int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated (P = S with DG_LINE_GRID) */
     int32_t n_neg;    /* cfg.neg_samples (<= DG_MAX_NEG) */
     int32_t depth_h, depth_w; /* size of the depth map (image resolution); 0 if no depth */
@@ -72,6 +77,11 @@ typedef struct dg_corr_desc {
        pos_inter_weight, neg_inter_weight, depth_feat_weight, each times correspondence_weight - balance);
        out_scalars[DG_OUT_TOTAL] = their weighted sum.  All zero: no total wanted. */
     float w_intra, w_inter, w_neg, w_depth;
+    /* size of orig_code / orig_code_pos when it differs from (h, w); 0, 0 = the same maps.  The reference's sample()
+       (src/modules.py:822-825) takes normalised coordinates, so the loss accepts producers whose code map has another resolution
+       than their feature map: FeaturePyramidNet returns low_res_feats (B,2048,7,7) next to code (B,dim,56,56), src/modules.py:732-766
+       (its 2048 feature channels exceed this library's C <= 768).  Needs general coordinates (no DG_IDENTITY_GRID). */
+    int32_t code_h, code_w;
 } dg_corr_desc;
 
 /* indices into out_scalars[] of dg_corr_forward */
@@ -103,7 +113,7 @@ size_t dg_corr_workspace_bytes(const dg_corr_desc* desc);
  * (modules.py:1256-1278).
  *
  *  orig_feats, orig_feats_pos : fp32 (B,C,h,w) contiguous NCHW
- *  orig_code,  orig_code_pos  : fp32 (B,D,h,w)
+ *  orig_code,  orig_code_pos  : fp32 (B,D,h,w), or (B,D,code_h,code_w) when the descriptor names a code-map size
  *  depth                      : fp32 (B,1,depth_h,depth_w) or NULL (required with DG_DEPTH_TERM)
  *  coords1, coords2           : fp32 (B,S,S,2) in [-1,1]  (what the reference passes to sample()); (B,S,1,2) with DG_LINE_GRID
  *  perms                      : int64 (n_neg,B) = super_perm() draws (modules.py:1184-1188,1341)
@@ -141,7 +151,7 @@ int dg_corr_forward_draw(const dg_corr_desc* desc,
  *                 loss means) and DG_OUT_TOTAL are used, effective d/d(loss mean i) = g[i] + g[DG_OUT_TOTAL] * w_i;
  *                 the cd means carry no gradient
  *                 (DG_OUT_LOSS_INTRA..DG_OUT_LOSS_DEPTH order)
- *  grad_code, grad_code_pos : fp32 (B,D,h,w), overwritten.
+ *  grad_code, grad_code_pos : fp32, the shape of orig_code ((B,D,h,w) or (B,D,code_h,code_w)), overwritten.
  *  coords1, coords2, perms  : the SAME arrays the forward of this workspace ran on.  With general coordinates the adjoint of
  *                 sample() gathers through inverse tap records that the FORWARD built from its coords (first launch of a
  *                 DG_NEED_GRAD forward); the backward does not rebuild them, so coords that differ from the forward's are

@@ -20,7 +20,8 @@ def load_golden(name):
 
 FORWARD_CASES = ["c1_none", "c1_fps", "nopointwise", "nozeroclamp", "stabalize", "nodepthloss", "zerodepth_fps",
                  "batch1", "S9", "S12", "S14_dim100", "corr_feats", "surveykat_none", "surveykat_fps",
-                 "salience", "simple"]   # the last two: coords of the use_salience / depth_sampling='simple' samplers
+                 "salience", "simple",   # these two: coords of the use_salience / depth_sampling='simple' samplers
+                 "fpn_none", "fpn_fps"]  # feature maps (B,C,7,7) next to code maps (B,D,28,28): the FeaturePyramidNet contract
 
 
 def cfg_from_fixture(fx, **over):
@@ -38,6 +39,34 @@ def cfg_from_fixture(fx, **over):
         kw["use_salience"] = bool(fx["use_salience"])
     kw.update(over)
     return O.default_cfg(**kw)
+
+
+def load_golden_seeded(name):
+    """Fixtures whose INPUTS are re-drawn from a stored seed instead of being stored (tests/golden/make_round4_fixtures.py:
+    the headline-width vectors); the stored checksum pins the draw."""
+    import torch
+    fx = load_golden(name)
+    B, C, D, hf, wf, hc, wc, Himg = (int(v) for v in fx["input_shape"])
+    g = torch.Generator().manual_seed(int(fx["input_seed"]))
+    f = torch.randn(B, C, hf, wf, generator=g)
+    fp = torch.randn(B, C, hf, wf, generator=g)
+    c = torch.randn(B, D, hc, wc, generator=g)
+    cp = torch.randn(B, D, hc, wc, generator=g)
+    d = torch.randint(0, 256, (B, 1, Himg, Himg), generator=g).float()
+    dp = torch.randint(0, 256, (B, 1, Himg, Himg), generator=g).float()
+    ts = (f, fp, c, cp, d, dp)
+    chk = np.asarray([float(t.double().sum()) for t in ts] + [float(t.double().abs().sum()) for t in ts])
+    assert np.allclose(chk, fx["input_checksum"], rtol=1e-12, atol=1e-9), "the seeded inputs differ from the ones the reference ran on"
+    for k, t in zip(("feats", "feats_pos", "code", "code_pos", "depth", "depth_pos"), ts):
+        fx[k] = t.numpy()
+    if "coords1" not in fx:          # identity-grid fixture: the pixel-centre grid
+        S = int(fx["feature_samples"])
+        lin = torch.linspace(-1.0, 1.0, S)
+        co = torch.empty(B, S, S, 2)
+        co[..., 0] = lin.view(1, 1, S)
+        co[..., 1] = lin.view(1, S, 1)
+        fx["coords1"] = fx["coords2"] = co.numpy()
+    return fx
 
 
 @pytest.fixture(scope="session")

@@ -188,3 +188,88 @@ def test_two_rank_allreduce_of_recorded_hip_gradients():
     ob = sum(_shard_grads(r, world)[1] for r in range(world)) / world
     assert (got_w - ow).norm() <= 3e-2 * ow.norm(), float((got_w - ow).norm() / ow.norm())
     assert (got_b - ob).norm() <= 3e-2 * ob.norm() + 1e-7
+
+
+# ---- the N > 1 step schedule of bench.py: DoubleBufferedExchange over gloo with a stub compute ----------
+def _schedule_worker(rank, world, port, ret):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from depthg_amd.parallel import DoubleBufferedExchange
+    n = 1000
+    buckets = [GradBucket(n, "cpu", dist) for _ in range(2)]
+    trace, seen = [], []
+    sched = None
+
+    def compute(k):
+        # the step's kernels end by filling bucket k with THIS step's gradients: here a pattern that names (rank, step)
+        step_no = sched.count
+        buckets[k].flat.fill_(float(1000 * rank + step_no))
+        buckets[k].flat[1] = float(rank)
+        return step_no
+
+    sched = DoubleBufferedExchange(buckets, compute, comm_stream=None, trace=trace)
+    # time-based clock warm-up as in bench.py: the ranks run DIFFERENT counts of it (no collective in there, or the pairs of the
+    # timed steps' collectives would slip against each other and the run would deadlock or average different steps)
+    t0, warm_calls = time.perf_counter(), 0
+    while time.perf_counter() - t0 < (0.05 if rank == 0 else 0.25) or warm_calls < 3 + 4 * rank:
+        sched.warm()
+        warm_calls += 1
+    dist.barrier()
+    K = 7
+    for i in range(K):
+        out = sched.step()
+        k = i & 1
+        # (CPU buckets: the exchange has completed) bucket k = mean over ranks of this step's pattern on every rank
+        seen.append((out, k, float(buckets[k].flat[0]), float(buckets[k].flat[1]), float(buckets[1 - k].flat[0])))
+    sched.drain()
+    dist.barrier()
+    ret[rank] = (warm_calls, seen, [t for t in trace if t[0] != "warm"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_schedule_with_stub_compute():
+    """bench.py's N > 1 schedule, the class itself, two gloo ranks: buckets alternate, the wait on a bucket's previous collective
+    precedes its refill, the refill precedes its exchange, warm-up steps of different counts per rank issue no collective, every
+    step's bucket ends as the mean over ranks of THAT step's gradients, and the other bucket still holds the previous step's."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_schedule_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        res = {r: ret[r] for r in range(world)}
+    assert res[0][0] != res[1][0] and res[1][0] >= 7              # the ranks warmed up for different counts
+    for r in range(world):
+        _, seen, trace = res[r]
+        for i, (out, k, v0, v1, other) in enumerate(seen):
+            assert out == i and k == (i & 1)
+            assert v0 == pytest.approx(500.0 + i) and v1 == pytest.approx(0.5)        # mean over the two ranks of 1000 r + i, r
+            if i > 0:
+                assert other == pytest.approx(500.0 + i - 1)                          # the other buffer: last step's average, intact
+        want = []
+        for i in range(len(seen)):
+            want += [("wait", i & 1, i), ("compute", i & 1, i), ("exchange", i & 1, i)]
+        want += [("drain", 0, len(seen)), ("drain", 1, len(seen))]
+        assert trace == want
+    assert res[0][1] == res[1][1]                                  # bit-identical averaged buckets on both ranks
+
+
+def test_step_schedule_ablation_switches():
+    """`exchange=False` / `alternate=False` (bench.py --ablate) on one process without a process group: no collective, one bucket."""
+    from depthg_amd.parallel import DoubleBufferedExchange
+    buckets = [GradBucket(4, "cpu", None) for _ in range(2)]
+    trace = []
+    s = DoubleBufferedExchange(buckets, lambda k: buckets[k].flat.add_(1.0), exchange=False, alternate=False, trace=trace)
+    for _ in range(3):
+        s.step()
+    s.drain()
+    assert float(buckets[0].flat[0]) == 3.0 and float(buckets[1].flat[0]) == 0.0
+    assert [t[0] for t in trace] == ["wait", "compute"] * 3 + ["drain", "drain"]

@@ -100,6 +100,40 @@ def test_head_is_deterministic_and_draws_its_own_masks(dev):
     assert 0.05 < frac < 0.16                                              # Dropout2d(p=.1) zeroes whole channels (quirk Q10)
 
 
+@pytest.mark.parametrize("proj,feats_dropout", [("linear", True), ("nonlinear", False), ("linear", False), (None, True)])
+def test_head_random_stream_follows_the_reference(proj, feats_dropout, dev):
+    """only the Dropout2d uses that exist draw (src/modules.py:122-132), so with projection_type "linear" the returned
+    feats carry the SECOND draw of the pass, with cfg.dropout off nothing is drawn for them, and whatever is drawn next comes
+    from the same generator position as behind the reference's nn.Dropout2d sequence.  Also: features that require grad are
+    refused (no d/d image_feat kernel), and under no_grad the head keeps no hidden tile."""
+    from depthg_amd.head import ProjectionHead
+    torch.manual_seed(0)
+    head = ProjectionHead(64, 16, proj).to(dev).train()
+    feat = torch.randn(3, 64, 9, 9, device=dev)
+    torch.manual_seed(21)
+    code, feats = head(feat, feats_dropout)
+    nxt = torch.rand(4, device=dev)
+    torch.manual_seed(21)
+    drop = torch.nn.Dropout2d(0.1).train()
+    ones = torch.ones(3, 64, 1, 1, device=dev)
+    ndraws = (0 if proj is None else (2 if proj == "nonlinear" else 1)) + (1 if feats_dropout else 0)
+    draws = [drop(ones) for _ in range(ndraws)]
+    nxt_ref = torch.rand(4, device=dev)
+    assert torch.equal(nxt, nxt_ref)
+    if feats_dropout:
+        assert torch.allclose(feats, feat * draws[-1], rtol=1e-6, atol=0)
+    else:
+        assert feats is feat
+    if proj is None:
+        assert code is feat
+        return
+    with pytest.raises(RuntimeError, match="require grad"):
+        head(feat.clone().requires_grad_(True))
+    with torch.no_grad():
+        c2, _ = head(feat, feats_dropout)
+    assert c2.grad_fn is None and torch.isfinite(c2).all()
+
+
 def test_cluster_lookup_matches_reference_vectors(dev):
     from depthg_amd.head import ClusterLookup
     fx = load_golden("head.npz")

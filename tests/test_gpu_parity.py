@@ -547,7 +547,7 @@ def test_module_forward_with_sampler(mode, dev):
     loss = ContrastiveCorrelationLoss(cfg)
     drawn = []
     orig = loss._draw_coords
-    loss._draw_coords = lambda *a: (drawn.append(orig(*a)) or drawn[-1])
+    loss._draw_coords = lambda *a, **k: (drawn.append(orig(*a, **k)) or drawn[-1])
     cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
     out = loss(f.to(dev), fp.to(dev), sal.to(dev), salp.to(dev), cg, cpg, d.to(dev), dp.to(dev))
     total = O.total_loss(cfg, out)

@@ -339,3 +339,24 @@ def test_bench_cpu_baseline_reports_both_thread_counts(monkeypatch):
     assert r["cores"] in (16, 24) and "threads" in r["sample"]
     assert len(r["also"]) == 1 and r["also"][0]["cores"] in (16, 24) and r["also"][0]["cores"] != r["cores"]
     assert "value" in r["also"][0] or "skipped" in r["also"][0]
+
+
+def test_head_draws_only_the_masks_the_reference_draws():
+    """DinoFeaturizer calls Dropout2d once per use that exists (src/modules.py:122-132: cluster1's input always,
+    cluster2's only for projection_type "nonlinear", the returned feats only with cfg.dropout).  draw_keep_masks draws exactly
+    those, in that order, with the generator calls F.dropout2d makes - so the masks AND every later draw of the step (second
+    featurizer pass, sample coordinates, super_perm) stay on the reference's random stream in every configuration."""
+    import torch
+    from depthg_amd.head import draw_keep_masks
+    B, C, p = 3, 40, 0.1
+    for use in ((True, True, True), (True, False, True), (True, True, False), (True, False, False)):
+        torch.manual_seed(11)
+        got = draw_keep_masks(B, C, "cpu", p, use=use)
+        after = torch.rand(3)
+        torch.manual_seed(11)
+        drop = torch.nn.Dropout2d(p).train()
+        want = [(drop(torch.ones(B, C, 2, 2))[:, :, 0, 0] != 0).float() if u else None for u in use]
+        after_ref = torch.rand(3)
+        for g, w in zip(got, want):
+            assert (g is None and w is None) or torch.equal(g, w)
+        assert torch.equal(after, after_ref), use

@@ -132,7 +132,7 @@ def test_forward_against_reference(case):
     close(code_pos.grad, fx["grad_code_pos"], atol=2e-6 * max(np.abs(fx["grad_code_pos"]).max(), 1e-12) + 1e-9, rtol=1e-4)
 
 
-@pytest.mark.parametrize("case", ["c1_fps", "zerodepth_fps", "S9", "S12"])
+@pytest.mark.parametrize("case", ["c1_fps", "zerodepth_fps", "S9", "S12", "fpn_fps"])
 def test_forward_fps_coords_regenerated(case):
     """coords drawn by the oracle's own FPS (not injected) equal the reference's."""
     fx = load_golden(f"forward_{case}.npz")
@@ -140,6 +140,30 @@ def test_forward_fps_coords_regenerated(case):
     c1, c2 = O.draw_coords(cfg, T(fx["feats"]), T(fx["feats_pos"]), T(fx["depth"]), T(fx["depth_pos"]))
     assert np.array_equal(c1.numpy(), fx["coords1"])
     assert np.array_equal(c2.numpy(), fx["coords2"])
+
+
+@pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident"])
+def test_forward_headline_width_against_reference(case):
+    """The headline width (C=384, D=70, 28x28, S=28) at B=2, vectors from the imported reference with its own torch.rand
+    coordinates (`rand`) and on the pixel-centre grid (`ident`); inputs re-drawn from the stored seed."""
+    from conftest import load_golden_seeded
+    fx = load_golden_seeded(f"forward_{case}.npz")
+    cfg = cfg_from_fixture(fx)
+    code = T(fx["code"]).requires_grad_(True)
+    code_pos = T(fx["code_pos"]).requires_grad_(True)
+    out = O.forward(cfg, T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), T(fx["depth_pos"]),
+                    coords1=T(fx["coords1"]), coords2=T(fx["coords2"]), perms=[T(p) for p in fx["perms"]])
+    for i, k in ((0, "pos_intra_loss"), (2, "pos_inter_loss"), (6, "depth_feat_loss")):
+        close(out[i], fx[k], atol=2e-8, rtol=1e-5)
+    close(out[4].mean(), fx["neg_inter_loss_mean"], atol=2e-8, rtol=1e-5)
+    sub = int(fx["sub"])
+    for n, i in (("pos_intra_cd", 1), ("pos_inter_cd", 3), ("neg_inter_loss", 4), ("neg_inter_cd", 5)):
+        close(out[i].reshape(-1)[::sub], fx[n], atol=3e-6, rtol=1e-5)
+    total = O.total_loss(cfg, out)
+    close(total, fx["total"], atol=2e-8, rtol=1e-5)
+    total.backward()
+    for got, want in ((code.grad, fx["grad_code"]), (code_pos.grad, fx["grad_code_pos"])):
+        close(got, want, atol=2e-6 * max(np.abs(want).max(), 1e-12) + 1e-10, rtol=1e-4)
 
 
 def test_decay_table_and_traces():
