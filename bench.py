@@ -218,6 +218,9 @@ def main():
                     help="untimed steps are run for this many seconds BEFORE the --warmup steps, so that the GPU has left its idle "
                          "power state when the timed region starts (an idle MI355X needs tens of ms of load to reach its "
                          "sustained clock; reported as `clock_warmup_steps`)")
+    ap.add_argument("--exact-masks", action="store_true",
+                    help="cfg.dg_exact_masks: the clamp mask 1[cd >= 0] from fp32 dot products instead of the fp16 cd of the MFMA "
+                         "chain (gradient error 1.4e-2 -> below 2e-3 relative L2; dense ViT-S grids; the default is the fast path)")
     ap.add_argument("--ablate", choices=["", "noexchange", "onegraph"], default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
@@ -249,7 +252,7 @@ def main():
     # plus the collective's, 0.05-0.14 ms, would make the host the limit of a 0.3-ms step); N > 1 adds the collective on a side
     # stream and nothing else.  --eager / --sync-allreduce opt out (the JSON line says which schedule ran).
     graph_mode = not args.eager and not args.sync_allreduce
-    cfg = make_cfg(conf, dg_graph_safe=graph_mode)
+    cfg = make_cfg(conf, dg_graph_safe=graph_mode, dg_exact_masks=args.exact_masks)
     loss_fn = ContrastiveCorrelationLoss(cfg)
     f, fp, c, cp, d, dp = synth_inputs(H["B"], 1234 + rank, dev, H)
     c.requires_grad_(True)
@@ -491,6 +494,7 @@ def main():
             "dtype": "bf16 (feats) / f16 (code) MFMA inputs, f32 accumulate", "data": "synthetic",
             "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if graph_mode else " [eager step]"),
                        "name": args.config, "schedule": "hipGraph replay" if graph_mode else "eager",
+                       "exact_masks": bool(args.exact_masks),
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
                        "ranks_seen": dist_diag["ranks_seen"] if dist_diag else 1,
                        "clock_warmup_steps": clock_warmup_steps,

@@ -40,8 +40,9 @@ struct Plan {
     size_t part[DG_MAX_NEG + 3];
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
     size_t ticket;                          // the depth blocks' ticket of the k_gs launch
-    size_t maskbits[DG_MAX_NEG + 2];        // exact clamp masks of the pair-sets (k_cd_mask; small sample grids), xmask: in use
-    bool xmask;
+    size_t maskbits[DG_MAX_NEG + 2];        // exact clamp masks of the pair-sets (k_cd_mask), xmask: in use on a small sample grid,
+    bool xmask, xmask_dense;                // xmask_dense: on the dense identity grid (DG_EXACT_MASKS)
+    size_t clo[2];                          // ... with pointwise: the parts of the normalised code the fp16 C parts drop (k_cd_mask3)
     size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
     size_t total;
 };
@@ -115,7 +116,15 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
 #ifdef DG_NO_XMASK      // developer A/B: the fp16 masks everywhere
     p.xmask = false;
 #endif
-    for (int t = 0; t < p.T; ++t) p.maskbits[t] = take(p.xmask ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
+    // DG_EXACT_MASKS: the dense identity grid at the widths of the one-wave-per-SIMD kernel (dg_corr2.hip) takes the same mask words,
+    // computed from channel-last fp32 copies of the two code maps (the workspace's nhwc_c regions, otherwise unused on this grid)
+    p.xmask_dense = (d->flags & DG_EXACT_MASKS) && p.ident && p.grad && (d->flags & DG_ZERO_CLAMP) && !(d->flags & DG_STABALIZE) &&
+                    p.KF == 384 && p.KD == 96 && p.D <= 80 && p.Ppad >= 160 && p.B <= 64;
+    if ((d->flags & DG_EXACT_MASKS) && p.grad && (d->flags & DG_ZERO_CLAMP) && !p.xmask && !p.xmask_dense)
+        return fail(DG_ERR_UNSUPPORTED, "DG_EXACT_MASKS: exact clamp masks exist on small sample grids (always on there) and on the dense "
+                                        "identity grid with C <= 384 (padded to 384), D <= 80, P >= 160, B <= 64, zero_clamp without stabalize");
+    for (int t = 0; t < p.T; ++t) p.maskbits[t] = take((p.xmask || p.xmask_dense) ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
+    for (int i = 0; i < 2; ++i) p.clo[i] = take((p.xmask_dense && p.pointwise) ? B * (size_t)(p.Ppad / 32) * p.KD * 64 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
     p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
     p.gr_rank = take((size_t)DG_MAX_JOBS * B * 2);
@@ -215,7 +224,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
         j.Gout = p.grad ? reinterpret_cast<uint16_t*>(ws + p.gbuf[t]) : nullptr;
-        j.maskbits = p.xmask ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[t]) : nullptr;
+        j.maskbits = (p.xmask || p.xmask_dense) ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[t]) : nullptr;
         j.slot_loss = t < 2 ? t : DG_OUT_LOSS_NEG;
         j.slot_cd = t < 2 ? DG_OUT_CD_INTRA + t : DG_OUT_CD_NEG;
         j.fin_scale = (float)(1.0 / (t < 2 ? numel : numel * p.N));
@@ -339,6 +348,26 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         DG_HIP(dg_launch_prep_dense(g, stream));
+        if (p.xmask_dense && !p.pointwise) {
+            // exact clamp masks without `pointwise` (the code operands are then built by k_prep_dense itself, without the parts the
+            // split-fp16 form below needs): position-major fp32 rows of the two code maps (on this grid position p IS pixel p), then
+            // the sign of every raw fp32 dot product (k_cd_mask) as one word per (S tile, R position) for all pair-sets
+            DgTransposeArgs t;
+            memset(&t, 0, sizeof(t));
+            t.nmaps = 2;
+            t.src[0] = orig_code; t.dst[0] = F32(p.nhwc_c[0]); t.K[0] = p.D; t.K4[0] = p.D4; t.HW[0] = p.h * p.w;
+            t.src[1] = orig_code_pos; t.dst[1] = F32(p.nhwc_c[1]); t.K[1] = p.D; t.K4[1] = p.D4; t.HW[1] = p.h * p.w;
+            DG_HIP(dg_launch_transpose(t, p.B, stream));
+            DgCdMaskArgs m;
+            memset(&m, 0, sizeof(m));
+            m.rowsR = F32(p.nhwc_c[0]);
+            for (int tt = 0; tt < p.T; ++tt) {
+                m.rowsS[tt] = F32(p.nhwc_c[op_of(p, tt)]); m.sidx[tt] = map_of(p, tt, perms);
+                m.bits[tt] = reinterpret_cast<uint32_t*>(ws + p.maskbits[tt]);
+            }
+            m.T = p.T; m.B = p.B; m.P = p.P; m.Ppad = p.Ppad; m.D = p.D; m.D4 = p.D4;
+            DG_HIP(dg_launch_cd_mask(m, stream));
+        }
     } else {
         // general coordinates: the first launch already reads the batch maps, so they are drawn by a launch of their own - which
         // also carries the other jobs that depend on nothing but the call's inputs: the depth indicators and, on gradient passes,
@@ -434,8 +463,22 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             c.dc.code[0] = orig_code; c.dc.code[1] = orig_code_pos;
             for (int o = 0; o < 2; ++o) { c.dc.blob[o] = ws + p.op[o]; c.dc.inv_norm[o] = F32(p.inv[o]); c.dc.ccolpart[o] = F32(p.ccolpart[o]); }
             c.dc.B = p.B; c.dc.D = p.D; c.dc.KF = p.KF; c.dc.KD = p.KD; c.dc.h = p.h; c.dc.w = p.w; c.dc.P = p.P; c.dc.Ppad = p.Ppad;
+            if (p.xmask_dense) { c.dc.clo[0] = ws + p.clo[0]; c.dc.clo[1] = ws + p.clo[1]; }
         }
         DG_HIP(dg_launch_colmean(c, stream));
+    }
+    if (p.xmask_dense && p.pointwise) {
+        // exact clamp masks: cd from split fp16 operands (the C parts + what they drop, both written by the launch above)
+        DgCdMask3Args m;
+        memset(&m, 0, sizeof(m));
+        m.opR = ws + p.op[0]; m.loR = ws + p.clo[0];
+        for (int tt = 0; tt < p.T; ++tt) {
+            m.opS[tt] = ws + p.op[op_of(p, tt)]; m.loS[tt] = ws + p.clo[op_of(p, tt)]; m.sidx[tt] = map_of(p, tt, perms);
+            m.bits[tt] = reinterpret_cast<uint32_t*>(ws + p.maskbits[tt]);
+        }
+        const DgBlob bl(p.KF, p.KD);
+        m.T = p.T; m.B = p.B; m.Ppad = p.Ppad; m.blob_bytes = bl.bytes; m.off_c = bl.off_c; m.KD = p.KD;
+        DG_HIP(dg_launch_cd_mask3(m, stream));
     }
     if (p.pointwise) {
         DgRowmeanArgs r;
@@ -483,11 +526,20 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         if (p.depth) {
             g.dep_op = ws + p.op[0]; g.dep_nz = F32(p.nz); g.dep_dR = F32(p.dRA[p.T]); g.dep_part = F32(p.part[p.T]);
             g.dep_ticket = reinterpret_cast<unsigned int*>(ws + p.ticket);
-            dep_maskbits = p.xmask ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[0]) : nullptr;   // cd of the depth term = intra's cd
+            dep_maskbits = (p.xmask || p.xmask_dense) ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[0]) : nullptr;   // cd of the depth term = intra's cd
             g.dep_shift = desc->shift_depth; g.dep_nrb = dep_nrb; g.dep_blocks = p.B * dep_nrb;
             clamp_bounds(desc, g.dep_lo, g.dep_hi);
         }
-        DG_HIP(dg_launch_gs(g, dep_maskbits, stream));
+        if (p.xmask_dense && p.depth) {
+            // the G-stream blocks as a launch of the plain kernel (two blocks per CU), then the depth blocks alone in the masked
+            // form (256 registers per wave); the last depth block reduces the call's partial sums
+            DgGsArgs gstream = g;
+            gstream.dep_blocks = 0; gstream.fin.out = nullptr;
+            DG_HIP(dg_launch_gs(gstream, nullptr, stream));
+            DG_HIP(dg_launch_gs(g, dep_maskbits, stream, true));
+        } else {
+            DG_HIP(dg_launch_gs(g, dep_maskbits, stream));
+        }
     } else {
         DG_HIP(dg_launch_finish(f, stream));
     }

@@ -408,6 +408,9 @@ struct DgDenseCodeArgs {
     const float* inv_norm[2];
     float* ccolpart[2];
     int32_t B, D, KF, KD, h, w, P, Ppad;     // B == 0: not used
+    // exact clamp masks (DG_EXACT_MASKS): the part of the normalised code the fp16 C part drops, (x - fp16(x)) * 2048 as fp16, in
+    // the C part's own granule layout, [image][tile][KD/8][32 positions][8]; null: not wanted
+    char* clo[2];
 };
 
 // Consumer lists of the grouped ragged row blocks of k_corr2 (dg_corr2.hip): for every key (= set of pair-sets that stream the
@@ -589,7 +592,7 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
 bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD);
-hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream);   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
+hipError_t dg_launch_gs(const struct DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t s, bool depth_only = false);   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
@@ -603,6 +606,19 @@ struct DgCdMaskArgs {
     int32_t T, B, P, Ppad, D, D4;
 };
 hipError_t dg_launch_cd_mask(const DgCdMaskArgs& a, hipStream_t s);
+// The same mask words on the dense identity grid from SPLIT fp16 operands: cd = hi.hi + (hi.lo + lo.hi) / 2048 on the fp16 MFMA with
+// fp32 accumulation - the operand error drops from 2^-11 to 2^-22 relative, i.e. to the rounding noise of an fp32 dot product,
+// at 3 instead of 16 times the work of the fp16 chain (k_cd_mask's fp32 MFMA runs at 1/16 of the fp16 rate).
+struct DgCdMask3Args {
+    const char* opR;                         // operand-1 blobs (hi = their C parts)
+    const char* loR;                         // ... and the dropped parts (DgDenseCodeArgs.clo)
+    const char* opS[DG_MAX_NEG + 2];         // streamed operand of pair-set t
+    const char* loS[DG_MAX_NEG + 2];
+    const int64_t* sidx[DG_MAX_NEG + 2];     // batch map of the streamed operand (null: identity)
+    uint32_t* bits[DG_MAX_NEG + 2];          // [B][Ppad/32][Ppad] out (the format of DgCdMaskArgs.bits)
+    int32_t T, B, Ppad, blob_bytes, off_c, KD;
+};
+hipError_t dg_launch_cd_mask3(const DgCdMask3Args& a, hipStream_t s);
 hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);

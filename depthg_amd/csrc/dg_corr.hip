@@ -761,11 +761,16 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t
     // against every S tile, loaded up front and waited for once.  The block without them sits at k_gs's 128 registers (9 spilled);
     // eight more spill 80 (KD = 96) / 454 (KD = 128) and cost 11 - 27 us at C3's shape, so the masked form is its own
     // instantiation of k_gs with 256 registers per wave (one block per CU: small sample grids have few blocks).
+    // Dense grids with DG_EXACT_MASKS (more than eight tiles): the word of tile t + 1 is requested while tile t is worked on.
     uint32_t mw[XM ? 8 : 1];
+    uint32_t mw_next = 0u;
+    const bool mw_pre = ntiles <= 8;
+    const uint32_t* const mw_row = XM ? dep_maskbits + (size_t)n * ntiles * a.Ppad + (act ? rtile : 0) * 32 + r : nullptr;
     if constexpr (XM) {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8)       // (clamped tile indices, no guards: guarded loads are issued and waited for one by one)
-            mw[t8] = dep_maskbits[((size_t)n * ntiles + min(t8, ntiles - 1)) * a.Ppad + (act ? rtile : 0) * 32 + r];
+            mw[t8] = mw_row[(size_t)min(t8, ntiles - 1) * a.Ppad];
+        mw_next = mw[0];
     }
     auto fetch = [&](int t) {
         const char* src = img + (size_t)t * BL::BYTES + BL::OFF_C;
@@ -789,9 +794,14 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t
     for (int t = 0; t < ntiles; ++t) {
         uint32_t mwd = 0u;
         if constexpr (XM) {
-            mwd = mw[0];
+            if (mw_pre) {
+                mwd = mw[0];
 #pragma unroll
-            for (int t8 = 1; t8 < 8; ++t8) mwd = t == t8 ? mw[t8] : mwd;
+                for (int t8 = 1; t8 < 8; ++t8) mwd = t == t8 ? mw[t8] : mwd;
+            } else {
+                mwd = mw_next;
+                mw_next = mw_row[(size_t)min(t + 1, ntiles - 1) * a.Ppad];
+            }
         }
         if (t + 1 < ntiles) fetch(t + 1);                 // in flight during this tile's arithmetic
         __syncthreads();                                   // tile t is in buffer t & 1; everybody is done with the other one
@@ -1028,8 +1038,11 @@ __global__ __launch_bounds__((GS_CW + 1) * 64, 2) void k_gs_xm(const DgGsArgs a,
     gs_body<NKF, NKD, true>(a, dep_maskbits);
 }
 
-hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream) {
-    dim3 grid(((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B + a.dep_blocks), block((GS_CW + 1) * 64);
+// depth_only: the depth term's blocks alone (DG_EXACT_MASKS on the dense grid: the G-stream blocks run as a launch of the plain
+// kernel with two blocks per CU, the depth blocks - which need the intra pair-set's mask words - as one of the 256-register form)
+hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream, bool depth_only) {
+    dim3 grid((depth_only ? 0 : ((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B) + a.dep_blocks), block((GS_CW + 1) * 64);
+    if (grid.x == 0) return hipSuccess;
     DgGsArgs a2 = a;
 #ifdef DG_DEVTOOLS
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)

@@ -415,6 +415,97 @@ __global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
     if (pr >= a.P) word = ~0u;
     if (h == 0) a.bits[t][((size_t)n * nt + st) * a.Ppad + pr] = word;
 }
+// Exact clamp masks on the dense identity grid from split fp16 operands (DgCdMask3Args).  One block = 8 waves = 8 consecutive R
+// tiles of one (pair-set, image); the block walks the S tiles, whose hi / lo code rows (the first 2 NKC granule rows of the C
+// part and of its companion) go through two LDS buffers, register-staged one tile ahead.  Per S tile and wave 3 NKC fp16 MFMAs:
+// hi.hi into one accumulator, hi.lo' + lo'.hi into a second (lo' = 2048 lo, so that no operand is a fp16 subnormal);
+// cd = acc0 + acc1 / 2048 carries the rounding noise of an fp32 dot product (operands exact to 2^-22).  Output: the word format
+// of k_cd_mask (bit i of word (S tile, R position) = S position 32 tile + i).
+typedef int v4i_m3 __attribute__((ext_vector_type(4)));
+template <int NKC>
+__global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
+    using v4i = v4i_m3;
+    constexpr int HB = 2 * NKC * 512;                    // bytes of the hi (or lo) rows of one tile that the chain reads
+    constexpr int NPC = 2 * HB / 16;                     // 16-byte pieces of one staged tile (hi then lo)
+    __shared__ __attribute__((aligned(16))) char buf[2][2 * HB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int nt = a.Ppad >> 5, n = blockIdx.y, t = blockIdx.z;
+    const int rt = blockIdx.x * 8 + wid;
+    const bool act = rt < nt;
+    const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
+    const size_t lo_tile = (size_t)a.KD * 64;            // bytes of one tile's lo part
+    // stationary fragments: granule 2k + h of R position r, hi and lo
+    v4i Rh[NKC], Rl[NKC];
+    {
+        const char* rb = a.opR + ((size_t)n * nt + (act ? rt : 0)) * a.blob_bytes + a.off_c;
+        const char* rl = a.loR + ((size_t)n * nt + (act ? rt : 0)) * lo_tile;
+#pragma unroll
+        for (int k = 0; k < NKC; ++k) {
+            Rh[k] = *reinterpret_cast<const v4i*>(rb + ((2 * k + h) * 32 + r) * 16);
+            Rl[k] = *reinterpret_cast<const v4i*>(rl + ((2 * k + h) * 32 + r) * 16);
+        }
+    }
+    const char* const sh = a.opS[t] + (size_t)nS * nt * a.blob_bytes + a.off_c;
+    const char* const sl = a.loS[t] + (size_t)nS * nt * lo_tile;
+    // staging registers of two tiles: the loads of tile st + 2 are requested while tile st is worked on and tile st + 1 waits in
+    // the other pair - one tile of look-ahead left the block waiting for memory (83 us for 33 us of MFMAs at the headline)
+    v4i sa0, sa1 = v4i{0, 0, 0, 0}, sb0, sb1 = v4i{0, 0, 0, 0};
+    auto piece_src = [&](int st, int pc) -> const char* {          // piece pc of tile st: hi rows first, then lo rows
+        return pc < HB / 16 ? sh + (size_t)st * a.blob_bytes + pc * 16 : sl + (size_t)st * lo_tile + (pc - HB / 16) * 16;
+    };
+    auto fetch = [&](int st, v4i& p0, v4i& p1) {
+        const int sc = st < nt ? st : nt - 1;                      // (past the end: a harmless re-load)
+        p0 = *reinterpret_cast<const v4i*>(piece_src(sc, tid));
+        if (tid + 512 < NPC) p1 = *reinterpret_cast<const v4i*>(piece_src(sc, tid + 512));
+    };
+    auto stash = [&](int b, const v4i& p0, const v4i& p1) {
+        *reinterpret_cast<v4i*>(buf[b] + tid * 16) = p0;
+        if (tid + 512 < NPC) *reinterpret_cast<v4i*>(buf[b] + (tid + 512) * 16) = p1;
+    };
+    static_assert(NPC <= 1024, "two pieces per thread");
+    uint32_t* const out = a.bits[t] + (size_t)n * nt * a.Ppad + (act ? rt : 0) * 32 + r;
+    auto compute = [&](int st) {
+        if (!act) return;
+        const char* tile = buf[st & 1];
+        f32x16 a0 = f32x16{}, a1 = f32x16{};
+#pragma unroll
+        for (int k = 0; k < NKC; ++k) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(tile + ((2 * k + h) * 32 + r) * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(tile + HB + ((2 * k + h) * 32 + r) * 16);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rh[k]), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rl[k]), a1, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, Rh[k]), a1, 0, 0, 0);
+        }
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) word |= (fmaf(a1[i], 1.f / 2048.f, a0[i]) >= 0.f ? 1u : 0u) << ((i & 3) + 8 * (i >> 2) + 4 * h);
+        word |= (uint32_t)__shfl_xor((int)word, 32);
+        if (h == 0) out[(size_t)st * a.Ppad] = word;
+    };
+    fetch(0, sa0, sa1);
+    stash(0, sa0, sa1);
+    fetch(1, sa0, sa1);
+    fetch(2, sb0, sb1);
+    for (int st = 0; st < nt; st += 2) {
+        // buf[0]: tile st; (sa): tile st + 1; (sb): tile st + 2
+        __syncthreads();
+        compute(st);
+        stash(1, sa0, sa1);
+        fetch(st + 3, sa0, sa1);
+        if (st + 1 >= nt) break;
+        __syncthreads();
+        compute(st + 1);
+        stash(0, sb0, sb1);
+        fetch(st + 4, sb0, sb1);
+    }
+}
+hipError_t dg_launch_cd_mask3(const DgCdMask3Args& a, hipStream_t s) {
+    if (a.KD != 96) return hipErrorInvalidValue;
+    const int nt = a.Ppad / 32;
+    hipLaunchKernelGGL(k_cd_mask3<5>, dim3((nt + 7) / 8, a.B, a.T), dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t dg_launch_cd_mask(const DgCdMaskArgs& a, hipStream_t s) {
     if (a.D4 > 128) return hipErrorInvalidValue;
     const int nt = a.Ppad / 32;
@@ -640,9 +731,17 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
     const int tid = threadIdx.x, HW = a.h * a.w, nt = a.Ppad / 32, KD = a.KD;
     const DgBlob L(a.KF, a.KD);
     const int nch = min(8, a.D - 8 * g);                  // live channels of this group (<= 0: padding group, zeros)
-    for (int p = a.P + tid; p < a.Ppad; p += 256) reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+    char* const xl = xt + (size_t)a.Ppad * 16;           // (clo wanted: the dropped parts, same [position][8 channels] image)
+    const bool want_lo = a.clo[o] != nullptr;
+    for (int p = a.P + tid; p < a.Ppad; p += 256) {
+        reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+        if (want_lo) reinterpret_cast<uint4*>(xl)[p] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (nch <= 0) {
-        for (int p = tid; p < a.P; p += 256) reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+        for (int p = tid; p < a.P; p += 256) {
+            reinterpret_cast<uint4*>(xt)[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (want_lo) reinterpret_cast<uint4*>(xl)[p] = make_uint4(0u, 0u, 0u, 0u);
+        }
     } else {
         const float* src = a.code[o] + ((size_t)n * a.D + 8 * g) * HW;
         const float* inv = a.inv_norm[o] + (size_t)n * a.Ppad;
@@ -665,6 +764,12 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = c < nch ? (_Float16)(t[j][c] * iv[j]) : (_Float16)0.f;
                 *reinterpret_cast<f16x8*>(xt + pp[j] * 16) = v;
+                if (want_lo) {
+                    f16x8 l;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) l[c] = c < nch ? (_Float16)((t[j][c] * iv[j] - (float)v[c]) * 2048.f) : (_Float16)0.f;
+                    *reinterpret_cast<f16x8*>(xl + pp[j] * 16) = l;
+                }
             }
         }
     }
@@ -673,6 +778,8 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
     for (int id = tid; id < nt * 32; id += 256) {          // C part: granule g of every position
         const int tl = id >> 5, qq = id & 31;
         *reinterpret_cast<uint4*>(blob0 + (size_t)tl * L.bytes + L.c(qq, g)) = reinterpret_cast<const uint4*>(xt)[id];
+        if (want_lo)
+            *reinterpret_cast<uint4*>(a.clo[o] + ((size_t)n * nt + tl) * (KD * 64) + (g * 32 + qq) * 16) = reinterpret_cast<const uint4*>(xl)[id];
     }
     for (int id = tid; id < nt * 32; id += 256) {          // P part: granule cc of channel d = 8 g + c
         const int tl = id >> 5, cc = (id >> 3) & 3, c = id & 7;
@@ -814,7 +921,7 @@ hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s) {
     int nz = a.gr.nkeys > 0 ? 3 : 2, smem = 0;
     if (a.dc.B > 0) {
         if (a.nops != 2) return hipErrorInvalidValue;       // (the dense path has two operands; their csum moves to the k_rowmean launch)
-        ny = max(ny, 2 * (a.dc.KD / 8)); nz = 4; smem = a.dc.Ppad * 16;
+        ny = max(ny, 2 * (a.dc.KD / 8)); nz = 4; smem = a.dc.Ppad * 16 * ((a.dc.clo[0] || a.dc.clo[1]) ? 2 : 1);
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_colmean), smem);
         if (e != hipSuccess) return e;
     }

@@ -46,7 +46,7 @@ extern "C" {
                                         (simple_depth_informed_sampling returns (B,n,1,2), src/modules.py:828-883,1299-1302);
                                         the depth term resizes depth to (1,S) (modules.py:1261-1262 with c1.shape[2:] = (1,S)) */
 
-#define DG_EXACT_MASKS    (1u << 8)  /* cfg.dg_exact_masks (build-side key): on a gradient pass of the zero_clamp recipe the clamp mask
+#define DG_EXACT_MASKS    (1u << 8)  /* build-side cfg key `dg_exact_masks`: on a gradient pass of the zero_clamp recipe the clamp mask
                                         1[cd >= 0] (modules.py:1250-1252) is decided by an fp32 cd wherever the fp16 cd the MFMAs
                                         compute is too close to zero to be trusted; without the flag the fp16 cd decides on the
                                         dense grids (the small sample grids always take exact masks) */

@@ -16,7 +16,8 @@ for tag in tags:
     _lib.LIB_PATH = os.path.join(ROOT, "depthg_amd", "lib", f"libdepthg_{tag}.so")
     libs[tag] = _lib.load()
 dev = torch.device("cuda:0")
-C, D, hw, N, S = 384, 70, 28, 2, 28
+hw = int(os.environ.get("CMP_HW", "28"))
+C, D, N, S = 384, 70, 2, hw
 g = torch.Generator().manual_seed(128)
 f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
 c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
@@ -96,4 +97,36 @@ if diff.numel():
             dd = (ta - tb).abs()
             print("gradient-tile view at", base, ": max |d| per R tile:", [round(float(x), 4) for x in dd.amax(dim=(0, 2, 3))])
             print("   per channel group:", [round(float(x), 4) for x in dd.amax(dim=(0, 1, 3))], " scale of values:", float(tb.abs().max()))
+            break
+# (round 4) which accumulator registers / lanes of the raw gradient tiles differ: tile = [group 3][i>>2 (4)][lane 64][i&3 (4)]
+if diff.numel():
+    lo = int(os.environ.get("CMP_BASE", int(d64[0]) // 256 * 256))        # CMP_BASE: byte offset of the buffer to view (dRA of a pair-set)
+    ngt = B * nt * 3 * 1024
+    for base in (lo,):
+        if base >= 0 and base + ngt * 4 <= a.numel():
+            ta = a[base:base + ngt * 4].view(torch.float32).view(B, nt, 3, 4, 64, 4)
+            tb0 = b[base:base + ngt * 4].view(torch.float32).view(B, nt, 3, 4, 64, 4)
+            dd0 = (ta - tb0).abs()
+            for grp in range(3):
+                print(f"group {grp}: max |d| even tiles {float(dd0[:, 0::2, grp].max()):.4f} odd tiles {float(dd0[:, 1::2, grp].max()):.4f}; per register:",
+                      [round(float(x), 3) for x in dd0[:, :, grp].amax(dim=(0, 1, 3)).reshape(-1)], "lanes with a difference:",
+                      [int(i) for i in (dd0[:, :, grp].amax(dim=(0, 1, 2, 4)) > 0).nonzero().flatten()])
+            # which tiles
+            print("tiles with a difference (image 0):", [int(i) for i in (dd0[0].amax(dim=(1, 2, 3, 4)) > 0).nonzero().flatten()])
+            nzd = (dd0 > 0).nonzero()
+            print("differing elements:", nzd.shape[0], "first ten (image, tile, group, i>>2, lane, i&3):", nzd[:10].tolist())
+            for idx in nzd[:6].tolist():
+                print("   ", idx, "A", float(ta[tuple(idx)]), "B", float(tb0[tuple(idx)]))
+            tb = b[base:base + ngt * 4].view(torch.float32).view(B, nt, 3, 4, 64, 4)
+            dd = (ta - tb).abs()
+            per_reg = dd[:, :, 0].amax(dim=(0, 1, 3)).permute(0, 1).reshape(16)     # [i>>2][i&3]
+            print("group 0: max |d| per accumulator register i:", [round(float(x), 4) for x in dd[:, :, 0].amax(dim=(0, 1, 3)).reshape(-1)])
+            print("group 0: max |d| per lane:", [round(float(x), 3) for x in dd[:, :, 0].amax(dim=(0, 1, 2, 4))])
+            nz = (dd[:, :, 0] > 0).float().mean().item()
+            print("group 0: fraction of differing elements (all tiles):", nz, " even tiles only:", (dd[:, 0::2, 0] > 0).float().mean().item())
+            rel = (dd[:, 0::2, 0] / (tb[:, 0::2, 0].abs() + 1e-6))
+            print("group 0, even tiles: median relative diff", float(rel.median()), "mean", float(rel.mean()))
+            t0a, t0b = ta[0, 0, 0], tb[0, 0, 0]
+            print("tile 0 lane 3: A", [round(float(x), 4) for x in t0a[:, 3, :].flatten()])
+            print("tile 0 lane 3: B", [round(float(x), 4) for x in t0b[:, 3, :].flatten()])
             break

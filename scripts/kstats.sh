@@ -3,7 +3,7 @@
 cfg=${1:-headline}; shift
 out=/root/repo/gpurun_out/kstats_$cfg${TAG:+_$TAG}; rm -rf $out
 mkdir -p $out
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 /root/repo/bench.py --config $cfg --no-cpu-baseline --steps 50 "$@" > $out/bench.json 2>/dev/null )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 /root/repo/bench.py --config $cfg --no-cpu-baseline --steps 50 --clock-warmup-s 0.25 "$@" > $out/bench.json 2>/dev/null )
 python3 - <<PY
 import csv, glob
 f = glob.glob("$out/**/*kernel_stats.csv", recursive=True)[0]

@@ -17,7 +17,7 @@ import bench                                            # noqa: E402
 from depthg_amd import ContrastiveCorrelationLoss      # noqa: E402
 from oracle import depthg_oracle as O                   # noqa: E402
 
-CASES = [("headline", 32, 1234), ("C2", 16, 202), ("C3", 32, 303), ("C4shard", 8, 404), ("C5", 2, 505)]
+CASES = [("headline", 32, 1234), ("C2", 16, 202), ("C3", 32, 303), ("C4shard", 8, 404), ("C5", 2, 505), ("C5", 8, 506)]
 
 
 def measure(name, B, seed, dev):

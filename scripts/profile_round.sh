@@ -16,7 +16,7 @@ for c in headline C2 C3 C4shard; do python3 /root/repo/bench.py --config $c --ea
 # the N > 1 schedule with one rank (RCCL initialised, step replayed from two hipGraphs, collective on the side stream)
 python3 /root/repo/bench.py --force-dist --no-cpu-baseline 2>/dev/null | grep "^{" > $out/${tag}_bench_force_dist.json
 python3 /root/repo/scripts/parity_table.py $out/${tag}_parity.md > /dev/null 2>&1
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --steps 50 --warmup 5 --clock-warmup-s 0.25 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null )
 cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/depthg_corr.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.dg_version() == _lib.DG_VERSION == 107
+    assert lib.dg_version() == _lib.DG_VERSION == 108
 
 
 def test_descriptor_validation_and_workspace():
@@ -41,7 +41,8 @@ def test_descriptor_validation_and_workspace():
 
 def test_struct_layout_matches_header():
     from depthg_amd._lib import CorrDesc
-    assert ctypes.sizeof(CorrDesc) == 18 * 4
+    assert ctypes.sizeof(CorrDesc) == 20 * 4
+    assert [f[0] for f in CorrDesc._fields_][-2:] == ["code_h", "code_w"]
     assert [f[0] for f in CorrDesc._fields_][:10] == ["B", "C", "D", "h", "w", "S", "n_neg", "depth_h", "depth_w", "flags"]
 
 
