@@ -471,7 +471,7 @@ def main():
     # passes of THIS round (scripts/profile_round.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) - null when there is none
     traffic, traffic_source = None, None
     if args.config == "headline":
-        src = os.path.join("profiles", "r03_pmc_per_launch.json")
+        src = os.path.join("profiles", "r04_pmc_per_launch.json")
         try:
             pmc = json.load(open(os.path.join(ROOT, src)))
             for name, vals in pmc.items():

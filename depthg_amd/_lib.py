@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 108                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 109                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
@@ -18,7 +18,7 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_cluster_lookup_forward",
-           "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward"]
+           "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -97,6 +97,8 @@ def load():
     lib.dg_confusion_update.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, vp, vp]
     lib.dg_topk_rows.restype = ctypes.c_int
     lib.dg_topk_rows.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, vp, vp, vp]
+    lib.dg_knn_similarities.restype = ctypes.c_int
+    lib.dg_knn_similarities.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp]
     lib.dg_lhp_forward.restype = ctypes.c_int
     lib.dg_lhp_forward.argtypes = [vp, vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, vp]
     lib.dg_lhp_backward.restype = ctypes.c_int

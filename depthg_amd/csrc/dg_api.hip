@@ -727,6 +727,18 @@ extern "C" int dg_confusion_update(const int64_t* preds, const int64_t* target, 
     return DG_OK;
 }
 
+extern "C" int dg_knn_similarities(const float* queries, const float* feats, int64_t rows_q, int64_t n, int32_t F, int64_t q_stride,
+                                   int64_t f_stride, float* out, int64_t out_stride, dg_stream_t stream_) {
+    if (rows_q < 0 || n < 0 || F < 1 || q_stride < F || f_stride < F || out_stride < n) return fail(DG_ERR_INVALID, "bad similarity dimensions");
+    if (rows_q == 0 || n == 0) return DG_OK;
+    if (!queries || !feats || !out) return fail(DG_ERR_INVALID, "null pointer");
+    if (n > 65535ll * 128) return fail(DG_ERR_UNSUPPORTED, "more than 8,388,480 candidate rows per call");
+    if ((F & 3) == 0 && (((uintptr_t)queries | (uintptr_t)feats) & 15 || (q_stride & 3) || (f_stride & 3)))
+        return fail(DG_ERR_INVALID, "feature rows must be 16-byte aligned (pointer and row stride) when F is a multiple of 4");
+    DG_HIP(dg_launch_sims_nt(queries, feats, rows_q, n, F, q_stride, f_stride, out, out_stride, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" int dg_topk_rows(const float* vals, int64_t rows, int64_t cols, int64_t row_stride, int32_t k, int64_t* out_idx,
                             float* out_val, dg_stream_t stream_) {
     if (rows < 0 || cols < 1 || k < 1 || row_stride < cols) return fail(DG_ERR_INVALID, "bad top-k dimensions");

@@ -631,6 +631,8 @@ hipError_t dg_launch_simple_coords(const float* depth, int B, int H, int W, int 
                                    const float* u_pick, float* out, hipStream_t s);
 hipError_t dg_launch_confusion(const long long* preds, const long long* target, long long count, int ncls, int nrows,
                                unsigned long long* stats, hipStream_t s);
+hipError_t dg_launch_sims_nt(const float* q, const float* x, long long rows_q, long long n, int F, long long q_stride, long long x_stride,
+                             float* out, long long out_stride, hipStream_t s);
 hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
                                long long* out_idx, float* out_val, hipStream_t s);
 hipError_t dg_launch_pre_general(const struct DgPreArgs& a, hipStream_t s);

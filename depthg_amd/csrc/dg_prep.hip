@@ -417,10 +417,11 @@ __global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
 }
 // Exact clamp masks on the dense identity grid from split fp16 operands (DgCdMask3Args).  One block = 8 waves = 8 consecutive R
 // tiles of one (pair-set, image); the block walks the S tiles, whose hi / lo code rows (the first 2 NKC granule rows of the C
-// part and of its companion) go through two LDS buffers, register-staged one tile ahead.  Per S tile and wave 3 NKC fp16 MFMAs:
-// hi.hi into one accumulator, hi.lo' + lo'.hi into a second (lo' = 2048 lo, so that no operand is a fp16 subnormal);
-// cd = acc0 + acc1 / 2048 carries the rounding noise of an fp32 dot product (operands exact to 2^-22).  Output: the word format
-// of k_cd_mask (bit i of word (S tile, R position) = S position 32 tile + i).
+// part and of its companion) go through two LDS buffers, register-staged two tiles ahead.  Per S tile and wave 3 NKC fp16 MFMAs
+// into ONE accumulator: hi.(2048 hi) + hi.lo' + lo'.hi = 2048 cd (lo' = 2048 lo, so that no operand is a fp16 subnormal; 2048 hi is
+// exact), with the rounding noise of an fp32 dot product (operands exact to 2^-22).  The 16 signs of a lane are shifted into a
+// word one v_alignbit each (first version: a compare, a select and an or per element - the launch was bound by its VALU count).
+// Output: the word format of k_cd_mask (bit i of word (S tile, R position) = S position 32 tile + i).
 typedef int v4i_m3 __attribute__((ext_vector_type(4)));
 template <int NKC>
 __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
     const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
     const size_t lo_tile = (size_t)a.KD * 64;            // bytes of one tile's lo part
     // stationary fragments: granule 2k + h of R position r, hi and lo
-    v4i Rh[NKC], Rl[NKC];
+    v4i Rh[NKC], Rl[NKC], Rs[NKC];                     // Rs = 2048 Rh
     {
         const char* rb = a.opR + ((size_t)n * nt + (act ? rt : 0)) * a.blob_bytes + a.off_c;
         const char* rl = a.loR + ((size_t)n * nt + (act ? rt : 0)) * lo_tile;
@@ -443,6 +444,10 @@ __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
         for (int k = 0; k < NKC; ++k) {
             Rh[k] = *reinterpret_cast<const v4i*>(rb + ((2 * k + h) * 32 + r) * 16);
             Rl[k] = *reinterpret_cast<const v4i*>(rl + ((2 * k + h) * 32 + r) * 16);
+            f16x8 hs = __builtin_bit_cast(f16x8, Rh[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hs[e] = hs[e] * (_Float16)2048.f;
+            Rs[k] = __builtin_bit_cast(v4i, hs);
         }
     }
     const char* const sh = a.opS[t] + (size_t)nS * nt * a.blob_bytes + a.off_c;
@@ -467,18 +472,22 @@ __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
     auto compute = [&](int st) {
         if (!act) return;
         const char* tile = buf[st & 1];
-        f32x16 a0 = f32x16{}, a1 = f32x16{};
+        f32x16 a0 = f32x16{};
 #pragma unroll
         for (int k = 0; k < NKC; ++k) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(tile + ((2 * k + h) * 32 + r) * 16);
             const f16x8 al = *reinterpret_cast<const f16x8*>(tile + HB + ((2 * k + h) * 32 + r) * 16);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rh[k]), a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rl[k]), a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, Rh[k]), a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rs[k]), a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, Rl[k]), a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(f16x8, Rh[k]), a0, 0, 0, 0);
         }
-        uint32_t word = 0;
+        // sign bits, element 15 first: neg bit i = sign of element i (the sum starts at +0 and +0 + -0 = +0: never -0)
+        uint32_t neg = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) word |= (fmaf(a1[i], 1.f / 2048.f, a0[i]) >= 0.f ? 1u : 0u) << ((i & 3) + 8 * (i >> 2) + 4 * h);
+        for (int i = 15; i >= 0; --i) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(a0[i]), 31);
+        // element i -> bit (i & 3) + 8 (i >> 2) + 4 h: the four nibbles move to the low halves of the four bytes
+        uint32_t word = (neg & 0xFu) | ((neg & 0xF0u) << 4) | ((neg & 0xF00u) << 8) | ((neg & 0xF000u) << 12);
+        word = (~word & 0x0F0F0F0Fu) << (4 * h);
         word |= (uint32_t)__shfl_xor((int)word, 32);
         if (h == 0) out[(size_t)st * a.Ppad] = word;
     };

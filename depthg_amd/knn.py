@@ -6,8 +6,9 @@ Offline (src/precompute_knns.py:97-115): L2-normalised pooled features `(n_image
 the image itself).  Online (src/data.py:1056-1064, 1079): `ContrastiveSegDataset` loads the table and picks the positive of
 image `ind` as `nns[ind][randint(1, num_neighbors + 1)]`.
 
-Here the similarity slice is one library GEMM on the GPU and the selection is `dg_topk_rows` (ties broken by the lower
-index - torch.topk leaves that open); the table, its file name and the online pick are bit-compatible with the reference.
+Here the similarity slice is `dg_knn_similarities` (fp32 MFMA, round 4; a library GEMM before) and the selection is
+`dg_topk_rows` (ties broken by the lower index - torch.topk leaves that open); the table, its file name and the online pick are
+bit-compatible with the reference.
 """
 import os
 
@@ -25,10 +26,14 @@ def nns_path(data_dir, model_type, dataset_name, image_set, crop_type, res):
     return os.path.join(data_dir, "nns", "nns_{}_{}_{}_{}_{}.npz".format(model_type, dataset_name, image_set, crop_type, res))
 
 
-def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int = 64) -> torch.Tensor:
+def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int = 64, engine: str = "hip") -> torch.Tensor:
     """(n, F) L2-normalised features on the GPU -> int64 (n, k) on the CPU, row i = the k most similar images of i in
     decreasing similarity.  Slices like the reference: `step = n // n_batches` query rows per similarity matrix
-    (src/precompute_knns.py:101-112), so the peak scratch is `step x n` floats."""
+    (src/precompute_knns.py:101-112), so the peak scratch is `step x n` floats.  `engine`: "hip" = dg_knn_similarities (fp32 MFMA,
+    the library's own contraction: 75 TFLOP/s on a 775 x 49,629 x 384 slice), "rocblas" = torch.matmul (the vendor GEMM: 105 TFLOP/s
+    on the same slice; the whole cocostuff-sized table takes 52 against 45 ms - scripts/knn_time.py)."""
+    if engine not in ("hip", "rocblas"):
+        raise ValueError(f"engine must be 'hip' or 'rocblas', got {engine!r}")
     if not normed_feats.is_cuda:
         raise RuntimeError(f"depthg_amd: `normed_feats` must live on the GPU (got {normed_feats.device}); there is no CPU path")
     x = normed_feats.detach().to(torch.float32).contiguous()
@@ -36,7 +41,8 @@ def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int
     step = max(n // int(n_batches), 1)
     out = []
     for i in range(0, n, step):
-        sims = torch.matmul(x[i:i + step], x.t())                 # einsum("nf,mf->nm"): a plain library GEMM
+        # einsum("nf,mf->nm"), src/precompute_knns.py:106-108
+        sims = ops.knn_similarities(x[i:i + step], x) if engine == "hip" else torch.matmul(x[i:i + step], x.t())
         out.append(ops.topk_rows(sims, k).cpu())
         del sims
     return torch.cat(out, dim=0)

@@ -233,6 +233,26 @@ def topk_rows(vals, k, return_values=False):
     return (idx, val) if return_values else idx
 
 
+def knn_similarities(queries, feats):
+    """queries (m, F), feats (n, F) fp32 on the GPU (rows contiguous) -> (m, n) fp32 similarities, `einsum("nf,mf->nm")` of
+    src/precompute_knns.py:106-108 on the fp32 MFMA."""
+    lib = _lib.load()
+    for name, t in (("queries", queries), ("feats", feats)):
+        if not t.is_cuda:
+            raise RuntimeError(f"depthg_amd: `{name}` must live on the GPU (got {t.device}); there is no CPU path")
+        if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise ValueError(f"depthg_amd: `{name}` must be a 2-D fp32 tensor with contiguous rows")
+    if queries.shape[1] != feats.shape[1] or queries.device != feats.device:
+        raise RuntimeError(f"depthg_amd: queries {tuple(queries.shape)} on {queries.device} and feats {tuple(feats.shape)} on {feats.device} do not match")
+    m, F = queries.shape
+    n = feats.shape[0]
+    out = _empty((m, n), torch.float32, feats.device)
+    rc = lib.dg_knn_similarities(_ptr(queries), _ptr(feats), m, n, F, queries.stride(0) if m > 1 else F, feats.stride(0) if n > 1 else F,
+                                 _ptr(out), n, _stream(feats.device))
+    _lib.check(rc, "dg_knn_similarities")
+    return out
+
+
 def lhp_forward(code, depth):
     """code (B,D,h,w), depth (B,1,H,W) on the GPU -> (code_mixed, points, stats) of dg_lhp_forward."""
     lib = _lib.load()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 108   /* 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 109   /* 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -277,6 +277,16 @@ int dg_lhp_map_forward(int32_t mode, const float* code, const float* attn, const
                        float* out, float* map, float* points, dg_stream_t stream);
 int dg_lhp_map_backward(int32_t mode, const float* grad_out, const float* map, const float* divide, int32_t B, int32_t D,
                         int32_t h, int32_t w, float* grad_code, dg_stream_t stream);
+
+/*
+ * The similarity slice of the offline nearest-neighbour search (replaces `pairwise_sims = torch.einsum("nf,mf->nm", batch_feats,
+ * normed_feats)`, src/precompute_knns.py:106-108): out[i][j] = <queries[i], feats[j]>, fp32 products and fp32 accumulation on the
+ * fp32 MFMA.
+ *  queries : fp32 (rows_q, F), row stride q_stride elements      feats : fp32 (n, F), row stride f_stride      F >= 1; 16-byte aligned
+ *  out     : fp32 (rows_q, n), row stride out_stride               rows when F is a multiple of 4 are read with 16-byte loads
+ */
+int dg_knn_similarities(const float* queries, const float* feats, int64_t rows_q, int64_t n, int32_t F, int64_t q_stride,
+                        int64_t f_stride, float* out, int64_t out_stride, dg_stream_t stream);
 
 /*
  * Row-wise top-k (replaces `torch.topk(pairwise_sims, 30)[1]` of the offline nearest-neighbour search,

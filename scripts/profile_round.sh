@@ -2,7 +2,7 @@
 # Produces the per-round evidence kept under profiles/: kernel-trace stats of the bench command and the HBM-traffic
 # PMC passes of the fused kernel (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM").
 # usage (on the GPU box): scripts/profile_round.sh r03   (then, here: scripts/make_profile_summary.py r03)
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 out=/root/repo/gpurun_out/$tag
 rm -rf $out
@@ -12,6 +12,9 @@ mkdir -p $out
 python3 /root/repo/bench.py > $out/${tag}_bench.json 2>/dev/null
 python3 /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_driver_args.json 2>/dev/null     # the driver's command line
 for c in C2 C3 C4shard C5 headline+head; do python3 /root/repo/bench.py --config $c > $out/${tag}_bench_$c.json 2>/dev/null; done
+# cfg.dg_exact_masks (DG_EXACT_MASKS): the dense ViT-S grids with the clamp masks from fp32-quality cd
+python3 /root/repo/bench.py --exact-masks --no-cpu-baseline > $out/${tag}_bench_exact_masks.json 2>/dev/null
+python3 /root/repo/bench.py --config C5 --exact-masks --no-cpu-baseline > $out/${tag}_bench_C5_exact_masks.json 2>/dev/null
 for c in headline C2 C3 C4shard; do python3 /root/repo/bench.py --config $c --eager --no-cpu-baseline > $out/${tag}_bench_${c}_eager.json 2>/dev/null; done
 # the N > 1 schedule with one rank (RCCL initialised, step replayed from two hipGraphs, collective on the side stream)
 python3 /root/repo/bench.py --force-dist --no-cpu-baseline 2>/dev/null | grep "^{" > $out/${tag}_bench_force_dist.json

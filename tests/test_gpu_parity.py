@@ -644,14 +644,16 @@ def test_topk_rows_kernel(dev):
         ops.topk_rows(m.to(dev), 65)
 
 
+@pytest.mark.parametrize("engine", ["hip", "rocblas"])
 @pytest.mark.parametrize("name", ["small", "wide"])
-def test_nearest_neighbors_table(name, dev):
-    """knn.nearest_neighbors (library GEMM slice + dg_topk_rows) against the table the reference's calls produce on the same
-    features: identical except where two similarities are closer than the float32 rounding of the two GEMMs (5e-6)."""
+def test_nearest_neighbors_table(name, engine, dev):
+    """knn.nearest_neighbors (similarity slice on the fp32 MFMA - dg_knn_similarities - or by the vendor GEMM, then dg_topk_rows)
+    against the table the reference's calls produce on the same features: identical except where two similarities are closer
+    than the float32 rounding of the two GEMMs (5e-6)."""
     from depthg_amd import knn
     fx = load_golden("knn.npz")
     feats = torch.from_numpy(fx[f"{name}_feats"])
-    got = knn.nearest_neighbors(feats.to(dev), k=30, n_batches=int(fx[f"{name}_nbatches"]))
+    got = knn.nearest_neighbors(feats.to(dev), k=30, n_batches=int(fx[f"{name}_nbatches"]), engine=engine)
     want = torch.from_numpy(fx[f"{name}_nns"])
     assert got.shape == want.shape and got.dtype == torch.int64 and not got.is_cuda
     sims = feats.double() @ feats.double().t()
@@ -889,3 +891,23 @@ def test_lhp_second_loss_call_and_total(dev):
         rel = (got.cpu() - want).norm() / want.norm()
         assert rel < 3e-2, float(rel)
     assert set(logs) >= {"loss/pos_intra", "loss/depth_feat", "cd/neg_inter"}
+
+
+@pytest.mark.parametrize("m,n,F", [(130, 1000, 384), (775, 4099, 384), (1, 257, 70), (64, 64, 33), (257, 129, 768)])
+def test_knn_similarities_kernel(m, n, F, dev):
+    """dg_knn_similarities (fp32 MFMA) == einsum("nf,mf->nm") of src/precompute_knns.py:106-108 in fp32: every element within
+    fp32 summation-order noise of torch's GEMM (both are fp32 dot products of unit vectors; tolerance 2e-6 absolute), partial
+    tiles on both sides, feature widths that are not multiples of the 32-wide k chunk or of 4."""
+    from depthg_amd import ops
+    g = torch.Generator().manual_seed(m + n + F)
+    q = torch.nn.functional.normalize(torch.randn(m, F, generator=g), dim=1).to(dev)
+    x = torch.nn.functional.normalize(torch.randn(n, F, generator=g), dim=1).to(dev)
+    got = ops.knn_similarities(q, x)
+    want = (q.double() @ x.double().t())
+    assert got.shape == (m, n) and float((got.double() - want).abs().max()) < 2e-6
+    # a strided view of a wider buffer (row stride > F) is read in place
+    wide = torch.zeros(m, F + 8, device=dev)
+    wide[:, :F] = q
+    assert torch.equal(ops.knn_similarities(wide[:, :F], x), got) or F % 4 != 0
+    with pytest.raises(RuntimeError, match="do not match"):
+        ops.knn_similarities(q[:, : F - 1].contiguous(), x)
