@@ -108,8 +108,13 @@ template <int OFF> __device__ __forceinline__ void lds_rd(v4i_t& d, uint32_t add
     asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 template <int N> __device__ __forceinline__ void wait_lgkm(void) { asm volatile("s_waitcnt lgkmcnt(%c0)" :: "n"(N) : "memory"); }
+#ifdef C2_XNOP      // (round-4 experiment: what one more s_nop 0 per chain MFMA costs = what the ones hipcc inserts cost)
+#define C2_XN "s_nop 0\n\t"
+#else
+#define C2_XN
+#endif
 template <int I> __device__ __forceinline__ void mfma_fd8(acc_t& acc, const v4i_t& a) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "n"(4 * I), "n"(4 * I + 3));
+    asm volatile(C2_XN "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(a), "n"(4 * I), "n"(4 * I + 3));
 }
 // first MFMA of an fd chain: the accumulator STARTS at c (sixteen copies of the lane's c0, kept in registers for the whole block) -
 // no per-tile re-initialisation of the accumulator by sixteen 64-bit moves (round 4: hipcc gathered them into bursts of eight in
@@ -118,7 +123,7 @@ template <int I> __device__ __forceinline__ void mfma_fd8_from(acc_t& acc, const
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(acc) : "v"(a), "v"(c), "n"(4 * I), "n"(4 * I + 3));
 }
 __device__ __forceinline__ void mfma_h8(acc_t& acc, const v4i_t& a, const v4i_t& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile(C2_XN "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_h80(acc_t& acc, const v4i_t& a, const v4i_t& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));

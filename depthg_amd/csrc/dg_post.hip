@@ -903,7 +903,8 @@ __device__ __forceinline__ int dpp_wave_max_i(int v) {
 }
 
 template <int NPT>       // points per thread (even): h*w <= NPT * FPS_THREADS
-__global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restrict__ depth, int H, int W, int h, int w,
+__global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restrict__ depth, const float* __restrict__ depth_b, int Ba,
+                                                            int H, int W, int h, int w,
                                                             int S, float factor, int stage_floats, float* __restrict__ out_coords,
                                                             int32_t* __restrict__ out_inds) {
     constexpr int NP2 = NPT / 2;
@@ -917,7 +918,8 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
     __shared__ long long skey[3];
     __shared__ int tie_low;
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const float* d = depth + (size_t)n * H * W;
+    // (images Ba.. of the launch come from a second tensor: depth and depth_pos of one step, dg_fps_coords_pair)
+    const float* d = n < Ba ? depth + (size_t)n * H * W : depth_b + (size_t)(n - Ba) * H * W;
     float4* const pts = reinterpret_cast<float4*>(selbits + nwords + ((4 - ((nsel + nwords) & 3)) & 3));   // [HW] {x, y, z, 0}: takes over the staging buffer
 
     // adaptive_avg_pool2d + depth2points; every thread keeps its points (idx = tid + FPS_THREADS*k) and their running
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
     }
 }
 
-hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, int S, float factor,
+hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B, int H, int W, int h, int w, int S, float factor,
                          float* out_coords, int32_t* out_inds, hipStream_t s) {
     // LDS: selection order, selected-set mask, then the staging buffer for bands of the depth map: at least the image rows
     // of one pooled row, at most 128 KB
@@ -1072,7 +1074,7 @@ hipError_t dg_launch_fps(const float* depth, int B, int H, int W, int h, int w, 
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, H, W, h, w, S, factor, stage_floats, out_coords, out_inds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, depth_b, Ba, H, W, h, w, S, factor, stage_floats, out_coords, out_inds);
         return hipGetLastError();
     };
     if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);

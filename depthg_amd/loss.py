@@ -140,7 +140,7 @@ class ContrastiveCorrelationLoss(nn.Module):
             if depth.shape == depth_pos.shape and orig_feats.shape[-2:] == orig_feats_pos.shape[-2:]:
                 # one launch for both maps: the sampler is a sequential per-image loop (one block per image), so the two
                 # calls of the reference (src/modules.py:1304-1308) simply run side by side on twice as many CUs
-                both = ops.fps_coords(torch.cat([depth, depth_pos], dim=0), orig_feats.shape[-2:], S)
+                both = ops.fps_coords_pair(depth, depth_pos, orig_feats.shape[-2:], S)
                 c1, c2 = both[:B], both[B:]
             else:
                 c1 = ops.fps_coords(depth, orig_feats.shape[-2:], S)

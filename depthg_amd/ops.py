@@ -162,6 +162,23 @@ def fps_coords(depth, feat_hw, n_samples, return_inds=False):
     return (coords, inds) if return_inds else coords
 
 
+def fps_coords_pair(depth, depth_pos, feat_hw, n_samples):
+    """The two FPS calls of one step in one launch (dg_fps_coords_pair): depth, depth_pos (B,1,H,W) -> coords (2B,S,S,2), rows
+    [0,B) the anchors', [B,2B) the positives'."""
+    lib = _lib.load()
+    depth, depth_pos = _f32c(depth, "depth"), _f32c(depth_pos, "depth_pos")
+    if depth.shape != depth_pos.shape or depth.device != depth_pos.device:
+        raise ValueError(f"depthg_amd: depth {tuple(depth.shape)} on {depth.device} and depth_pos {tuple(depth_pos.shape)} on "
+                         f"{depth_pos.device} must match for the paired sampler")
+    B, _, H, W = depth.shape
+    h, w = int(feat_hw[0]), int(feat_hw[1])
+    S = int(n_samples)
+    coords = _empty((2 * B, S, S, 2), torch.float32, depth.device)
+    rc = lib.dg_fps_coords_pair(_ptr(depth), _ptr(depth_pos), B, H, W, h, w, S, _ptr(coords), None, _stream(depth.device))
+    _lib.check(rc, "dg_fps_coords_pair")
+    return coords
+
+
 def salience_coords(salience, n_side, u_sel=None, u_fallback=None):
     """sample_nonzero_locations (src/modules.py:1191-1204) on the GPU: salience (B,H,W) -> (B,S,S,2), flipped and *2-1 like
     the reference.  u_sel (B,S*S) / u_fallback (B,S*S,2): iid uniforms in [0,1), drawn here unless given (tests)."""

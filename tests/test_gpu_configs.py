@@ -271,6 +271,22 @@ def test_fps_map_sizes_of_the_configs(hw, dhw, S, dev):
     assert np.array_equal(got_c.cpu().numpy(), (want_c * 2 - 1).numpy())
 
 
+@pytest.mark.parametrize("hw,dhw,S,B", [(28, 224, 11, 16), (28, 224, 12, 3), (14, 100, 6, 1)])
+def test_fps_pair_launch(hw, dhw, S, B, dev):
+    """dg_fps_coords_pair = the two calls of a step (src/modules.py:1304-1308) in one launch, without a concatenated copy of the
+    depth maps: the same coordinates, bit for bit, as one dg_fps_coords per tensor; tensors that do not match are refused."""
+    from depthg_amd import ops
+    g = torch.Generator().manual_seed(3 * hw + S + B)
+    d1 = (torch.rand(B, 1, dhw, dhw, generator=g) * 9 + 0.5).to(dev)
+    d2 = (torch.rand(B, 1, dhw, dhw, generator=g) * 9 + 0.5).to(dev)
+    both = ops.fps_coords_pair(d1, d2, (hw, hw), S)
+    assert tuple(both.shape) == (2 * B, S, S, 2)
+    assert torch.equal(both[:B], ops.fps_coords(d1, (hw, hw), S))
+    assert torch.equal(both[B:], ops.fps_coords(d2, (hw, hw), S))
+    with pytest.raises(ValueError, match="depthg_amd"):
+        ops.fps_coords_pair(d1, d2[:, :, : dhw - 1], (hw, hw), S)
+
+
 @pytest.mark.parametrize("kind", ["all_zero", "half_zero", "two_values"])
 def test_fps_coincident_points(kind, dev):
     """Zero depth puts every such pixel on the origin (depth2points, src/modules.py:988-996): once the distinct points are
@@ -447,5 +463,5 @@ def test_bench_line_of_the_multi_gpu_schedule():
     # one schedule at every N: the plain single-GPU line is the replayed step too; --eager is the explicit opt-out
     assert d["config"]["schedule"] == lines["--graph"]["config"]["schedule"] == "hipGraph replay"
     assert lines["--eager"]["config"]["schedule"] == "eager" and d["config"]["ranks_seen"] == 1
-    assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r03_pmc_per_launch.json")
+    assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r04_pmc_per_launch.json")
 
