@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+#define C2_RED_BYTES 256   // behind the tile buffers: the block-end reduction's [8 fragment slots][4] dwords + [8] output pointers
 #ifndef C2_PF
 #define C2_PF 4            // LDS fragment reads in flight ahead of the MFMA that consumes them
 #endif
@@ -206,6 +207,12 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     unsigned long long t_entry;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
 #endif
+#ifdef C2_BLOCKLOG          // (finer stamps are kept in registers and stored at the block's end: a store in between would be one more
+    unsigned long long bl_t[5] = {(unsigned long long)wall_clock64(), 0, 0, 0, 0};     //  vector-memory operation under the counted waits)
+#define BL_T(i) do { bl_t[i] = wall_clock64(); } while (0)
+#else
+#define BL_T(i) do {} while (0)
+#endif
 
     // ---- XCD-aware block order (as k_corr_main): every XCD owns B/8 whole images; full row blocks first, ragged last
     int bid;
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     // from k_group_ragged) share one block, 8 / L of them at a time, each fragment with its own pair-set and image.  Without
     // lists (or for the consumers beyond a group's blocks: FALLBACK) a ragged block serves one (jid, n) as before.
     int n_first = 0, jid_first = 0, rb = 0, mS = 0;        // (first fragment's (n, jid); mS = image index of the streamed operand)
+    const int64_t* sidx_p = nullptr;                        // its batch-map entry (null: mS is final)
     int fj[RF], fn[RF], ft[RF];                             // per fragment of this wave: pair-set, image, row tile (-1: none)
     {
         const int nh = args.njobs;                          // pair-set jobs only (the depth term runs in the k_gs launch)
@@ -263,14 +271,17 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         }
 #ifdef C2_BLOCKLOG          // developer build: per-block timeline (DG_BLOCKLOG=<file>, scripts/blocklog.py)
         if (args.blocklog && threadIdx.x == 0) {
-            unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8;
+            unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16;
             e[0] = __builtin_amdgcn_s_getreg(63492); e[1] = __builtin_amdgcn_s_getreg(63508); e[6] = kind; e[7] = rb;
             e[2] = wall_clock64(); e[3] = e[2]; e[4] = e[2]; e[5] = e[2];
         }
 #endif
 #pragma unroll
         for (int f = 0; f < RF; ++f) { fj[f] = jid; fn[f] = n; ft[f] = (rb * NW + wid) * RF + f; if (ft[f] >= ntiles) ft[f] = -1; }
-        mS = args.jobs[jid].sidx ? (int)args.jobs[jid].sidx[n] : n;
+        // (the batch-map entry is loaded with the block's other small inputs below and consumed BEHIND the stationary-fragment loads:
+        //  as an ordinary load it was a memory round trip of its own in front of everything else - 1.5 of the 5.1 us a block
+        //  spent before its first tile, round-4 block log)
+        mS = n; sidx_p = args.jobs[jid].sidx ? args.jobs[jid].sidx + n : nullptr;
         jid_first = jid; n_first = n;
         if (kind == 2 && grouped) {
             // this (jid, n) is served by a grouped block unless its rank lies beyond the group's blocks
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         }
         if (kind == 1) {
             // image n of this chunk is the STREAMED image; the consumers come from the list of (key, n)
-            mS = n;
+            mS = n; sidx_p = nullptr;
             const int cnt = args.gr_count[gkey * args.B + n];
             const int c0 = gpart * args.gr_cpb;
             if (c0 >= cnt) return;
@@ -300,7 +311,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         }
     }
     const DgJob& job = args.jobs[jid_first];                // (of a grouped block: the group's first pair-set - same S array, Scsum)
-    const int nS = __builtin_amdgcn_readfirstlane(mS);
 
     // ---- the two 32-row tiles of R owned by this wave
     bool act[RF];
@@ -313,14 +323,23 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         pr[f] = act[f] ? ft[f] * 32 + r : 0;
         Rblob[f] = args.jobs[fj[f]].Rop + ((size_t)fn[f] * ntiles + (act[f] ? ft[f] : 0)) * BL::BYTES;
     }
+    // (the block end's output pointers, fetched with the other job fields: as kernel-argument loads at the block end each was a
+    //  scalar-memory round trip of its own with nothing else to do - round-4 block log: 1.3 us behind the block barrier)
+    float* dRp[RF];
+    float* partp[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) { dRp[f] = args.jobs[fj[f]].dR; partp[f] = args.jobs[fj[f]].part; }
     (void)n_first;
 
     // ---- small per-block inputs first (their latency runs under the 270 KB that follow): the B per-image sums of the row means
     //      (m0), this lane's row means, the streamed operand's code column sums.  asm loads: hipcc would wait for a load it knows
     //      with vmcnt(0) at its first use, i.e. for every DMA piece issued since; they are consumed behind the first counted wait.
     float rimg_v[RF] = {0.f, 0.f}, rvec_v[RF] = {0.f, 0.f}, cs_pre[NDF];
+    int mS_ld = 0;
+    const float* const zsrc = reinterpret_cast<const float*>(args.dummy);          // any valid address
     {
-        const float* zsrc = reinterpret_cast<const float*>(args.dummy);          // any valid address
+        const void* p_sidx = sidx_p ? reinterpret_cast<const void*>(sidx_p) : reinterpret_cast<const void*>(zsrc);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(mS_ld) : "v"(p_sidx) : "memory");      // (low word of the int64 entry)
 #pragma unroll
         for (int f = 0; f < RF; ++f) {
             const DgJob& jf = args.jobs[fj[f]];
@@ -329,21 +348,21 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             const float* p_rv = jf.rvec ? jf.rvec + (size_t)fn[f] * Ppad + pr[f] : zsrc;
             asm volatile("global_load_dword %0, %1, off" : "=v"(rvec_v[f]) : "v"(p_rv) : "memory");
         }
-#pragma unroll
-        for (int d = 0; d < NDF; ++d) {
-            const float* p_cs = job.Scsum ? job.Scsum + (size_t)nS * KD + 32 * d + r : zsrc;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(cs_pre[d]) : "v"(p_cs) : "memory");
-        }
     }
 
     // ---- stationary operand: feature fragments -> accumulator registers, code fragments -> arch VGPRs
     const uint32_t smem_a = lds_addr(smem);
     const int sw = (r >> 2) & 3;
     const int fb0 = r * 64 + ((h ^ sw) * 16), fb1 = r * 64 + (((2 + h) ^ sw) * 16);        // dg_f_off(r, 2 ks + h), ks even / odd
-    sfor<RF * NKF>([&](auto I) {
-        constexpr int f = I.value / NKF, ks = I.value % NKF;
-        agpr_load16<I.value>(Rblob[f] + ((ks & 1) ? fb1 : fb0) + (ks >> 1) * 2048);
-    });
+    // (fragment 0 only: fragment 1's 24 KB per wave are first used in phase B of tile 0 and are issued BEHIND the pieces of tile 0 -
+    //  round 4: the block's first tile waited for all 67 KB per wave, 15.5 k cycles of a 98-k-cycle block)
+    auto load_rfrag = [&](auto F) {
+        sfor<NKF>([&](auto KS) {
+            constexpr int f = F.value, ks = KS.value;
+            agpr_load16<f * NKF + ks>(Rblob[f] + ((ks & 1) ? fb1 : fb0) + (ks >> 1) * 2048);
+        });
+    };
+    load_rfrag(std::integral_constant<int, 0>{});
     v4i_t Rc[RF][NKC];                                    // B operands of the cd chain: granule 2k + h of row r
 #pragma unroll
     for (int f = 0; f < RF; ++f)
@@ -353,6 +372,15 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             //  iteration, draining the DMA pipeline; these complete before the first tile's counted wait: they are older)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rc[f][k]) : "v"(Rblob[f] + BL::OFF_C + ((2 * k + h) * 32 + r) * 16) : "memory");
     sfor<RF * 2 * 4>([&](auto I) { agpr_zero4<ADR + 4 * I.value>(); });
+    // the streamed image: its batch-map entry has landed (it is the oldest load; younger: 2 RF small inputs, NKF + RF NKC fragment loads)
+    static_assert(2 * RF + NKF + RF * NKC == 38, "literal wait count below");
+    asm volatile("s_waitcnt vmcnt(38)" : "+v"(mS_ld) :: "memory");
+    const int nS = __builtin_amdgcn_readfirstlane(sidx_p ? mS_ld : mS);
+#pragma unroll
+    for (int d = 0; d < NDF; ++d) {
+        const float* p_cs = job.Scsum ? job.Scsum + (size_t)nS * KD + 32 * d + r : zsrc;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(cs_pre[d]) : "v"(p_cs) : "memory");
+    }
     acc_t dRv[RF];                                        // gradient accumulator of channel group 2 (groups 0, 1: accumulator file)
 #pragma unroll
     for (int f = 0; f < RF; ++f) dRv[f] = acc_t{};
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     // ---- XM: mask words of this wave's fragments, [wave][fragment][4 slots][64 dwords] behind the tile buffers.  The word of S tile
     //      T is fetched three tiles ahead (fragment 1, whose epilogue runs one phase later: two), always IN FRONT of the tile pieces
     //      issued in the same iteration, so the counted wait that covers those pieces covers it
-    const uint32_t mring_a = smem_a + NBUF * BUF + 128;
+    const uint32_t mring_a = smem_a + NBUF * BUF + C2_RED_BYTES;
     const char* mbase[RF] = {nullptr, nullptr};
     uint32_t mvoff[RF] = {0u, 0u};
     auto mask_issue = [&](const int f, const int T) {
@@ -387,6 +415,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         dma_piece<K.value * 4096>(dst, dma_voff, sb);
     };
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 0, 0); });
+    static_assert(RF == 2, "fragment 1 behind tile 0");
+    load_rfrag(std::integral_constant<int, 1>{});         // a[4 NKF ..]: landed at the counted wait in front of phase B (tile 0)
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 1, 1); });
     sfor<PIECES>([&](auto K) { issue_tile_piece(K, 2, 2); });
 
@@ -404,9 +434,12 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     v4i_t ga[RF][2];                                     // -G as fp16 A fragments: k-step sp holds accumulator elements 8sp..8sp+7
     v4i_t ra[PF], bP[2 * NDF];
 
-    // tile 0 landed (everything older - the small inputs, the fragment loads - is complete as well)
-    static_assert(2 * PIECES == 18, "literal wait count below");
-    asm volatile("s_waitcnt vmcnt(18)" : "+v"(rimg_v[0]), "+v"(rimg_v[1]), "+v"(rvec_v[0]), "+v"(rvec_v[1]), "+v"(cs_pre[0]), "+v"(cs_pre[1]), "+v"(cs_pre[2]) :: "memory");
+    BL_T(1);
+    // tile 0 landed (everything older - the small inputs, the fragment loads of fragment 0, the code fragments - is complete as
+    // well); younger: fragment 1's NKF loads, the pieces of tiles 1 and 2
+    static_assert(2 * PIECES + NKF == 42, "literal wait count below");
+    asm volatile("s_waitcnt vmcnt(42)" : "+v"(rimg_v[0]), "+v"(rimg_v[1]), "+v"(rvec_v[0]), "+v"(rvec_v[1]), "+v"(cs_pre[0]), "+v"(cs_pre[1]), "+v"(cs_pre[2]) :: "memory");
+    BL_T(2);
     // per-fragment scalars: fd'' - shift = Yf - rowmean + (m0 - shift); the chain starts at c0_lane
     double c0pair[RF];                                    // (c0_lane, c0_lane): source of the v_mov_b64 accumulator initialisation
     {
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     };
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
-    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + 128);
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + C2_RED_BYTES);
     #ifndef C2_STAMP_N
 #define C2_STAMP_N 0
 #define C2_STAMP_J 0
@@ -566,6 +599,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
                 });
             }
             // ================= phase B: Y chain of fragment 1, epilogue of fragment 0 in its gaps =================
+            // Tile 0: fragment 1's stationary fragments (issued behind the pieces of tile 0) have landed - younger than the last
+            // of them are the pieces of tiles 1 and 2 and what phase A issued (9 pieces, XM: its mask words; no G store at tile
+            // 0).  Every later tile: weaker than what the tile barrier already asked for one phase ago, never waits.
+            static_assert(3 * PIECES == 27, "literal wait count below");
+            asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
             sfor<NS>([&](auto ST) {
                 constexpr int st = ST.value;
                 if constexpr (ACT1) chain_slot(std::integral_constant<int, NS + st>{}, std::integral_constant<int, 1>{});
@@ -656,7 +694,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
     asm volatile("" : "+v"(Yc[1]));
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[3] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[3] = wall_clock64(); }
 #endif
     if (act[1]) run(std::true_type{}, std::true_type{});
     else if (act[0]) run(std::true_type{}, std::false_type{});
@@ -664,7 +702,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
     BSTAMP(2);
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[4] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[4] = wall_clock64(); }
 #endif
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
@@ -674,7 +712,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     sfor<RF>([&](auto FI) {
         constexpr int f = FI.value;
         if (!act[f]) return;
-        float* const dRj = args.jobs[fj[f]].dR;
+        float* const dRj = dRp[f];
         float* base = dRj ? dRj + ((size_t)fn[f] * ntiles + ft[f]) * (32 * DP) + lane * 4 : nullptr;
         // x in the layout of dR (rows in registers, channel on the lane) = X * I (selector fragments), as in k_corr_main
         v4i_t sel[2];
@@ -715,6 +753,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         });
         lsumf[f] = lsum; csumf[f] = csum;
     });
+    BL_T(3);
     // per fragment slot: its sums and whose they are; the first slot of every (pair-set, image) adds its run up, in slot order
 #pragma unroll
     for (int f = 0; f < RF; ++f) {
@@ -723,22 +762,40 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
             float* e = red + (wid * RF + f) * 4;
             e[0] = act[f] ? ls : 0.f; e[1] = act[f] ? cs : 0.f;
             reinterpret_cast<int*>(e)[2] = act[f] ? fj[f] : -1; reinterpret_cast<int*>(e)[3] = fn[f];
+            reinterpret_cast<float**>(red + NW * RF * 4)[wid * RF + f] = partp[f];
         }
     }
     __syncthreads();
+    BL_T(4);
     if (tid < NW * RF) {
+        // every slot's record at once (independent reads: one LDS latency - walking the slots of the run one read after the other
+        // was 1.3 us of every block, round-4 block log), then the run's sums in slot order, in registers
+        // (floats read as floats, ints as ints: a 16-byte int-vector read of the records let hipcc's type-based alias analysis
+        //  treat the float members as unrelated to the stores above - it stored ONE sum twice)
         const int* ri = reinterpret_cast<const int*>(red);
+        float ea[NW * RF], eb[NW * RF];
+        int ej[NW * RF], en[NW * RF];
+#pragma unroll
+        for (int s2 = 0; s2 < NW * RF; ++s2) { ea[s2] = red[s2 * 4]; eb[s2] = red[s2 * 4 + 1]; ej[s2] = ri[s2 * 4 + 2]; en[s2] = ri[s2 * 4 + 3]; }
         const int j = ri[tid * 4 + 2], nn = ri[tid * 4 + 3];
-        const bool first = j >= 0 && (tid == 0 || ri[(tid - 1) * 4 + 2] != j || ri[(tid - 1) * 4 + 3] != nn);
-        if (first && args.jobs[j].part) {
+        const int pj = ri[(tid > 0 ? tid - 1 : 0) * 4 + 2], pn = ri[(tid > 0 ? tid - 1 : 0) * 4 + 3];
+        float* const part_j = reinterpret_cast<float* const*>(red + NW * RF * 4)[tid];
+        const bool first = j >= 0 && (tid == 0 || pj != j || pn != nn);
+        if (first && part_j) {
             float a = 0.f, b = 0.f;
-            for (int s2 = tid; s2 < NW * RF && ri[s2 * 4 + 2] == j && ri[s2 * 4 + 3] == nn; ++s2) { a += red[s2 * 4]; b += red[s2 * 4 + 1]; }
-            float* part = args.jobs[j].part + (size_t)(nn * args.nrb + rb) * 2;
+            bool in_run = true;
+#pragma unroll
+            for (int s2 = 0; s2 < NW * RF; ++s2) {
+                const bool mine = s2 >= tid;
+                in_run = in_run && (!mine || (ej[s2] == j && en[s2] == nn));
+                if (mine && in_run) { a += ea[s2]; b += eb[s2]; }
+            }
+            float* part = part_j + (size_t)(nn * args.nrb + rb) * 2;
             part[0] = a; part[1] = b;
         }
     }
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 8; e[5] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[5] = wall_clock64(); for (int i = 0; i < 5; ++i) e[8 + i] = bl_t[i]; }
 #endif
 #ifdef C2_STAMPS
     BSTAMP(3);
@@ -777,14 +834,14 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
     if (args.njobs > 0 && args.jobs[0].maskbits) {
         // exact clamp masks (DG_EXACT_MASKS on the dense grid): the mask words of k_cd_mask instead of the sign of the fp16 cd;
         // 8 KiB more LDS for the four-slot word ring of the eight fragments
-        const int smem_x = 4 * BL::BYTES + 128 + 4 * 2 * 4 * 256;
+        const int smem_x = 4 * BL::BYTES + C2_RED_BYTES + 4 * 2 * 4 * 256;
         auto kx = k_corr2<24, 6, 5, true>;
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
         hipLaunchKernelGGL(kx, dim3(dg_corr2_grid(args)), dim3(256), smem_x, stream, args);
         return hipGetLastError();
     }
-    const int smem = 4 * BL::BYTES + 128;
+    const int smem = 4 * BL::BYTES + C2_RED_BYTES;
     auto kern = k_corr2<24, 6, 5, false>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
@@ -806,15 +863,15 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
     if (const char* blog_file = getenv("DG_BLOCKLOG")) {
         static unsigned long long* blog_buf = nullptr;
         const int grid = dg_corr2_grid(args);
-        if (!blog_buf && hipMalloc(&blog_buf, 8192 * 64) != hipSuccess) return hipErrorOutOfMemory;
+        if (!blog_buf && hipMalloc(&blog_buf, 8192 * 128) != hipSuccess) return hipErrorOutOfMemory;
         if (grid <= 8192) {
             DgCorrArgs a2 = args;
             a2.blocklog = blog_buf;
-            (void)hipMemsetAsync(blog_buf, 0, (size_t)grid * 64, stream);
+            (void)hipMemsetAsync(blog_buf, 0, (size_t)grid * 128, stream);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a2);
-            static unsigned long long hostb[8192 * 8];
-            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 64, hipMemcpyDeviceToHost) == hipSuccess)
-                if (FILE* fp = fopen(blog_file, "wb")) { fwrite(hostb, 8, (size_t)grid * 8, fp); fclose(fp); }
+            static unsigned long long hostb[8192 * 16];
+            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 128, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* fp = fopen(blog_file, "wb")) { fwrite(hostb, 8, (size_t)grid * 16, fp); fclose(fp); }
             return hipGetLastError();
         }
     }

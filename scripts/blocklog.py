@@ -3,7 +3,7 @@
 Every block logs hw id, xcc id and four 100 MHz wall-clock stamps: entry, first tile landed, tile loop done, exit."""
 import sys
 import numpy as np
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.int64)
 a = a[a[:, 2] > 0]
 hw, xcc = a[:, 0], a[:, 1] & 0xf
 cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)      # cu, sh, se, xcc
@@ -29,3 +29,20 @@ print(f"blocks per CU: {len(a) / len(first):.2f}; first start {np.mean(first):.2
       f"last end mean {np.mean(last):.1f} min {np.min(last):.1f} max {np.max(last):.1f} us")
 print(f"gap between consecutive blocks on a CU: mean {gaps.mean():.2f} median {np.median(gaps):.2f} p90 {np.percentile(gaps, 90):.2f} us; "
       f"busy per CU mean {np.mean(busy):.1f} us")
+# prologue / epilogue by the block's position on its CU (1st, 2nd, 3rd ... block the CU ran): the first round starts on all CUs at once
+rank = np.zeros(len(a), dtype=int)
+for c in sorted(set(cu.tolist())):
+    m = np.where(cu == c)[0]
+    o = m[np.argsort(T[m, 0])]
+    rank[o] = np.arange(len(o))
+for k in range(rank.max() + 1):
+    m = (rank == k) & (kind == 0)
+    if m.any():
+        print(f"block #{k} of its CU (full blocks): n={m.sum():4d} start {T[m, 0].mean():6.1f} us  prologue mean {pro[m].mean():5.2f} median {np.median(pro[m]):5.2f} "
+              f"p90 {np.percentile(pro[m], 90):5.2f}  loop {loop[m].mean():6.2f}  epilogue {epi[m].mean():5.2f} us")
+# finer stamps (kept in registers, stored at the end): 8 kernel entry, 9 prologue loads issued, 10 first tile landed, 11 FOLD + raw tiles done, 12 behind the block barrier
+F = (a[:, 8:13] - t0) * 10.0 / 1000.0
+m = (kind == 0)
+print("full blocks, mean us: entry->decoded %.2f | ->loads issued %.2f | ->tile 0 landed %.2f | ->loop start %.2f || loop %.2f || ->FOLD+stores %.2f | ->barrier %.2f | ->end %.2f" % (
+    (T[m, 0] - F[m, 0]).mean(), (F[m, 1] - T[m, 0]).mean(), (F[m, 2] - F[m, 1]).mean(), (T[m, 1] - F[m, 2]).mean(), (T[m, 2] - T[m, 1]).mean(),
+    (F[m, 3] - T[m, 2]).mean(), (F[m, 4] - F[m, 3]).mean(), (T[m, 3] - F[m, 4]).mean()))
