@@ -192,7 +192,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 
 // NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
 template <int NKF, int NKD, int NKC, bool XM = false>
-__global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
+__global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     using BL = BlobT<NKF, NKD>;
     constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
     constexpr int BUF = BL::BYTES, NS = NKF + NKC, PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
@@ -214,14 +214,33 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
 #define BL_T(i) do {} while (0)
 #endif
 
-    // ---- XCD-aware block order (as k_corr_main): every XCD owns B/8 whole images; full row blocks first, ragged last
+    // ---- PERSISTENT workgroups (round 4): the launch has one workgroup per CU (a multiple of 8: the XCDs are dealt round-robin) and
+    //      each walks the work items orig = blockIdx.x, + gridDim.x, ... - what the dispatcher did with one workgroup per item, minus
+    //      its 0.8 us between two workgroups of a CU.  All four waves take the same items (wave-uniform control flow).
+    const int nitems = args_k.njobs * args_k.B * args_k.nrb + (args_k.gr_list ? args_k.B * args_k.gr_blocks_per_image : 0);
+    for (int orig = blockIdx.x; orig < nitems; orig += gridDim.x) {
+    // The kernel arguments are read through a pointer hipcc cannot see through, once per item: as loop invariants it kept the job
+    // table's fields in scalar registers across the walk, spilled seventy of them into VGPR lanes and took accumulator registers
+    // for its own values (the audit of tests/test_host_cpu.py).  Still the kernel-argument segment: scalar loads, as before.
+    const DgCorrArgs __attribute__((address_space(4)))* args_p =
+        (const DgCorrArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(args_p));
+    const DgCorrArgs& args = *(const DgCorrArgs*)args_p;
+#ifdef C2_BLOCKLOG
+    bl_t[0] = wall_clock64();
+#endif
+    // ---- XCD-aware item order (as k_corr_main): every XCD owns B/8 whole images; full row blocks first, ragged last
     int bid;
     {
-        const int nwg = gridDim.x, orig = blockIdx.x;
+        const int nwg = nitems;
         const int q = nwg >> 3, rem = nwg & 7, xcd = orig & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
     }
-    const int tid = threadIdx.x, lane = tid & 63;
+    // (the thread index through an opaque statement, per item: nothing derived from it is carried across items in registers the
+    //  tile loop needs - hipcc hoisted all of it out of the walk and parked the overflow in accumulator registers)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int Ppad = args.Ppad, ntiles = Ppad >> 5;
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         const bool grouped = ragged && args.gr_list != nullptr;
         int kind = 0;                                       // 0 full, 1 grouped ragged, 2 ragged of one (jid, n)
         int jid = 0, n = 0, gkey = 0, gpart = 0;
-        if ((gridDim.x & 7) == 0 && (args.B & 7) == 0) {
+        if ((nitems & 7) == 0 && (args.B & 7) == 0) {
             // every XCD owns B/8 whole images; inside that chunk the long blocks go first: pair-set jobs with a full row block,
             // then the ragged ones
             const int imgs = args.B >> 3;
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         }
 #ifdef C2_BLOCKLOG          // developer build: per-block timeline (DG_BLOCKLOG=<file>, scripts/blocklog.py)
         if (args.blocklog && threadIdx.x == 0) {
-            unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16;
+            unsigned long long* e = args.blocklog + (size_t)orig * 16;
             e[0] = __builtin_amdgcn_s_getreg(63492); e[1] = __builtin_amdgcn_s_getreg(63508); e[6] = kind; e[7] = rb;
             e[2] = wall_clock64(); e[3] = e[2]; e[4] = e[2]; e[5] = e[2];
         }
@@ -286,14 +305,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         if (kind == 2 && grouped) {
             // this (jid, n) is served by a grouped block unless its rank lies beyond the group's blocks
             const int key = args.gr_key[jid];
-            if ((int)args.gr_rank[jid * args.B + n] < args.gr_nblk[key] * args.gr_cpb) return;
+            if ((int)args.gr_rank[jid * args.B + n] < args.gr_nblk[key] * args.gr_cpb) continue;
         }
         if (kind == 1) {
             // image n of this chunk is the STREAMED image; the consumers come from the list of (key, n)
             mS = n; sidx_p = nullptr;
             const int cnt = args.gr_count[gkey * args.B + n];
             const int c0 = gpart * args.gr_cpb;
-            if (c0 >= cnt) return;
+            if (c0 >= cnt) continue;
             jid_first = args.gr_first[gkey];
             bool any = false;
 #pragma unroll
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
     asm volatile("" : "+v"(Yc[1]));
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[3] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[3] = wall_clock64(); }
 #endif
     if (act[1]) run(std::true_type{}, std::true_type{});
     else if (act[0]) run(std::true_type{}, std::false_type{});
@@ -702,7 +721,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
     BSTAMP(2);
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[4] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[4] = wall_clock64(); }
 #endif
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
@@ -795,7 +814,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         }
     }
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)blockIdx.x * 16; e[5] = wall_clock64(); for (int i = 0; i < 5; ++i) e[8 + i] = bl_t[i]; }
+    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[5] = wall_clock64(); for (int i = 0; i < 5; ++i) e[8 + i] = bl_t[i]; }
 #endif
 #ifdef C2_STAMPS
     BSTAMP(3);
@@ -804,12 +823,29 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args) {
         for (int i = tid; i < NW * 25 * 6 + NW * 4; i += 256) args.stamps[i] = st_lds[i];
     }
 #endif
+    }       // (next work item)
 }
 
 // blocks of a launch: per image the pair-sets' row blocks; with grouped ragged row blocks (args.gr_list)
 // also the groups' blocks (the one-(pair-set, image) ragged blocks stay in the grid: they return at once when a group serves them)
 static int dg_corr2_grid(const DgCorrArgs& args) {
     return args.njobs * args.B * args.nrb + (args.gr_list ? args.B * args.gr_blocks_per_image : 0);
+}
+
+// workgroups of the launch: one per CU (persistent: each walks the items blockIdx.x, + gridDim.x, ...), a multiple of 8 so that an
+// item's XCD is its index modulo 8 at every step of the walk
+static int dg_corr2_launch_grid(const DgCorrArgs& args) {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        ncu = n / 8 * 8;
+#ifdef DG_DEVTOOLS
+        if (const char* g = getenv("DG_C2_GRID")) ncu = atoi(g);     // developer A/B: 0 = one workgroup per item (the round-3 launch)
+#endif
+    }
+    const int items = dg_corr2_grid(args);
+    return (ncu <= 0 || items < ncu) ? items : ncu;
 }
 
 // Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
@@ -838,7 +874,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         auto kx = k_corr2<24, 6, 5, true>;
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
-        hipLaunchKernelGGL(kx, dim3(dg_corr2_grid(args)), dim3(256), smem_x, stream, args);
+        hipLaunchKernelGGL(kx, dim3(dg_corr2_launch_grid(args)), dim3(256), smem_x, stream, args);
         return hipGetLastError();
     }
     const int smem = 4 * BL::BYTES + C2_RED_BYTES;
@@ -852,7 +888,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         DgCorrArgs a2 = args;
         a2.stamps = stamp_buf;
         (void)dg_set_max_smem(reinterpret_cast<const void*>(kern), smem + (4 * 25 * 6 + 16) * 4);
-        hipLaunchKernelGGL(kern, dim3(dg_corr2_grid(args)), dim3(256), smem + (4 * 25 * 6 + 16) * 4, stream, a2);
+        hipLaunchKernelGGL(kern, dim3(dg_corr2_launch_grid(args)), dim3(256), smem + (4 * 25 * 6 + 16) * 4, stream, a2);
         uint32_t host[4 * 25 * 6 + 16];
         if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6 + 16, fp); fclose(fp); }
@@ -868,7 +904,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
             DgCorrArgs a2 = args;
             a2.blocklog = blog_buf;
             (void)hipMemsetAsync(blog_buf, 0, (size_t)grid * 128, stream);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, a2);
+            hipLaunchKernelGGL(kern, dim3(dg_corr2_launch_grid(args)), dim3(256), smem, stream, a2);
             static unsigned long long hostb[8192 * 16];
             if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(hostb, blog_buf, (size_t)grid * 128, hipMemcpyDeviceToHost) == hipSuccess)
                 if (FILE* fp = fopen(blog_file, "wb")) { fwrite(hostb, 8, (size_t)grid * 16, fp); fclose(fp); }
@@ -876,7 +912,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(dg_corr2_grid(args)), dim3(256), smem, stream, args);
+    hipLaunchKernelGGL(kern, dim3(dg_corr2_launch_grid(args)), dim3(256), smem, stream, args);
     return hipGetLastError();
 }
 

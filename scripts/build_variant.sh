@@ -6,6 +6,7 @@ tag=$1; shift
 src=${SRC:-dg_corr2}
 cd "$(dirname "$0")/../depthg_amd/csrc"
 mkdir -p ../lib/obj_$tag
+[ "$src" = dg_corr2 ] && set -- -mllvm -disable-machine-licm "$@"
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c $src.hip -o ../lib/obj_$tag/$src.o
 objs=$(ls ../lib/obj/*.o | grep -v "/$src.o")
 hipcc -shared -fPIC --offload-arch=gfx950 $objs ../lib/obj_$tag/$src.o -o ../lib/libdepthg_$tag.so
