@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--exact-masks", action="store_true",
                     help="cfg.dg_exact_masks: the clamp mask 1[cd >= 0] from fp32 dot products instead of the fp16 cd of the MFMA "
                          "chain (gradient error 1.4e-2 -> below 2e-3 relative L2; dense ViT-S grids; the default is the fast path)")
-    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph"], default="", help=argparse.SUPPRESS)
+    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph", "twocalls"], default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -279,8 +279,12 @@ def main():
     def compute_with_head(bucket=None):
         for prm in head_params:
             prm.grad = None
-        code, feats = head(f)              # f / fp are the frozen backbone's outputs here; three Dropout2d draws per pass
-        code_pos, feats_pos = head(fp)
+        # f / fp are the frozen backbone's outputs here; three Dropout2d draws per pass, both passes in one set of launches
+        if args.ablate == "twocalls":      # (the round-3 form: one call per pass, autograd adds the two passes' weight gradients)
+            code, feats = head(f)
+            code_pos, feats_pos = head(fp)
+        else:
+            (code, feats), (code_pos, feats_pos) = head.forward_pair(f, fp)
         loss_fn(feats, feats_pos, None, None, code, code_pos, d, dp)
         total = loss_fn.total
         total.backward(gradient=seed_grad)

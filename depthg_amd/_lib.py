@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 110                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 111                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
@@ -17,7 +17,8 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
-           "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_cluster_lookup_forward",
+           "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
+           "dg_head_backward_pair", "dg_cluster_lookup_forward",
            "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities"]
 
 
@@ -65,6 +66,10 @@ def load():
     lib.dg_head_workspace_bytes.argtypes = [i32] * 4
     lib.dg_head_backward.restype = ctypes.c_int
     lib.dg_head_backward.argtypes = [i32] * 4 + [vp] * 3 + [f32] + [vp] * 10 + [ctypes.c_size_t, vp]
+    lib.dg_head_forward_pair.restype = ctypes.c_int
+    lib.dg_head_forward_pair.argtypes = [i32] * 4 + [vp] * 11 + [f32] + [vp] * 7
+    lib.dg_head_backward_pair.restype = ctypes.c_int
+    lib.dg_head_backward_pair.argtypes = [i32] * 4 + [vp] * 4 + [f32] + [vp] * 11 + [ctypes.c_size_t, vp]
     lib.dg_cluster_lookup_forward.restype = ctypes.c_int
     lib.dg_cluster_lookup_forward.argtypes = [vp, vp, f32] + [i32] * 4 + [vp] * 6
     lib.dg_cluster_lookup_backward.restype = ctypes.c_int

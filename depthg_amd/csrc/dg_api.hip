@@ -885,12 +885,21 @@ extern "C" size_t dg_head_weights_bytes(int32_t C, int32_t D) {
     return head_weights_bytes(C, D);
 }
 
-extern "C" int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
-                               const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
-                               const float* keep1, const float* keep2, const float* keep3, float keep_scale,
-                               float* code, float* feats_out, void* hidden, void* wscratch, dg_stream_t stream_) {
+// images Bs.. of a tensor that continues in a second allocation: (second base - first base) in elements, minus the Bs images in front
+template <typename T>
+static long long pair_delta(const T* first, const T* second, int32_t Bs, long long stride) {
+    if (!second) return 0;
+    return (long long)((reinterpret_cast<intptr_t>(second) - reinterpret_cast<intptr_t>(first)) / (intptr_t)sizeof(T)) - (long long)Bs * stride;
+}
+
+// B images in all; the first Bs from feat / into code / feats_out, the rest from / into the *2 tensors (null: one tensor, Bs = B)
+static int head_forward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat2,
+                             const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                             const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                             float* code, float* code2, float* feats_out, float* feats_out2, void* hidden, void* wscratch, dg_stream_t stream_) {
     if (int rc = head_check(B, C, D, P)) return rc;
     if (!feat || !w1 || !b1 || !code || !wscratch) return fail(DG_ERR_INVALID, "null pointer");
+    if (Bs < B && (!feat2 || !code2 || ((feats_out != nullptr) != (feats_out2 != nullptr)))) return fail(DG_ERR_INVALID, "null pointer of the second pass");
     const bool nonlinear = w2a != nullptr;
     if (nonlinear && (!b2a || !w2b || !b2b)) return fail(DG_ERR_INVALID, "cluster2 needs all four of its tensors");
     hipStream_t s = static_cast<hipStream_t>(stream_);
@@ -902,8 +911,30 @@ extern "C" int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const
     a.keep1 = keep1; a.keep2 = keep2; a.keep3 = keep3; a.scale = keep_scale;
     a.code = code; a.feats_out = feats_out; a.hidden = static_cast<__bf16*>(hidden);
     a.B = B; a.C = C; a.D = D; a.P = P;
+    a.Bs = Bs;
+    a.d_feat = pair_delta(feat, feat2, Bs, (long long)C * P);
+    a.d_code = pair_delta(code, code2, Bs, (long long)D * P);
+    a.d_fo = pair_delta(feats_out, feats_out2, Bs, (long long)C * P);
     DG_HIP(dg_launch_head_fwd(a, s));
     return DG_OK;
+}
+
+extern "C" int dg_head_forward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat,
+                               const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                               const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                               float* code, float* feats_out, void* hidden, void* wscratch, dg_stream_t stream_) {
+    return head_forward_impl(B, B, C, D, P, feat, nullptr, w1, b1, w2a, b2a, w2b, b2b, keep1, keep2, keep3, keep_scale, code, nullptr,
+                             feats_out, nullptr, hidden, wscratch, stream_);
+}
+
+extern "C" int dg_head_forward_pair(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat_pos,
+                                    const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                                    const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                                    float* code, float* code_pos, float* feats_out, float* feats_out_pos, void* hidden, void* wscratch,
+                                    dg_stream_t stream_) {
+    if (B < 1 || B > (1 << 20)) return fail(DG_ERR_INVALID, "bad head dimensions");
+    return head_forward_impl(2 * B, B, C, D, P, feat, feat_pos, w1, b1, w2a, b2a, w2b, b2b, keep1, keep2, keep3, keep_scale, code, code_pos,
+                             feats_out, feats_out_pos, hidden, wscratch, stream_);
 }
 
 extern "C" size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32_t P) {
@@ -911,12 +942,14 @@ extern "C" size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32
     return head_plan(B, C, D, P).total;
 }
 
-extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
-                                float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
-                                float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
-                                void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat2, const float* keep1,
+                              const float* keep2, float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
+                              const float* grad_code2, float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b,
+                              float* grad_b2b, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     if (int rc = head_check(B, C, D, P)) return rc;
     if (!feat || !grad_code || !grad_w1 || !grad_b1 || !workspace) return fail(DG_ERR_INVALID, "null pointer");
+    if (Bs < B && (!feat2 || !grad_code2)) return fail(DG_ERR_INVALID, "null pointer of the second pass");
+    const long long d_feat = pair_delta(feat, feat2, Bs, (long long)C * P), d_g = pair_delta(grad_code, grad_code2, Bs, (long long)D * P);
     const bool nonlinear = grad_w2a != nullptr;
     if (nonlinear && (!hidden || !wscratch || !grad_b2a || !grad_w2b || !grad_b2b)) return fail(DG_ERR_INVALID, "null cluster2 pointer");
     const HeadPlan h = head_plan(B, C, D, P);
@@ -932,29 +965,51 @@ extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, cons
     // d W1[d][k] = scale * keep1[b][k] * sum_p g[d][p] f[k][p]      (with cluster2: in the launch of d W2a below, which reads the same f)
     if (!nonlinear) {
         DgHeadWgradArgs w{grad_code, feat, keep1, F32(h.p1), B, D, C, P, h.s1};
+        w.A2 = nullptr; w.keep_2 = nullptr; w.part2 = nullptr; w.M2 = 0;
+        w.Bs = Bs; w.dA = d_g; w.dB = d_feat; w.dA2 = 0;
         DG_HIP(dg_launch_head_wgrad(w, false, false, s));
         reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s1, keep1 ? keep_scale : 1.f);
     }
     if (!nonlinear) {        // d b1 = row sums of d code
-        DG_HIP(dg_launch_head_rowsum(grad_code, false, grad_b1, nullptr, B, D, P, s));
+        DG_HIP(dg_launch_head_rowsum(grad_code, false, grad_b1, nullptr, B, D, P, s, Bs, d_g));
         DG_HIP(dg_launch_head_reduce(red, s));
         return DG_OK;
     }
     __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
     const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + (size_t)2 * D * C + (size_t)C * C;
-    DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P};
+    DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P, Bs, d_g};
     DG_HIP(dg_launch_head_dh(d, s));
     reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
     reduce(F32(h.pb2a), grad_b2a, nullptr, C, B * h.tiles, 1.f);
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
+    wb.A2 = nullptr; wb.keep_2 = nullptr; wb.part2 = nullptr; wb.M2 = 0;
+    wb.Bs = Bs; wb.dA = d_g; wb.dB = 0; wb.dA2 = 0;
     DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
     reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
     DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
+    wa.Bs = Bs; wa.dA = 0; wa.dB = d_feat; wa.dA2 = d_g;
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);
     DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
+}
+
+extern "C" int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* keep1, const float* keep2,
+                                float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
+                                float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
+                                void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    return head_backward_impl(B, B, C, D, P, feat, nullptr, keep1, keep2, keep_scale, hidden, wscratch, grad_code, nullptr, grad_w1, grad_b1,
+                              grad_w2a, grad_b2a, grad_w2b, grad_b2b, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_head_backward_pair(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat_pos, const float* keep1,
+                                     const float* keep2, float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
+                                     const float* grad_code_pos, float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a,
+                                     float* grad_w2b, float* grad_b2b, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (B < 1 || B > (1 << 20)) return fail(DG_ERR_INVALID, "bad head dimensions");
+    return head_backward_impl(2 * B, B, C, D, P, feat, feat_pos, keep1, keep2, keep_scale, hidden, wscratch, grad_code, grad_code_pos, grad_w1,
+                              grad_b1, grad_w2a, grad_b2a, grad_w2b, grad_b2b, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int dg_cluster_lookup_forward(const float* x, const float* clusters, float alpha, int32_t B, int32_t D, int32_t n, int32_t P,

@@ -661,7 +661,13 @@ struct DgHeadFwdArgs {
     __bf16* hidden;                        // (B,C,P) bf16: ReLU output saved for the backward, or null
     int32_t B, C, D, P;
     unsigned long long* stamps;            // developer timing stamps (null in production)
+    // two passes of the featurizer in one launch (dg_head_forward_pair: img, then img_pos): images Bs.. of feat / code / feats_out
+    // live in a second tensor each; d_* = (its base - the first's base) in elements - Bs images, added to the offset of those images
+    int32_t Bs;
+    long long d_feat, d_code, d_fo;
 };
+// element offset of image b of a tensor that continues in a second allocation from image Bs on (see DgHeadFwdArgs)
+__host__ __device__ inline long long dg_img_off(int b, long long stride, int Bs, long long delta) { return (long long)b * stride + (b >= Bs ? delta : 0); }
 
 struct DgHeadDhArgs {
     const float* gcode;      // (B,D,P) fp32
@@ -671,6 +677,7 @@ struct DgHeadDhArgs {
     float* part_bd;          // [B * tiles][D] per-block row sums of d code (bias gradients of the output convolutions)
     float* part_b2a;         // [B * tiles][C] per-block row sums of d hidden_pre
     int32_t B, C, D, P;
+    int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
 };
 
 struct DgHeadWgradArgs {
@@ -680,6 +687,7 @@ struct DgHeadWgradArgs {
     int32_t B, M, N, P, splits;
     // optional second product with the same Bm in the same launch (M2 > 0): A2 (B, M2, P) fp32, its keep mask and partial sums
     const void* A2; const float* keep_2; float* part2; int32_t M2;
+    int32_t Bs; long long dA, dB, dA2;   // (pair: images Bs.. of A / Bm / A2 in second tensors, offsets in their elements; 0: one tensor)
 };
 
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
@@ -689,7 +697,7 @@ hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf
 struct DgHeadReduceJob { const float* part; float* out; float* out2; int32_t n, splits; float scale; };
 struct DgHeadReduceArgs { DgHeadReduceJob jobs[6]; int32_t njobs; };
 hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s);
-hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s);
+hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s, int Bs = 1 << 30, long long dX = 0);
 
 // ---- the probes (dg_probe.hip; ClusterLookup src/modules.py:647-675, linear-probe loss src/train_segmentation.py:421-434)
 struct DgClusterArgs {

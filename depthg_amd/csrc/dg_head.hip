@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                 for (int u = 0; u < U; ++u) {
                     const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
                     const int kc = k < C ? k : C - 1, pc = p + 3 < P ? p : P - 4;
-                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.feat + ((size_t)b * C + kc) * P + pc));
+                    v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.feat + dg_img_off(b, (long long)C * P, a.Bs, a.d_feat) + (size_t)kc * P + pc));
                     kf3[u] = k3p[(size_t)b * C + kc];        // (raw: an operation on a loaded value here makes hipcc wait for ALL loads issued so far)
                 }
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                     const int i = (it + u) * NTH + tid, k = i / Q, q4 = i - k * Q, p = p0 + 4 * q4;
                     const bool ok = k < C && p + 3 < P;
                     const f32x4 vv = ok ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + ((size_t)b * C + k) * P + p) = vv * (a.keep3 ? kf3[u] * s3 : 1.f);
+                    if (a.feats_out && ok) *reinterpret_cast<f32x4*>(a.feats_out + dg_img_off(b, (long long)C * P, a.Bs, a.d_fo) + (size_t)k * P + p) = vv * (a.keep3 ? kf3[u] * s3 : 1.f);
                     bf16x4 o4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o4[e] = (__bf16)vv[e];
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                 const float f3 = (a.keep3 && k < C) ? a.keep3[(size_t)b * C + k] * s3 : 1.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = (k < C && p + e < P) ? a.feat[((size_t)b * C + k) * P + p + e] : 0.f;
-                    if (a.feats_out && k < C && p + e < P) a.feats_out[((size_t)b * C + k) * P + p + e] = v * f3;
+                    const float v = (k < C && p + e < P) ? a.feat[dg_img_off(b, (long long)C * P, a.Bs, a.d_feat) + (size_t)k * P + p + e] : 0.f;
+                    if (a.feats_out && k < C && p + e < P) a.feats_out[dg_img_off(b, (long long)C * P, a.Bs, a.d_fo) + (size_t)k * P + p + e] = v * f3;
                     o4[e] = (__bf16)v;
                 }
                 *reinterpret_cast<bf16x4*>(Ft + k * FROW + q4 * 8) = o4;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = 16 * (wid + NW * i) + 4 * g + r;
-                if (d < D && p < P) a.code[((size_t)b * D + d) * P + p] = fmaf(acc2a[i][j][r], s1, bb[r]) + (nonlinear ? acc2b[i][j][r] : 0.f);
+                if (d < D && p < P) a.code[dg_img_off(b, (long long)D * P, a.Bs, a.d_code) + (size_t)d * P + p] = fmaf(acc2a[i][j][r], s1, bb[r]) + (nonlinear ? acc2b[i][j][r] : 0.f);
             }
         }
     }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int idx = tid + 256 * u, d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
-            v[u] = *reinterpret_cast<const f32x4*>(a.gcode + ((size_t)b * D + (d < D ? d : D - 1)) * P + (p < P ? p : P - 4));
+            v[u] = *reinterpret_cast<const f32x4*>(a.gcode + dg_img_off(b, (long long)D * P, a.Bs, a.d_gcode) + (size_t)(d < D ? d : D - 1) * P + (p < P ? p : P - 4));
         }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
             float rs = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = (d < D && p + e < P) ? a.gcode[((size_t)b * D + d) * P + p + e] : 0.f;
+                const float v = (d < D && p + e < P) ? a.gcode[dg_img_off(b, (long long)D * P, a.Bs, a.d_gcode) + (size_t)d * P + p + e] : 0.f;
                 rs += v;
                 o[e] = (__bf16)v;
             }
@@ -549,8 +549,8 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const DgHeadWgradArgs a) {
     };
     auto fetch = [&](const int s) {
         const int b = s / steps_img, p = (s - b * steps_img) * 32 + 8 * g;
-        const TA* Ab = static_cast<const TA*>(a.A) + (size_t)b * a.M * a.P;
-        const TB* Bb = static_cast<const TB*>(a.Bm) + (size_t)b * a.N * a.P;
+        const TA* Ab = static_cast<const TA*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA);
+        const TB* Bb = static_cast<const TB*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB);
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_raw(ra[i], Ab, m0 + 16 * i + c16, a.M, p);
 #pragma unroll
@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const DgHeadWgradArgs a) {
 // fragment read fall into eight different bank groups); each wave owns a 64 x 64 sub-tile = 2 x 2 MFMAs of 32x32x16 per 16
 // positions.  The loads of step s + 1 are in flight while step s multiplies; one barrier per step.
 template <typename TA, typename TB>
-__device__ __forceinline__ void wgrad2_body(const DgHeadWgradArgs& a, const void* Aop, const float* keep, float* part, const int M,
-                                            const int m0, const int n0, const int split) {
+__device__ __forceinline__ void wgrad2_body(const DgHeadWgradArgs& a, const void* Aop, const long long dAop, const float* keep, float* part,
+                                            const int M, const int m0, const int n0, const int split) {
     constexpr int PS = 32, RS = PS * 2 + 16, TILE = 128 * RS;     // positions per step; row stride (80 bytes)
     extern __shared__ __attribute__((aligned(16))) char wsm[];     // [2 stages][A, B][TILE]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -620,8 +620,8 @@ __device__ __forceinline__ void wgrad2_body(const DgHeadWgradArgs& a, const void
     auto fetch = [&](const int s) {
         const int b = s / steps_img, p = (s - b * steps_img) * PS + 16 * half;
         const int m = m0 + lrow, n = n0 + lrow;
-        const TA* Ar = static_cast<const TA*>(Aop) + ((size_t)b * M + (m < M ? m : 0)) * a.P;
-        const TB* Br = static_cast<const TB*>(a.Bm) + ((size_t)b * a.N + (n < a.N ? n : 0)) * a.P;
+        const TA* Ar = static_cast<const TA*>(Aop) + dg_img_off(b, (long long)M * a.P, a.Bs, dAop) + (size_t)(m < M ? m : 0) * a.P;
+        const TB* Br = static_cast<const TB*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + (size_t)(n < a.N ? n : 0) * a.P;
         const float kp = (keep && n < a.N) ? keep[(size_t)b * a.N + n] : 1.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -705,8 +705,8 @@ __global__ __launch_bounds__(256, 2) void k_head_wgrad2(const DgHeadWgradArgs a)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int split = xcd + 8 * (slot / ntile), tile = slot % ntile;
     const int tm = tile / tn, n0 = (tile - tm * tn) * 128;
-    if (tm < tm1) wgrad2_body<TA, TB>(a, a.A, a.keep, a.part, a.M, tm * 128, n0, split);
-    else wgrad2_body<TA2, TB>(a, a.A2, a.keep_2, a.part2, a.M2, (tm - tm1) * 128, n0, split);
+    if (tm < tm1) wgrad2_body<TA, TB>(a, a.A, a.dA, a.keep, a.part, a.M, tm * 128, n0, split);
+    else wgrad2_body<TA2, TB>(a, a.A2, a.dA2, a.keep_2, a.part2, a.M2, (tm - tm1) * 128, n0, split);
 }
 
 template <typename TA, typename TB, typename TA2 = TA>
@@ -722,7 +722,7 @@ static hipError_t launch_wgrad(const DgHeadWgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_head_wgrad<TA, TB>), grid, dim3(256), 0, s, a);
     if (a.M2 > 0) {
         DgHeadWgradArgs b = a;
-        b.A = a.A2; b.M = a.M2; b.keep = a.keep_2; b.part = a.part2; b.M2 = 0;
+        b.A = a.A2; b.dA = a.dA2; b.M = a.M2; b.keep = a.keep_2; b.part = a.part2; b.M2 = 0;
         hipLaunchKernelGGL((k_head_wgrad<TA2, TB>), dim3((a.N + 127) / 128, (b.M + 127) / 128, a.splits), dim3(256), 0, s, b);
     }
     return hipGetLastError();
@@ -775,12 +775,13 @@ hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s) {
 
 // bias gradients: out[row] (and out2[row]) = sum over images and positions of X[image][row][:]   (one block per row, fixed order)
 template <typename T>
-__global__ __launch_bounds__(256) void k_head_rowsum(const T* __restrict__ X, float* __restrict__ out, float* __restrict__ out2, int B, int R, int P) {
+__global__ __launch_bounds__(256) void k_head_rowsum(const T* __restrict__ X, float* __restrict__ out, float* __restrict__ out2, int B, int R, int P,
+                                                     int Bs, long long dX) {
     __shared__ float red[256];
     const int row = blockIdx.x;
     float s = 0.f;
     for (int b = 0; b < B; ++b) {
-        const T* x = X + ((size_t)b * R + row) * P;
+        const T* x = X + dg_img_off(b, (long long)R * P, Bs, dX) + (size_t)row * P;
         for (int p = threadIdx.x; p < P; p += 256) s += (float)x[p];
     }
     red[threadIdx.x] = s;
@@ -788,8 +789,8 @@ __global__ __launch_bounds__(256) void k_head_rowsum(const T* __restrict__ X, fl
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) { out[row] = red[0]; if (out2) out2[row] = red[0]; }
 }
-hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s) {
-    if (bf16) hipLaunchKernelGGL(k_head_rowsum<__bf16>, dim3(R), dim3(256), 0, s, static_cast<const __bf16*>(X), out, out2, B, R, P);
-    else hipLaunchKernelGGL(k_head_rowsum<float>, dim3(R), dim3(256), 0, s, static_cast<const float*>(X), out, out2, B, R, P);
+hipError_t dg_launch_head_rowsum(const void* X, bool bf16, float* out, float* out2, int B, int R, int P, hipStream_t s, int Bs, long long dX) {
+    if (bf16) hipLaunchKernelGGL(k_head_rowsum<__bf16>, dim3(R), dim3(256), 0, s, static_cast<const __bf16*>(X), out, out2, B, R, P, Bs, dX);
+    else hipLaunchKernelGGL(k_head_rowsum<float>, dim3(R), dim3(256), 0, s, static_cast<const float*>(X), out, out2, B, R, P, Bs, dX);
     return hipGetLastError();
 }

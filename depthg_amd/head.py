@@ -86,6 +86,84 @@ class _HeadFunction(torch.autograd.Function):
         return (None, None, None, None, R(gw1, 0), R(gb1, 1), R(gw2a, 2), R(gb2a, 3), R(gw2b, 4), R(gb2b, 5))
 
 
+class _HeadPairFunction(torch.autograd.Function):
+    """Both featurizer passes of a step (img, img_pos) through ONE set of launches (dg_head_forward_pair / dg_head_backward_pair):
+    the same numbers as two _HeadFunction calls whose weight gradients autograd adds up - without the six additions, with half
+    the launches, and with no concatenated copy of the features."""
+
+    @staticmethod
+    def forward(ctx, feat, feat_pos, keeps, scale, want_feats, w1, b1, w2a, b2a, w2b, b2b):
+        lib = _lib.load()
+        f, fp = _gpu32(feat, "image_feat"), _gpu32(feat_pos, "image_feat_pos")
+        if f.shape != fp.shape or f.device != fp.device:
+            raise ValueError(f"depthg_amd: the two passes' features must match: {tuple(f.shape)} on {f.device} and {tuple(fp.shape)} on {fp.device}")
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise RuntimeError("depthg_amd: ProjectionHead received features that require grad; the head has no gradient with "
+                               "respect to its input (frozen backbone) - detach them")
+        B, C, h, w = f.shape
+        D, P, dev = w1.shape[0], h * w, f.device
+        nonlinear = w2a is not None
+        need_grad = any(ctx.needs_input_grad[5:])
+        code, code_pos = _empty((B, D, h, w), torch.float32, dev), _empty((B, D, h, w), torch.float32, dev)
+        fo = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
+        fo_pos = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
+        hidden = _empty((2 * B, C, P), torch.bfloat16, dev) if (nonlinear and need_grad) else None
+        k1, k2, k3 = keeps if keeps is not None else (None, None, None)          # (2B, C) each: the first pass's rows first
+        W = lambda t: _gpu32(t, "head parameter").reshape(t.shape[0], -1) if t is not None else None
+        w1c, w2ac, w2bc = W(w1), W(w2a), W(w2b)
+        wscratch = _empty((lib.dg_head_weights_bytes(C, D),), torch.uint8, dev)
+        rc = lib.dg_head_forward_pair(B, C, D, P, _ptr(f), _ptr(fp), _ptr(w1c), _ptr(_gpu32(b1, "bias")), _ptr(w2ac),
+                                      _ptr(_gpu32(b2a, "bias")) if nonlinear else None, _ptr(w2bc),
+                                      _ptr(_gpu32(b2b, "bias")) if nonlinear else None, _ptr(k1), _ptr(k2), _ptr(k3), float(scale),
+                                      _ptr(code), _ptr(code_pos), _ptr(fo), _ptr(fo_pos), _ptr(hidden), _ptr(wscratch), _stream(dev))
+        _lib.check(rc, "dg_head_forward_pair")
+        ctx.dims, ctx.scale, ctx.nonlinear = (B, C, D, P), float(scale), nonlinear
+        ctx.shapes = tuple(t.shape if t is not None else None for t in (w1, b1, w2a, b2a, w2b, b2b))
+        ctx.save_for_backward(f, fp, k1, k2, hidden, wscratch)
+        ctx.set_materialize_grads(False)
+        if fo is not None:
+            ctx.mark_non_differentiable(fo, fo_pos)
+        return code, code_pos, fo, fo_pos
+
+    @staticmethod
+    def backward(ctx, gcode, gcode_pos, _gf, _gfp):
+        lib = _lib.load()
+        f, fp, k1, k2, hidden, wscratch = ctx.saved_tensors
+        B, C, D, P = ctx.dims
+        dev = f.device
+        if ctx.nonlinear and hidden is None:
+            raise RuntimeError("depthg_amd: head backward without the saved hidden activations")
+        # (a pass whose code took no part in the loss contributes nothing: a zero upstream)
+        g = _gpu32(gcode, "grad_code") if gcode is not None else torch.zeros((B, D, P), dtype=torch.float32, device=dev)
+        gp = _gpu32(gcode_pos, "grad_code_pos") if gcode_pos is not None else torch.zeros((B, D, P), dtype=torch.float32, device=dev)
+        nb = lib.dg_head_workspace_bytes(2 * B, C, D, P)
+        ws = _empty(nb, torch.uint8, dev)
+        gw1, gb1 = _empty((D, C), torch.float32, dev), _empty((D,), torch.float32, dev)
+        gw2a = gb2a = gw2b = gb2b = None
+        if ctx.nonlinear:
+            gw2a, gb2a = _empty((C, C), torch.float32, dev), _empty((C,), torch.float32, dev)
+            gw2b, gb2b = _empty((D, C), torch.float32, dev), _empty((D,), torch.float32, dev)
+        rc = lib.dg_head_backward_pair(B, C, D, P, _ptr(f), _ptr(fp), _ptr(k1), _ptr(k2), ctx.scale, _ptr(hidden), _ptr(wscratch),
+                                       _ptr(g), _ptr(gp), _ptr(gw1), _ptr(gb1), _ptr(gw2a), _ptr(gb2a), _ptr(gw2b), _ptr(gb2b),
+                                       _ptr(ws), nb, _stream(dev))
+        _lib.check(rc, "dg_head_backward_pair")
+        sh = ctx.shapes
+        R = lambda t, i: t.reshape(sh[i]) if t is not None else None
+        return (None, None, None, None, None, R(gw1, 0), R(gb1, 1), R(gw2a, 2), R(gb2a, 3), R(gw2b, 4), R(gb2b, 5))
+
+
+def draw_keep_masks_pair(B, C, device, p=0.1, use=(True, True, True)):
+    """The six Dropout2d draws of a step's two featurizer passes in the reference's order - those of pass 1 (cluster1's input,
+    cluster2's input, the returned feats), then those of pass 2 - as THREE (2B, C) tensors whose halves are drawn in place: the
+    torch generator advances exactly as it does for two draw_keep_masks calls, and nothing is concatenated."""
+    ks = [torch.empty(2 * B, C, device=device, dtype=torch.float32) if u else None for u in use]
+    for half in (slice(0, B), slice(B, 2 * B)):
+        for k in ks:
+            if k is not None:
+                k[half].bernoulli_(1.0 - p)
+    return tuple(ks)
+
+
 def draw_keep_masks(B, C, device, p=0.1, use=(True, True, True)):
     """The Dropout2d draws of one featurizer pass, in the reference's order (cluster1's input, cluster2's input, the returned
     feats; src/modules.py:122-132): (B, C) keep flags, one bernoulli_(1 - p) each, as F.dropout2d draws its (B, C, 1, 1) noise.
@@ -116,6 +194,27 @@ def run_head(cluster1, cluster2, image_feat, training, feats_dropout, p=0.1, kee
     return code, (feats if want_feats else image_feat)
 
 
+def run_head_pair(cluster1, cluster2, image_feat, image_feat_pos, training, feats_dropout, p=0.1, keeps=None):
+    """run_head for the two passes of a training step at once: ((code, feats), (code_pos, feats_pos)).  `keeps`: three (2B, C)
+    tensors (draw_keep_masks_pair) or None (drawn here, in the order two run_head calls would draw)."""
+    B, C = image_feat.shape[:2]
+    nl = cluster2 is not None
+    if training:
+        if keeps is None:
+            keeps = draw_keep_masks_pair(B, C, image_feat.device, p, use=(True, nl, bool(feats_dropout)))
+        k1, k2, k3 = keeps
+        keeps = (k1, k2 if nl else None, k3 if feats_dropout else None)
+    else:
+        keeps = None
+    c1 = cluster1[0]
+    c2a, c2b = (cluster2[0], cluster2[2]) if nl else (None, None)
+    want_feats = bool(training and feats_dropout)
+    code, code_pos, feats, feats_pos = _HeadPairFunction.apply(
+        image_feat, image_feat_pos, keeps, 1.0 / (1.0 - p), want_feats, c1.weight, c1.bias,
+        c2a.weight if nl else None, c2a.bias if nl else None, c2b.weight if nl else None, c2b.bias if nl else None)
+    return (code, feats if want_feats else image_feat), (code_pos, feats_pos if want_feats else image_feat_pos)
+
+
 class ProjectionHead(nn.Module):
     """cluster1 / cluster2 of DinoFeaturizer with the reference's module and parameter names; forward(image_feat, feats_dropout,
     keeps) -> (code, feats): feats = Dropout2d(image_feat) when `feats_dropout` (cfg.dropout) and the module trains, else
@@ -138,6 +237,18 @@ class ProjectionHead(nn.Module):
             return image_feat, feats
         return run_head(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
                         self.training, feats_dropout, self.p, keeps)
+
+    def forward_pair(self, image_feat, image_feat_pos, feats_dropout=True, keeps=None):
+        """forward(image_feat) and forward(image_feat_pos) of one training step (src/train_segmentation.py:303-306) as one set of
+        launches: ((code, feats), (code_pos, feats_pos)), the same values and - after backward - the same parameter gradients."""
+        if self.proj_type is None:
+            ka = kb = None
+            if keeps is not None:
+                B = image_feat.shape[0]
+                ka, kb = (None, None, keeps[2][:B]), (None, None, keeps[2][B:])
+            return self.forward(image_feat, feats_dropout, ka), self.forward(image_feat_pos, feats_dropout, kb)
+        return run_head_pair(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
+                             image_feat_pos, self.training, feats_dropout, self.p, keeps)
 
 
 class _ClusterFunction(torch.autograd.Function):

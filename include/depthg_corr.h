@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 110   /* 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 111   /* 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -357,6 +357,24 @@ int dg_head_backward(int32_t B, int32_t C, int32_t D, int32_t P, const float* fe
                      float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
                      float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a, float* grad_w2b, float* grad_b2b,
                      void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * Both featurizer passes of a training step in one set of launches (src/train_segmentation.py:303-306: `self.net(img)`, then
+ * `self.net(img_pos)`, with the same weights): B images from feat, B from feat_pos, as if they were one batch of 2B - the weight
+ * gradients come out summed over both passes (what autograd's accumulation of the two calls yields), one launch per kernel
+ * instead of two, no concatenated copy of the features.  keep1/2/3, hidden: (2B, ...), the first pass's B rows first.
+ * code / code_pos, feats_out / feats_out_pos, grad_code / grad_code_pos: separate (B, ...) tensors.  The backward's workspace:
+ * dg_head_workspace_bytes(2 B, C, D, P).  (version 111)
+ */
+int dg_head_forward_pair(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat_pos,
+                         const float* w1, const float* b1, const float* w2a, const float* b2a, const float* w2b, const float* b2b,
+                         const float* keep1, const float* keep2, const float* keep3, float keep_scale,
+                         float* code, float* code_pos, float* feats_out, float* feats_out_pos, void* hidden, void* wscratch,
+                         dg_stream_t stream);
+int dg_head_backward_pair(int32_t B, int32_t C, int32_t D, int32_t P, const float* feat, const float* feat_pos, const float* keep1,
+                          const float* keep2, float keep_scale, const void* hidden, const void* wscratch, const float* grad_code,
+                          const float* grad_code_pos, float* grad_w1, float* grad_b1, float* grad_w2a, float* grad_b2a,
+                          float* grad_w2b, float* grad_b2b, void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * ClusterLookup.forward (src/modules.py:664-675): inner = <normalize(x), normalize(clusters)>, probs = one-hot(arg-max) when

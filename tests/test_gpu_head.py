@@ -190,3 +190,57 @@ def test_probe_cross_entropy_vs_oracle(B, n, hw, HW, dev):
     (got * 1.5).backward()
     assert abs(float(got) - float(want)) < 1e-5 * abs(float(want))
     assert _rel(lg.grad.cpu(), 1.5 * lr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,D,hw,proj", [(4, 384, 70, 28, "nonlinear"), (3, 384, 70, 15, "nonlinear"), (2, 384, 70, 28, "linear"),
+                                            (5, 64, 16, 9, "nonlinear"), (2, 384, 70, 28, None)])
+def test_head_pair_equals_two_calls(B, C, D, hw, proj, dev):
+    """ProjectionHead.forward_pair = the two featurizer passes of a training step (src/train_segmentation.py:303-306: net(img),
+    net(img_pos), same weights) as one set of launches.  Against two forward() calls with the same keep masks: code, code_pos, feats,
+    feats_pos BIT-identical (the same kernels on the same tiles); the six parameter gradients - summed over both passes by one
+    split reduction instead of by autograd's addition of two - within 1e-5 relative; the torch generator ends where it ends
+    behind two calls; odd batch sizes, position counts off the fast paths, the linear head and projection_type None included."""
+    from depthg_amd.head import ProjectionHead, draw_keep_masks_pair
+    g = torch.Generator().manual_seed(31 * C + hw + B)
+    f, fp = (torch.randn(B, C, hw, hw, generator=g) * 2.0).to(dev), (torch.randn(B, C, hw, hw, generator=g) * 2.0).to(dev)
+    up, up_pos = torch.randn(B, D if proj else C, hw, hw, generator=g).to(dev), torch.randn(B, D if proj else C, hw, hw, generator=g).to(dev)
+    torch.manual_seed(C + hw)
+    head = ProjectionHead(C, D, proj).to(dev).train()
+    torch.manual_seed(77)
+    keeps = draw_keep_masks_pair(B, C, dev, 0.1, use=(proj is not None, proj == "nonlinear", True))
+    end_pair = torch.rand(3, device=dev)
+    ka = tuple(k[:B] if k is not None else None for k in keeps)
+    kb = tuple(k[B:] if k is not None else None for k in keeps)
+    # two calls
+    c1, f1 = head(f, True, ka)
+    c2, f2 = head(fp, True, kb)
+    if proj is not None:
+        ((c1 * up).sum() + (c2 * up_pos).sum()).backward()
+        want = [p.grad.clone() for p in head.parameters()]
+        for p in head.parameters():
+            p.grad = None
+    # one pair call
+    (pc1, pf1), (pc2, pf2) = head.forward_pair(f, fp, True, keeps)
+    assert torch.equal(pc1, c1) and torch.equal(pc2, c2) and torch.equal(pf1, f1) and torch.equal(pf2, f2)
+    if proj is not None:
+        ((pc1 * up).sum() + (pc2 * up_pos).sum()).backward()
+        for p, w, (name, _) in zip(head.parameters(), want, head.named_parameters()):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            assert _rel(p.grad, w) < 1e-5, (name, _rel(p.grad, w))
+        # one pass alone in the loss: the other's upstream is absent, not an error
+        for p in head.parameters():
+            p.grad = None
+        (qc1, _), (qc2, _) = head.forward_pair(f, fp, True, keeps)
+        (qc1 * up).sum().backward()
+        assert all(torch.isfinite(p.grad).all() for p in head.parameters())
+    # masks drawn inside: the generator advances as for two calls
+    torch.manual_seed(77)
+    head.forward_pair(f, fp, True)
+    end_inside = torch.rand(3, device=dev)
+    torch.manual_seed(77)
+    head(f, True)
+    head(fp, True)
+    end_two = torch.rand(3, device=dev)
+    assert torch.equal(end_inside, end_two) and torch.equal(end_pair, end_two)
+    with pytest.raises(ValueError, match="depthg_amd"):
+        head.forward_pair(f, fp[:, :, : hw - 1], True) if proj is not None else (_ for _ in ()).throw(ValueError("depthg_amd: n/a"))
