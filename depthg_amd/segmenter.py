@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from .depth_decay import legacy_decay_step
-from .head import ClusterLookup, ProjectionHead, probe_cross_entropy, run_head
+from .head import ClusterLookup, ProjectionHead, probe_cross_entropy, run_head, run_head_pair
 from .lhp import LocalHiddenPositiveProjection, OriginalLocalHiddenPositiveProjection
 from .loss import ContrastiveCorrelationLoss
 from .training import correspondence_total
@@ -84,6 +84,21 @@ class StandInFeaturizer(nn.Module):
             code = image_feat
             feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
         return (feats, code, attn) if self.training else (feats, code)
+
+    def forward_pair(self, img, img_pos):
+        """forward(img) and forward(img_pos) of one training step (src/train_segmentation.py:194-212) with the head's two passes in
+        one set of launches (run_head_pair): the frozen backbone has no random draws, so the six Dropout2d draws come in the
+        reference's order.  Training mode with a projection head only; returns ((feats, code, attn), (feats_pos, code_pos, attn_pos))."""
+        if not self.training or self.proj_type is None:
+            return self.forward(img), self.forward(img_pos)
+        self.model.eval()
+        with torch.no_grad():
+            assert img.shape[2] % self.patch_size == 0 and img.shape[3] % self.patch_size == 0
+            image_feat, image_feat_pos = self.model(img), self.model(img_pos)
+            attn, attn_pos = self._last_selfattention(img, image_feat), self._last_selfattention(img_pos, image_feat_pos)
+        (code, feats), (code_pos, feats_pos) = run_head_pair(self.cluster1, self.cluster2 if self.proj_type == "nonlinear" else None,
+                                                             image_feat, image_feat_pos, True, bool(self.cfg.dropout), float(self.dropout.p))
+        return (feats, code, attn), (feats_pos, code_pos, attn_pos)
 
 
 class UnsupervisedSegmenter(nn.Module):
@@ -147,12 +162,19 @@ class UnsupervisedSegmenter(nn.Module):
         depth = batch["depth"] if self.use_depth else None
         depth_pos = batch["depth_pos"] if self.use_depth else None
 
-        feats, code, attn = self.net(img)                                                            # :194-200
+        # (both featurizer passes at once where nothing that draws random numbers stands between them in the reference - the LHP
+        #  module does - and the featurizer offers it)
+        paired = cfg.correspondence_weight > 0 and not getattr(cfg, "lhp", False) and hasattr(self.net, "forward_pair") and self.net.training
+        if paired:
+            (feats, code, attn), (feats_pos, code_pos, _) = self.net.forward_pair(img, img_pos)     # :194-200, :207-212
+        else:
+            feats, code, attn = self.net(img)                                                        # :194-200
         lhp_code = self.lhp_module(code, depth, img, attn) if getattr(cfg, "lhp", False) else None    # :202-203
         logs: Dict[str, torch.Tensor] = {}
         loss = 0
         if cfg.correspondence_weight > 0:
-            feats_pos, code_pos, _ = self.net(img_pos)                                               # :207-212
+            if not paired:
+                feats_pos, code_pos, _ = self.net(img_pos)                                           # :207-212
             lhp_code_pos = self.lhp_module(code_pos, None) if getattr(cfg, "lhp", False) else None   # :214-215
             salience = batch["mask"].to(torch.float32).squeeze(1) if cfg.use_salience else None      # :233-238
             salience_pos = batch["mask_pos"].to(torch.float32).squeeze(1) if cfg.use_salience else None
