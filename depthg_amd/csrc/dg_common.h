@@ -678,6 +678,7 @@ struct DgHeadDhArgs {
     float* part_b2a;         // [B * tiles][C] per-block row sums of d hidden_pre
     int32_t B, C, D, P;
     int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
+    int32_t staged;                  // (set by the launcher) 1: hidden / d hidden through an LDS image of whole rows (P a multiple of 8)
 };
 
 struct DgHeadWgradArgs {

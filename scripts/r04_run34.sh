@@ -1,0 +1,8 @@
+cd /root/repo
+for i in 1 2; do
+for tag in hip ch16; do
+  if [ $tag = hip ]; then unset DEPTHG_LIB; else export DEPTHG_LIB=$PWD/depthg_amd/lib/libdepthg_$tag.so; fi
+  for c in C3 C2; do
+  timeout 300 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag $c', d['ms_per_step'])"
+  done
+done; done
