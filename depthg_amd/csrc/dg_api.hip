@@ -695,6 +695,13 @@ extern "C" int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, i
     return DG_OK;
 }
 
+extern "C" int dg_rand_coords_state(uint64_t* state, int64_t n, float* out, dg_stream_t stream_) {
+    if (!state || !out) return fail(DG_ERR_INVALID, "null pointer");
+    if (n < 1 || n > (1ll << 24)) return fail(DG_ERR_INVALID, "dg_rand_coords_state: n=%lld outside [1, 2^24]", (long long)n);
+    DG_HIP(dg_launch_rand_coords_state(reinterpret_cast<unsigned long long*>(state), out, (int)n, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
+}
+
 extern "C" int dg_salience_coords(const float* salience, int32_t B, int32_t H, int32_t W, int32_t n, const float* u_sel,
                                   const float* u_fallback, float* out_coords, dg_stream_t stream_) {
     if (!salience || !u_sel || !u_fallback || !out_coords) return fail(DG_ERR_INVALID, "null pointer");

@@ -153,9 +153,20 @@ class ContrastiveCorrelationLoss(nn.Module):
                 self._ident_cache = (key, identity_coords(B, S, dev))
             c = self._ident_cache[1]
             return c, c, True
+        if getattr(cfg, "dg_graph_safe", False):
+            # the step is recorded in a hipGraph: both coordinate sets from the device-resident generator the negatives' batch maps
+            # use, one launch (torch's generator inside a graph: one launch per tensor and two 64-bit fills per replay)
+            c1, c2 = ops.rand_coords_state(self._graph_state(dev), coord_shape)
+            return c1, c2, False
         c1 = _rand_coords(coord_shape, dev)
         c2 = _rand_coords(coord_shape, dev)
         return c1, c2, False
+
+    def _graph_state(self, dev):
+        """Generator state on the device (hipGraph-capturable step: nothing about a draw is baked into a launch)."""
+        if self._perm_state is None or self._perm_state.device != dev:
+            self._perm_state = ops.new_perm_state(dev)
+        return self._perm_state
 
     @staticmethod
     def _check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth):
@@ -199,10 +210,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                                                      depth, depth_pos, same_maps=orig_code.shape[-2:] == orig_feats.shape[-2:])
         state = None
         if getattr(self.cfg, "dg_graph_safe", False):
-            # generator state on the device (hipGraph-capturable step: nothing about the draw is baked into the launch)
-            if self._perm_state is None or self._perm_state.device != orig_feats.device:
-                self._perm_state = ops.new_perm_state(orig_feats.device)
-            state = self._perm_state
+            state = self._graph_state(orig_feats.device)
         # the negatives' batch maps (super_perm, src/modules.py:1340-1342) are drawn by the forward itself: perms=None
         # (seed from torch's CPU generator unless the device generator is in use); `shared` is only ever set together with the
         # identity grid drawn above

@@ -346,6 +346,18 @@ def new_perm_state(device):
     return torch.tensor([seed, 0, 0], dtype=torch.int64, device=device)
 
 
+def rand_coords_state(state, shape):
+    """Two coordinate tensors of `shape` (B, S, S2, 2), uniform in [-1, 1), from the device-resident generator `state`
+    (new_perm_state) in ONE launch - for steps recorded in a hipGraph (dg_rand_coords_state); advances the state."""
+    lib = _lib.load()
+    if state.dtype != torch.int64 or state.numel() != 3 or not state.is_cuda:
+        raise ValueError("rand_coords_state: state must be the int64[3] device tensor of new_perm_state")
+    both = _empty((2,) + tuple(int(v) for v in shape), torch.float32, state.device)
+    rc = lib.dg_rand_coords_state(_ptr(state), both.numel(), _ptr(both), _stream(state.device))
+    _lib.check(rc, "dg_rand_coords_state")
+    return both[0], both[1]
+
+
 def super_perms(count, size, device, keys=None, state=None):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one kernel.  `state` (new_perm_state):
     the draw is keyed by device memory and advances it - safe to record in a hipGraph (every replay draws anew)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 111   /* 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 112   /* 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -323,6 +323,11 @@ int dg_super_perms_seeded(uint64_t seed, int32_t count, int32_t B, int64_t* out,
  * yields new permutations on every replay - the reference draws them with the device generator at the same place,
  * src/modules.py:1184-1188,1336-1339. */
 int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out, dg_stream_t stream);
+/* The random sample coordinates of a step (`torch.rand(B, S, S, 2) * 2 - 1` for coords1 and coords2, src/modules.py:1310-1321) from
+ * the same device-resident generator: n floats in [-1, 1) into `out`, one launch for both coordinate sets; advances the state.  For
+ * steps recorded in a hipGraph (cfg.dg_graph_safe), where torch's generator costs two launches per tensor and two fills per replay;
+ * the values are NOT torch's stream (neither are that mode's permutations).  (version 112) */
+int dg_rand_coords_state(uint64_t* state, int64_t n, float* out, dg_stream_t stream);
 
 /*
  * The segmentation head of DinoFeaturizer (replaces `cluster1(dropout(f)) + cluster2(dropout(f))` and the third

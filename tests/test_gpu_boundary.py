@@ -346,3 +346,53 @@ def test_exact_masks_flag_where_it_does_not_apply(dev):
         co = O.identity_coords(2, 14).to(dev)
         ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), c.to(dev), cp.to(dev), d.to(dev), co, co,
                                                      [p.to(dev) for p in perms], shared_coords=True, identity_grid=True)
+
+
+# ------------------------------------------------------------------------------------------ coordinates of a graph-recorded step
+@pytest.mark.gpu
+def test_rand_coords_from_the_device_generator(dev):
+    """cfg.dg_graph_safe: the random sample coordinates (`torch.rand(B, S, S, 2) * 2 - 1` twice, src/modules.py:1310-1321) come from the
+    device-resident generator of the negatives' batch maps (dg_rand_coords_state), one launch for both sets: uniform on [-1, 1)
+    (mean 0, variance 1/3, all 24-bit grid points), the two sets and successive calls differ, the state's draw count advances by one per
+    call, the same seed gives the same sequence; recorded in a hipGraph every replay draws anew.  Without the flag the module keeps
+    torch's generator (tests/test_gpu_parity.py::test_module_rng_path_fps_and_rand)."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from oracle import depthg_oracle as O
+    torch.manual_seed(5)
+    st = ops.new_perm_state(dev)
+    c1, c2 = ops.rand_coords_state(st, (32, 11, 11, 2))
+    d1, d2 = ops.rand_coords_state(st, (32, 11, 11, 2))
+    assert c1.shape == (32, 11, 11, 2) and int(st[1]) == 2
+    allv = torch.cat([c1.flatten(), c2.flatten(), d1.flatten(), d2.flatten()])
+    assert float(allv.min()) >= -1.0 and float(allv.max()) < 1.0
+    assert abs(float(allv.mean())) < 0.02 and abs(float(allv.var()) - 1.0 / 3.0) < 0.02
+    assert not torch.equal(c1, c2) and not torch.equal(c1, d1)
+    assert torch.equal((allv + 1) * 8388608, torch.round((allv + 1) * 8388608))        # u * 2 - 1 with u on the 2^-24 grid
+    torch.manual_seed(5)
+    st2 = ops.new_perm_state(dev)
+    e1, e2 = ops.rand_coords_state(st2, (32, 11, 11, 2))
+    assert torch.equal(e1, c1) and torch.equal(e2, c2)
+    # the module: graph-safe calls draw from the state (and advance it: coordinates, then the negatives' maps), plain calls from torch
+    g = torch.Generator().manual_seed(3)
+    B, C, D, hw = 4, 64, 16, 14
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+    cfg = O.default_cfg(feature_samples=5, neg_samples=2, dim=D, dg_outputs="reduced", depth_feat_correlation_loss=False, dg_graph_safe=True)
+    lf = ContrastiveCorrelationLoss(cfg)
+    lf(f, fp, None, None, c, cp)
+    a = lf.last_scalars.clone()
+    n1 = int(lf._perm_state[1])
+    lf(f, fp, None, None, c, cp)
+    assert int(lf._perm_state[1]) == n1 + 2 and not torch.equal(lf.last_scalars, a)      # (one draw for the coordinates, one for the maps)
+    # recorded once, replayed twice: different coordinates each time
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lf(f, fp, None, None, c, cp)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            lf(f, fp, None, None, c, cp)
+            out = lf.last_scalars
+        graph.replay(); torch.cuda.synchronize(); r1 = out.clone()
+        graph.replay(); torch.cuda.synchronize(); r2 = out.clone()
+    assert torch.isfinite(r1).all() and not torch.equal(r1, r2)
