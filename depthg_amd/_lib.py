@@ -13,7 +13,7 @@ DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARE
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
-           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_fps_coords_pair", "dg_rand_coords_state", "dg_super_perms",
+           "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_fps_coords_pair", "dg_rand_coords_state", "dg_rand_keep_state", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
@@ -94,6 +94,8 @@ def load():
     lib.dg_fps_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_rand_coords_state.restype = ctypes.c_int
     lib.dg_rand_coords_state.argtypes = [vp, ctypes.c_int64, vp, vp]
+    lib.dg_rand_keep_state.restype = ctypes.c_int
+    lib.dg_rand_keep_state.argtypes = [vp, ctypes.c_int64, ctypes.c_float, vp, vp]
     lib.dg_fps_coords_pair.restype = ctypes.c_int
     lib.dg_fps_coords_pair.argtypes = [vp, vp] + [ctypes.c_int32] * 6 + [vp, vp, vp]
     lib.dg_super_perms.restype = ctypes.c_int

@@ -702,6 +702,13 @@ extern "C" int dg_rand_coords_state(uint64_t* state, int64_t n, float* out, dg_s
     return DG_OK;
 }
 
+extern "C" int dg_rand_keep_state(uint64_t* state, int64_t n, float p_keep, float* out, dg_stream_t stream_) {
+    if (!state || !out) return fail(DG_ERR_INVALID, "null pointer");
+    if (n < 1 || n > (1ll << 24) || !(p_keep >= 0.f && p_keep <= 1.f)) return fail(DG_ERR_INVALID, "dg_rand_keep_state: n=%lld, p_keep=%g", (long long)n, (double)p_keep);
+    DG_HIP(dg_launch_rand_coords_state(reinterpret_cast<unsigned long long*>(state), out, (int)n, static_cast<hipStream_t>(stream_), p_keep));
+    return DG_OK;
+}
+
 extern "C" int dg_salience_coords(const float* salience, int32_t B, int32_t H, int32_t W, int32_t n, const float* u_sel,
                                   const float* u_fallback, float* out_coords, dg_stream_t stream_) {
     if (!salience || !u_sel || !u_fallback || !out_coords) return fail(DG_ERR_INVALID, "null pointer");

@@ -1099,21 +1099,31 @@ hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long
 
 // ------------------------------------------------------------------------------------------
 // The random sample coordinates of a step (`torch.rand(B, S, S, 2) * 2 - 1`, twice: src/modules.py:1310-1321) from the
-// device-resident generator of dg_super_perm_row: `n` floats in [-1, 1), keyed by {state[0], state[1]} READ FROM THE DEVICE; the one
-// block advances the draw count when it is done, so the permutations drawn next (and the next step's coordinates) use another
+// device-resident generator of dg_super_perm_row: `n` floats in [-1, 1), keyed by {state[0], state[1]} READ FROM THE DEVICE; the
+// block that finishes last advances the draw count, so the permutations drawn next (and the next step's coordinates) use another
 // key.  For steps recorded in a hipGraph (cfg.dg_graph_safe): torch's own generator costs two launches per tensor there and two
 // 64-bit fills per replay for its seed / offset.  Counters 2^31 .. : disjoint from the permutation keys' row * B + i.
-__global__ __launch_bounds__(1024) void k_rand_coords_state(unsigned long long* __restrict__ state, float* __restrict__ out, int n) {
+// keep_p >= 0: Bernoulli(keep_p) keep flags (1 / 0) instead - the Dropout2d draws of a graph-recorded step (dg_rand_keep_state).
+__global__ __launch_bounds__(256) void k_rand_coords_state(unsigned long long* __restrict__ state, float* __restrict__ out, int n, float keep_p) {
     const unsigned long long seed = state[0], draw = state[1];
     const uint64_t key = seed + 0x9E3779B97F4A7C15ull * draw;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float u = (float)(dg_philox(key, 0x80000000u + (uint32_t)i) >> 8) * (1.0f / 16777216.0f);      // [0, 1)
-        out[i] = u * 2.f - 1.f;
+        out[i] = keep_p >= 0.f ? (u < keep_p ? 1.f : 0.f) : u * 2.f - 1.f;
     }
-    __syncthreads();                                        // (every thread has read the state)
-    if (threadIdx.x == 0) state[1] = draw + 1;
+    __syncthreads();                                        // (every thread of the block has read the state)
+    if (threadIdx.x == 0) {
+        // the block that finishes last advances the draw count (ticket in state[2], as dg_super_perm_row)
+        __threadfence();
+        if (atomicAdd(&state[2], 1ull) == (unsigned long long)gridDim.x - 1) {
+            state[1] = draw + 1;
+            state[2] = 0;
+            __threadfence();
+        }
+    }
 }
-hipError_t dg_launch_rand_coords_state(unsigned long long* state, float* out, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_rand_coords_state, dim3(1), dim3(1024), 0, s, state, out, n);
+hipError_t dg_launch_rand_coords_state(unsigned long long* state, float* out, int n, hipStream_t s, float keep_p) {
+    const int blocks = n >= 256 * 256 ? 256 : (n + 255) / 256;     // (ten Philox rounds per value: one block was 15 us for the 74 k mask flags of a step)
+    hipLaunchKernelGGL(k_rand_coords_state, dim3(blocks), dim3(256), 0, s, state, out, n, keep_p);
     return hipGetLastError();
 }

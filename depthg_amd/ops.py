@@ -358,6 +358,23 @@ def rand_coords_state(state, shape):
     return both[0], both[1]
 
 
+def keep_masks_state(state, rows, C, p=0.1, use=(True, True, True)):
+    """The Dropout2d keep masks of a graph-recorded step from the device-resident generator, ONE launch: a tuple of three (rows, C)
+    tensors of 1 / 0 (keep with probability 1 - p), None where `use` is False - what ProjectionHead.forward(_pair) takes as `keeps`
+    (rows = B, or 2B for forward_pair).  Advances the state; not torch's random stream."""
+    lib = _lib.load()
+    if state.dtype != torch.int64 or state.numel() != 3 or not state.is_cuda:
+        raise ValueError("keep_masks_state: state must be the int64[3] device tensor of new_perm_state")
+    k = sum(1 for u in use if u)
+    if k == 0:
+        return (None, None, None)
+    buf = _empty((k, int(rows), int(C)), torch.float32, state.device)
+    rc = lib.dg_rand_keep_state(_ptr(state), buf.numel(), float(1.0 - p), _ptr(buf), _stream(state.device))
+    _lib.check(rc, "dg_rand_keep_state")
+    it = iter(range(k))
+    return tuple(buf[next(it)] if u else None for u in use)
+
+
 def super_perms(count, size, device, keys=None, state=None):
     """(count, size) int64: independent super_perm draws (src/modules.py:1184-1188), one kernel.  `state` (new_perm_state):
     the draw is keyed by device memory and advances it - safe to record in a hipGraph (every replay draws anew)."""

@@ -328,6 +328,10 @@ int dg_super_perms_state(uint64_t* state, int32_t count, int32_t B, int64_t* out
  * steps recorded in a hipGraph (cfg.dg_graph_safe), where torch's generator costs two launches per tensor and two fills per replay;
  * the values are NOT torch's stream (neither are that mode's permutations).  (version 112) */
 int dg_rand_coords_state(uint64_t* state, int64_t n, float* out, dg_stream_t stream);
+/* Dropout2d keep flags of a graph-recorded step from the same generator: n floats, 1 with probability p_keep else 0 (what the head's
+ * keep1 / keep2 / keep3 take; the reference draws them with nn.Dropout2d, src/modules.py:122-132).  One launch for all the masks of a
+ * step; advances the state; not torch's stream.  (version 112) */
+int dg_rand_keep_state(uint64_t* state, int64_t n, float p_keep, float* out, dg_stream_t stream);
 
 /*
  * The segmentation head of DinoFeaturizer (replaces `cluster1(dropout(f)) + cluster2(dropout(f))` and the third

@@ -244,3 +244,25 @@ def test_head_pair_equals_two_calls(B, C, D, hw, proj, dev):
     assert torch.equal(end_inside, end_two) and torch.equal(end_pair, end_two)
     with pytest.raises(ValueError, match="depthg_amd"):
         head.forward_pair(f, fp[:, :, : hw - 1], True) if proj is not None else (_ for _ in ()).throw(ValueError("depthg_amd: n/a"))
+
+
+def test_keep_masks_from_the_device_generator(dev):
+    """ops.keep_masks_state (dg_rand_keep_state): the Dropout2d masks of a hipGraph-recorded step from the device-resident generator,
+    one launch - flags 1 / 0 with keep frequency 1 - p, only the requested ones, successive draws differ, and the head takes them
+    as `keeps` exactly like masks drawn by torch."""
+    from depthg_amd import ops
+    from depthg_amd.head import ProjectionHead
+    torch.manual_seed(11)
+    st = ops.new_perm_state(dev)
+    k1, k2, k3 = ops.keep_masks_state(st, 64, 384, 0.1)
+    assert k1.shape == (64, 384) and int(st[1]) == 1
+    allk = torch.stack([k1, k2, k3])
+    assert bool(((allk == 0) | (allk == 1)).all()) and abs(float(allk.mean()) - 0.9) < 0.01
+    assert not torch.equal(k1, k2)
+    a, b, c = ops.keep_masks_state(st, 64, 384, 0.1, use=(True, False, True))
+    assert b is None and not torch.equal(a, k1) and int(st[1]) == 2
+    head = ProjectionHead(384, 70).to(dev).train()
+    f, fp = torch.randn(32, 384, 28, 28, device=dev), torch.randn(32, 384, 28, 28, device=dev)
+    (c1, f1), (c2, f2) = head.forward_pair(f, fp, True, (k1, k2, k3))
+    assert torch.isfinite(c1).all() and torch.isfinite(c2).all()
+    assert bool((f1.abs().sum((2, 3))[k3[:32] == 0] == 0).all()) and bool((f2.abs().sum((2, 3))[k3[32:] == 0] == 0).all())
