@@ -867,9 +867,11 @@ static int head_check(int32_t B, int32_t C, int32_t D, int32_t P) {
 static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P, int32_t M2 = 0) {     // (M2: a second product in the same launch)
     const int tiles = ((M + 127) / 128 + (M2 + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
 #ifndef HEAD_SPLIT_TARGET
-#define HEAD_SPLIT_TARGET 512
+    // about two blocks per CU; three when both featurizer passes of a step share the launch (1600 position steps at the headline:
+    // 512 / 640 / 768 / 896 blocks gave 136 / 132 / 128 / 133 us for the two weight-gradient launches and their reduction)
+    const int HEAD_SPLIT_TARGET = steps >= 1200 ? 768 : 512;
 #endif
-    int s = (HEAD_SPLIT_TARGET + tiles - 1) / tiles;        // about two blocks per CU
+    int s = (HEAD_SPLIT_TARGET + tiles - 1) / tiles;
     s = (s + 7) & ~7;                                       // a multiple of 8: k_head_wgrad2 keeps the tiles of a split on one XCD
     return s > steps ? steps : s;
 }
