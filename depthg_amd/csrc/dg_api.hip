@@ -196,16 +196,25 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 
 // k_gs jobs: one per pair-set; the producing job of the G tiles is helper_job(t) of the fused launch (R = operand 1,
 // S = operand 2 of pair-set t)
+// Without `pointwise` the intra pair-set (t = 0) has NO job here (round 4): it correlates the anchors with themselves at the same
+// coordinates, so fd, cd and with them -G are symmetric and the gradient through the streamed side equals the one through the
+// stationary side, which the fused kernel accumulates in registers anyway - the backward doubles that one (as it always did for the
+// depth term) instead of reading 1/7 of the G tiles again.  With `pointwise` -G is NOT symmetric: the reference centres fd by its
+// ROW means only (fd -= fd.mean([3, 4]), src/modules.py:1238-1239), -G[p][q] - -G[q][p] = mask (rowmean_q - rowmean_p) - invisible
+// on i.i.d. features, 1e-2 of the gradient on the FPS recipes (the test with exact masks caught it).
+static bool intra_is_symmetric(const Plan& p) { return !p.pointwise; }
 static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArgs& g) {
     memset(&g, 0, sizeof(g));
-    g.njobs = p.T; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD; g.D = p.D;
-    for (int t = 0; t < p.T; ++t) {
+    const int t0 = intra_is_symmetric(p) ? 1 : 0;
+    g.njobs = p.T - t0; g.B = p.B; g.P = p.P; g.Ppad = p.Ppad; g.KF = p.KF; g.KD = p.KD; g.D = p.D;
+    for (int t = t0; t < p.T; ++t) {
         const int o2 = op_of(p, t);
-        g.jobs[t].G = reinterpret_cast<const uint16_t*>(ws + p.gbuf[t]);
-        g.jobs[t].Rop = ws + p.op[0]; g.jobs[t].ridx = nullptr;
-        g.jobs[t].Sop = ws + p.op[o2]; g.jobs[t].sidx = map_of(p, t, perms);
-        g.jobs[t].ScInv = reinterpret_cast<const float*>(ws + p.inv[o2]);
-        g.jobs[t].dS = reinterpret_cast<float*>(ws + p.dRB[t]);
+        DgGsJob& J = g.jobs[t - t0];
+        J.G = reinterpret_cast<const uint16_t*>(ws + p.gbuf[t]);
+        J.Rop = ws + p.op[0]; J.ridx = nullptr;
+        J.Sop = ws + p.op[o2]; J.sidx = map_of(p, t, perms);
+        J.ScInv = reinterpret_cast<const float*>(ws + p.inv[o2]);
+        J.dS = reinterpret_cast<float*>(ws + p.dRB[t]);
     }
 }
 
@@ -591,8 +600,8 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     };
     // dRA[t]: the fused kernel's raw accumulator-order tiles (stationary operand = operand 1 for every pair-set);
     // dRB[t]: k_gs output, row-major, normalisation backward already applied
-    add(p.dRA[0], nullptr, 0, 0, f, 0, 1);
-    add(p.dRB[0], nullptr, 0, 0, f, 0, 0);
+    if (intra_is_symmetric(p)) add(p.dRA[0], nullptr, 0, 0, 2.0f * f, 0, 1);      // -G symmetric: d/dc1 + d/dc2 = 2 d/dc1 (no k_gs job, build_gs_jobs)
+    else { add(p.dRA[0], nullptr, 0, 0, f, 0, 1); add(p.dRB[0], nullptr, 0, 0, f, 0, 0); }
     add(p.dRA[1], nullptr, 1, 0, f, 0, 1);
     add(p.dRB[1], nullptr, 1, 1, f, 1, 0);
     for (int k = 0; k < p.N; ++k) {
