@@ -196,6 +196,27 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 
 // k_gs jobs: one per pair-set; the producing job of the G tiles is helper_job(t) of the fused launch (R = operand 1,
 // S = operand 2 of pair-set t)
+// A second stream of the library's own (one per device, created on the first call that is not being captured into a graph) for the
+// launches that may run beside each other inside one call; null while none exists and the caller's stream is capturing (creating
+// one there is not a capturable operation: the call then launches in sequence).
+struct SideStream { hipStream_t s; hipEvent_t fork, join; };
+static SideStream* side_stream_for(hipStream_t caller) {
+    static std::mutex mu;
+    static std::map<int, SideStream> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = table.find(dev);
+    if (it != table.end()) return &it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    SideStream ss;
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+    return &table.emplace(dev, ss).first->second;
+}
+
 // Without `pointwise` the intra pair-set (t = 0) has NO job here (round 4): it correlates the anchors with themselves at the same
 // coordinates, so fd, cd and with them -G are symmetric and the gradient through the streamed side equals the one through the
 // stationary side, which the fused kernel accumulates in registers anyway - the backward doubles that one (as it always did for the
@@ -540,12 +561,24 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             clamp_bounds(desc, g.dep_lo, g.dep_hi);
         }
         if (p.xmask_dense && p.depth) {
-            // the G-stream blocks as a launch of the plain kernel (two blocks per CU), then the depth blocks alone in the masked
-            // form (256 registers per wave); the last depth block reduces the call's partial sums
+            // the G-stream blocks as a launch of the plain kernel (two blocks per CU) and the depth blocks alone in the masked form
+            // (256 registers per wave; the last depth block reduces the call's partial sums) - SIDE BY SIDE on a second stream
+            // where the library has one (fork / join by events, capturable into a hipGraph): the stream launch is bound by HBM
+            // bytes, the 128 depth blocks by a latency chain on half the CUs (one behind the other: 76 + 52 us)
             DgGsArgs gstream = g;
             gstream.dep_blocks = 0; gstream.fin.out = nullptr;
-            DG_HIP(dg_launch_gs(gstream, nullptr, stream));
-            DG_HIP(dg_launch_gs(g, dep_maskbits, stream, true));
+            SideStream* side = side_stream_for(stream);
+            if (side) {
+                DG_HIP(hipEventRecord(side->fork, stream));
+                DG_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+                DG_HIP(dg_launch_gs(g, dep_maskbits, side->s, true));
+                DG_HIP(hipEventRecord(side->join, side->s));
+                DG_HIP(dg_launch_gs(gstream, nullptr, stream));
+                DG_HIP(hipStreamWaitEvent(stream, side->join, 0));
+            } else {
+                DG_HIP(dg_launch_gs(gstream, nullptr, stream));
+                DG_HIP(dg_launch_gs(g, dep_maskbits, stream, true));
+            }
         } else {
             DG_HIP(dg_launch_gs(g, dep_maskbits, stream));
         }
