@@ -1036,19 +1036,29 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
     const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + (size_t)2 * D * C + (size_t)C * C;
     DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P, Bs, d_g};
-    DG_HIP(dg_launch_head_dh(d, s));
-    reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
-    reduce(F32(h.pb2a), grad_b2a, nullptr, C, B * h.tiles, 1.f);
+    // d W2b = d code x hidden^T needs nothing of k_head_dh: it runs BESIDE it on the library's second stream where there is one (fork
+    // / join by events, capturable): two launches that each leave most of the chip idle (27 and 37 us at the paired headline shape)
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
     wb.A2 = nullptr; wb.keep_2 = nullptr; wb.part2 = nullptr; wb.M2 = 0;
     wb.Bs = Bs; wb.dA = d_g; wb.dB = 0; wb.dA2 = 0;
-    DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
+    SideStream* side = side_stream_for(s);
+    if (side) {
+        DG_HIP(hipEventRecord(side->fork, s));
+        DG_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+        DG_HIP(dg_launch_head_wgrad(wb, false, true, side->s));
+        DG_HIP(hipEventRecord(side->join, side->s));
+    }
+    DG_HIP(dg_launch_head_dh(d, s));
+    reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
+    reduce(F32(h.pb2a), grad_b2a, nullptr, C, B * h.tiles, 1.f);
+    if (!side) DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
     reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
     DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
     wa.Bs = Bs; wa.dA = 0; wa.dB = d_feat; wa.dA2 = d_g;
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);
+    if (side) DG_HIP(hipStreamWaitEvent(s, side->join, 0));
     DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
 }
