@@ -19,6 +19,10 @@
 //     D  dR_1 += G_1^T ScP (6 MFMAs)                                 gaps: rest of that epilogue, G store, fd init of fragment 0
 // An accumulator is read by the VALU no sooner than two MFMAs after the chain that wrote it (the asm MFMAs are invisible to
 // hipcc's hazard recogniser).  Outputs are those of k_corr_main: G tiles (fp16) for k_gs, raw gradient tiles, block sums.
+//
+// Round 4: the workgroups are PERSISTENT (one per CU, walking the work items).  BUILD THIS FILE WITH `-mllvm -disable-machine-licm`
+// (the Makefile's rule for dg_corr2.o, scripts/build_variant.sh, the audit in tests/test_host_cpu.py): without it hipcc hoists
+// constants of the item body out of the walk and spills scalar registers into VGPR lanes (correct, slower).
 #include "dg_common.h"
 #include <utility>
 #include <cstdio>
