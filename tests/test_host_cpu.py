@@ -378,3 +378,22 @@ def test_head_draws_only_the_masks_the_reference_draws():
         for g, w in zip(got, want):
             assert (g is None and w is None) or torch.equal(g, w)
         assert torch.equal(after, after_ref), use
+
+
+def test_round4_entry_points_refuse_cpu_tensors_and_bad_state():
+    """The entry points added in round 4 have no CPU path either, and the device-generator helpers check their state tensor before a
+    pointer reaches the library: forward_pair (two passes whose features do not match), rand_coords_state / keep_masks_state (state
+    not the int64[3] device tensor), fps_coords_pair (depth maps that do not match)."""
+    from depthg_amd import ops
+    from depthg_amd.head import ProjectionHead
+    head = ProjectionHead(64, 16).train()
+    f = torch.randn(2, 64, 9, 9)
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        head.forward_pair(f, f.clone())
+    for bad in (torch.zeros(3, dtype=torch.int64), torch.zeros(4, dtype=torch.int32)):
+        with pytest.raises(ValueError, match="state must be"):
+            ops.rand_coords_state(bad, (2, 3, 3, 2))
+        with pytest.raises(ValueError, match="state must be"):
+            ops.keep_masks_state(bad, 4, 64)
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        ops.fps_coords_pair(torch.rand(2, 1, 32, 32), torch.rand(2, 1, 32, 32), (8, 8), 3)
