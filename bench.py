@@ -501,6 +501,8 @@ def main():
             "config": {"workload": conf["what"] + (" [step replayed from a hipGraph]" if graph_mode else " [eager step]"),
                        "name": args.config, "schedule": "hipGraph replay" if graph_mode else "eager",
                        "exact_masks": bool(args.exact_masks),
+                       "random_draws": ("device-resident generator (coordinates, batch maps, Dropout2d masks: one launch each)" if graph_mode
+                                        else "torch generator for coordinates and masks, library seed for the batch maps"),
                        "global_batch": H["B"] * world, "parallelism": f"dp{world}",
                        "ranks_seen": dist_diag["ranks_seen"] if dist_diag else 1,
                        "clock_warmup_steps": clock_warmup_steps,
