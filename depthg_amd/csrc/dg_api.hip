@@ -247,6 +247,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
                            int* depth_index) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     corr_args_base(p, desc, ws, a);
+    a.wctr = p.grad ? reinterpret_cast<uint32_t*>(ws + p.ticket) + 16 : nullptr;      // (behind the depth blocks' ticket word)
     const double numel = (double)p.B * p.P * p.P;
     int nj = 0;
     for (int t = 0; t < p.T; ++t) {
@@ -483,6 +484,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             c.ccolpart[o] = F32(p.ccolpart[o]); c.csum[o] = F32(p.csum[o]);
         }
         c.zero_word = (p.grad && p.depth) ? reinterpret_cast<unsigned int*>(ws + p.ticket) : nullptr;
+        c.zero_words9 = a.wctr;
         if (a.gr_list) {           // the consumer lists of k_corr2's grouped ragged blocks ride along (extra blocks of this launch)
             const int nd = a.jobs[a.njobs - 1].kind == DG_JOB_DEPTH ? 1 : 0;
             c.gr.nh = a.njobs - nd; c.gr.nkeys = a.gr_nkeys; c.gr.B = p.B;

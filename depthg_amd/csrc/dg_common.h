@@ -217,6 +217,8 @@ struct DgCorrArgs {
     int32_t pos_w;        // > 0: positions are pixel indices y*w + x of a w x w identity grid (DG_IDENTITY_GRID); the un-reduced outputs
                           //      (materialise) are written at the reference's position x*w + y
     int32_t debug;        // developer ablation bits (0 in production)
+    uint32_t* wctr;       // k_corr2's persistent workgroups: [0..7] items handed out so far per XCD (beyond each workgroup's first), [8]
+                          // workgroups that have left; all zero at launch (k_colmean) and again when the last workgroup leaves; null: static walk
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
     // ragged last row blocks grouped by streamed operand (dg_corr2.hip; lists written by k_group_ragged); gr_list null: off
@@ -461,6 +463,7 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
     int32_t ngroups[DG_MAX_NEG + 2];   // feats partial-sum groups per image (tiles, or source rows on the dense path)
     int32_t nops, B, P, Ppad, KF, KD;
     unsigned int* zero_word;           // a word this launch sets to 0 (the depth blocks' ticket of the k_gs launch), or null
+    unsigned int* zero_words9;         // nine words this launch sets to 0 (DgCorrArgs.wctr), or null
     DgGroupArgs gr;                    // gr.nkeys > 0: blockIdx.z == 2 writes the consumer lists of k_corr2's grouped ragged blocks
     DgDenseCodeArgs dc;                // dc.B > 0: blockIdx.z == 3 builds the dense code operands (and blockIdx.z == 1 is the k_rowmean launch's)
 };

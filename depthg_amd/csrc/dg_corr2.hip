@@ -195,7 +195,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
-template <int NKF, int NKD, int NKC, bool XM = false>
+template <int NKF, int NKD, int NKC, bool XM = false, bool DYN = false>      // DYN: the dynamic walk (many items per workgroup), below
 __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     using BL = BlobT<NKF, NKD>;
     constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
@@ -222,7 +222,33 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     //      each walks the work items orig = blockIdx.x, + gridDim.x, ... - what the dispatcher did with one workgroup per item, minus
     //      its 0.8 us between two workgroups of a CU.  All four waves take the same items (wave-uniform control flow).
     const int nitems = args_k.njobs * args_k.B * args_k.nrb + (args_k.gr_list ? args_k.B * args_k.gr_blocks_per_image : 0);
-    for (int orig = blockIdx.x; orig < nitems; orig += gridDim.x) {
+    // The walk is DYNAMIC where a workgroup has many items (six or more on average: config 5's 56 x 56 grid, 12 per workgroup, whose
+    // grouped and full items of different lengths a fixed round-robin balances badly: 3.43 -> 3.31 ms): a workgroup's first item is
+    // its own index, every further one the next not yet taken on its XCD (one counter per XCD: an item's XCD stays its index modulo
+    // 8).  With three or four items per workgroup (the headline) the fixed walk keeps the row blocks that stream the same operand
+    // in step and is 0.6 % faster; nothing finer than a 47-us item could make up for a workgroup that starts late either way.  The
+    // next index is asked for in front of the item's tile loop (thread 0; the answer is needed 40 us later; asked at the very start
+    // of the item the request stood in front of every load of the block's start in the in-order vmcnt queue: +3 % on the kernel)
+    // and passed on through LDS at the item's end; an item that turns out to be served by a group asks and waits on the spot.
+    __shared__ int next_item_s;
+    int next_orig = 0;
+    for (int orig = blockIdx.x; orig < nitems; orig = next_orig) {
+    unsigned taken = 0;                 // (thread 0) items of this XCD handed out before this request
+    // (pointer and mode re-derived per item from the kernel arguments: two scalar registers less across the tile loops)
+    constexpr bool dyn = DYN;       // (the launcher's choice: counters present, a grid of whole XCD rounds, six or more items per workgroup)
+    auto request = [&]() {
+        if (dyn && threadIdx.x == 0) taken = __hip_atomic_fetch_add(&args_k.wctr[blockIdx.x & 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // all threads: the item after this one (dynamic: thread 0's answer through LDS; one barrier)
+    auto advance = [&]() {
+        if constexpr (DYN) {
+            if (threadIdx.x == 0) next_item_s = (int)(blockIdx.x & 7) + 8 * (int)((gridDim.x >> 3) + taken);
+            __syncthreads();
+            next_orig = next_item_s;
+        } else {
+            next_orig = orig + (int)gridDim.x;
+        }
+    };
     // The kernel arguments are read through a pointer hipcc cannot see through, once per item: as loop invariants it kept the job
     // table's fields in scalar registers across the walk, spilled seventy of them into VGPR lanes and took accumulator registers
     // for its own values (the audit of tests/test_host_cpu.py).  Still the kernel-argument segment: scalar loads, as before.
@@ -309,14 +335,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         if (kind == 2 && grouped) {
             // this (jid, n) is served by a grouped block unless its rank lies beyond the group's blocks
             const int key = args.gr_key[jid];
-            if ((int)args.gr_rank[jid * args.B + n] < args.gr_nblk[key] * args.gr_cpb) continue;
+            if ((int)args.gr_rank[jid * args.B + n] < args.gr_nblk[key] * args.gr_cpb) { request(); advance(); continue; }
         }
         if (kind == 1) {
             // image n of this chunk is the STREAMED image; the consumers come from the list of (key, n)
             mS = n; sidx_p = nullptr;
             const int cnt = args.gr_count[gkey * args.B + n];
             const int c0 = gpart * args.gr_cpb;
-            if (c0 >= cnt) continue;
+            if (c0 >= cnt) { request(); advance(); continue; }
             jid_first = args.gr_first[gkey];
             bool any = false;
 #pragma unroll
@@ -719,6 +745,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #ifdef C2_BLOCKLOG
     if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[3] = wall_clock64(); }
 #endif
+    request();
     if (act[1]) run(std::true_type{}, std::true_type{});
     else if (act[0]) run(std::true_type{}, std::false_type{});
     else run(std::false_type{}, std::false_type{});
@@ -827,7 +854,16 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         for (int i = tid; i < NW * 25 * 6 + NW * 4; i += 256) args.stamps[i] = st_lds[i];
     }
 #endif
+    advance();
     }       // (next work item)
+    // the last workgroup to leave puts the counters back to zero (a re-launch on the same workspace - dg_corr_relaunch_main - finds
+    // them as k_colmean left them for this one)
+    if (DYN && threadIdx.x == 0) {
+        uint32_t* const wctr = args_k.wctr;
+        if (__hip_atomic_fetch_add(&wctr[8], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            for (int k = 0; k < 9; ++k) __hip_atomic_store(&wctr[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // blocks of a launch: per image the pair-sets' row blocks; with grouped ragged row blocks (args.gr_list)
@@ -875,14 +911,18 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         // exact clamp masks (DG_EXACT_MASKS on the dense grid): the mask words of k_cd_mask instead of the sign of the fp16 cd;
         // 8 KiB more LDS for the four-slot word ring of the eight fragments
         const int smem_x = 4 * BL::BYTES + C2_RED_BYTES + 4 * 2 * 4 * 256;
-        auto kx = k_corr2<24, 6, 5, true>;
+        const int gx = dg_corr2_launch_grid(args);
+        const bool dynx = args.wctr != nullptr && (gx & 7) == 0 && dg_corr2_grid(args) >= 6 * gx;
+        auto kx = dynx ? k_corr2<24, 6, 5, true, true> : k_corr2<24, 6, 5, true, false>;
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
-        hipLaunchKernelGGL(kx, dim3(dg_corr2_launch_grid(args)), dim3(256), smem_x, stream, args);
+        hipLaunchKernelGGL(kx, dim3(gx), dim3(256), smem_x, stream, args);
         return hipGetLastError();
     }
     const int smem = 4 * BL::BYTES + C2_RED_BYTES;
-    auto kern = k_corr2<24, 6, 5, false>;
+    const int g0 = dg_corr2_launch_grid(args);
+    const bool dyn0 = args.wctr != nullptr && (g0 & 7) == 0 && dg_corr2_grid(args) >= 6 * g0;
+    auto kern = dyn0 ? k_corr2<24, 6, 5, false, true> : k_corr2<24, 6, 5, false, false>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
 #if defined(DG_DEVTOOLS) && defined(C2_STAMPS)

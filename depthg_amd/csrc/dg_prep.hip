@@ -898,6 +898,7 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char cm_smem[];     // blockIdx.z == 3: [Ppad] 16-byte code rows
     const int n = blockIdx.x, o = blockIdx.y;
     if (a.zero_word && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.zero_word = 0u;
+    if (a.zero_words9 && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x < 9) a.zero_words9[threadIdx.x] = 0u;
     auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) { colsum_reduce(part, n, ngroups, K, scale, out); };
     if (blockIdx.z == 3) {                                // dense code operands from channel planes: y = operand * (KD / 8) + channel group
         const int GD = a.dc.KD / 8;

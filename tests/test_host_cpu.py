@@ -303,7 +303,7 @@ def test_corr2_owns_the_accumulator_file(tmp_path):
     # scalar spills land in VGPR lanes (v_writelane / v_readlane): a few in the per-item code are tolerable, none inside a tile loop
     # (blocks of loop depth 2: the kernel walks work items, depth 1, and each item walks its tiles)
     for m in re.finditer(r"\.sgpr_spill_count:\s+(\d+)", text):
-        assert int(m.group(1)) <= 4
+        assert int(m.group(1)) <= 8
     depth, in_tile_loop = 0, []
     for line in text.splitlines():
         m = re.search(r"^\.LBB\d+_\d+:.*Depth=(\d+)", line)
