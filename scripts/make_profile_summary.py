@@ -55,6 +55,8 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
     c = json.loads(l)
     name = c['config']['name'] + (" (`--force-dist`: the N > 1 schedule with one rank)" if c['config'].get('allreduce', 'none') != 'none'
                                   else " (`--eager`)" if c['config'].get('schedule') == "eager" else "")
+    if c['config'].get('exact_masks'):
+        name += " (`--exact-masks`: cfg.dg_exact_masks)"
     if "driver_args" in f:
         name += " (`--steps 20 --warmup 5`, the driver's command line)"
     o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
