@@ -888,6 +888,19 @@ static int dg_corr2_launch_grid(const DgCorrArgs& args) {
     return (ncu <= 0 || items < ncu) ? items : ncu;
 }
 
+// which walk the persistent workgroups take: dynamic (per-XCD work counters) at six or more items per workgroup, the fixed round-robin
+// below that.  DG_C2_WALK=dynamic|static overrides (read once; for tests/test_gpu_configs.py, which checks that both give the same bits)
+static bool dg_corr2_dynamic_walk(const DgCorrArgs& args, int grid) {
+    static const int forced = [] {
+        const char* e = getenv("DG_C2_WALK");
+        return !e ? 0 : (e[0] == 'd' ? 1 : (e[0] == 's' ? -1 : 0));
+    }();
+    const int items = dg_corr2_grid(args);
+    if (args.wctr == nullptr || (grid & 7) != 0 || items <= grid) return false;
+    if (forced) return forced > 0;
+    return items >= 6 * grid;
+}
+
 // Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
 // shapes this form does not cover (the caller then uses k_corr_main).
 bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD) {
@@ -912,7 +925,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         // 8 KiB more LDS for the four-slot word ring of the eight fragments
         const int smem_x = 4 * BL::BYTES + C2_RED_BYTES + 4 * 2 * 4 * 256;
         const int gx = dg_corr2_launch_grid(args);
-        const bool dynx = args.wctr != nullptr && (gx & 7) == 0 && dg_corr2_grid(args) >= 6 * gx;
+        const bool dynx = dg_corr2_dynamic_walk(args, gx);
         auto kx = dynx ? k_corr2<24, 6, 5, true, true> : k_corr2<24, 6, 5, true, false>;
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
@@ -921,7 +934,7 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
     }
     const int smem = 4 * BL::BYTES + C2_RED_BYTES;
     const int g0 = dg_corr2_launch_grid(args);
-    const bool dyn0 = args.wctr != nullptr && (g0 & 7) == 0 && dg_corr2_grid(args) >= 6 * g0;
+    const bool dyn0 = dg_corr2_dynamic_walk(args, g0);
     auto kern = dyn0 ? k_corr2<24, 6, 5, false, true> : k_corr2<24, 6, 5, false, false>;
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;

@@ -465,3 +465,39 @@ def test_bench_line_of_the_multi_gpu_schedule():
     assert lines["--eager"]["config"]["schedule"] == "eager" and d["config"]["ranks_seen"] == 1
     assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r04_pmc_per_launch.json")
 
+
+
+_WALK_CHILD = r"""
+import sys, hashlib, torch
+sys.path.insert(0, {root!r})
+import bench
+from depthg_amd import ContrastiveCorrelationLoss
+dev = torch.device("cuda:0")
+conf = bench.CONFIGS["headline"]; H = conf["H"]
+cfg = bench.make_cfg(conf)
+f, fp, c, cp, d, dp = bench.synth_inputs(H["B"], 77, dev, H)
+c.requires_grad_(True); cp.requires_grad_(True)
+torch.manual_seed(3)
+lf = ContrastiveCorrelationLoss(cfg)
+lf(f, fp, None, None, c, cp, d, dp)
+lf.total.backward()
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in (lf.last_scalars, c.grad, cp.grad):
+    h.update(t.detach().cpu().numpy().tobytes())
+print("WALK", h.hexdigest(), [float(v) for v in lf.last_scalars[:4]])
+"""
+
+
+def test_fused_kernel_walks_give_the_same_bits():
+    """k_corr2's persistent workgroups take their items either in a fixed round-robin or, with six or more items per workgroup
+    (config 5 at B = 32), from per-XCD work counters.  Which workgroup computes an item must not matter: the headline step with
+    the walk forced either way (DG_C2_WALK, read once per process) gives bit-identical scalars and gradients."""
+    seen = {}
+    for walk in ("static", "dynamic"):
+        env = dict(os.environ, DG_C2_WALK=walk)
+        r = subprocess.run([sys.executable, "-c", _WALK_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("WALK")][-1]
+        seen[walk] = line
+    assert seen["static"] == seen["dynamic"], seen
