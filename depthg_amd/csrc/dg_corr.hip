@@ -886,7 +886,12 @@ __device__ __forceinline__ void gs_body(const DgGsArgs& a, const uint32_t* dep_m
     // operand - get consecutive logical ids on one XCD, so its P parts are fetched into one L2 once
     // the depth term's blocks FIRST (they are long latency chains: started last they would be this launch's tail), then the
     // G-stream blocks
-    if ((int)blockIdx.x < a.dep_blocks) { gs_depth_block<NKF, NKD, XM>(a, dep_maskbits, (int)blockIdx.x, gs_smem); return; }
+    if ((int)blockIdx.x < a.dep_blocks) {
+        if (DG_DBG(a.debug) & 8192) return;                 // (ablation: no depth-term blocks)
+        gs_depth_block<NKF, NKD, XM>(a, dep_maskbits, (int)blockIdx.x, gs_smem);
+        return;
+    }
+    if (DG_DBG(a.debug) & 16384) return;                    // (ablation: the depth-term blocks alone)
     int bid;
     {
         const int nwg = (int)gridDim.x - a.dep_blocks, orig = (int)blockIdx.x - a.dep_blocks;
