@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--exact-masks", action="store_true",
                     help="cfg.dg_exact_masks: the clamp mask 1[cd >= 0] from fp32 dot products instead of the fp16 cd of the MFMA "
                          "chain (gradient error 1.4e-2 -> below 2e-3 relative L2; dense ViT-S grids; the default is the fast path)")
-    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph", "twocalls", "torchmasks"], default="", help=argparse.SUPPRESS)
+    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph", "twocalls", "torchmasks", "writefeats"], default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -286,7 +286,10 @@ def main():
         else:
             # (graph-recorded step: the six Dropout2d masks from the device-resident generator, one launch)
             keeps = ops.keep_masks_state(loss_fn._graph_state(dev), 2 * H["B"], H["C"], head.p) if (graph_mode and args.ablate != "torchmasks") else None
-            (code, feats), (code_pos, feats_pos) = head.forward_pair(f, fp, True, keeps)
+            # (on the identity grid the Dropout2d of the returned feats is applied by the loss's operand preparation:
+            #  --ablate writefeats is the form that writes the dropped tensors and reads them back)
+            defer = args.ablate != "writefeats" and loss_fn.takes_deferred_dropout(f.shape[-2:])
+            (code, feats), (code_pos, feats_pos) = head.forward_pair(f, fp, True, keeps, defer)
         loss_fn(feats, feats_pos, None, None, code, code_pos, d, dp)
         total = loss_fn.total
         total.backward(gradient=seed_grad)

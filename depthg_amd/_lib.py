@@ -8,14 +8,14 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 112                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 113                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
 EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_forward", "dg_corr_backward",
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_fps_coords_pair", "dg_rand_coords_state", "dg_rand_keep_state", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
-           "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw",
+           "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw", "dg_corr_forward_masked",
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
            "dg_head_backward_pair", "dg_cluster_lookup_forward",
@@ -46,6 +46,7 @@ def load():
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
     lib = ctypes.CDLL(LIB_PATH)
     vp, cp = ctypes.c_void_p, ctypes.POINTER(CorrDesc)
+    i32, f32 = ctypes.c_int32, ctypes.c_float
     lib.dg_version.restype = ctypes.c_int
     if lib.dg_version() != DG_VERSION:
         raise RuntimeError(f"depthg_amd: {LIB_PATH} is version {lib.dg_version()}, the Python layer expects {DG_VERSION}; "
@@ -57,7 +58,8 @@ def load():
     lib.dg_corr_forward.argtypes = [cp] + [vp] * 10 + [ctypes.c_size_t, vp]
     lib.dg_corr_forward_draw.restype = ctypes.c_int
     lib.dg_corr_forward_draw.argtypes = [cp] + [vp] * 8 + [ctypes.c_uint64, vp, vp, vp, ctypes.c_size_t, vp]
-    i32, f32 = ctypes.c_int32, ctypes.c_float
+    lib.dg_corr_forward_masked.restype = ctypes.c_int
+    lib.dg_corr_forward_masked.argtypes = [cp] + [vp] * 8 + [i32, ctypes.c_uint64, vp, vp, vp, f32, vp, vp, ctypes.c_size_t, vp]
     lib.dg_head_forward.restype = ctypes.c_int
     lib.dg_head_forward.argtypes = [i32] * 4 + [vp] * 10 + [f32] + [vp] * 5
     lib.dg_head_weights_bytes.restype = ctypes.c_size_t

@@ -323,11 +323,13 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
 }
 
 struct DrawArgs { int64_t* out; uint64_t seed; unsigned long long* state; };
+struct FeatKeep { const float* keep[2]; float scale; };      // deferred Dropout2d of the two feature maps (dg_corr_forward_masked)
 
 static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                              const float* orig_code, const float* orig_code_pos, const float* depth,
                              const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
-                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_);
+                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_,
+                             const FeatKeep* fk = nullptr);
 
 extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                                const float* orig_code, const float* orig_code_pos, const float* depth,
@@ -348,13 +350,30 @@ extern "C" int dg_corr_forward_draw(const dg_corr_desc* desc, const float* orig_
                              out_scalars, workspace, workspace_bytes, stream_);
 }
 
+extern "C" int dg_corr_forward_masked(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                                      const float* orig_code, const float* orig_code_pos, const float* depth,
+                                      const float* coords1, const float* coords2, int64_t* perms, int32_t draw_perms, uint64_t seed,
+                                      void* perm_state, const float* feat_keep, const float* feat_pos_keep, float keep_scale,
+                                      float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!desc) return fail(DG_ERR_INVALID, "null descriptor");
+    if (desc->n_neg > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", desc->n_neg);
+    if ((feat_keep || feat_pos_keep) && !(keep_scale > 0.f)) return fail(DG_ERR_INVALID, "keep_scale %g with keep flags", (double)keep_scale);
+    const DrawArgs draw{perms, seed, static_cast<unsigned long long*>(perm_state)};
+    const FeatKeep fk{{feat_keep, feat_pos_keep}, keep_scale};
+    return corr_forward_impl(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
+                             draw_perms ? &draw : nullptr, out_scalars, workspace, workspace_bytes, stream_, &fk);
+}
+
 static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                              const float* orig_code, const float* orig_code_pos, const float* depth,
                              const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
-                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_, const FeatKeep* fk) {
     Plan p;
     int rc = make_plan(desc, p);
     if (rc != DG_OK) return rc;
+    if (fk && (fk->keep[0] || fk->keep[1]) && !p.ident)
+        return fail(DG_ERR_UNSUPPORTED, "deferred feature dropout (feat_keep) is built for the identity grid only: "
+                                        "with sampled coordinates hand the dropped features in");
     if (!orig_feats || !orig_feats_pos || !orig_code || !orig_code_pos || !coords1 || !coords2 || !out_scalars || !workspace)
         return fail(DG_ERR_INVALID, "null tensor pointer");
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null with n_neg=%d", p.N);
@@ -377,6 +396,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
+        if (fk) { g.fkeep[0] = fk->keep[0]; g.fkeep[1] = fk->keep[1]; g.fscale = fk->scale; }
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         DG_HIP(dg_launch_prep_dense(g, stream));
         if (p.xmask_dense && !p.pointwise) {

@@ -400,6 +400,10 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     int32_t draw_count;
     int32_t code_split;      // 1: the code role only writes inv_norm (per-pixel norms from whole channel planes); the code parts of
                              //    the blobs + ccolpart come from the k_colmean launch (DgDenseCodeArgs), csum from the k_rowmean launch
+    // Dropout2d of the feature maps applied HERE instead of by their producer (dg_corr_forward_masked): fkeep[o] (B,K) keep flags
+    // 1 / 0 of source o or null, the kept channels scaled by fscale = 1/(1-p) - the product the producer would have written
+    const float* fkeep[2];
+    float fscale;
 };
 
 // Code operands of the identity grid from whole channel planes (extra blocks of the k_colmean launch, after the norms of

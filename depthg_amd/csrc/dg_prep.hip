@@ -551,7 +551,8 @@ hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s) {
 // 32 positions, image): per channel the tile is 128 contiguous, 128-byte aligned bytes of the plane; the block normalises its 32
 // positions and writes the tile's whole F part (24 KB at C = 384, contiguous).
 // (Round 2 kept the reference's order: one block per source row, 112-byte segments in, rows of 28 different tiles out.)
-template <int MAXU>      // channels per thread = KF / 8 <= MAXU
+template <int MAXU, bool FK>      // FK: the deferred Dropout2d of the source's channels (its own instantiation: 28 registers)
+     // channels per thread = KF / 8 <= MAXU
 __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl, int tile, int n, int o) {
     // thread (xl = tid & 31, k0 = tid >> 5) owns position xl of the tile and the channels k0 + 8u: all of them are loaded in one
     // batch (KF/8 <= 96 loads in flight per thread), the squared norm is reduced over the 8 threads of a position through LDS,
@@ -568,10 +569,27 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     const int nu = KF >> 3;
     float t[MAXU];
     float ss = 0.f;
+    // Dropout2d of this source's channels (nn.Dropout2d in DinoFeaturizer.forward, src/modules.py:122-137, deferred to here by
+    // dg_corr_forward_masked): x * (keep * scale), the fp32 product its producer would have stored - same bits downstream.  The
+    // flags are requested in front of the map's values so that both batches of loads are in flight together.
+    float f[FK ? MAXU : 1];
+    const float* const kp = (FK && a.fkeep[o]) ? a.fkeep[o] + (size_t)n * K : nullptr;
+    if constexpr (FK) {
+        if (kp) {
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) { const int k = k0 + 8 * u; f[u] = (u < nu && k < K) ? kp[k] : 0.f; }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
         const int k = k0 + 8 * u;
         t[u] = (u < nu && x < w && k < K) ? src[(size_t)k * a.h * a.w] : 0.f;
+    }
+    if constexpr (FK) {
+        if (kp) {
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) t[u] = t[u] * (f[u] * a.fscale);
+        }
     }
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) ss = fmaf(t[u], t[u], ss);
@@ -813,7 +831,7 @@ __device__ __forceinline__ void dense_code_planes(const DgDenseCodeArgs& a, char
 // One launch prepares everything the fused kernel needs on the identity grid:
 //   z = 0,1: feats operands (one block per tile), z = 2,3: code operands / norms, z = 4: depth indicators.
 // grid tiles * B * (4 or 5) blocks (1-D, XCD-aware image-major order), block 256, dynamic LDS = max of the roles.
-template <int MAXU, int UNC>
+template <int MAXU, int UNC, bool FK = false>
 __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     extern __shared__ float sl[];
     // XCD-aware order (blocks are dealt round-robin over the 8 XCDs): consecutive logical ids - the source rows of one
@@ -832,7 +850,7 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
         return;
     }
     if (z < 2) {
-        if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU>(a, sl, x, n, z);
+        if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU, FK>(a, sl, x, n, z);
     } else if (z < 4) {
         if (a.code_split) {
             if (x * 256 < a.h * a.w) prep_dense_code_norms<UNC>(a, x, n, z - 2);
@@ -861,6 +879,10 @@ hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {
         return hipGetLastError();
     };
     // registers per thread follow the widths
+    if (a.fkeep[0] || a.fkeep[1]) {      // (deferred Dropout2d of the feature maps: dg_corr_forward_masked)
+        if (a.D <= 72) return a.KF <= 384 ? launch(k_prep_dense<48, 18, true>) : launch(k_prep_dense<96, 18, true>);
+        return a.KF <= 384 ? launch(k_prep_dense<48, 32, true>) : launch(k_prep_dense<96, 32, true>);
+    }
     if (a.D <= 72) return a.KF <= 384 ? launch(k_prep_dense<48, 18>) : launch(k_prep_dense<96, 18>);
     return a.KF <= 384 ? launch(k_prep_dense<48, 32>) : launch(k_prep_dense<96, 32>);
 }

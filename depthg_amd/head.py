@@ -194,9 +194,12 @@ def run_head(cluster1, cluster2, image_feat, training, feats_dropout, p=0.1, kee
     return code, (feats if want_feats else image_feat)
 
 
-def run_head_pair(cluster1, cluster2, image_feat, image_feat_pos, training, feats_dropout, p=0.1, keeps=None):
+def run_head_pair(cluster1, cluster2, image_feat, image_feat_pos, training, feats_dropout, p=0.1, keeps=None, defer_feats_dropout=False):
     """run_head for the two passes of a training step at once: ((code, feats), (code_pos, feats_pos)).  `keeps`: three (2B, C)
-    tensors (draw_keep_masks_pair) or None (drawn here, in the order two run_head calls would draw)."""
+    tensors (draw_keep_masks_pair) or None (drawn here, in the order two run_head calls would draw).  `defer_feats_dropout`: the
+    Dropout2d of the returned feats is drawn as always but NOT applied - `feats` / `feats_pos` come back as ops.DeferredDropout
+    (the input maps + their keep flags), which ContrastiveCorrelationLoss applies inside its operand preparation: the dropped
+    tensors (38.5 MB each at the headline shape) are neither written here nor read there."""
     B, C = image_feat.shape[:2]
     nl = cluster2 is not None
     if training:
@@ -209,9 +212,17 @@ def run_head_pair(cluster1, cluster2, image_feat, image_feat_pos, training, feat
     c1 = cluster1[0]
     c2a, c2b = (cluster2[0], cluster2[2]) if nl else (None, None)
     want_feats = bool(training and feats_dropout)
+    deferred = None
+    if want_feats and defer_feats_dropout:
+        deferred, want_feats = keeps[2], False
+        keeps = (keeps[0], keeps[1], None)
     code, code_pos, feats, feats_pos = _HeadPairFunction.apply(
         image_feat, image_feat_pos, keeps, 1.0 / (1.0 - p), want_feats, c1.weight, c1.bias,
         c2a.weight if nl else None, c2a.bias if nl else None, c2b.weight if nl else None, c2b.bias if nl else None)
+    if deferred is not None:
+        from .ops import DeferredDropout
+        scale = 1.0 / (1.0 - p)
+        return ((code, DeferredDropout(image_feat, deferred[:B], scale)), (code_pos, DeferredDropout(image_feat_pos, deferred[B:], scale)))
     return (code, feats if want_feats else image_feat), (code_pos, feats_pos if want_feats else image_feat_pos)
 
 
@@ -238,9 +249,10 @@ class ProjectionHead(nn.Module):
         return run_head(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
                         self.training, feats_dropout, self.p, keeps)
 
-    def forward_pair(self, image_feat, image_feat_pos, feats_dropout=True, keeps=None):
+    def forward_pair(self, image_feat, image_feat_pos, feats_dropout=True, keeps=None, defer_feats_dropout=False):
         """forward(image_feat) and forward(image_feat_pos) of one training step (src/train_segmentation.py:303-306) as one set of
-        launches: ((code, feats), (code_pos, feats_pos)), the same values and - after backward - the same parameter gradients."""
+        launches: ((code, feats), (code_pos, feats_pos)), the same values and - after backward - the same parameter gradients.
+        `defer_feats_dropout`: see run_head_pair (feats / feats_pos as ops.DeferredDropout for the loss to apply)."""
         if self.proj_type is None:
             ka = kb = None
             if keeps is not None:
@@ -248,7 +260,7 @@ class ProjectionHead(nn.Module):
                 ka, kb = (None, None, keeps[2][:B]), (None, None, keeps[2][B:])
             return self.forward(image_feat, feats_dropout, ka), self.forward(image_feat_pos, feats_dropout, kb)
         return run_head_pair(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
-                             image_feat_pos, self.training, feats_dropout, self.p, keeps)
+                             image_feat_pos, self.training, feats_dropout, self.p, keeps, defer_feats_dropout)
 
 
 class _ClusterFunction(torch.autograd.Function):

@@ -56,7 +56,14 @@ class _CorrLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, orig_code, orig_code_pos, orig_feats, orig_feats_pos, depth, coords1, coords2, perms, desc, holder):
         ws = ops.alloc_workspace(desc, orig_feats.device)
-        if perms is None:                  # the forward draws the negatives itself (holder["draw_state"]: device generator or None)
+        fk = holder.get("feat_keep")
+        if fk is not None:                 # Dropout2d of the feature maps applied inside the operand preparation (identity grid)
+            drew = perms is None
+            out, perms = ops.corr_forward_masked(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
+                                                 perms, ws, holder.get("draw_state"), fk[0], fk[1], fk[2])
+            if drew:
+                holder["perms"] = perms
+        elif perms is None:                # the forward draws the negatives itself (holder["draw_state"]: device generator or None)
             out, perms = ops.corr_forward_draw(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
                                                ws, state=holder.get("draw_state"))
             holder["perms"] = perms
@@ -113,6 +120,16 @@ class ContrastiveCorrelationLoss(nn.Module):
         scale = g("correspondence_weight") - balance
         return (g("pos_intra_weight") * scale, g("pos_inter_weight") * scale, g("neg_inter_weight") * scale,
                 g("depth_feat_weight") * scale if depth_term else 0.0)
+
+    def takes_deferred_dropout(self, feat_hw, code_hw=None) -> bool:
+        """True when a call with feature maps of size `feat_hw` runs the identity grid (_draw_coords), i.e. when the Dropout2d of the
+        feature maps can be applied inside the operand preparation (ops.DeferredDropout) instead of by the featurizer."""
+        cfg = self.cfg
+        if getattr(cfg, "use_salience", False) or cfg.depth_sampling in ("simple", "fps", "fps_depth_feat"):
+            return False
+        S = int(cfg.feature_samples)
+        return bool(getattr(cfg, "dg_dense_grid", False)) and (code_hw is None or tuple(code_hw) == tuple(feat_hw)) and \
+            S == feat_hw[0] == feat_hw[1]
 
     # -- coordinate selection, src/modules.py:1287-1321 -------------------------------------------
     def _draw_coords(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, depth, depth_pos, same_maps=True):
@@ -202,6 +219,7 @@ class ContrastiveCorrelationLoss(nn.Module):
 
     def forward(self, orig_feats, orig_feats_pos, orig_salience, orig_salience_pos, orig_code, orig_code_pos,
                 depth=None, depth_pos=None):
+        orig_feats, orig_feats_pos, feat_keep = self._unwrap_deferred(orig_feats, orig_feats_pos)
         self._check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth)
         if depth_pos is not None and depth is not None and (depth_pos.device != depth.device or depth_pos.shape[0] != depth.shape[0]):
             raise RuntimeError(f"depthg_amd: depth_pos {tuple(depth_pos.shape)} on {depth_pos.device} does not match depth "
@@ -215,14 +233,45 @@ class ContrastiveCorrelationLoss(nn.Module):
         # (seed from torch's CPU generator unless the device generator is in use); `shared` is only ever set together with the
         # identity grid drawn above
         return self.forward_with(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, None,
-                                 shared_coords=shared, identity_grid=shared, draw_state=state, _checked=True)
+                                 shared_coords=shared, identity_grid=shared, draw_state=state, _checked=True, feat_keep=feat_keep)
+
+    @staticmethod
+    def _unwrap_deferred(orig_feats, orig_feats_pos):
+        """ops.DeferredDropout in place of a feature map (the head's forward_pair(..., defer_feats_dropout=True)): the un-dropped
+        maps and (keep, keep_pos, scale) for dg_corr_forward_masked - or None when neither is deferred.  Two different scales
+        cannot ride in one call: the second map is then materialised here."""
+        da = orig_feats if isinstance(orig_feats, ops.DeferredDropout) else None
+        db = orig_feats_pos if isinstance(orig_feats_pos, ops.DeferredDropout) else None
+        if da is None and db is None:
+            return orig_feats, orig_feats_pos, None
+        if da is not None and db is not None and da.scale != db.scale:
+            orig_feats_pos, db = db.materialize(), None
+        scale = da.scale if da is not None else db.scale
+        f32 = lambda k: k.detach().to(torch.float32).contiguous()
+        return (da.feats if da is not None else orig_feats, db.feats if db is not None else orig_feats_pos,
+                (f32(da.keep) if da is not None else None, f32(db.keep) if db is not None else None, scale))
 
     # -- everything after the RNG draws (explicit coords / perms: parity tests, DP shards) ----------
     def forward_with(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms,
-                     shared_coords=False, identity_grid=False, draw_state=None, _checked=False):
+                     shared_coords=False, identity_grid=False, draw_state=None, _checked=False, feat_keep=None):
         cfg = self.cfg
+        if feat_keep is None:
+            orig_feats, orig_feats_pos, feat_keep = self._unwrap_deferred(orig_feats, orig_feats_pos)
         if not _checked:
             self._check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth)
+        if feat_keep is not None:
+            ka, kb, kscale = feat_keep
+            for name, k in (("orig_feats", ka), ("orig_feats_pos", kb)):
+                if k is not None and (tuple(k.shape) != tuple(orig_feats.shape[:2]) or k.device != orig_feats.device):
+                    raise RuntimeError(f"depthg_amd: keep flags of `{name}` are {tuple(k.shape)} on {k.device}; the maps are "
+                                       f"{tuple(orig_feats.shape)} on {orig_feats.device}")
+            if not identity_grid:
+                # sampled coordinates: the samplers read the maps themselves - the dropped tensors are formed here (same values)
+                if ka is not None:
+                    orig_feats = orig_feats * (ka * kscale)[:, :, None, None]
+                if kb is not None:
+                    orig_feats_pos = orig_feats_pos * (kb * kscale)[:, :, None, None]
+                feat_keep = None
         B, C, h, w = orig_feats.shape
         D, hc, wc = orig_code.shape[1:]
         same_maps = (hc, wc) == (h, w)
@@ -264,7 +313,7 @@ class ContrastiveCorrelationLoss(nn.Module):
                              identity_grid=bool(identity_grid), weights=self._total_weights(depth_term),
                              line_grid=line_grid, code_hw=None if same_maps else (hc, wc),
                              exact_masks=bool(getattr(cfg, "dg_exact_masks", False)))
-        holder = {"draw_state": draw_state}
+        holder = {"draw_state": draw_state, "feat_keep": feat_keep}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
         out, total = _CorrLossFunction.apply(code_in.contiguous(), code_pos_in.contiguous(), feats, feats_pos, depth_c,

@@ -110,6 +110,58 @@ def corr_forward_draw(desc, feats, feats_pos, code, code_pos, depth, coords1, co
     return out, perms
 
 
+class DeferredDropout:
+    """Feature maps whose Dropout2d (`feats = self.dropout(image_feat)`, src/modules.py:122-137) has been DRAWN but not applied:
+    `feats` (B,C,h,w) un-dropped, `keep` (B,C) flags 1 / 0, `scale` = 1/(1-p).  ContrastiveCorrelationLoss takes one in place of
+    orig_feats / orig_feats_pos and applies the mask inside its operand preparation on the identity grid (dg_corr_forward_masked:
+    the same bits, without the dropped tensor's round trip through HBM); anything else calls materialize()."""
+
+    def __init__(self, feats, keep, scale):
+        if keep.dim() != 2 or tuple(keep.shape) != tuple(feats.shape[:2]) or keep.device != feats.device:
+            raise ValueError(f"depthg_amd: keep flags {tuple(keep.shape)} on {keep.device} do not match feature maps "
+                             f"{tuple(feats.shape)} on {feats.device}")
+        if not scale > 0:
+            raise ValueError(f"depthg_amd: keep scale must be positive, got {scale}")
+        self.feats, self.keep, self.scale = feats, keep, float(scale)
+
+    shape = property(lambda self: self.feats.shape)
+    device = property(lambda self: self.feats.device)
+    dtype = property(lambda self: self.feats.dtype)
+    is_cuda = property(lambda self: self.feats.is_cuda)
+
+    def dim(self):
+        return self.feats.dim()
+
+    def materialize(self):
+        return self.feats * (self.keep.to(torch.float32) * self.scale)[:, :, None, None]
+
+
+def corr_forward_masked(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, perms, workspace, state, keep, keep_pos,
+                        scale):
+    """dg_corr_forward_masked: the forward on UN-dropped feature maps + their Dropout2d keep flags (identity grid).  perms None:
+    drawn inside (as corr_forward_draw).  Returns (out, perms)."""
+    lib = _lib.load()
+    dev = feats.device
+    out = _empty(_lib.DG_OUT_COUNT, torch.float32, dev)
+    draw, seed = 0, 0
+    if perms is None:
+        draw = 1
+        perms = _empty((int(desc.n_neg), int(desc.B)), torch.long, dev)
+        if state is None:
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        elif state.dtype != torch.int64 or state.numel() != 3 or state.device != dev:
+            raise ValueError("corr_forward_masked: state must be the int64[3] tensor of new_perm_state on the same device")
+    for k in (keep, keep_pos):
+        if k is not None and (k.dtype != torch.float32 or not k.is_contiguous() or k.device != dev or tuple(k.shape) != (int(desc.B), int(desc.C))):
+            raise ValueError(f"corr_forward_masked: keep flags must be contiguous fp32 (B,C) = ({desc.B},{desc.C}) on {dev}")
+    rc = lib.dg_corr_forward_masked(ctypes.byref(desc), _ptr(feats), _ptr(feats_pos), _ptr(code), _ptr(code_pos), _ptr(depth),
+                                    _ptr(coords1), _ptr(coords2), _ptr(perms), draw, seed, _ptr(state) if draw else None,
+                                    _ptr(keep), _ptr(keep_pos), float(scale), _ptr(out), _ptr(workspace), workspace.numel(),
+                                    _stream(dev))
+    _lib.check(rc, "dg_corr_forward_masked")
+    return out, perms
+
+
 def corr_backward(desc, grad_scalars, coords1, coords2, perms, workspace, shape_code):
     lib = _lib.load()
     dev = grad_scalars.device

@@ -85,7 +85,7 @@ class StandInFeaturizer(nn.Module):
             feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
         return (feats, code, attn) if self.training else (feats, code)
 
-    def forward_pair(self, img, img_pos):
+    def forward_pair(self, img, img_pos, defer_feats_dropout=False):
         """forward(img) and forward(img_pos) of one training step (src/train_segmentation.py:194-212) with the head's two passes in
         one set of launches (run_head_pair): the frozen backbone has no random draws, so the six Dropout2d draws come in the
         reference's order.  Training mode with a projection head only; returns ((feats, code, attn), (feats_pos, code_pos, attn_pos))."""
@@ -97,7 +97,8 @@ class StandInFeaturizer(nn.Module):
             image_feat, image_feat_pos = self.model(img), self.model(img_pos)
             attn, attn_pos = self._last_selfattention(img, image_feat), self._last_selfattention(img_pos, image_feat_pos)
         (code, feats), (code_pos, feats_pos) = run_head_pair(self.cluster1, self.cluster2 if self.proj_type == "nonlinear" else None,
-                                                             image_feat, image_feat_pos, True, bool(self.cfg.dropout), float(self.dropout.p))
+                                                             image_feat, image_feat_pos, True, bool(self.cfg.dropout), float(self.dropout.p),
+                                                             None, defer_feats_dropout)
         return (feats, code, attn), (feats_pos, code_pos, attn_pos)
 
 
@@ -166,7 +167,12 @@ class UnsupervisedSegmenter(nn.Module):
         #  module does - and the featurizer offers it)
         paired = cfg.correspondence_weight > 0 and not getattr(cfg, "lhp", False) and hasattr(self.net, "forward_pair") and self.net.training
         if paired:
-            (feats, code, attn), (feats_pos, code_pos, _) = self.net.forward_pair(img, img_pos)     # :194-200, :207-212
+            # (on the dense identity grid the Dropout2d of the returned feats is applied by the loss's operand preparation: the
+            #  dropped feature tensors are never written - ops.DeferredDropout)
+            p = getattr(self.net, "patch_size", None)
+            defer = p is not None and self.contrastive_corr_loss_fn.takes_deferred_dropout((img.shape[2] // p, img.shape[3] // p))
+            (feats, code, attn), (feats_pos, code_pos, _) = self.net.forward_pair(img, img_pos, defer) if defer else \
+                self.net.forward_pair(img, img_pos)                                                  # :194-200, :207-212
         else:
             feats, code, attn = self.net(img)                                                        # :194-200
         lhp_code = self.lhp_module(code, depth, img, attn) if getattr(cfg, "lhp", False) else None    # :202-203

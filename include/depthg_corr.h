@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 112   /* 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 113   /* 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -144,6 +144,29 @@ int dg_corr_forward_draw(const dg_corr_desc* desc,
                          const float* coords1, const float* coords2, int64_t* perms_out, uint64_t seed, void* perm_state,
                          float* out_scalars,
                          void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * dg_corr_forward / dg_corr_forward_draw with the Dropout2d of the two feature maps applied INSIDE the operand preparation
+ * instead of by their producer (`feats = self.dropout(image_feat)`, nn.Dropout2d, src/modules.py:122-137: the last thing
+ * DinoFeaturizer.forward does to the tensor this loss receives as orig_feats / orig_feats_pos).  The caller hands in the
+ * UN-dropped features and the draw:
+ *  feat_keep, feat_pos_keep : fp32 (B,C) keep flags 1 / 0 of orig_feats / orig_feats_pos, either may be NULL (no dropout)
+ *  keep_scale               : 1/(1-p), applied to the kept channels
+ * The operands are built from x * (keep * keep_scale) - the fp32 product the producer would have stored - so every output has
+ * the bits of the call on the dropped features; what is saved is that tensor's round trip through HBM (38.5 MB written and read
+ * per map at the headline shape).  Identity grid only (DG_IDENTITY_GRID); DG_ERR_UNSUPPORTED otherwise.
+ *  perms, draw_perms, seed, perm_state : draw_perms != 0: as perms_out / seed / perm_state of dg_corr_forward_draw; 0: perms
+ *                                        is read, as by dg_corr_forward.
+ * dg_corr_backward does not read the feature maps.  (version 113)
+ */
+int dg_corr_forward_masked(const dg_corr_desc* desc,
+                           const float* orig_feats, const float* orig_feats_pos,
+                           const float* orig_code, const float* orig_code_pos,
+                           const float* depth,
+                           const float* coords1, const float* coords2, int64_t* perms, int32_t draw_perms, uint64_t seed,
+                           void* perm_state, const float* feat_keep, const float* feat_pos_keep, float keep_scale,
+                           float* out_scalars,
+                           void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * Backward (replaces autograd through helper()/sample(), SURVEY.md section 9 "Gradient"):

@@ -396,3 +396,91 @@ def test_rand_coords_from_the_device_generator(dev):
         graph.replay(); torch.cuda.synchronize(); r1 = out.clone()
         graph.replay(); torch.cuda.synchronize(); r2 = out.clone()
     assert torch.isfinite(r1).all() and not torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("B,C,D,hw,pointwise", [(4, 384, 70, 28, True), (3, 64, 24, 12, False), (2, 768, 90, 14, True)])
+def test_deferred_feature_dropout_gives_the_same_bits(B, C, D, hw, pointwise, dev):
+    """ops.DeferredDropout / dg_corr_forward_masked (version 113): the Dropout2d of the feature maps - `feats = self.dropout(image_feat)`,
+    the last step of DinoFeaturizer.forward (src/modules.py:122-137) - applied inside the loss's operand preparation.  Against the
+    call on the dropped tensors x * (keep * scale): every output scalar and both code gradients BIT-identical, with given batch maps
+    and with maps drawn inside; one map deferred, the other not; with sampled coordinates the loss forms the dropped tensors itself
+    (same bits again); the C entry point refuses keep flags off the identity grid."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops, _lib
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(7 * C + hw)
+    N = 3
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float().to(dev)
+    ka, kb = (torch.rand(B, C, generator=g) > 0.1).float().to(dev), (torch.rand(B, C, generator=g) > 0.1).float().to(dev)
+    scale = 1.0 / 0.9
+    fa, fb = f * (ka * scale)[:, :, None, None], fp * (kb * scale)[:, :, None, None]
+    perms = [p.to(dev) for p in O.super_perms(N, B, torch.Generator().manual_seed(3))] if hasattr(O, "super_perms") else \
+        list(ops.super_perms(N, B, dev))
+
+    def run(loss, x, xp, dense, given_perms, c1=None, c2=None):
+        c = torch.randn(B, D, hw, hw, generator=torch.Generator().manual_seed(11)).to(dev).requires_grad_(True)
+        cp = torch.randn(B, D, hw, hw, generator=torch.Generator().manual_seed(12)).to(dev).requires_grad_(True)
+        if c1 is None:
+            c1 = c2 = O.identity_coords(B, hw).to(dev)
+        torch.manual_seed(99)
+        loss.forward_with(x, xp, c, cp, d, c1, c2, perms if given_perms else None, shared_coords=dense, identity_grid=dense)
+        loss.total.backward()
+        return loss.scalars.detach().clone(), c.grad.clone(), cp.grad.clone(), loss.last_call[1].clone()
+
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=True, pointwise=pointwise)
+    loss = ContrastiveCorrelationLoss(cfg)
+    assert loss.takes_deferred_dropout((hw, hw)) and not loss.takes_deferred_dropout((hw, hw + 1))
+    for given in (True, False):
+        want = run(loss, fa, fb, True, given)
+        got = run(loss, ops.DeferredDropout(f, ka, scale), ops.DeferredDropout(fp, kb, scale), True, given)
+        half = run(loss, ops.DeferredDropout(f, ka, scale), fb, True, given)
+        for w, a, b in zip(want, got, half):
+            assert torch.isfinite(w.float()).all() and torch.equal(w, a) and torch.equal(w, b)
+    # sampled coordinates: the loss materialises
+    S = 5
+    cfg_s = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced", pointwise=pointwise)
+    loss_s = ContrastiveCorrelationLoss(cfg_s)
+    assert not loss_s.takes_deferred_dropout((hw, hw))
+    c1, c2 = (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev), (torch.rand(B, S, S, 2, generator=g) * 2 - 1).to(dev)
+    want = run(loss_s, fa, fb, False, True, c1, c2)
+    got = run(loss_s, ops.DeferredDropout(f, ka, scale), ops.DeferredDropout(fp, kb, scale), False, True, c1, c2)
+    for w, a in zip(want, got):
+        assert torch.equal(w, a)
+    # the C entry point off the identity grid
+    desc = ops.make_desc(B, C, D, hw, hw, S, N, pointwise=pointwise, zero_clamp=True, stabalize=False, depth_term=False, need_grad=False,
+                         shared_coords=False, shifts=(0.1, 0.1, 0.1, 0.0), depth_hw=(0, 0), identity_grid=False, weights=(1, 1, 1, 0))
+    cz = torch.randn(B, D, hw, hw, device=dev)
+    with pytest.raises(RuntimeError, match="identity grid"):
+        ops.corr_forward_masked(desc, f, fp, cz, cz, None, c1, c2, torch.stack(perms), ops.alloc_workspace(desc, dev), None, ka, kb, scale)
+
+
+def test_head_pair_with_deferred_dropout_feeds_the_loss_the_same_bits(dev):
+    """ProjectionHead.forward_pair(..., defer_feats_dropout=True): the same six Dropout2d draws (the torch generator ends where it
+    ends otherwise), the same code maps, feats as ops.DeferredDropout - and the loss on them returns the bits of the loss on the
+    feats the head would have written, head gradients included."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from depthg_amd.head import ProjectionHead
+    from oracle import depthg_oracle as O
+    B, C, D, hw, N = 4, 384, 70, 28, 2
+    g = torch.Generator().manual_seed(2)
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    d = torch.randint(0, 256, (B, 1, 112, 112), generator=g).float().to(dev)
+    torch.manual_seed(4)
+    head = ProjectionHead(C, D).to(dev).train()
+    loss = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=True))
+    res = []
+    for defer in (False, True):
+        for p in head.parameters():
+            p.grad = None
+        torch.manual_seed(21)
+        (code, feats), (code_pos, feats_pos) = head.forward_pair(f, fp, True, None, defer)
+        end = torch.rand(2, device=dev)
+        assert isinstance(feats, ops.DeferredDropout) == defer and isinstance(feats_pos, ops.DeferredDropout) == defer
+        torch.manual_seed(22)
+        loss(feats, feats_pos, None, None, code, code_pos, d, d)
+        loss.total.backward()
+        res.append([code.detach().clone(), code_pos.detach().clone(), loss.scalars.detach().clone(), end] + [p.grad.clone() for p in head.parameters()])
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    fa = res and feats.materialize()
+    assert bool((fa.abs().sum((2, 3))[feats.keep == 0] == 0).all())

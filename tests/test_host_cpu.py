@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/depthg_corr.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.dg_version() == _lib.DG_VERSION == 112
+    assert lib.dg_version() == _lib.DG_VERSION == 113
 
 
 def test_descriptor_validation_and_workspace():
@@ -397,3 +397,34 @@ def test_round4_entry_points_refuse_cpu_tensors_and_bad_state():
             ops.keep_masks_state(bad, 4, 64)
     with pytest.raises(RuntimeError, match="must live on the GPU"):
         ops.fps_coords_pair(torch.rand(2, 1, 32, 32), torch.rand(2, 1, 32, 32), (8, 8), 3)
+
+
+def test_deferred_dropout_host_logic():
+    """ops.DeferredDropout and the loss's handling of it, as far as no launch is involved: the wrapper validates its keep flags, the
+    loss unwraps to (maps, (keep, keep_pos, scale)), mixed scales materialise the second map, and takes_deferred_dropout follows
+    _draw_coords' branch order (salience / depth samplers first, then the dense identity grid)."""
+    import torch
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from oracle import depthg_oracle as O
+    f, fp = torch.randn(2, 8, 4, 4), torch.randn(2, 8, 4, 4)
+    k = (torch.rand(2, 8) > 0.3).float()
+    with pytest.raises(ValueError):
+        ops.DeferredDropout(f, k[:, :7], 1.1)
+    with pytest.raises(ValueError):
+        ops.DeferredDropout(f, k, 0.0)
+    da = ops.DeferredDropout(f, k, 1.25)
+    assert da.shape == f.shape and da.dim() == 4 and torch.equal(da.materialize(), f * (k * 1.25)[:, :, None, None])
+    loss = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=4, neg_samples=1, dim=8, dg_dense_grid=True))
+    a, b, fk = loss._unwrap_deferred(f, fp)
+    assert a is f and b is fp and fk is None
+    a, b, fk = loss._unwrap_deferred(da, fp)
+    assert a is f and b is fp and torch.equal(fk[0], k) and fk[1] is None and fk[2] == 1.25
+    a, b, fk = loss._unwrap_deferred(da, ops.DeferredDropout(fp, k, 2.0))          # two scales: the second map is materialised
+    assert a is f and torch.equal(b, fp * (k * 2.0)[:, :, None, None]) and fk[1] is None and fk[2] == 1.25
+    assert loss.takes_deferred_dropout((4, 4)) and not loss.takes_deferred_dropout((4, 5)) and not loss.takes_deferred_dropout((4, 4), (8, 8))
+    for over in (dict(use_salience=True), dict(depth_sampling="fps"), dict(depth_sampling="simple"), dict(dg_dense_grid=False), dict(feature_samples=3)):
+        cfg = O.default_cfg(**{**dict(feature_samples=4, neg_samples=1, dim=8, dg_dense_grid=True), **over})
+        assert not ContrastiveCorrelationLoss(cfg).takes_deferred_dropout((4, 4)), over
+    # keep flags that do not match the maps are refused before any launch
+    with pytest.raises(RuntimeError, match="keep flags"):
+        loss.forward_with(f, fp, f, fp, None, torch.zeros(2, 4, 4, 2), torch.zeros(2, 4, 4, 2), None, feat_keep=(k[:1], None, 1.1))
