@@ -398,6 +398,7 @@ def test_rand_coords_from_the_device_generator(dev):
     assert torch.isfinite(r1).all() and not torch.equal(r1, r2)
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C,D,hw,pointwise", [(4, 384, 70, 28, True), (3, 64, 24, 12, False), (2, 768, 90, 14, True)])
 def test_deferred_feature_dropout_gives_the_same_bits(B, C, D, hw, pointwise, dev):
     """ops.DeferredDropout / dg_corr_forward_masked (version 113): the Dropout2d of the feature maps - `feats = self.dropout(image_feat)`,
@@ -454,6 +455,7 @@ def test_deferred_feature_dropout_gives_the_same_bits(B, C, D, hw, pointwise, de
         ops.corr_forward_masked(desc, f, fp, cz, cz, None, c1, c2, torch.stack(perms), ops.alloc_workspace(desc, dev), None, ka, kb, scale)
 
 
+@pytest.mark.gpu
 def test_head_pair_with_deferred_dropout_feeds_the_loss_the_same_bits(dev):
     """ProjectionHead.forward_pair(..., defer_feats_dropout=True): the same six Dropout2d draws (the torch generator ends where it
     ends otherwise), the same code maps, feats as ops.DeferredDropout - and the loss on them returns the bits of the loss on the
