@@ -219,3 +219,45 @@ def test_training_steps_across_sample_decay_and_lhp():
         if "experiment_name" in over:
             assert cfg3.lhp_weight == 1.0                     # src/train_segmentation.py:337
 
+
+
+@pytest.mark.gpu
+def test_training_step_on_the_dense_grid_defers_the_feature_dropout():
+    """training_step on the identity grid (feature_samples = the feature map's side, dg_dense_grid) with cfg.dropout: the featurizer
+    hands the loss its un-dropped maps + the Dropout2d draw (ops.DeferredDropout) and the loss's operand preparation applies it.
+    Against the same step with the deferral switched off (the head writes the dropped maps): the same bits in the loss, the logs and
+    every gradient, and the torch generator ends at the same place."""
+    from depthg_amd import ops
+    from depthg_amd.segmenter import UnsupervisedSegmenter, default_segmenter_cfg
+    dev = torch.device("cuda:0")
+    res = []
+    for defer in (True, False):
+        cfg = default_segmenter_cfg(dim=70, dropout=True, feature_samples=14, depth_sampling="none", dg_dense_grid=True, dg_outputs="reduced",
+                                    fps_sample_decay=False)
+        torch.manual_seed(3)
+        m = UnsupervisedSegmenter(27, cfg).to(dev)
+        m.train()
+        seen = []
+        fn = m.contrastive_corr_loss_fn
+        assert fn.takes_deferred_dropout((14, 14))
+        if not defer:
+            fn.takes_deferred_dropout = lambda *a, **k: False
+        orig = fn.forward
+        fn.forward = lambda *a, **k: (seen.append(isinstance(a[0], ops.DeferredDropout)), orig(*a, **k))[1]
+        grads = {}
+        torch.manual_seed(5)
+        loss, logs = m.training_step(_batch(4, torch.Generator().manual_seed(11), dev), 0,
+                                     grad_sync=lambda: grads.update({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        assert seen == [defer]
+        res.append((loss.detach().clone(), {k: v.clone() for k, v in logs.items()}, grads, torch.rand(3, device=dev)))
+    (la, ga, gra, ea), (lb, gb, grb, eb) = res
+    assert torch.isfinite(la) and torch.equal(la, lb) and torch.equal(ea, eb)
+    assert ga.keys() == gb.keys() and all(torch.equal(ga[k], gb[k]) for k in ga)
+    # (the linear probe is a torch nn.Conv2d: its weight gradient - MIOpen's, with atomics - differs in the last bit from run to run
+    #  whatever this library does; everything this library computes is bit-reproducible)
+    assert gra.keys() == grb.keys() and len(gra) > 6
+    for k in gra:
+        if k == "linear_probe.weight":
+            assert float((gra[k] - grb[k]).abs().max()) <= 1e-5 * float(grb[k].abs().max())
+        else:
+            assert torch.equal(gra[k], grb[k]), k
