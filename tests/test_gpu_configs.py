@@ -467,6 +467,23 @@ def test_bench_line_of_the_multi_gpu_schedule():
 
 
 
+def test_bench_reports_a_failed_graph_capture_and_times_the_eager_step():
+    """A hipGraph capture that fails (injected: DG_BENCH_FAIL_CAPTURE) must neither change the schedule silently nor cost the run its
+    line: stderr names the rank and the error, config.schedule carries the reason, the step is the host-launched one - alone and
+    under the N > 1 schedule; --strict-graph turns it into exit code 3."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29693", DG_BENCH_FAIL_CAPTURE="1")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clock-warmup-s", "0.02"]
+    for extra in ([], ["--force-dist"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert "capture failed" in d["config"]["schedule"] and "injected" in d["config"]["schedule"] and "eager" in d["config"]["workload"]
+        assert "hipGraph capture failed on rank 0" in r.stderr and d["ms_per_step"] > 0 and d["roofline"]["kernel"] == "k_corr2"
+    r = subprocess.run(base + ["--strict-graph"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 3 and not r.stdout.strip().startswith("{")
+
+
 _WALK_CHILD = r"""
 import sys, hashlib, torch
 sys.path.insert(0, {root!r})
