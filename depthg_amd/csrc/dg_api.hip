@@ -471,18 +471,18 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         }
         g.njobs = nj;
         g.direct = p.rows ? 1 : 0;
-        DG_HIP(dg_launch_gather(g, p.KF, stream));
         if (p.xmask) {
-            DgCdMaskArgs m;
-            memset(&m, 0, sizeof(m));
+            // exact clamp masks of the small sample grids: the sign of every fp32 code dot product from the sampled rows
+            // (k_plane_sample's, like the gather's input) - extra blocks of the gather launch (its own launch until round 4)
+            DgCdMaskArgs& m = g.cd;
             m.rowsR = F32(p.rows_c[0]);
             for (int t = 0; t < p.T; ++t) {
                 m.rowsS[t] = F32(p.rows_c[op_of(p, t)]); m.sidx[t] = map_of(p, t, perms);
                 m.bits[t] = reinterpret_cast<uint32_t*>(ws + p.maskbits[t]);
             }
             m.T = p.T; m.B = p.B; m.P = p.P; m.Ppad = p.Ppad; m.D = p.D; m.D4 = p.D4;
-            DG_HIP(dg_launch_cd_mask(m, stream));
         }
+        DG_HIP(dg_launch_gather(g, p.KF, stream));
     }
 
     // (the launch plan of step 4 is needed here already: the consumer lists of k_corr2's grouped ragged blocks are written by

@@ -268,10 +268,23 @@ struct DgGatherJob {
     int32_t h, w;            // size of the map `src` holds (not read in direct mode)
 };
 #define DG_MAX_GATHER 20
+// exact clamp masks of the small sample grids (k_cd_mask; dg_prep.hip)
+struct DgCdMaskArgs {
+    const float* rowsR;                      // sampled code rows of operand 1: (B, P, D4) fp32
+    const float* rowsS[DG_MAX_NEG + 2];      // ... of the streamed operand of pair-set t
+    const int64_t* sidx[DG_MAX_NEG + 2];     // batch map of the streamed operand (null: identity)
+    uint32_t* bits[DG_MAX_NEG + 2];          // [B][Ppad/32][Ppad] out
+    int32_t T, B, P, Ppad, D, D4;
+};
+
 struct DgGatherArgs {
     DgGatherJob jobs[DG_MAX_GATHER];
     int32_t njobs, B, S, Sh, P, Ppad, KF, KD;   // sample grid: Sh rows x S columns (Sh == S, or 1 with DG_LINE_GRID)
     int32_t direct;          // 1: src holds the SAMPLED rows already, [B][P][K4] per job (k_plane_sample): no taps, no batch map
+    // cd.T > 0: the exact clamp masks ride in this launch (they read the sampled code rows, like the gather: one launch less on the
+    // small sample grids) - blockIdx.z >= njobs: slice (z - njobs) / cd_xper is pair-set t, the rest extends blockIdx.x
+    DgCdMaskArgs cd;
+    int32_t cd_xper;
 };
 
 struct DgPlaneArgs {        // k_plane_sample: sample() of all operands straight from the NCHW maps, small sample grids
@@ -605,13 +618,6 @@ hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);
 // Exact clamp masks of the pair-sets on small sample grids: 1[<c1_p, c2_q> >= 0] from the fp32 sampled code rows (the sign of cd
 // does not depend on the normalisation), packed as one word per (S tile, R position).
-struct DgCdMaskArgs {
-    const float* rowsR;                      // sampled code rows of operand 1: (B, P, D4) fp32
-    const float* rowsS[DG_MAX_NEG + 2];      // ... of the streamed operand of pair-set t
-    const int64_t* sidx[DG_MAX_NEG + 2];     // batch map of the streamed operand (null: identity)
-    uint32_t* bits[DG_MAX_NEG + 2];          // [B][Ppad/32][Ppad] out
-    int32_t T, B, P, Ppad, D, D4;
-};
 hipError_t dg_launch_cd_mask(const DgCdMaskArgs& a, hipStream_t s);
 // The same mask words on the dense identity grid from SPLIT fp16 operands: cd = hi.hi + (hi.lo + lo.hi) / 2048 on the fp16 MFMA with
 // fp32 accumulation - the operand error drops from 2^-11 to 2^-22 relative, i.e. to the rounding noise of an fp32 dot product,

@@ -45,12 +45,75 @@ hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 
+// One (S tile, R tile) pair of the exact clamp masks (k_cd_mask below; also extra blocks of the k_gather_norm launch)
+template <int NC>      // 16-byte chunks of a code row per lane: D4 <= 8 NC
+__device__ __forceinline__ void cd_mask_tile(const DgCdMaskArgs& a, const int w, const int n, const int t) {
+    // One wave per (S tile, R tile) pair: the 32 x 32 raw dot products on the fp32 MFMA (v_mfma_f32_32x32x2_f32: fp32 products,
+    // fp32 accumulation - the sign of the reference's fp32 cd, which the fp16 MFMA of k_corr_main flips for |cd| < ~1e-3).
+    // Lane (j = lane & 31, h = lane >> 5) holds the 16-byte chunks 2m + h of S row j (A) and of R row j (B); k-step (m, e) of the
+    // MFMA pairs element e of chunk 2m (lanes h = 0) with element e of chunk 2m + 1 (h = 1) - the MFMA does not care which two
+    // elements of the rows share a step.  A chunk past the row (odd chunk counts, NC larger than the row) is read at a clamped
+    // address and zeroed.  The lane ends with column j of the tile: the bits of R position j for 16 of the 32 S positions
+    // (rows (reg & 3) + 8 (reg >> 2) + 4 h - the bit order k_corr_main's epilogue reads); the halves are OR-ed across lane ^ 32.
+    // (Measured at C3's shape, 3584 tile pairs: an LDS-staged fp32 FMA form 50 us, LDS-bound; rows through the scalar cache as
+    // SGPR operands of v_pk_fma_f32 27 us, bound by the scalar-cache misses of each row; this form with 8-byte loads 19 us.)
+    const int nt = a.Ppad >> 5, D4 = a.D4, nq = D4 >> 2;
+    if (w >= nt * nt) return;
+    const int st = w / nt, rt = w - st * nt;
+    const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int ps = st * 32 + j, pr = rt * 32 + j;
+    const float* srow = a.rowsS[t] + ((size_t)nS * a.P + min(ps, a.P - 1)) * D4;
+    const float* rrow = a.rowsR + ((size_t)n * a.P + min(pr, a.P - 1)) * D4;
+    f32x4 av[NC], bv[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        const int c = min(2 * m + h, nq - 1);
+        av[m] = *reinterpret_cast<const f32x4*>(srow + 4 * c);
+        bv[m] = *reinterpret_cast<const f32x4*>(rrow + 4 * c);
+    }
+    // (hipcc's scheduler otherwise sinks every load next to the MFMA that consumes it - the accumulator chain is serial, so it
+    //  sees nothing to gain - and the wave walks 2 NC memory round trips one after the other: 14 us instead of .. at C3's shape)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < NC; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[m][e] = 2 * m + h < nq ? av[m][e] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[m][e], acc, 0, 0, 0);
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) word |= (acc[i] >= 0.f ? 1u : 0u) << ((i & 3) + 8 * (i >> 2) + 4 * h);
+    word |= (uint32_t)__shfl_xor((int)word, 32);
+    // padding: cd = 0 there, inside the clamp (what the fp16 path sees)
+    const int nvalid = a.P - st * 32;
+    if (nvalid < 32) word |= ~0u << max(nvalid, 0);
+    if (pr >= a.P) word = ~0u;
+    if (h == 0) a.bits[t][((size_t)n * nt + st) * a.Ppad + pr] = word;
+}
+
 // block = 256 threads = 4 waves; block handles 32 consecutive positions (one operand tile),
 // wave w handles positions w, w+4, ...; lane l handles channels 4l + 256 m.  Output goes straight into
 // the tile blob (dg_common.h): feats -> F part (bf16, swizzled rows), code -> C part (fp16, granule-major)
 // and P part (fp16, P-major, dg_perm32 order; transposed through LDS).
-template <int MAXM>
+template <int MAXM, int NC = 0>      // NC > 0: the launch carries the exact clamp masks (cd_mask_tile<NC>) in extra z slices
 __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
+    int zjob = (int)blockIdx.z;
+    if constexpr (NC > 0) {
+        // (the mask slices FIRST: fp32-MFMA work that runs beside the memory-bound gather blocks instead of behind them)
+        const int ncd = a.cd.T * a.cd_xper;
+        if (zjob < ncd) {
+            const int t = zjob / a.cd_xper;
+            cd_mask_tile<NC>(a.cd, ((zjob - t * a.cd_xper) * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6), (int)blockIdx.y, t);
+            return;
+        }
+        zjob -= ncd;
+    }
     // [KD<=128][32 positions] for the P part, rows of 40 halves (80 bytes) with the four 16-byte granules of a row XOR-ed by
     // (channel >> 4) & 3: a wave writes one position column of up to 32 channels 4 apart at a time - with rows of 64 bytes all
     // of them fell into ONE bank (3.6 M conflict cycles per launch at config 3's shape, a fifth of the kernel)
@@ -59,7 +122,7 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     __shared__ float colred[4][MAXM * 256];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pt = blockIdx.x, n = blockIdx.y;
-    const DgGatherJob& J = a.jobs[blockIdx.z];
+    const DgGatherJob& J = a.jobs[zjob];
     const int K4 = J.K4, Kpad = J.Kpad;
     const int ns = J.srcidx ? (int)J.srcidx[n] : n;
     const int mh = J.h, mw = J.w;                  // the map this job samples (feature and code maps may differ in size)
@@ -197,6 +260,24 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
 
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
     dim3 grid(a.Ppad / 32, a.B, a.njobs), block(256);
+    if (a.cd.T > 0) {
+        // the exact clamp masks as extra z slices: one wave per (S tile, R tile) pair, 4 per block, cd_xper slices of gridDim.x blocks
+        if (a.cd.D4 > 128) return hipErrorInvalidValue;
+        const int nt = a.Ppad / 32, need = (nt * nt + 3) / 4;
+        DgGatherArgs a2 = a;
+        a2.cd_xper = (need + nt - 1) / nt;
+        grid.z = a.njobs + a.cd.T * a2.cd_xper;
+        const int nc = a.cd.D4 <= 72 ? 9 : (a.cd.D4 <= 104 ? 13 : 16);
+#define DG_GN(M_, N_) hipLaunchKernelGGL((k_gather_norm<M_, N_>), grid, block, 0, s, a2)
+#define DG_GN3(M_) { if (nc == 9) DG_GN(M_, 9); else if (nc == 13) DG_GN(M_, 13); else DG_GN(M_, 16); }
+        if (maxK4 <= 256) DG_GN3(1)
+        else if (maxK4 <= 512) DG_GN3(2)
+        else if (maxK4 <= 768) DG_GN3(3)
+        else return hipErrorInvalidValue;
+#undef DG_GN3
+#undef DG_GN
+        return hipGetLastError();
+    }
     if (maxK4 <= 256)      hipLaunchKernelGGL(k_gather_norm<1>, grid, block, 0, s, a);
     else if (maxK4 <= 512) hipLaunchKernelGGL(k_gather_norm<2>, grid, block, 0, s, a);
     else if (maxK4 <= 768) hipLaunchKernelGGL(k_gather_norm<3>, grid, block, 0, s, a);
@@ -364,56 +445,9 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArg
 // dot product of the two sampled fp32 code rows (norm() divides by positive numbers), and at P = 121 / 144 positions that is half
 // a GFLOP of fp32 for the whole batch: one block per (S tile, image, pair-set) forms the 32 x P dot products in fp32 and packs
 // them as one word per (S tile, R position) - bit i = position 32 tile + i - which the fused kernel reads instead of comparing.
-template <int NC>      // 16-byte chunks of a code row per lane: D4 <= 8 NC
+template <int NC>
 __global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
-    // One wave per (S tile, R tile) pair: the 32 x 32 raw dot products on the fp32 MFMA (v_mfma_f32_32x32x2_f32: fp32 products,
-    // fp32 accumulation - the sign of the reference's fp32 cd, which the fp16 MFMA of k_corr_main flips for |cd| < ~1e-3).
-    // Lane (j = lane & 31, h = lane >> 5) holds the 16-byte chunks 2m + h of S row j (A) and of R row j (B); k-step (m, e) of the
-    // MFMA pairs element e of chunk 2m (lanes h = 0) with element e of chunk 2m + 1 (h = 1) - the MFMA does not care which two
-    // elements of the rows share a step.  A chunk past the row (odd chunk counts, NC larger than the row) is read at a clamped
-    // address and zeroed.  The lane ends with column j of the tile: the bits of R position j for 16 of the 32 S positions
-    // (rows (reg & 3) + 8 (reg >> 2) + 4 h - the bit order k_corr_main's epilogue reads); the halves are OR-ed across lane ^ 32.
-    // (Measured at C3's shape, 3584 tile pairs: an LDS-staged fp32 FMA form 50 us, LDS-bound; rows through the scalar cache as
-    // SGPR operands of v_pk_fma_f32 27 us, bound by the scalar-cache misses of each row; this form with 8-byte loads 19 us.)
-    const int nt = a.Ppad >> 5, D4 = a.D4, nq = D4 >> 2;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y, t = blockIdx.z;
-    if (w >= nt * nt) return;
-    const int st = w / nt, rt = w - st * nt;
-    const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
-    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    const int ps = st * 32 + j, pr = rt * 32 + j;
-    const float* srow = a.rowsS[t] + ((size_t)nS * a.P + min(ps, a.P - 1)) * D4;
-    const float* rrow = a.rowsR + ((size_t)n * a.P + min(pr, a.P - 1)) * D4;
-    f32x4 av[NC], bv[NC];
-#pragma unroll
-    for (int m = 0; m < NC; ++m) {
-        const int c = min(2 * m + h, nq - 1);
-        av[m] = *reinterpret_cast<const f32x4*>(srow + 4 * c);
-        bv[m] = *reinterpret_cast<const f32x4*>(rrow + 4 * c);
-    }
-    // (hipcc's scheduler otherwise sinks every load next to the MFMA that consumes it - the accumulator chain is serial, so it
-    //  sees nothing to gain - and the wave walks 2 NC memory round trips one after the other: 14 us instead of .. at C3's shape)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int m = 0; m < NC; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) av[m][e] = 2 * m + h < nq ? av[m][e] : 0.f;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int m = 0; m < NC; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][e], bv[m][e], acc, 0, 0, 0);
-    uint32_t word = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) word |= (acc[i] >= 0.f ? 1u : 0u) << ((i & 3) + 8 * (i >> 2) + 4 * h);
-    word |= (uint32_t)__shfl_xor((int)word, 32);
-    // padding: cd = 0 there, inside the clamp (what the fp16 path sees)
-    const int nvalid = a.P - st * 32;
-    if (nvalid < 32) word |= ~0u << max(nvalid, 0);
-    if (pr >= a.P) word = ~0u;
-    if (h == 0) a.bits[t][((size_t)n * nt + st) * a.Ppad + pr] = word;
+    cd_mask_tile<NC>(a, blockIdx.x * 4 + (threadIdx.x >> 6), blockIdx.y, blockIdx.z);
 }
 // Exact clamp masks on the dense identity grid from split fp16 operands (DgCdMask3Args).  One block = 8 waves = 8 consecutive R
 // tiles of one (pair-set, image); the block walks the S tiles, whose hi / lo code rows (the first 2 NKC granule rows of the C
