@@ -816,14 +816,25 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     {
         // small sample grids: tiles of a 32-channel group + tap lists of several sources in LDS (k_scatter_small)
         const bool half = (a.DP / 32) * a.B * 2 < 512;               // 32-channel blocks would not even fill the CUs twice
-        const int CGv = half ? 16 : 32;
+        // ... and 16-channel blocks fewer than half the CUs (config 4's shard of 8 images: 96 blocks): 8 channels per block.  Measured:
+        // config 4 shard 0.2106 -> 0.2071 ms; config 2 (192 blocks of 16 channels) 0.1939 -> 0.1950 and config 3 (512) 0.220 -> 0.231
+        // the other way - the tap records are loaded once per block, whatever its channel count
+        bool quarter = (a.DP / 16) * a.B * 2 < 128;
+#ifdef DG_DEVTOOLS
+        if (const char* sc = getenv("DG_SCAT_SMALL_CG")) quarter = atoi(sc) == 8;
+#endif
+        const int CGv = quarter ? 8 : (half ? 16 : 32);
         const size_t per_src = rec + (size_t)a.Ppad * (CGv + 1) * 4;
         int rb = (int)((size_t)(150 * 1024) / per_src);
         rb = rb > SCAT_RMAX ? SCAT_RMAX : rb;
         if (HW <= SCAT_THREADS && rb >= 2) {
             const int sm = (int)(rb * per_src);
             const dim3 sgrid(a.DP / CGv, a.B, 2);
-            if (half) {
+            if (quarter) {
+                e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_small<8>), sm);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_scatter_small<8>, sgrid, dim3(SCAT_THREADS), sm, s, a, rb);
+            } else if (half) {
                 e = dg_set_max_smem(reinterpret_cast<const void*>(k_scatter_small<16>), sm);
                 if (e != hipSuccess) return e;
                 hipLaunchKernelGGL(k_scatter_small<16>, sgrid, dim3(SCAT_THREADS), sm, s, a, rb);
