@@ -384,6 +384,8 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
     char* ws = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
 
+    DgPreArgs pre_late;
+    memset(&pre_late, 0, sizeof(pre_late));
     // 1.+2. operands.  Identity grid: one launch builds both feats and both code operands straight from NCHW (+ the
     //       depth indicators).  General coords: channel-last copies (the gather reads whole channel vectors per tap), then
     //       sample + normalise + operand blobs.
@@ -431,6 +433,11 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             if (p.grad && (size_t)p.hc * p.wc <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
             q.B = p.B; q.h = p.hc; q.w = p.wc; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;      // (h, w): the maps the tap records index = the code maps
             if (p.B > 8192 && q.count > 0) return fail(DG_ERR_UNSUPPORTED, "B=%d too large for the in-call draw", p.B);
+            // Nothing in front of the fused kernel reads the depth indicators or the tap records: they ride as extra blocks of the
+            // gather launch below (round 4); only the draw - the sampler's first input - keeps a launch of its own
+            pre_late = q;
+            pre_late.count = 0;
+            q.depth = nullptr; q.taps = nullptr;
             DG_HIP(dg_launch_pre_general(q, stream));
         }
         if (p.rows) {
@@ -482,6 +489,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             }
             m.T = p.T; m.B = p.B; m.P = p.P; m.Ppad = p.Ppad; m.D = p.D; m.D4 = p.D4;
         }
+        g.pre = pre_late;
         DG_HIP(dg_launch_gather(g, p.KF, stream));
     }
 

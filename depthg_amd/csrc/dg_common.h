@@ -268,6 +268,14 @@ struct DgGatherJob {
     int32_t h, w;            // size of the map `src` holds (not read in direct mode)
 };
 #define DG_MAX_GATHER 20
+// the jobs of a call with general coordinates that depend on nothing but its inputs (k_pre_general; dg_post.hip)
+struct DgPreArgs {
+    uint64_t seed; unsigned long long* state; int64_t* perms; int32_t count;      // draws (count == 0: none)
+    const float* depth; float* nz; float* nzsum; int32_t dH, dW;                  // depth indicators
+    const float* coords1; const float* coords2; char* taps;                       // inverse tap records [2][B]
+    int32_t B, h, w, S, Sh, P, Ppad;
+};
+
 // exact clamp masks of the small sample grids (k_cd_mask; dg_prep.hip)
 struct DgCdMaskArgs {
     const float* rowsR;                      // sampled code rows of operand 1: (B, P, D4) fp32
@@ -285,6 +293,11 @@ struct DgGatherArgs {
     // small sample grids) - blockIdx.z >= njobs: slice (z - njobs) / cd_xper is pair-set t, the rest extends blockIdx.x
     DgCdMaskArgs cd;
     int32_t cd_xper;
+    // pre_blocks > 0: the depth indicators and the inverse tap records of the sample() adjoint (the roles of k_pre_general that nothing
+    // in front of the fused kernel reads) ride here too, in the LAST z slices: block id (linear over the extra slices) < pre_nz: the
+    // depth indicators of image id; then 2 B tap-record blocks.  (pre.count is not used: the draw of the batch maps keeps its launch)
+    DgPreArgs pre;
+    int32_t pre_blocks, pre_nz, pre_z0;
 };
 
 struct DgPlaneArgs {        // k_plane_sample: sample() of all operands straight from the NCHW maps, small sample grids
@@ -506,12 +519,6 @@ struct DgRowmeanArgs {
 // General coordinates, first launch of the forward: the jobs that depend on nothing but the call's inputs, side by side -
 // blocks [0, count) draw the negatives' batch maps, the next B (depth != null) resize the depth indicators, the last 2 B
 // (taps != null: gradient passes) build the inverse tap records the adjoint of sample() gathers through.
-struct DgPreArgs {
-    uint64_t seed; unsigned long long* state; int64_t* perms; int32_t count;      // draws (count == 0: none)
-    const float* depth; float* nz; float* nzsum; int32_t dH, dW;                  // depth indicators
-    const float* coords1; const float* coords2; char* taps;                       // inverse tap records [2][B]
-    int32_t B, h, w, S, Sh, P, Ppad;
-};
 
 struct DgScatterSrc {
     const float* buf;      // gradient tiles [B][Ppad/32][DP/32][4][64][4] (dg_gtile_off).  raw == 1: the fused kernel's

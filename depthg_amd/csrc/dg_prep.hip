@@ -8,6 +8,7 @@
 //   k_rowmean        r[n][p] = a[n][p] . mean_q b[n][q]   (row means of fd for `pointwise`,
 //                    src/modules.py:1236-1239 restated as a rank-1 term)
 #include "dg_common.h"
+#include "dg_taps.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------
@@ -104,6 +105,18 @@ __device__ __forceinline__ void cd_mask_tile(const DgCdMaskArgs& a, const int w,
 template <int MAXM, int NC = 0>      // NC > 0: the launch carries the exact clamp masks (cd_mask_tile<NC>) in extra z slices
 __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     int zjob = (int)blockIdx.z;
+    if (a.pre_blocks > 0 && zjob >= a.pre_z0) {
+        // the input-only jobs of the call (k_pre_general's, except the draw): depth indicators, inverse tap records
+        extern __shared__ __attribute__((aligned(16))) char gn_dyn[];
+        const int lid = ((zjob - a.pre_z0) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (lid < a.pre_nz) depth_nz_image(a.pre.depth, a.pre.nz, a.pre.nzsum, lid, a.pre.dH, a.pre.dW, a.pre.Sh, a.pre.S, a.pre.Ppad);
+        else if (lid < a.pre_blocks) {
+            const DgTapsArgs t{a.pre.coords1, a.pre.coords2, a.pre.taps, a.pre.B, a.pre.h, a.pre.w, a.pre.S, a.pre.Sh, a.pre.P};
+            const int b = lid - a.pre_nz;
+            build_taps_block<256>(t, b % a.pre.B, b / a.pre.B, gn_dyn);
+        }
+        return;
+    }
     if constexpr (NC > 0) {
         // (the mask slices FIRST: fp32-MFMA work that runs beside the memory-bound gather blocks instead of behind them)
         const int ncd = a.cd.T * a.cd_xper;
@@ -258,31 +271,42 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
     }
 }
 
-hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK4, hipStream_t s) {
+hipError_t dg_launch_gather(const DgGatherArgs& a_in, int maxK4, hipStream_t s) {
+    DgGatherArgs a = a_in;
     dim3 grid(a.Ppad / 32, a.B, a.njobs), block(256);
+    int nc = 0;
     if (a.cd.T > 0) {
         // the exact clamp masks as extra z slices: one wave per (S tile, R tile) pair, 4 per block, cd_xper slices of gridDim.x blocks
         if (a.cd.D4 > 128) return hipErrorInvalidValue;
         const int nt = a.Ppad / 32, need = (nt * nt + 3) / 4;
-        DgGatherArgs a2 = a;
-        a2.cd_xper = (need + nt - 1) / nt;
-        grid.z = a.njobs + a.cd.T * a2.cd_xper;
-        const int nc = a.cd.D4 <= 72 ? 9 : (a.cd.D4 <= 104 ? 13 : 16);
-#define DG_GN(M_, N_) hipLaunchKernelGGL((k_gather_norm<M_, N_>), grid, block, 0, s, a2)
-#define DG_GN3(M_) { if (nc == 9) DG_GN(M_, 9); else if (nc == 13) DG_GN(M_, 13); else DG_GN(M_, 16); }
-        if (maxK4 <= 256) DG_GN3(1)
-        else if (maxK4 <= 512) DG_GN3(2)
-        else if (maxK4 <= 768) DG_GN3(3)
-        else return hipErrorInvalidValue;
-#undef DG_GN3
-#undef DG_GN
-        return hipGetLastError();
+        a.cd_xper = (need + nt - 1) / nt;
+        grid.z += a.cd.T * a.cd_xper;
+        nc = a.cd.D4 <= 72 ? 9 : (a.cd.D4 <= 104 ? 13 : 16);
     }
-    if (maxK4 <= 256)      hipLaunchKernelGGL(k_gather_norm<1>, grid, block, 0, s, a);
-    else if (maxK4 <= 512) hipLaunchKernelGGL(k_gather_norm<2>, grid, block, 0, s, a);
-    else if (maxK4 <= 768) hipLaunchKernelGGL(k_gather_norm<3>, grid, block, 0, s, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
+    int smem = 0;
+    a.pre_nz = a.pre.depth ? a.B : 0;
+    a.pre_blocks = a.pre_nz + (a.pre.taps ? 2 * a.B : 0);
+    a.pre_z0 = (int)grid.z;
+    if (a.pre_blocks > 0) {
+        const int per = (int)(grid.x * grid.y);
+        grid.z += (a.pre_blocks + per - 1) / per;
+        if (a.pre.taps) smem = (int)(dg_taps_record_bytes(a.pre.h * a.pre.w, a.pre.P) + (size_t)a.pre.h * a.pre.w * 4 + 16);
+    }
+    auto launch = [&](auto kern) -> hipError_t {
+        if (smem > 0) {
+            const hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, smem, s, a);
+        return hipGetLastError();
+    };
+#define DG_GN4(M_) { if (nc == 0) return launch(k_gather_norm<M_, 0>); if (nc == 9) return launch(k_gather_norm<M_, 9>); \
+                     if (nc == 13) return launch(k_gather_norm<M_, 13>); return launch(k_gather_norm<M_, 16>); }
+    if (maxK4 <= 256) DG_GN4(1)
+    if (maxK4 <= 512) DG_GN4(2)
+    if (maxK4 <= 768) DG_GN4(3)
+#undef DG_GN4
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------

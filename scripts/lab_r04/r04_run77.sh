@@ -1,5 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_boundary.py -q -m gpu -x 2>&1 | tail -2
+timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -2
 for i in 1 2 3; do
 for tag in pre hip; do
   if [ $tag = hip ]; then unset DEPTHG_LIB; else export DEPTHG_LIB=$PWD/depthg_amd/lib/libdepthg_$tag.so; fi
