@@ -85,6 +85,8 @@ class StandInFeaturizer(nn.Module):
             feats = self.dropout(image_feat) if self.cfg.dropout else image_feat    # :129-137 (identity in eval mode)
         return (feats, code, attn) if self.training else (feats, code)
 
+    supports_deferred_dropout = True      # forward_pair(..., defer_feats_dropout=True) hands back ops.DeferredDropout feats
+
     def forward_pair(self, img, img_pos, defer_feats_dropout=False):
         """forward(img) and forward(img_pos) of one training step (src/train_segmentation.py:194-212) with the head's two passes in
         one set of launches (run_head_pair): the frozen backbone has no random draws, so the six Dropout2d draws come in the
@@ -170,7 +172,8 @@ class UnsupervisedSegmenter(nn.Module):
             # (on the dense identity grid the Dropout2d of the returned feats is applied by the loss's operand preparation: the
             #  dropped feature tensors are never written - ops.DeferredDropout)
             p = getattr(self.net, "patch_size", None)
-            defer = p is not None and self.contrastive_corr_loss_fn.takes_deferred_dropout((img.shape[2] // p, img.shape[3] // p))
+            defer = p is not None and getattr(self.net, "supports_deferred_dropout", False) and \
+                self.contrastive_corr_loss_fn.takes_deferred_dropout((img.shape[2] // p, img.shape[3] // p))
             (feats, code, attn), (feats_pos, code_pos, _) = self.net.forward_pair(img, img_pos, defer) if defer else \
                 self.net.forward_pair(img, img_pos)                                                  # :194-200, :207-212
         else:
