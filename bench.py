@@ -196,6 +196,68 @@ def cpu_baseline(conf, seconds_budget=20.0):
             "also": [{"cores": r["cores"], "value": r["value"], "unit": "steps/s", "sample_B": r["Bs"]} for r in other] + skipped}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`--gpus N` (N > 1) with WORLD_SIZE unset: start the N ranks as a CHILD `python -m torch.distributed.run` (one process per
+    GPU, rendezvous on 127.0.0.1) from this parent, which has made no GPU call (torch.cuda.device_count() does not initialise the
+    device on this image; nothing here re-execs an initialised process).  Rank 0's JSON line is relayed as the last line of
+    stdout.  Non-zero exit when the node has fewer than N GPUs, when a rank fails, or when the line was not produced by N ranks."""
+    dry = bool(os.environ.get("DG_BENCH_DRYRUN"))
+    have = torch.cuda.device_count()
+    if have < n and not dry:
+        print(f"[bench] --gpus {n}: this node shows {have} GPU(s); not running a {n}-GPU line on fewer devices", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] starting the ranks: " + " ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)         # banners of the launcher / RCCL: kept, but not on stdout
+    if r.returncode != 0:
+        print(f"[bench] the {n}-rank run exited {r.returncode}", file=sys.stderr)
+        return r.returncode
+    if line is None:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 4
+    got = json.loads(line)
+    seen = got.get("config", {}).get("ranks_seen")
+    if got.get("n_gpus") != n or seen != n:
+        print(f"[bench] asked for {n} ranks, the line reports n_gpus={got.get('n_gpus')} ranks_seen={seen}", file=sys.stderr)
+        return 5
+    print(line, flush=True)
+    return 0
+
+
+def dryrun_rank(args, world, rank):
+    """DG_BENCH_DRYRUN=1 (tests/test_dp_gloo.py, no GPU): the rank rendezvous over gloo, counts its peers with an all-reduce and
+    rank 0 prints a line of the usual shape with no measurement in it - what is checked is the launch path, not the step."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run: no step was timed", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dryrun": True,
+                          "config": {"name": args.config, "ranks_seen": int(one.item()), "parallelism": f"dp{world}"}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,9 +291,18 @@ def main():
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: THIS process never touches the GPU, it starts the N ranks itself
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a line quoted for N GPUs must have been produced by N ranks
+        print(f"[bench] --gpus {args.gpus} but the launcher created WORLD_SIZE={world} ranks: refusing to run", file=sys.stderr)
+        raise SystemExit(2)
+    if os.environ.get("DG_BENCH_DRYRUN"):
+        raise SystemExit(dryrun_rank(args, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)                  # one process per GPU: bind before the process group is created
@@ -243,9 +314,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
     from depthg_amd import ContrastiveCorrelationLoss, ops
     from depthg_amd.parallel import GradBucket
 
@@ -456,6 +524,12 @@ def main():
             dist_diag["drain_ms"] = round((time.perf_counter() - t_d) * 1e3, 4)      # host wait for the tail: last collectives + barrier
             stall = sum(a.elapsed_time(b) for a, b in evs) / nprobe
             dist_diag["exchange_wait_ms"] = round(stall, 5)
+    if use_dist:
+        # a rank that fell back to the host-launched step is named on the line whichever rank it was (rank 0 prints)
+        notes = [None] * world
+        dist.all_gather_object(notes, capture_note[0])
+        notes = [n for n in notes if n]
+        capture_note[0] = "; ".join(notes) if notes else None
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed   # every rank completes `steps` steps of its own B=32 shard
 

@@ -273,3 +273,34 @@ def test_step_schedule_ablation_switches():
     s.drain()
     assert float(buckets[0].flat[0]) == 3.0 and float(buckets[1].flat[0]) == 0.0
     assert [t[0] for t in trace] == ["wait", "compute"] * 3 + ["drain", "drain"]
+
+
+def _run_bench(args, env_extra, drop=()):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(drop)}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_n_spawns_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must be a 2-rank run: the parent starts the ranks (a child
+    torch.distributed.run, before any GPU call) and relays rank 0's line; DG_BENCH_DRYRUN keeps it on gloo and times nothing."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"DG_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                    # the JSON line is the only thing on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_a_line_for_more_gpus_than_ranks():
+    # a launcher that made ONE rank for --gpus 2: no line, non-zero exit (round 4's bench printed n_gpus: 1 and exited 0)
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "DG_BENCH_DRYRUN": "1"})
+    assert r.returncode == 2 and "refusing" in r.stderr and not r.stdout.strip()
+    # and without the dry-run switch in this GPU-less container: fewer devices than ranks asked for
+    if not torch.cuda.is_available():
+        r = _run_bench(["--gpus", "2"], {}, drop=("DG_BENCH_DRYRUN",))
+        assert r.returncode == 2 and "GPU(s)" in r.stderr and not r.stdout.strip()
