@@ -199,7 +199,7 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 // A second stream of the library's own (one per device, created on the first call that is not being captured into a graph) for the
 // launches that may run beside each other inside one call; null while none exists and the caller's stream is capturing (creating
 // one there is not a capturable operation: the call then launches in sequence).
-struct SideStream { hipStream_t s; hipEvent_t fork, join; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex use; };
 static SideStream* side_stream_for(hipStream_t caller) {
     static std::mutex mu;
     static std::map<int, SideStream> table;
@@ -210,12 +210,55 @@ static SideStream* side_stream_for(hipStream_t caller) {
     if (it != table.end()) return &it->second;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    SideStream ss;
-    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+        if (fork) (void)hipEventDestroy(fork);          // nothing half-made stays behind: the call launches in sequence instead
+        (void)hipStreamDestroy(s);
         return nullptr;
-    return &table.emplace(dev, ss).first->second;
+    }
+    SideStream& ss = table[dev];        // (std::map nodes do not move: the pointer stays valid; std::mutex is not copyable)
+    ss.s = s; ss.fork = fork; ss.join = join;
+    return &ss;
 }
+
+// One fork .. join region on the device's side stream.  The stream and its event pair are shared by every caller on the device, so
+// the region holds the stream's lock from the fork record to the join wait: two host threads (or two caller streams) cannot interleave
+// their records and waits.  Whatever happens after the fork - a failed launch returns through DG_HIP - the destructor still records
+// the join and makes the caller's stream wait for it: the side stream is never left unjoined (inside a hipGraph capture that would be
+// a forked capture that cannot end).
+struct SideRegion {
+    SideStream* side;
+    hipStream_t caller;
+    std::unique_lock<std::mutex> lk;
+    bool forked = false, join_recorded = false, joined = false;
+    explicit SideRegion(hipStream_t caller_) : side(side_stream_for(caller_)), caller(caller_) {
+        if (side) lk = std::unique_lock<std::mutex>(side->use);
+    }
+    explicit operator bool() const { return side != nullptr; }
+    hipStream_t stream() const { return side->s; }
+    hipError_t fork() {
+        hipError_t e = hipEventRecord(side->fork, caller);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(side->s, side->fork, 0);
+        forked = e == hipSuccess;
+        return e;
+    }
+    hipError_t record_join() {
+        hipError_t e = hipEventRecord(side->join, side->s);
+        join_recorded = e == hipSuccess;
+        return e;
+    }
+    hipError_t join() {
+        if (!forked || joined) return hipSuccess;
+        if (!join_recorded) { hipError_t e = record_join(); if (e != hipSuccess) return e; }
+        hipError_t e = hipStreamWaitEvent(caller, side->join, 0);
+        joined = e == hipSuccess;
+        return e;
+    }
+    ~SideRegion() { if (side && forked && !joined) (void)join(); }
+};
 
 // Without `pointwise` the intra pair-set (t = 0) has NO job here (round 4): it correlates the anchors with themselves at the same
 // coordinates, so fd, cd and with them -G are symmetric and the gradient through the streamed side equals the one through the
@@ -597,14 +640,13 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             // bytes, the 128 depth blocks by a latency chain on half the CUs (one behind the other: 76 + 52 us)
             DgGsArgs gstream = g;
             gstream.dep_blocks = 0; gstream.fin.out = nullptr;
-            SideStream* side = side_stream_for(stream);
+            SideRegion side(stream);
             if (side) {
-                DG_HIP(hipEventRecord(side->fork, stream));
-                DG_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
-                DG_HIP(dg_launch_gs(g, dep_maskbits, side->s, true));
-                DG_HIP(hipEventRecord(side->join, side->s));
+                DG_HIP(side.fork());
+                DG_HIP(dg_launch_gs(g, dep_maskbits, side.stream(), true));
+                DG_HIP(side.record_join());
                 DG_HIP(dg_launch_gs(gstream, nullptr, stream));
-                DG_HIP(hipStreamWaitEvent(stream, side->join, 0));
+                DG_HIP(side.join());
             } else {
                 DG_HIP(dg_launch_gs(gstream, nullptr, stream));
                 DG_HIP(dg_launch_gs(g, dep_maskbits, stream, true));
@@ -819,8 +861,6 @@ extern "C" int dg_knn_similarities(const float* queries, const float* feats, int
     if (rows_q == 0 || n == 0) return DG_OK;
     if (!queries || !feats || !out) return fail(DG_ERR_INVALID, "null pointer");
     if (n > 65535ll * 128) return fail(DG_ERR_UNSUPPORTED, "more than 8,388,480 candidate rows per call");
-    if ((F & 3) == 0 && (((uintptr_t)queries | (uintptr_t)feats) & 15 || (q_stride & 3) || (f_stride & 3)))
-        return fail(DG_ERR_INVALID, "feature rows must be 16-byte aligned (pointer and row stride) when F is a multiple of 4");
     DG_HIP(dg_launch_sims_nt(queries, feats, rows_q, n, F, q_stride, f_stride, out, out_stride, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
@@ -1071,12 +1111,11 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
     wb.A2 = nullptr; wb.keep_2 = nullptr; wb.part2 = nullptr; wb.M2 = 0;
     wb.Bs = Bs; wb.dA = d_g; wb.dB = 0; wb.dA2 = 0;
-    SideStream* side = side_stream_for(s);
+    SideRegion side(s);
     if (side) {
-        DG_HIP(hipEventRecord(side->fork, s));
-        DG_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
-        DG_HIP(dg_launch_head_wgrad(wb, false, true, side->s));
-        DG_HIP(hipEventRecord(side->join, side->s));
+        DG_HIP(side.fork());
+        DG_HIP(dg_launch_head_wgrad(wb, false, true, side.stream()));
+        DG_HIP(side.record_join());
     }
     DG_HIP(dg_launch_head_dh(d, s));
     reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
@@ -1088,7 +1127,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);
-    if (side) DG_HIP(hipStreamWaitEvent(s, side->join, 0));
+    if (side) DG_HIP(side.join());
     DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
 }

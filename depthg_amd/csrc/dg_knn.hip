@@ -110,8 +110,10 @@ hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols
 // The contraction of the nearest-neighbour search itself (reference src/precompute_knns.py:106-108,
 // `pairwise_sims = einsum("nf,mf->nm", batch_feats, normed_feats)`): sims[i][j] = <q_i, x_j> in fp32 on the fp32 MFMA
 // (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation in k order - an fp32 dot product, no reduced-precision
-// operands, so near-ties between neighbours fall as they do for an fp32 GEMM).  Round 4: the library GEMM ran this skinny
-// shape (775 x 49,629 x 384 per slice) at 10 TFLOP/s.
+// operands, so near-ties between neighbours fall as they do for an fp32 GEMM).  Measured on a 775 x 49,629 x 384 slice
+// (scripts/knn_time.py): this kernel 75 TFLOP/s, the vendor GEMM (torch.matmul -> rocBLAS) 105 TFLOP/s; the whole cocostuff-sized
+// table 52 against 45 ms.  It is the default engine all the same (depthg_amd/knn.py says why: a fixed k order -> the same table
+// bits on every ROCm version; the 7 ms are paid once, offline).
 // One block = 128 query rows x 128 candidate rows, four waves of 64 x 64 (2 x 2 accumulator tiles); K in chunks of 32 through
 // two LDS buffers, rows of 36 floats ([row][k], as in memory: the staging is 16-byte loads -> 16-byte LDS stores), the next chunk
 // register-staged during the MFMAs of the current one.  The MFMA pairs k-index h of a lane's operand with the other half
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(256) void k_sims_nt(const float* __restrict__ q, co
     const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;                 // this wave's 64 x 64 corner of the block tile
     // staging: float4 piece i of a chunk = row i / 8, k-quad i % 8; four pieces per thread and operand
     f32x4 pa[4], pb[4];
-    const bool vec = (F & 3) == 0;
+    // 16-byte loads where every row starts on a 16-byte boundary and F is a multiple of 4; scalar loads otherwise (any stride)
+    const bool vec = (F & 3) == 0 && ((q_stride | x_stride) & 3) == 0 && ((((uintptr_t)q) | ((uintptr_t)x)) & 15) == 0;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -26,6 +26,32 @@ def _gpu32(t, name):
     return t.detach().to(torch.float32).contiguous()
 
 
+def _check_keeps(keeps, rows, C, device, what):
+    """The library receives the keep flags as raw pointers and indexes keep[b * C + k] for b < rows: a mask of another shape
+    (the (B, C) per-pass masks handed to the (2B, C) pair call), dtype, device or stride would be read out of bounds or as
+    garbage.  Refuse it here.  Returns the 3-tuple (None entries stay None)."""
+    if keeps is None:
+        return (None, None, None)
+    if not isinstance(keeps, (tuple, list)) or len(keeps) != 3:
+        raise ValueError(f"depthg_amd: `keeps` of {what} must be a 3-tuple (cluster1's, cluster2's, the returned feats' Dropout2d "
+                         f"keep flags; None where that draw does not exist), got {type(keeps).__name__}")
+    for i, k in enumerate(keeps):
+        if k is None:
+            continue
+        if not isinstance(k, torch.Tensor):
+            raise ValueError(f"depthg_amd: keeps[{i}] of {what} must be a tensor or None, got {type(k).__name__}")
+        if tuple(k.shape) != (rows, C):
+            raise ValueError(f"depthg_amd: keeps[{i}] of {what} must have shape ({rows}, {C}) - one flag per (image, channel) - "
+                             f"got {tuple(k.shape)}")
+        if k.dtype != torch.float32:
+            raise ValueError(f"depthg_amd: keeps[{i}] of {what} must be float32 0/1 flags, got {k.dtype}")
+        if k.device != device:
+            raise ValueError(f"depthg_amd: keeps[{i}] of {what} lives on {k.device}, the features on {device}")
+        if not k.is_contiguous():
+            raise ValueError(f"depthg_amd: keeps[{i}] of {what} must be contiguous (strides {k.stride()})")
+    return tuple(keeps)
+
+
 class _HeadFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, keeps, scale, want_feats, w1, b1, w2a, b2a, w2b, b2b):
@@ -45,7 +71,7 @@ class _HeadFunction(torch.autograd.Function):
         code = _empty((B, D, h, w), torch.float32, dev)
         feats_out = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
         hidden = _empty((B, C, P), torch.bfloat16, dev) if (nonlinear and need_grad) else None
-        k1, k2, k3 = keeps if keeps is not None else (None, None, None)
+        k1, k2, k3 = _check_keeps(keeps, B, C, dev, "ProjectionHead.forward")
         W = lambda t: _gpu32(t, "head parameter").reshape(t.shape[0], -1) if t is not None else None
         w1c, w2ac, w2bc = W(w1), W(w2a), W(w2b)
         wscratch = _empty((lib.dg_head_weights_bytes(C, D),), torch.uint8, dev)     # bf16 copies of the weights (first launch)
@@ -108,7 +134,7 @@ class _HeadPairFunction(torch.autograd.Function):
         fo = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
         fo_pos = _empty((B, C, h, w), torch.float32, dev) if want_feats else None
         hidden = _empty((2 * B, C, P), torch.bfloat16, dev) if (nonlinear and need_grad) else None
-        k1, k2, k3 = keeps if keeps is not None else (None, None, None)          # (2B, C) each: the first pass's rows first
+        k1, k2, k3 = _check_keeps(keeps, 2 * B, C, dev, "ProjectionHead.forward_pair")   # (2B, C) each: the first pass's rows first
         W = lambda t: _gpu32(t, "head parameter").reshape(t.shape[0], -1) if t is not None else None
         w1c, w2ac, w2bc = W(w1), W(w2a), W(w2b)
         wscratch = _empty((lib.dg_head_weights_bytes(C, D),), torch.uint8, dev)
@@ -242,7 +268,9 @@ class ProjectionHead(nn.Module):
         if self.proj_type is None:                                                                        # :125-126: code = image_feat
             feats = image_feat
             if self.training and feats_dropout:                                                           # :127-129: feats = Dropout2d(image_feat)
-                k3 = keeps[2] if keeps is not None else draw_keep_masks(image_feat.shape[0], image_feat.shape[1], image_feat.device,
+                if keeps is not None:
+                    _check_keeps(keeps, image_feat.shape[0], image_feat.shape[1], image_feat.device, "ProjectionHead.forward")
+                k3 = keeps[2] if keeps is not None and keeps[2] is not None else draw_keep_masks(image_feat.shape[0], image_feat.shape[1], image_feat.device,
                                                                          self.p, use=(False, False, True))[2]
                 feats = image_feat * (k3 * (1.0 / (1.0 - self.p)))[:, :, None, None]
             return image_feat, feats
@@ -257,7 +285,9 @@ class ProjectionHead(nn.Module):
             ka = kb = None
             if keeps is not None:
                 B = image_feat.shape[0]
-                ka, kb = (None, None, keeps[2][:B]), (None, None, keeps[2][B:])
+                _check_keeps(keeps, 2 * B, image_feat.shape[1], image_feat.device, "ProjectionHead.forward_pair")
+                if keeps[2] is not None:
+                    ka, kb = (None, None, keeps[2][:B]), (None, None, keeps[2][B:])
             return self.forward(image_feat, feats_dropout, ka), self.forward(image_feat_pos, feats_dropout, kb)
         return run_head_pair(self.cluster1, getattr(self, "cluster2", None) if self.proj_type == "nonlinear" else None, image_feat,
                              image_feat_pos, self.training, feats_dropout, self.p, keeps, defer_feats_dropout)

@@ -31,7 +31,11 @@ def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int
     decreasing similarity.  Slices like the reference: `step = n // n_batches` query rows per similarity matrix
     (src/precompute_knns.py:101-112), so the peak scratch is `step x n` floats.  `engine`: "hip" = dg_knn_similarities (fp32 MFMA,
     the library's own contraction: 75 TFLOP/s on a 775 x 49,629 x 384 slice), "rocblas" = torch.matmul (the vendor GEMM: 105 TFLOP/s
-    on the same slice; the whole cocostuff-sized table takes 52 against 45 ms - scripts/knn_time.py)."""
+    on the same slice; the whole cocostuff-sized table takes 52 against 45 ms - scripts/knn_time.py).
+    Why the slower engine is the default: its fp32 dot products run in a fixed k order that this library owns, so the table - and
+    with it every positive pick of a training run - has the same bits on every ROCm release, where the vendor GEMM's split of K is
+    free to change; near-ties (the fixtures' smallest gap is 8e-8) are the only rows that can differ.  The job is offline and
+    one-shot: 7 ms.  Pass engine="rocblas" when only speed matters."""
     if engine not in ("hip", "rocblas"):
         raise ValueError(f"engine must be 'hip' or 'rocblas', got {engine!r}")
     if not normed_feats.is_cuda:

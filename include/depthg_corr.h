@@ -311,8 +311,10 @@ int dg_lhp_map_backward(int32_t mode, const float* grad_out, const float* map, c
  * The similarity slice of the offline nearest-neighbour search (replaces `pairwise_sims = torch.einsum("nf,mf->nm", batch_feats,
  * normed_feats)`, src/precompute_knns.py:106-108): out[i][j] = <queries[i], feats[j]>, fp32 products and fp32 accumulation on the
  * fp32 MFMA.
- *  queries : fp32 (rows_q, F), row stride q_stride elements      feats : fp32 (n, F), row stride f_stride      F >= 1; 16-byte aligned
- *  out     : fp32 (rows_q, n), row stride out_stride               rows when F is a multiple of 4 are read with 16-byte loads
+ *  queries : fp32 (rows_q, F), row stride q_stride elements      feats : fp32 (n, F), row stride f_stride      F >= 1
+ *  out     : fp32 (rows_q, n), row stride out_stride
+ * Any row stride >= F and any 4-byte-aligned pointer is accepted: rows are read with 16-byte loads when F is a multiple of 4 and
+ * every row starts on a 16-byte boundary, with 4-byte loads otherwise - the same result bits either way.
  */
 int dg_knn_similarities(const float* queries, const float* feats, int64_t rows_q, int64_t n, int32_t F, int64_t q_stride,
                         int64_t f_stride, float* out, int64_t out_stride, dg_stream_t stream);

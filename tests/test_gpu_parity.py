@@ -905,9 +905,11 @@ def test_knn_similarities_kernel(m, n, F, dev):
     got = ops.knn_similarities(q, x)
     want = (q.double() @ x.double().t())
     assert got.shape == (m, n) and float((got.double() - want).abs().max()) < 2e-6
-    # a strided view of a wider buffer (row stride > F) is read in place
-    wide = torch.zeros(m, F + 8, device=dev)
-    wide[:, :F] = q
-    assert torch.equal(ops.knn_similarities(wide[:, :F], x), got) or F % 4 != 0
+    # a strided view of a wider buffer (row stride > F) is read in place: with a 16-byte-aligned row stride the vector loads run,
+    # with an odd one (and for every F that is not a multiple of 4) the scalar loads - the same bits either way
+    for pad in (8, 3):
+        wide = torch.zeros(m, F + pad, device=dev)
+        wide[:, :F] = q
+        assert torch.equal(ops.knn_similarities(wide[:, :F], x), got), (F, pad)
     with pytest.raises(RuntimeError, match="do not match"):
         ops.knn_similarities(q[:, : F - 1].contiguous(), x)

@@ -428,3 +428,36 @@ def test_deferred_dropout_host_logic():
     # keep flags that do not match the maps are refused before any launch
     with pytest.raises(RuntimeError, match="keep flags"):
         loss.forward_with(f, fp, f, fp, None, torch.zeros(2, 4, 4, 2), torch.zeros(2, 4, 4, 2), None, feat_keep=(k[:1], None, 1.1))
+
+
+def test_head_refuses_keep_masks_the_kernels_would_misread():
+    """The head kernels index keep[b * C + k] through raw pointers: every mask that is not a contiguous fp32 (rows, C) tensor on the
+    features' device is refused before a launch (the (B, C) per-pass masks handed to the (2B, C) pair call were read
+    out of bounds)."""
+    from depthg_amd.head import _check_keeps, ProjectionHead
+    B, C = 3, 8
+    dev = torch.device("cpu")
+    ok = tuple(torch.ones(2 * B, C) for _ in range(3))
+    assert _check_keeps(ok, 2 * B, C, dev, "t") == ok
+    assert _check_keeps(None, B, C, dev, "t") == (None, None, None)
+    assert _check_keeps((ok[0], None, None), 2 * B, C, dev, "t")[1] is None
+    bad = {
+        "shape (per-pass masks in the pair call)": tuple(torch.ones(B, C) for _ in range(3)),
+        "dtype": (torch.ones(2 * B, C, dtype=torch.bool), None, None),
+        "strides": (torch.ones(C, 2 * B).t(), None, None),
+        "arity": (ok[0], ok[1]),
+        "type": (ok[0], 1.0, None),
+        "device": (torch.ones(2 * B, C, device="meta"), None, None),
+    }
+    for what, k in bad.items():
+        with pytest.raises(ValueError):
+            _check_keeps(k, 2 * B, C, dev, what)
+    # the projection_type None path validates too (it multiplies in torch, where a (B,) mask would broadcast silently)
+    head = ProjectionHead(C, 4, None).train()
+    x = torch.randn(B, C, 2, 2)
+    with pytest.raises(ValueError):
+        head(x, True, (None, None, torch.ones(C)))
+    with pytest.raises(ValueError):
+        head.forward_pair(x, x, True, (None, None, torch.ones(B, C)))
+    (c, f), (cp, fp) = head.forward_pair(x, x, True, (None, None, torch.ones(2 * B, C)))
+    assert torch.allclose(f, x / 0.9)
