@@ -739,7 +739,6 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         // of its 32 positions), a 1e-4 bias of the loss sums and 2 % errors in those gradient elements on grids with P a multiple
         // of 32 (config 5's 56 x 56; found in round 4).  The wait states are spent HERE, with the accumulators as operands of the
         // statement, so that every compiler-generated read comes behind them.
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dRv[0]), "+v"(dRv[1]));
     };
     // "previous tile" state of fragment 1 in front of tile 0: cd = -1 everywhere (mask off, G = 0), zero gradient B fragments
 #pragma unroll

@@ -274,8 +274,13 @@ def test_exact_masks_on_the_dense_grid(B, hw, dev):
     for flag in (True, False):
         cfg.dg_exact_masks = flag
         out, tot, g, gp = _run_dense(cfg, prob, dev)
-        for i in (0, 2, 4, 6):
-            assert _relerr(out[i].mean(), ref[i].mean()) < (2e-4 if B * hw * hw < 4000 else 1e-4), (flag, i)
+        # loss means: 2e-5 relative on the grids without padded positions (32 x 32, 40 x 40: where round 4's dropped MFMA cost
+        # 7e-5 .. 1.4e-4 and a 2e-4 bound let it pass; measured now 1-4e-6), 1e-4 - the north_star tolerance - on the small 28 x 28
+        # problem, whose intra mean is a near-cancelling sum of 2 x 784^2 terms
+        errs = [_relerr(out[i].mean(), ref[i].mean()) for i in (0, 2, 4, 6)]
+        print(f"exact_masks={flag} B={B} {hw}x{hw} loss-mean errors:", ["%.2e" % e for e in errs])
+        for i, e in zip((0, 2, 4, 6), errs):
+            assert e < (2e-5 if hw % 8 == 0 else 1e-4), (flag, i, e)
         assert float(out[7].mean()) == pytest.approx(float(ref[7].mean()), rel=1e-6)
         res[flag] = [(float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max())) for a, b in ((g, cr.grad), (gp, cpr.grad))]
     print(f"exact masks B={B} {hw}x{hw}: with {res[True]}  without {res[False]}")

@@ -272,6 +272,65 @@ def test_nns_file_format_and_online_pick(tmp_path):
         knn.nearest_neighbors(torch.from_numpy(g["small_feats"]))
 
 
+def _corr2_asm(tmp_path, src=None, name="dg_corr2.s"):
+    import subprocess
+    src = src or os.path.join(ROOT, "depthg_amd", "csrc", "dg_corr2.hip")
+    out = tmp_path / name
+    # (the flags of the Makefile's rule for this file)
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm", "--cuda-device-only",
+                    "-I", os.path.join(ROOT, "depthg_amd", "csrc"), "-S", str(src), "-o", str(out)], check=True, capture_output=True, timeout=600)
+    return out.read_text()
+
+
+def test_corr2_mfma_results_are_not_touched_early(tmp_path):
+    """Every MFMA of dg_corr2.hip is `asm volatile`: hipcc's hazard recogniser does not see them, and round 4's wrong-result bug was
+    a compiler-generated v_mov one `s_nop 0` behind one of them.  scripts/mfma_hazards.py walks the generated code along every
+    path: no non-MFMA instruction (read OR write) and no MFMA SrcA/SrcB may touch an MFMA's destination registers fewer than 18
+    wait states behind it (the kernel's own rule; the matrix pipe's in-order issue is modelled, so "two MFMAs later" is legal).
+    The checker must also SEE the round-4 bug: the kernel with scripts/experiments/k_corr2_c5bias_revert.patch applied fails."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import mfma_hazards
+    bad, stats = mfma_hazards.audit(_corr2_asm(tmp_path))
+    assert stats["mfma"] >= 400, stats                      # four instantiations of ~120 MFMAs: the parser found the kernels
+    assert not bad, [f"line {J.line_no}: `{J.text}` {t} wait states behind line {M.line_no} `{M.text}`" for M, J, t in bad[:6]]
+    # the pre-fix statement of round 4, from the committed patch
+    csrc = os.path.join(ROOT, "depthg_amd", "csrc")
+    work = tmp_path / "rev"
+    work.mkdir()
+    shutil.copy(os.path.join(csrc, "dg_corr2.hip"), work / "dg_corr2.hip")
+    patch = os.path.join(ROOT, "scripts", "experiments", "k_corr2_c5bias_revert.patch")
+    subprocess.run(["patch", "-p3", "-d", str(work), "-i", patch], check=True, capture_output=True)
+    bad_rev, _ = mfma_hazards.audit(_corr2_asm(tmp_path, work / "dg_corr2.hip", "dg_corr2_rev.s"))
+    assert bad_rev and min(t for _, _, t in bad_rev) <= 4, "the audit no longer sees the round-4 hazard"
+    assert any(J.mnem.startswith("v_mov") for _, J, _ in bad_rev)
+
+
+def test_mfma_hazard_audit_model():
+    """The audit's own arithmetic on hand-written snippets: s_nop N = N + 1 wait states, an MFMA in between occupies the matrix pipe
+    for its passes, a dependent accumulate (SrcC == vDst) is free, SrcA/SrcB reads and plain writes are not, branches are followed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from mfma_hazards import audit
+    M = "v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]\n"
+    other = "v_mfma_f32_32x32x16_bf16 a[0:15], v[20:23], v[24:27], a[0:15]\n"
+    assert len(audit(M + "s_nop 0\nv_mov_b32 v40, v3\n")[0]) == 1                       # round 4's bug
+    assert not audit(M + "s_nop 15\ns_nop 0\nv_mov_b32 v40, v3\n")[0]                 # 1 + 16 + 1 = 18
+    assert len(audit(M + "s_nop 15\nv_mov_b32 v40, v3\n")[0]) == 1                      # 17
+    assert len(audit(M + M + M + "v_mov_b32 v40, v3\n")[0]) == 1                        # dependent chain: the registers belong to the LAST
+    assert not audit(M + M + M + "s_nop 15\ns_nop 0\nv_mov_b32 v40, v3\n")[0]          # MFMA of it, whose own walk decides
+    assert not audit(M + other + other + "s_nop 0\nv_mov_b32 v40, v3\n")[0]             # two independent MFMAs later: 8 + 8 + 1 + 1
+    assert len(audit(M + other + "v_mov_b32 v40, v3\n")[0]) == 1                         # one is not enough (9)
+    assert len(audit(M + "v_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[24:27], a[0:15]\n")[0]) == 1      # result as SrcA of the next MFMA
+    assert len(audit(M + "s_nop 3\nv_mov_b32 v2, 0\n")[0]) == 1                          # a WRITE under the late write-back
+    assert len(audit(M + "s_cbranch_scc1 .LBB0_2\ns_nop 15\ns_nop 7\n.LBB0_2:\nglobal_store_dword v[30:31], v5, off\n")[0]) == 1
+    assert not audit(M + "s_nop 15\ns_nop 7\nv_mov_b32 v40, v3\n", required=18)[0]
+
+
 def test_corr2_owns_the_accumulator_file(tmp_path):
     """dg_corr2.hip names accumulator registers literally in inline asm (the stationary feature fragments live there for a
     whole block).  hipcc must neither spill nor allocate values of its own into that file - it does both silently when the
