@@ -3,6 +3,7 @@
 #include "dg_common.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -44,15 +45,25 @@ struct Plan {
     bool xmask, xmask_dense;                // xmask_dense: on the dense identity grid (DG_EXACT_MASKS)
     size_t clo[2];                          // ... with pointwise: the parts of the normalised code the fp16 C parts drop (k_cd_mask3)
     size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
+    // the fused small-grid path (dg_small.hip): sampled rows -> ONE launch
+    bool small;
+    int nsplit;                             // blocks per (image, pair-set): 2 when the image has 5 tiles
+    size_t dRA2[DG_MAX_NEG + 2], dRBs[DG_MAX_NEG + 2], dRB2[DG_MAX_NEG + 2][2], part4, om;
     size_t total;
 };
+
+// developer A/B: DG_SMALL_PATH=0 keeps the multi-launch small-grid path of rounds 2-4 (needs C <= 768)
+static bool small_path_enabled() {
+    static const bool on = [] { const char* e = getenv("DG_SMALL_PATH"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (!d) return fail(DG_ERR_INVALID, "null descriptor");
     if (d->B < 1 || d->C < 1 || d->D < 1 || d->h < 1 || d->w < 1 || d->S < 1)
         return fail(DG_ERR_INVALID, "non-positive dimension in descriptor");
     if (d->n_neg < 0 || d->n_neg > DG_MAX_NEG) return fail(DG_ERR_UNSUPPORTED, "n_neg=%d outside [0,%d]", d->n_neg, DG_MAX_NEG);
-    if (d->C > 768) return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels not supported", d->C);
+    if (d->C > 8192) return fail(DG_ERR_UNSUPPORTED, "C=%d > 8192 feature channels not supported", d->C);
     if (d->D > 128) return fail(DG_ERR_UNSUPPORTED, "D=%d > 128 code channels not supported", d->D);
     if ((size_t)d->h * d->w > 16384) return fail(DG_ERR_UNSUPPORTED, "feature map %dx%d too large", d->h, d->w);
     if (d->code_h < 0 || d->code_w < 0 || (d->code_h == 0) != (d->code_w == 0))
@@ -66,6 +77,15 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.Ppad = (int)up(p.P, 32);
     p.KF = d->C <= 128 ? 128 : (d->C <= 384 ? 384 : 768);
     p.KD = d->D <= 96 ? 96 : 128;
+    // Sample grids of at most 160 positions (every recipe the reference ships: feature_samples = 11 / 12) take the fused small-grid
+    // kernel, which streams the feature channels in chunks and so has no width limit (FeaturePyramidNet: 2048).  The blob kernels
+    // (larger grids, the identity grid) hold whole channel vectors in registers / LDS: C <= 768 there.
+    p.small = !(d->flags & DG_IDENTITY_GRID) && dg_small_supported(p.Ppad, p.KD) && small_path_enabled();
+    p.nsplit = p.Ppad == 160 ? 2 : 1;
+    if (d->C > 768 && !p.small)
+        return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels are supported on sample grids of at most 160 positions "
+                                        "(feature_samples <= 12) only; this call has %d positions%s", d->C, p.P,
+                    (d->flags & DG_IDENTITY_GRID) ? " on the dense identity grid" : "");
     p.C4 = (int)up(d->C, 4); p.D4 = (int)up(d->D, 4);
     p.T = 2 + p.N;
     p.shared = (d->flags & DG_SHARED_COORDS) != 0;
@@ -90,7 +110,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     // (code maps of another size than the feature maps - the FeaturePyramidNet contract - take the channel-last gather path)
     p.rows = !p.ident && same_maps && (size_t)p.nops * p.P <= 2 * HW && HW <= 1024 && B <= 32767;
     for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(p.rows ? 0 : B * HW * p.C4 * 4); p.nhwc_c[i] = take(p.rows ? 0 : B * HWc * p.D4 * 4); }
-    for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(p.rows ? B * p.P * p.C4 * 4 : 0); p.rows_c[i] = take(p.rows ? B * p.P * p.D4 * 4 : 0); }
+    const bool want_rows = p.rows || p.small;      // (the fused small-grid kernel reads sampled rows whichever sampler wrote them)
+    for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(want_rows ? B * p.P * p.C4 * 4 : 0); p.rows_c[i] = take(want_rows ? B * p.P * p.D4 * 4 : 0); }
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
@@ -112,7 +133,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.ticket = take(256);
     // exact clamp masks: gradient passes of the zero_clamp recipe on small sample grids (fp32 sampled rows exist, <= 8 tiles, the
     // one-wave-per-SIMD form of k_corr_main)
-    p.xmask = p.rows && p.grad && (d->flags & DG_ZERO_CLAMP) && !(d->flags & DG_STABALIZE) && p.Ppad <= 256 && p.rf == 4;
+    p.xmask = p.rows && !p.small && p.grad && (d->flags & DG_ZERO_CLAMP) && !(d->flags & DG_STABALIZE) && p.Ppad <= 256 && p.rf == 4;
 #ifdef DG_NO_XMASK      // developer A/B: the fp16 masks everywhere
     p.xmask = false;
 #endif
@@ -120,7 +141,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     // computed from channel-last fp32 copies of the two code maps (the workspace's nhwc_c regions, otherwise unused on this grid)
     p.xmask_dense = (d->flags & DG_EXACT_MASKS) && p.ident && p.grad && (d->flags & DG_ZERO_CLAMP) && !(d->flags & DG_STABALIZE) &&
                     p.KF == 384 && p.KD == 96 && p.D <= 80 && p.Ppad >= 160 && p.B <= 64;
-    if ((d->flags & DG_EXACT_MASKS) && p.grad && (d->flags & DG_ZERO_CLAMP) && !p.xmask && !p.xmask_dense)
+    if ((d->flags & DG_EXACT_MASKS) && p.grad && (d->flags & DG_ZERO_CLAMP) && !p.xmask && !p.xmask_dense && !p.small)
         return fail(DG_ERR_UNSUPPORTED, "DG_EXACT_MASKS: exact clamp masks exist on small sample grids (always on there) and on the dense "
                                         "identity grid with C <= 384 (padded to 384), D <= 80, P >= 160, B <= 64, zero_clamp without stabalize");
     for (int t = 0; t < p.T; ++t) p.maskbits[t] = take((p.xmask || p.xmask_dense) ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
@@ -128,6 +149,17 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
     p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
     p.gr_rank = take((size_t)DG_MAX_JOBS * B * 2);
+    {
+        const bool two = p.small && p.grad && p.pointwise;       // the old_mean terms of the gradient (dg_small.hip)
+        const size_t gt = B * p.Ppad * p.KD * 4;
+        for (int t = 0; t < p.T; ++t) {
+            p.dRA2[t] = take(two ? gt : 0);
+            p.dRBs[t] = take(p.small && p.grad && p.nsplit == 2 ? gt : 0);
+            for (int k = 0; k < 2; ++k) p.dRB2[t][k] = take(two && k < p.nsplit ? gt : 0);
+        }
+        p.part4 = take(p.small ? (size_t)(p.T + 1) * B * p.nsplit * 16 : 0);
+        p.om = take(p.small ? (size_t)(p.T + 1) * 4 : 0);
+    }
     p.total = off;
     return DG_OK;
 }
@@ -366,6 +398,92 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
 }
 
 struct DrawArgs { int64_t* out; uint64_t seed; unsigned long long* state; };
+
+// ---- the fused small-grid path (dg_small.hip)
+static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, DgSmallArgs& a) {
+    memset(&a, 0, sizeof(a));
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    for (int o = 0; o < p.nops; ++o) { a.rowsF[o] = F32(p.rows_f[o]); a.rowsC[o] = F32(p.rows_c[o]); }
+    a.T = p.T; a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.C4 = p.C4; a.D = p.D; a.D4 = p.D4; a.KD = p.KD;
+    a.pointwise = p.pointwise ? 1 : 0; a.depth = p.depth ? 1 : 0; a.grad = p.grad ? 1 : 0;
+    clamp_bounds(d, a.lo, a.hi);
+    for (int t = 0; t < p.T; ++t) a.shift[t] = shift_of(d, t);
+    a.shift_depth = d->shift_depth;
+    a.nz = F32(p.nz); a.nzsum = F32(p.nzsum);
+    for (int t = 0; t <= p.T; ++t) a.dRA[t] = F32(p.dRA[t]);
+    for (int t = 0; t < p.T; ++t) {
+        a.dRA2[t] = F32(p.dRA2[t]);
+        a.dRB[t][0] = F32(p.dRB[t]); a.dRB[t][1] = F32(p.dRBs[t]);
+        a.dRB2[t][0] = F32(p.dRB2[t][0]); a.dRB2[t][1] = F32(p.dRB2[t][1]);
+    }
+    a.part = F32(p.part4); a.om = F32(p.om);
+    a.ticket = reinterpret_cast<unsigned int*>(ws + p.ticket) + 32;
+    const DgBlob bl(p.KF, p.KD);
+    a.xop = ws + p.op[0]; a.xinv = F32(p.inv[0]); a.blob_bytes = bl.bytes; a.blob_off_c = bl.off_c;
+    a.wtot[0] = d->w_intra; a.wtot[1] = d->w_inter; a.wtot[2] = d->w_neg; a.wtot[3] = d->w_depth;
+    a.nsplit = p.nsplit;
+}
+
+// sampled rows of every operand (the reference's sample(), src/modules.py:822-825, of feats / code at coords1 / coords2 and of the
+// negatives' permuted maps, :1323-1343) -> the fused kernel.  Launches: the draw + depth indicators + tap records + ticket word, the
+// sampler, the fused kernel.
+static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                         const float* orig_code, const float* orig_code_pos, const float* depth, const float* coords1,
+                         const float* coords2, const int64_t* perms, const DrawArgs* draw, float* out_scalars, char* ws,
+                         hipStream_t stream) {
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    DgSmallArgs a;
+    small_args(p, desc, ws, a);
+    a.out = out_scalars;
+    {
+        DgPreArgs q;
+        memset(&q, 0, sizeof(q));
+        if (draw && p.N > 0) { q.seed = draw->seed; q.state = draw->state; q.perms = draw->out; q.count = p.N; }
+        if (p.depth) { q.depth = depth; q.nz = F32(p.nz); q.nzsum = F32(p.nzsum); q.dH = desc->depth_h; q.dW = desc->depth_w; }
+        if (p.grad && (size_t)p.hc * p.wc <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
+        q.B = p.B; q.h = p.hc; q.w = p.wc; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;
+        q.zero_word = a.ticket;
+        if (p.B > 8192 && q.count > 0) return fail(DG_ERR_UNSUPPORTED, "B=%d too large for the in-call draw", p.B);
+        DG_HIP(dg_launch_pre_general(q, stream));
+    }
+    if (p.rows) {
+        DgPlaneArgs t;
+        memset(&t, 0, sizeof(t));
+        t.src[0] = orig_feats; t.src[1] = orig_feats_pos; t.src[2] = orig_code; t.src[3] = orig_code_pos;
+        t.K[0] = t.K[1] = p.C; t.K4[0] = t.K4[1] = p.C4; t.K[2] = t.K[3] = p.D; t.K4[2] = t.K4[3] = p.D4;
+        for (int o = 0; o < p.nops; ++o) { t.rows[o][0] = F32(p.rows_f[o]); t.rows[o][1] = F32(p.rows_c[o]); }
+        t.coords1 = coords1; t.coords2 = coords2; t.perms = perms;
+        t.nops = p.nops; t.B = p.B; t.h = p.h; t.w = p.w; t.S = p.S; t.Sh = p.Sh; t.P = p.P;
+        DG_HIP(dg_launch_plane_sample(t, stream));
+    } else {
+        // code maps of another size than the feature maps (the FeaturePyramidNet contract) or maps beyond the plane sampler's LDS:
+        // channel-last copies, then a bilinear gather into the same rows
+        DgTransposeArgs t;
+        memset(&t, 0, sizeof(t));
+        t.nmaps = 4;
+        t.src[0] = orig_feats; t.dst[0] = F32(p.nhwc_f[0]); t.K[0] = p.C; t.K4[0] = p.C4; t.HW[0] = p.h * p.w;
+        t.src[1] = orig_feats_pos; t.dst[1] = F32(p.nhwc_f[1]); t.K[1] = p.C; t.K4[1] = p.C4; t.HW[1] = p.h * p.w;
+        t.src[2] = orig_code; t.dst[2] = F32(p.nhwc_c[0]); t.K[2] = p.D; t.K4[2] = p.D4; t.HW[2] = p.hc * p.wc;
+        t.src[3] = orig_code_pos; t.dst[3] = F32(p.nhwc_c[1]); t.K[3] = p.D; t.K4[3] = p.D4; t.HW[3] = p.hc * p.wc;
+        DG_HIP(dg_launch_transpose(t, p.B, stream));
+        DgGatherRowsArgs g;
+        memset(&g, 0, sizeof(g));
+        int nj = 0;
+        for (int o = 0; o < p.nops; ++o) {
+            const int srcsel = o == 1 ? 1 : 0;          // op 1 reads the *_pos maps, negatives read orig_feats / orig_code
+            const float* coords = o == 0 ? coords1 : coords2;
+            const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
+            g.src[nj] = F32(p.nhwc_f[srcsel]); g.coords[nj] = coords; g.srcidx[nj] = idx; g.rows[nj] = F32(p.rows_f[o]);
+            g.K4[nj] = p.C4; g.h[nj] = p.h; g.w[nj] = p.w; ++nj;
+            g.src[nj] = F32(p.nhwc_c[srcsel]); g.coords[nj] = coords; g.srcidx[nj] = idx; g.rows[nj] = F32(p.rows_c[o]);
+            g.K4[nj] = p.D4; g.h[nj] = p.hc; g.w[nj] = p.wc; ++nj;
+        }
+        g.njobs = nj; g.B = p.B; g.S = p.S; g.Sh = p.Sh; g.P = p.P;
+        DG_HIP(dg_launch_gather_rows(g, stream));
+    }
+    DG_HIP(dg_launch_corr_small(a, stream));
+    return DG_OK;
+}
 struct FeatKeep { const float* keep[2]; float scale; };      // deferred Dropout2d of the two feature maps (dg_corr_forward_masked)
 
 static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
@@ -464,6 +582,9 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             m.T = p.T; m.B = p.B; m.P = p.P; m.Ppad = p.Ppad; m.D = p.D; m.D4 = p.D4;
             DG_HIP(dg_launch_cd_mask(m, stream));
         }
+    } else if (p.small) {
+        return forward_small(p, desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms, draw,
+                             out_scalars, ws, stream);
     } else {
         // general coordinates: the first launch already reads the batch maps, so they are drawn by a launch of their own - which
         // also carries the other jobs that depend on nothing but the call's inputs: the depth indicators and, on gradient passes,
@@ -705,6 +826,24 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     };
     // dRA[t]: the fused kernel's raw accumulator-order tiles (stationary operand = operand 1 for every pair-set);
     // dRB[t]: k_gs output, row-major, normalisation backward already applied
+    if (p.small) {
+        // the fused small-grid kernel (dg_small.hip): stationary-side tiles raw, streamed-side tiles final (one set per half of the
+        // stationary tiles), and with `pointwise` the same again for the old_mean term, whose factor old_mean_t lives on the device
+        for (int t = 0; t < p.T; ++t) {
+            const int gi = t < 2 ? t : 2;
+            const float ft = t < 2 ? f : fn;
+            const int64_t* route = t >= 2 ? perms + (size_t)(t - 2) * p.B : nullptr;
+            const int csel = t == 0 ? 0 : 1, dest = t == 1 ? 1 : 0;
+            add(p.dRA[t], nullptr, gi, 0, ft, 0, 1);
+            add(p.dRB[t], route, gi, csel, ft, dest, 0);
+            if (p.nsplit == 2) add(p.dRBs[t], route, gi, csel, ft, dest, 0);
+            if (p.pointwise) {
+                const float* om = F32(p.om) + t;
+                add(p.dRA2[t], nullptr, gi, 0, ft, 0, 1); s.src[n - 1].dfac = om;
+                for (int k = 0; k < p.nsplit; ++k) { add(p.dRB2[t][k], route, gi, csel, ft, dest, 0); s.src[n - 1].dfac = om; }
+            }
+        }
+    } else {
     if (intra_is_symmetric(p)) add(p.dRA[0], nullptr, 0, 0, 2.0f * f, 0, 1);      // -G symmetric: d/dc1 + d/dc2 = 2 d/dc1 (no k_gs job, build_gs_jobs)
     else { add(p.dRA[0], nullptr, 0, 0, f, 0, 1); add(p.dRB[0], nullptr, 0, 0, f, 0, 0); }
     add(p.dRA[1], nullptr, 1, 0, f, 0, 1);
@@ -712,6 +851,7 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     for (int k = 0; k < p.N; ++k) {
         add(p.dRA[2 + k], nullptr, 2, 0, fn, 0, 1);
         add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0, 0);
+    }
     }
     if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0, 1);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
     s.nsrc = n;
@@ -745,6 +885,13 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     if (which >= 2 && p.shared) return fail(DG_ERR_UNSUPPORTED, "materialising negatives needs the perms; not available with DG_SHARED_COORDS");
     if (!out_cd && !out_loss) return DG_OK;
     char* ws = static_cast<char*>(workspace);
+    if (p.small) {          // the fused small-grid kernel again, on the rows (and old_mean_t) the forward left in the workspace
+        DgSmallArgs m;
+        small_args(p, desc, ws, m);
+        m.mat = 1; m.mat_t = which; m.out_cd = out_cd; m.out_loss = out_loss; m.grad = 0;
+        DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
+        return DG_OK;
+    }
     DgCorrArgs a;
     corr_args_base(p, desc, ws, a);
     // stationary = operand 2 (on MFMA lanes) -> the stores of one accumulator register are contiguous along q
@@ -766,6 +913,14 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     if (rc != DG_OK) return rc;
     if (!workspace || workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace missing or too small");
     if (p.N > 0 && !perms) return fail(DG_ERR_INVALID, "perms is null");
+    if (p.small) {
+        // (the scalars of the re-launch go to the workspace's scratch vector: the call's own outputs are not touched)
+        DgSmallArgs m;
+        small_args(p, desc, static_cast<char*>(workspace), m);
+        m.out = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.scratch_out);
+        DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
+        return DG_OK;
+    }
     DgCorrArgs a;
     int depth_index;
     const int njA = build_corr_jobs(p, desc, static_cast<char*>(workspace), perms, a, &depth_index);
@@ -776,6 +931,7 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
 extern "C" const char* dg_corr_main_kernel_name(const dg_corr_desc* desc) {
     Plan p;
     if (make_plan(desc, p) != DG_OK) return nullptr;
+    if (p.small) return "k_corr_small";
     // the job table holds addresses only: a made-up workspace base and batch-map pointer decide nothing but null / non-null
     char* const ws = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 21);
     const int64_t* const perms = reinterpret_cast<const int64_t*>(static_cast<uintptr_t>(1) << 20);

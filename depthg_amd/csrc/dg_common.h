@@ -274,6 +274,7 @@ struct DgPreArgs {
     const float* depth; float* nz; float* nzsum; int32_t dH, dW;                  // depth indicators
     const float* coords1; const float* coords2; char* taps;                       // inverse tap records [2][B]
     int32_t B, h, w, S, Sh, P, Ppad;
+    unsigned int* zero_word;      // a word this launch sets to 0 (the ticket of the fused small-grid kernel), or null
 };
 
 // exact clamp masks of the small sample grids (k_cd_mask; dg_prep.hip)
@@ -406,6 +407,48 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 }
 #endif
 
+// ---- the fused small-sample-grid path (dg_small.hip; round 5): Ppad <= 160 positions per image (the S = 11 / 12 recipes of
+// paper_reproduction.sh:5-14 and everything below), any feature width.  ONE launch per call replaces operand building, column / row
+// means, exact clamp masks, the correlation and the streamed-side gradient: a block owns one (image, pair-set[, half of the
+// stationary tiles]) and reads the SAMPLED fp32 rows of its two operands once.
+struct DgSmallArgs {
+    const float* rowsF[DG_MAX_NEG + 2];   // [operand][B][P][C4] sampled feature rows (k_plane_sample / k_gather_rows), channels C..C4-1 zero
+    const float* rowsC[DG_MAX_NEG + 2];   // [operand][B][P][D4] sampled code rows
+    int32_t T, B, P, Ppad, C4, D, D4, KD; // T pair-sets (operand of pair-set t = t); KD in {96, 128}: padded code width of the gradient tiles
+    int32_t pointwise, depth, grad;
+    float lo, hi;                         // clamp bounds
+    float shift[DG_MAX_NEG + 2], shift_depth;
+    const float* nz;                      // [B][Ppad] depth indicators (depth term)
+    const float* nzsum;                   // [B]
+    float* dRA[DG_MAX_NEG + 3];           // gradient tiles (dg_gtile_off), raw (normalisation backward pending): d/d(normalised operand-0 code)
+                                          // of pair-set t from sum_q -G[p][q] y_q; [T] = the depth term
+    float* dRA2[DG_MAX_NEG + 2];          // pointwise: the same with -G replaced by the clamp mask (factor old_mean_t, see om)
+    float* dRB[DG_MAX_NEG + 2][2];        // final tiles (normalisation backward applied) of the streamed operand, one per half of the R tiles
+    float* dRB2[DG_MAX_NEG + 2][2];       // pointwise: mask form
+    float* part;                          // [T + 1][B][nsplit][4]: sum clamp(cd)(fd' - shift), sum clamp(cd), sum fd, sum cd
+    float* om;                            // [T] out: old_mean of pair-set t (0 without pointwise) - the factor of the "2" gradient sets
+    unsigned int* ticket;                 // zero at launch; the block that finishes last reduces `part` into `out`
+    char* xop;                            // operand-0 blobs: the C part (normalised fp16 code rows) is written for the backward tail
+    float* xinv;                          // [B][Ppad] 1 / max(||code||, eps) of operand 0
+    int32_t blob_bytes, blob_off_c;
+    float* out;                           // [DG_OUT_COUNT]
+    float wtot[4];
+    int32_t nsplit;                       // blocks per (image, pair-set): 1, or 2 when the image has 5 tiles (3 + 2 stationary tiles)
+    // materialise (dg_corr_materialize): the un-reduced tensors of pair-set mat_t (-1: the depth term's dd) instead of everything above
+    float* out_cd;                        // [B][P][P] or null
+    float* out_loss;
+    int32_t mat_t, mat;
+};
+
+struct DgGatherRowsArgs {   // k_gather_rows: sample() of channel-last maps into fp32 rows (code maps of another size, maps beyond the LDS)
+    const float* src[2 * (DG_MAX_NEG + 2)];      // NHWC fp32 [B][h*w][K4]
+    const float* coords[2 * (DG_MAX_NEG + 2)];   // [B][S][Sh][2]
+    const int64_t* srcidx[2 * (DG_MAX_NEG + 2)]; // batch map or null
+    float* rows[2 * (DG_MAX_NEG + 2)];           // [B][P][K4]
+    int32_t K4[2 * (DG_MAX_NEG + 2)], h[2 * (DG_MAX_NEG + 2)], w[2 * (DG_MAX_NEG + 2)];
+    int32_t njobs, B, S, Sh, P;
+};
+
 struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     const float* src[2];     // feats NCHW fp32 (B,K,h,w): orig_feats, orig_feats_pos
     const float* code[2];    // code NCHW fp32 (B,D,h,w): orig_code, orig_code_pos
@@ -529,8 +572,10 @@ struct DgScatterSrc {
     float factor;          // constant factor (1/numel etc.)
     int32_t dest;          // 0: grad_code, 1: grad_code_pos
     int32_t raw;           // see buf
+    const float* dfac;     // null, or a device scalar multiplied into the factor (the fused small-grid path: old_mean of the pair-set,
+                           // which only the forward's last block knows - dg_small.hip)
 };
-#define DG_MAX_SCATTER 32
+#define DG_MAX_SCATTER 48
 struct DgScatterArgs {
     DgScatterSrc src[DG_MAX_SCATTER];
     int32_t nsrc;
@@ -555,6 +600,7 @@ struct DgScatterArgs {
 };
 
 #ifdef __HIPCC__
+__device__ __forceinline__ float dg_src_factor(const DgScatterSrc& q) { return q.dfac ? q.factor * q.dfac[0] : q.factor; }
 // effective upstream gradient of loss mean i: direct + through the weighted total
 __device__ __forceinline__ float dg_gscal(const DgScatterArgs& a, int i) {
     return a.gscal ? a.gscal[i] + a.gscal[DG_OUT_TOTAL] * a.wtot[i] : a.gtot[0] * a.wtot[i];
@@ -656,6 +702,9 @@ hipError_t dg_launch_sims_nt(const float* q, const float* x, long long rows_q, l
 hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols, long long row_stride, int k,
                                long long* out_idx, float* out_val, hipStream_t s);
 hipError_t dg_launch_pre_general(const struct DgPreArgs& a, hipStream_t s);
+bool dg_small_supported(int Ppad, int KD);
+hipError_t dg_launch_corr_small(const struct DgSmallArgs& a, hipStream_t s);
+hipError_t dg_launch_gather_rows(const struct DgGatherRowsArgs& a, hipStream_t s);
 hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
 hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,
                                    float* dst, hipStream_t s);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
             for (int u = 0; u < 4; ++u) {
                 const bool live = k0 + u < cnt;
                 const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
-                sc[u] = live ? q.factor * dg_pick(gs, q.gidx) : 0.f;
+                sc[u] = live ? dg_src_factor(q) * dg_pick(gs, q.gidx) : 0.f;
                 const float* base = q.buf + tile_off;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) t[u][g] = *reinterpret_cast<const f32x4*>(base + (ok ? g * 256 : 0));
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
         if (hit) {
             const int o = base + __popcll(bal & ((1ull << lane) - 1));
             const DgScatterSrc& q = a.src[s];
-            if (o < COMB_MAXROUTE) { rl_p[o] = q.buf + (size_t)m * a.Ppad * a.DP; rl_w[o] = q.factor * dg_pick(gs, q.gidx); }
+            if (o < COMB_MAXROUTE) { rl_p[o] = q.buf + (size_t)m * a.Ppad * a.DP; rl_w[o] = dg_src_factor(q) * dg_pick(gs, q.gidx); }
         }
         __syncthreads();
         if (tid == 0) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
             for (int u = 0; u < 4; ++u) {
                 const bool live = k0 + u < nsrc_;
                 const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
-                sc[u] = live ? q.factor * dg_pick(gs, q.gidx) : 0.f;
+                sc[u] = live ? dg_src_factor(q) * dg_pick(gs, q.gidx) : 0.f;
                 const float* base = q.buf + tile_off;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) t[u][g] = *reinterpret_cast<const f32x4*>(base + (ok ? g * 256 : 0));
@@ -262,18 +262,21 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_build_taps(const DgScatterArgs
 __global__ __launch_bounds__(256) void k_pre_general(const DgPreArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pg[];
     int b = (int)blockIdx.x;
+    if (a.zero_word && b == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     if (b < a.count) { dg_super_perm_row(nullptr, a.seed, a.state, a.B, a.perms, b, a.count, reinterpret_cast<float*>(pg)); return; }
     b -= a.count;
     if (a.depth) {
         if (b < a.B) { depth_nz_image(a.depth, a.nz, a.nzsum, b, a.dH, a.dW, a.Sh, a.S, a.Ppad); return; }
         b -= a.B;
     }
+    if (!a.taps) return;                       // (a launch that only zeroes the ticket word)
     const DgTapsArgs t{a.coords1, a.coords2, a.taps, a.B, a.h, a.w, a.S, a.Sh, a.P};
     build_taps_block<256>(t, b % a.B, b / a.B, pg);
 }
 
 hipError_t dg_launch_pre_general(const DgPreArgs& a, hipStream_t s) {
-    const int nblk = a.count + (a.depth ? a.B : 0) + (a.taps ? 2 * a.B : 0);
+    int nblk = a.count + (a.depth ? a.B : 0) + (a.taps ? 2 * a.B : 0);
+    if (nblk == 0 && a.zero_word) nblk = 1;
     if (nblk == 0) return hipSuccess;
     size_t smem = a.count > 0 ? (size_t)a.B * 4 : 0;
     if (a.taps) {
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_grad(const DgScatterAr
     for (int s = 0; s < a.nsrc; ++s) {
         const DgScatterSrc& q = a.src[s];
         if (q.dest != dest || q.route == nullptr) continue;
-        const float sc = q.factor * dg_pick(gs, q.gidx);
+        const float sc = dg_src_factor(q) * dg_pick(gs, q.gidx);
         for (int n0 = 0; n0 < a.B; n0 += 64) {           // which images route here: one ballot per 64 images
             const int nn = n0 + (tid & 63);
             const bool hit = nn < a.B && (int)q.route[nn] == bdst;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void k_scatter_small(const DgScatterA
                 const int s = l_s[i], n = l_n[i];
                 const DgScatterSrc& q = a.src[s < 0 ? 0 : s];
                 const float* buf = s < 0 ? a.comb[dest] : q.buf;
-                const float sc = s < 0 ? 1.0f : q.factor * dg_pick(gs, q.gidx);
+                const float sc = s < 0 ? 1.0f : dg_src_factor(q) * dg_pick(gs, q.gidx);
                 const int cs = s < 0 ? (dest == 0 ? 0 : 1) : q.coords_sel;
                 push(buf, sc, cs, n);
             }
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_scatter_dense(const DgScatter
         if (hit) {
             const int o = base + __popcll(m & ((1ull << lane) - 1));
             const DgScatterSrc& q = a.src[s];
-            if (o < DENSE_MAXROUTE) { rl_p[o] = q.buf + (size_t)n * a.Ppad * a.DP; rl_w[o] = q.factor * dg_pick(gs, q.gidx); }
+            if (o < DENSE_MAXROUTE) { rl_p[o] = q.buf + (size_t)n * a.Ppad * a.DP; rl_w[o] = dg_src_factor(q) * dg_pick(gs, q.gidx); }
         }
         __syncthreads();
         if (tid == 0) {

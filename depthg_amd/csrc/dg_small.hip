@@ -1,0 +1,582 @@
+// The fused small-sample-grid path (round 5): Ppad <= 160 sampled positions per image - every recipe the reference ships runs here
+// (feature_samples = 11 / 12, paper_reproduction.sh:5-14; src/modules.py:1287, 1304-1347) - at ANY feature width (FeaturePyramidNet's
+// 2048 channels, src/modules.py:732-766).
+//
+// k_corr_small: ONE launch per call.  A block owns (image n, pair-set t[, half of the stationary tiles]) of helper()
+// (src/modules.py:1231-1254) or the depth term (:1256-1278) and reads the SAMPLED fp32 rows of its two operands once:
+//   phase 1  the feature rows stream through LDS in chunks of 64 channels (fp32 -> bf16 on the way, squared norms accumulated beside
+//            them), fd_raw = <a_p, b_q> of the un-normalised rows on the bf16 MFMA, one accumulator tile per (R tile, S tile) held in
+//            registers for the whole block; norm() (:789-790) is applied to the finished tiles as 1/|a_p| * 1/|b_q|;
+//   phase 2  the code rows are normalised in fp32 and split into fp16 hi + lo parts; cd = hi.hi + hi.lo + lo.hi in one accumulator
+//            (fp32-grade: the clamp mask 1[lo <= cd <= hi] is exact, for zero_clamp AND stabalize); pointwise centering from the
+//            block's own row sums (:1236-1239: the row mean is local, old_mean is not - see below); epilogue in registers;
+//            d/d(stationary code) += G^T y with the accumulator tile itself as the A operand; G goes to LDS (fp16) and comes back
+//            row-wise as the A operand of d/d(streamed code) = G x, which gets its normalisation backward right here.
+// old_mean (fd.mean() over the WHOLE batch, :1237) is not known inside a block.  Everything is linear in it:
+//   loss sum  = sum clamp(cd) (fd' - shift) + old_mean * sum clamp(cd)               fd' = fd - rowmean
+//   gradient  = [mask (fd' - shift)] . y     + old_mean * [mask] . y
+// so a pointwise block emits both terms (the second set of gradient tiles costs MFMAs and bytes, no launch and no grid barrier);
+// the block that finishes last (ticket) reduces the partial sums, forms old_mean_t and the output scalars and leaves old_mean_t in
+// `om`, which the backward tail multiplies into the weight of the second set (DgScatterSrc.dfac).
+// Gradient tiles, partial sums and the operand-0 C part / inverse norms are written in the formats the existing backward tail
+// (dg_post.hip k_grad_combine / k_scatter_small) reads.
+//
+// k_gather_rows: sample() (:822-825) of channel-last maps into the fp32 rows above, for calls whose maps k_plane_sample cannot take
+// (code maps of another size than the feature maps, maps beyond its LDS planes).
+#include "dg_common.h"
+#include <hip/hip_runtime.h>
+
+typedef int v4i_s __attribute__((ext_vector_type(4)));
+
+#define SM_THREADS 256
+
+// LDS images.  Feature chunk: [row][64 bf16] = 128-byte rows, granule (16 B) g of row r at slot g ^ ((r >> 1) & 7): the 16 lanes of
+// one ds_read_b128 pass (16 consecutive rows, one granule) cover all 64 banks.  Code: [row][<= 128 fp16] in 256-byte rows, slot
+// g ^ (r & 15).  G: [S position][R position] fp16 in 256-byte rows, same swizzle.
+__device__ __forceinline__ uint32_t sm_f(int row, int g) { return (uint32_t)row * 128u + (uint32_t)((g ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ uint32_t sm_c(int row, int g) { return (uint32_t)row * 256u + (uint32_t)((g ^ (row & 15)) << 4); }
+
+// 1.0 where g != 0 (the clamp mask back out of the stored -G: the epilogue never stores an exact zero for an element that is on)
+__device__ __forceinline__ f16x8 sm_mask_of(const f16x8 g) {
+    const v4i_s b = __builtin_bit_cast(v4i_s, g) & v4i_s{0x7fff7fff, 0x7fff7fff, 0x7fff7fff, 0x7fff7fff};
+    f16x8 t = __builtin_bit_cast(f16x8, b);
+    const _Float16 big = (_Float16)32768.f;
+    t = t * big;
+    t = t * big;                                   // >= 1 (or inf) for every non-zero input, subnormals included
+    f16x8 one;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) one[e] = (_Float16)1.f;
+    return __builtin_elementwise_min(t, one);
+}
+
+template <int NS, int NKD, bool PW>
+__global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_corr_small(const DgSmallArgs a) {
+    constexpr int NRM = NS == 5 ? 3 : NS;          // most stationary tiles of one block (5 tiles: blocks of 3 and 2)
+    constexpr int NDF = NKD / 2;                   // 32-channel groups of a gradient tile row
+    constexpr int KD = NKD * 16;
+    constexpr int NJ = NRM + NS;                   // loader passes: 256 threads = one tile of 32 rows x 8 granules
+    constexpr uint32_t FR0 = 0, FRB = NRM * 32 * 128, FS0 = 2 * FRB, FSB = NS * 32 * 128;            // phase 1
+    constexpr uint32_t XH = 0, YH = NRM * 32 * 256, YL = YH + NS * 32 * 256, GB = YL + NS * 32 * 256; // phase 2 (XL = GB until the epilogues)
+    static_assert(FS0 + 2 * FSB <= GB + NS * 32 * 256, "phase 1 fits the phase-2 image");
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    __shared__ float invF[NJ * 32], invC[NJ * 32], red[4 * 4];
+    __shared__ int last_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.P, B = a.B, NT = a.Ppad >> 5;
+    // block -> (image, pair-set, split): the blocks of one image sit on one XCD (ids are dealt round-robin over 8 XCDs), so the rows
+    // of its stationary operand come out of one L2
+    const int nsplit = a.nsplit;
+    const int njob = a.mat ? 1 : a.T + (a.depth ? 1 : 0);
+    const int per = njob * nsplit;
+    const int xk = (int)blockIdx.x >> 3;
+    const int n = ((int)blockIdx.x & 7) + 8 * (xk / per);
+    if (n >= B) return;
+    const int jj = xk % per;
+    const int sp = jj % nsplit;
+    int t = jj / nsplit;
+    if (a.mat) t = a.mat_t < 0 ? a.T : a.mat_t;
+    const bool depth_job = t == a.T;
+    const int rt0 = sp == 0 ? 0 : 3;
+    const int NR = nsplit == 1 ? NS : (sp == 0 ? 3 : 2);
+    const bool grad = a.grad != 0 && !a.mat;
+    const int opS = depth_job ? 0 : t;
+
+    // ---- loader geometry: pass j = stationary tile j (j < NR) or streamed tile j - NR; thread = (row of the tile, granule of 8 channels)
+    const int row32 = tid >> 3, gran = tid & 7;
+    auto pass_pos = [&](int j) { return j < NR ? (rt0 + j) * 32 + row32 : (j - NR) * 32 + row32; };
+    auto pass_idx = [&](int j) { return (j < NR ? j : NRM + (j - NR)) * 32 + row32; };        // index into invF / invC, LDS row = the same
+
+    f32x16 acc[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[st][i] = 0.f;
+
+    // (the lambdas below capture these copies, never `a` itself: a by-reference capture of the kernel argument makes hipcc copy the
+    //  whole struct to scratch in every thread)
+    const float* const rowsC_R = a.rowsC[0];
+    const float* const rowsC_S = a.rowsC[opS];
+    const int D4 = a.D4;
+    f32x4 vc[2][NJ][2];                            // the code rows (two chunks of 64 channels), loaded under the last feature chunk
+    auto issue_code = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool live = j < NR + NS;
+            const int pos = live ? pass_pos(j) : 0;
+            const float* src = (j < NR ? rowsC_R : rowsC_S) + ((size_t)n * P + (pos < P ? pos : 0)) * D4;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = c * 64 + gran * 8 + 4 * u;
+                    vc[c][j][u] = (live && pos < P && k < D4) ? *reinterpret_cast<const f32x4*>(src + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    };
+
+    if (!depth_job) {
+        const int C4 = a.C4, nch = (C4 + 63) >> 6;
+        const float* srcp[NJ];
+        bool ok[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool live = j < NR + NS;
+            const int pos = live ? pass_pos(j) : 0;
+            ok[j] = live && pos < P;
+            srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4 + gran * 8;
+        }
+        f32x4 v[NJ][2];
+        float ss[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
+        auto issue = [&](int ch) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = ch * 64 + gran * 8 + 4 * u;
+                    v[j][u] = (ok[j] && k < C4) ? *reinterpret_cast<const f32x4*>(srcp[j] + ch * 64 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j >= NR + NS) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[j][u][e];
+                        ss[j] = fmaf(x, x, ss[j]);
+                        o[4 * u + e] = (__bf16)x;
+                    }
+                const uint32_t at = j < NR ? FR0 + buf * FRB + sm_f(j * 32 + row32, gran) : FS0 + buf * FSB + sm_f((j - NR) * 32 + row32, gran);
+                *reinterpret_cast<bf16x8*>(sm + at) = o;
+            }
+        };
+        auto mfma_chunk = [&](int buf) {
+            if (wid < NR) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + FR0 + buf * FRB + sm_f(wid * 32 + r, 2 * ks + h));
+#pragma unroll
+                    for (int st = 0; st < NS; ++st) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sm + FS0 + buf * FSB + sm_f(st * 32 + r, 2 * ks + h));
+                        acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[st], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        issue(0);
+        stash(0);
+        __syncthreads();
+        // chunk ch + 1 is in flight (registers) while chunk ch is multiplied; the last chunk has the code rows in flight instead
+        // (peeled: the 144 registers of the code rows are live only there, where the feature staging registers are dead)
+#pragma unroll 1
+        for (int ch = 0; ch + 1 < nch; ++ch) {
+            const int buf = ch & 1;
+            issue(ch + 1);
+            mfma_chunk(buf);
+            stash(buf ^ 1);
+            __syncthreads();
+        }
+        issue_code();
+        mfma_chunk((nch - 1) & 1);
+        __syncthreads();
+        // 1 / max(|row|, eps) of the feature rows (norm(), src/modules.py:789-790), from the fp32 values
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float s = ss[j];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (j < NR + NS && gran == 0) invF[pass_idx(j)] = ok[j] ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
+        }
+    } else {
+        issue_code();
+    }
+
+    // ---- code rows: normalise in fp32, split into fp16 hi + 2048 (x - hi), LDS images for the cd chain
+    {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j >= NR + NS) continue;
+            const int pos = pass_pos(j);
+            const bool okc = pos < P;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(vc[c][j][u][e], vc[c][j][u][e], s);
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float inv = okc ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
+            const int idx = pass_idx(j);
+            if (gran == 0) invC[idx] = inv;
+            const bool isR = j < NR;
+            const int lrow = isR ? j * 32 + row32 : (j - NR) * 32 + row32;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int g = c * 8 + gran;
+                if (g >= KD / 8) continue;
+                f16x8 hi, lo;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = vc[c][j][u][e] * inv;
+                        const _Float16 xh = (_Float16)x;
+                        hi[4 * u + e] = xh;
+                        lo[4 * u + e] = (_Float16)((x - (float)xh) * 2048.f);
+                    }
+                *reinterpret_cast<f16x8*>(sm + (isR ? XH : YH) + sm_c(lrow, g)) = hi;
+                *reinterpret_cast<f16x8*>(sm + (isR ? GB : YL) + sm_c(lrow, g)) = lo;
+                // the backward tail applies norm()'s backward to the stationary-side tiles once, from operand 0's C part and inverse norms
+                if (isR && grad && t == 0 && g < a.KD / 8)
+                    *reinterpret_cast<f16x8*>(a.xop + ((size_t)n * NT + rt0 + j) * a.blob_bytes + a.blob_off_c + (g * 32 + row32) * 16) = hi;
+            }
+            if (isR && grad && t == 0 && gran == 0) a.xinv[(size_t)n * a.Ppad + pos] = inv;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2a: per stationary tile (wave) and streamed tile: cd, epilogue, -G to LDS, stationary-side gradient
+    const bool active = wid < NR;
+    f16x8 xl[NKD];
+    if (active) {
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) xl[ks] = *reinterpret_cast<const f16x8*>(sm + GB + sm_c(wid * 32 + r, 2 * ks + h));
+    }
+    __syncthreads();                               // XL has been read by its wave: the region becomes the -G image
+
+    f32x16 dR1[NDF], dR2[PW ? NDF : 1];
+#pragma unroll
+    for (int f = 0; f < NDF; ++f)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dR1[f][i] = 0.f; if (PW) dR2[f][i] = 0.f; }
+    float L1 = 0.f, L2 = 0.f, sfd = 0.f, csum = 0.f;
+    if (active) {
+        const int pr = (rt0 + wid) * 32 + r;
+        const bool rvalid = pr < P;
+        const float iFr = depth_job ? 0.f : invF[wid * 32 + r];
+        const float nzr = (depth_job && rvalid) ? a.nz[(size_t)n * a.Ppad + pr] : 0.f;
+        const float shift = depth_job ? a.shift_depth : a.shift[t];
+        const float lo = a.lo, hi = a.hi;
+        float rm = 0.f;
+        if (PW && !depth_job) {
+            float rs = 0.f;
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rs = fmaf(acc[st][i], invF[(NRM + st) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h], rs);
+            rs *= iFr;
+            rs += __shfl_xor(rs, 32, 64);
+            rm = rs / (float)P;
+        }
+        const float om_mat = (a.mat && PW && !depth_job) ? a.om[t] : 0.f;
+        const int nkc = (a.D + 15) >> 4;
+#pragma unroll 1
+        for (int st = 0; st < NS; ++st) {
+            // (a rolled loop: unrolled, hipcc hoists the gathers of every tile to the top and runs out of registers; the tile's
+            //  accumulator is picked out of the register file with selects)
+            f32x16 fdt = acc[0];
+#pragma unroll
+            for (int k = 1; k < NS; ++k)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) fdt[i] = st == k ? acc[k][i] : fdt[i];
+            f32x16 cdv;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cdv[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKD; ++ks) {
+                if (ks < nkc) {
+                    const f16x8 yh = *reinterpret_cast<const f16x8*>(sm + YH + sm_c(st * 32 + r, 2 * ks + h));
+                    const f16x8 yl = *reinterpret_cast<const f16x8*>(sm + YL + sm_c(st * 32 + r, 2 * ks + h));
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(sm + XH + sm_c(wid * 32 + r, 2 * ks + h));
+                    const f16x8 xs = xh * (_Float16)2048.f;                                    // exact (|x| <= 1)
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xs, cdv, 0, 0, 0);
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yl, xh, cdv, 0, 0, 0);
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xl[ks], cdv, 0, 0, 0);
+                }
+            }
+            uint16_t gh[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int sl = (i & 3) + 8 * (i >> 2) + 4 * h, s = st * 32 + sl;
+                const bool valid = rvalid && s < P;
+                float e, fdn = 0.f, ddv = 0.f;
+                if (depth_job) {
+                    ddv = nzr * a.nz[(size_t)n * a.Ppad + (s < a.Ppad ? s : 0)];
+                    e = ddv - shift;
+                } else {
+                    fdn = fdt[i] * iFr * invF[(NRM + st) * 32 + sl];
+                    e = (PW ? fdn - rm : fdn) - shift;
+                }
+                const float cd = cdv[i] * (1.f / 2048.f);
+                const float cl = fminf(fmaxf(cd, lo), hi);
+                if (valid) { L1 = fmaf(cl, e, L1); L2 += cl; sfd += fdn; csum += cd; }
+                const bool on = valid && cd >= lo && cd <= hi;
+                const _Float16 g16 = (_Float16)(on ? e : 0.f);
+                uint16_t hb = __builtin_bit_cast(uint16_t, g16);
+                if (PW && on && (hb & 0x7fffu) == 0) hb = 1;                                  // an element that is on never stores an exact zero
+                gh[i] = hb;
+                if (a.mat && valid) {
+                    const size_t o = ((size_t)n * P + pr) * P + s;
+                    if (a.out_cd) a.out_cd[o] = depth_job ? ddv : cd;
+                    if (a.out_loss) a.out_loss[o] = -cl * (e + om_mat);
+                }
+            }
+            if (grad) {
+                f16x8 ga[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ga[i >> 3][i & 7] = __builtin_bit_cast(_Float16, gh[i]);
+                if (!depth_job) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        *reinterpret_cast<uint16_t*>(sm + GB + sm_c(s, wid * 4 + (r >> 3)) + (r & 7) * 2) = gh[i];
+                    }
+                }
+                // dR[r][:] += sum_s G[s][r] y[s][:]: the accumulator tile is the A operand (k <-> s in accumulator order), B gathers y
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f16x8 gm;
+                    if (PW) gm = sm_mask_of(ga[q]);
+#pragma unroll
+                    for (int f = 0; f < NDF; ++f) {
+                        f16x8 b;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int s = st * 32 + 16 * q + 8 * (j >> 2) + 4 * h + (j & 3), d = 32 * f + r;
+                            b[j] = *reinterpret_cast<const _Float16*>(sm + YH + sm_c(s, d >> 3) + (d & 7) * 2);
+                        }
+                        dR1[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[q], b, dR1[f], 0, 0, 0);
+                        if (PW) dR2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm, b, dR2[f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (grad) {
+            // raw gradient tiles, accumulator order (dg_gtile_off): 1 KiB per wave instruction
+            float* o1 = a.dRA[t] + (((size_t)n * NT + rt0 + wid) * NDF) * 1024 + lane * 4;
+            float* o2 = (PW && !depth_job) ? a.dRA2[t] + (((size_t)n * NT + rt0 + wid) * NDF) * 1024 + lane * 4 : nullptr;
+#pragma unroll
+            for (int f = 0; f < NDF; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<f32x4*>(o1 + f * 1024 + g * 256) = f32x4{dR1[f][4 * g], dR1[f][4 * g + 1], dR1[f][4 * g + 2], dR1[f][4 * g + 3]};
+                    if (PW && o2) *reinterpret_cast<f32x4*>(o2 + f * 1024 + g * 256) = f32x4{dR2[f][4 * g], dR2[f][4 * g + 1], dR2[f][4 * g + 2], dR2[f][4 * g + 3]};
+                }
+        }
+    }
+    // block partial sums (fixed order: butterfly inside the wave, waves 0..3 in turn)
+    {
+        float v4[4] = {L1, L2, sfd, csum};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v4[k] += __shfl_xor(v4[k], o, 64);
+            if (lane == 0) red[wid * 4 + k] = v4[k];
+        }
+    }
+    __syncthreads();                               // (also: the -G image is complete)
+    if (a.mat) return;
+    if (tid == 0) {                                // (one thread: its fence below orders these stores before its ticket)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.part[(((size_t)t * B + n) * nsplit + sp) * 4 + k] = red[k] + red[4 + k] + red[8 + k] + red[12 + k];
+    }
+
+    // ---- phase 2b: d/d(streamed code) = G x over this block's stationary tiles, normalisation backward, final tiles
+    if (grad && !depth_job) {
+        for (int st = wid; st < NS; st += 4) {
+            f32x16 dS1[NDF], dS2[PW ? NDF : 1];
+#pragma unroll
+            for (int f = 0; f < NDF; ++f)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { dS1[f][i] = 0.f; if (PW) dS2[f][i] = 0.f; }
+            for (int rk = 0; rk < 2 * NR; ++rk) {
+                const f16x8 af = *reinterpret_cast<const f16x8*>(sm + GB + sm_c(st * 32 + r, 2 * rk + h));
+                f16x8 am;
+                if (PW) am = sm_mask_of(af);
+#pragma unroll
+                for (int f = 0; f < NDF; ++f) {
+                    f16x8 b;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int rr = 16 * rk + 8 * h + j, d = 32 * f + r;
+                        b[j] = *reinterpret_cast<const _Float16*>(sm + XH + sm_c(rr, d >> 3) + (d & 7) * 2);
+                    }
+                    dS1[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b, dS1[f], 0, 0, 0);
+                    if (PW) dS2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, b, dS2[f], 0, 0, 0);
+                }
+            }
+            // norm() backward with the streamed rows y (hi + lo): d = inv (g - y <g, y>), element i of a lane = position
+            // (i&3) + 8 (i>>2) + 4 h of the tile, channel 32 f + r: the dot product runs over the 32 lanes of the half wave
+            float* o1 = a.dRB[t][sp] + (((size_t)n * NT + st) * NDF) * 1024 + lane * 4;
+            float* o2 = PW ? a.dRB2[t][sp] + (((size_t)n * NT + st) * NDF) * 1024 + lane * 4 : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 w1[NDF], w2[PW ? NDF : 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e, sl = (i & 3) + 8 * (i >> 2) + 4 * h, s = st * 32 + sl;
+                    float yv[NDF], d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                    for (int f = 0; f < NDF; ++f) {
+                        const int d = 32 * f + r;
+                        const uint32_t at = sm_c(s, d >> 3) + (d & 7) * 2;
+                        yv[f] = (float)*reinterpret_cast<const _Float16*>(sm + YH + at) + (float)*reinterpret_cast<const _Float16*>(sm + YL + at) * (1.f / 2048.f);
+                        d1 = fmaf(dS1[f][i], yv[f], d1);
+                        if (PW) d2 = fmaf(dS2[f][i], yv[f], d2);
+                    }
+                    d1 = half_sum(d1);
+                    if (PW) d2 = half_sum(d2);
+                    const float iv = invC[(NRM + st) * 32 + sl];
+#pragma unroll
+                    for (int f = 0; f < NDF; ++f) {
+                        w1[f][e] = iv * (dS1[f][i] - yv[f] * d1);
+                        if (PW) w2[f][e] = iv * (dS2[f][i] - yv[f] * d2);
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < NDF; ++f) {
+                    *reinterpret_cast<f32x4*>(o1 + f * 1024 + g * 256) = w1[f];
+                    if (PW) *reinterpret_cast<f32x4*>(o2 + f * 1024 + g * 256) = w2[f];
+                }
+            }
+        }
+    }
+
+    // ---- the block that finishes last reduces the partial sums of the call into the output scalars (and old_mean_t for the backward)
+    if (tid == 0) {
+        __threadfence();
+        last_flag = atomicAdd(a.ticket, 1u) == (unsigned)(B * per) - 1u;
+    }
+    __syncthreads();
+    if (last_flag && wid == 0) {
+        __threadfence();
+        double accv[DG_OUT_COUNT];
+#pragma unroll
+        for (int i = 0; i < DG_OUT_COUNT; ++i) accv[i] = 0.0;
+        const double numel = (double)B * P * P;
+        const int nb = B * nsplit;
+        for (int tt = 0; tt < njob; ++tt) {
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            const volatile float* pp = a.part + (size_t)tt * nb * 4;
+            for (int i = lane; i < nb; i += 64)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s4[k] += (double)pp[i * 4 + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                for (int o = 32; o > 0; o >>= 1) s4[k] += __shfl_xor(s4[k], o, 64);
+            if (tt < a.T) {
+                const double om = a.pointwise ? s4[2] / numel : 0.0;
+                const double l = s4[0] + om * s4[1];
+                const int slot = tt < 2 ? tt : DG_OUT_LOSS_NEG;
+                const double scale = tt < 2 ? 1.0 / numel : 1.0 / (numel * (a.T - 2));
+                accv[slot] += -l * scale;
+                accv[DG_OUT_CD_INTRA + (tt < 2 ? tt : 2)] += s4[3] * scale;
+                if (lane == 0) a.om[tt] = (float)om;
+            } else {
+                accv[DG_OUT_LOSS_DEPTH] += -s4[0] / numel;
+            }
+        }
+        if (a.depth && a.nzsum) {                  // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
+            double m = 0.0;
+            for (int i = lane; i < B; i += 64) { const double s = a.nzsum[i]; m += s * s; }
+            for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+            accv[DG_OUT_DD] = m / numel;
+        }
+        if (lane == 0) {
+            accv[DG_OUT_TOTAL] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accv[DG_OUT_TOTAL] += (double)a.wtot[i] * (double)(float)accv[i];
+#pragma unroll
+            for (int i = 0; i < DG_OUT_COUNT; ++i) a.out[i] = (float)accv[i];
+            *a.ticket = 0u;                        // ready for the next launch (re-launches of a recorded step included)
+            __threadfence();
+        }
+    }
+}
+
+// LDS bytes of the phase-2 image (the larger one)
+static int small_smem(int NS) {
+    const int NRM = NS == 5 ? 3 : NS;
+    return (NRM + 3 * NS) * 32 * 256;
+}
+
+bool dg_small_supported(int Ppad, int KD) { return Ppad >= 32 && Ppad <= 160 && (KD == 96 || KD == 128); }
+
+hipError_t dg_launch_corr_small(const DgSmallArgs& a, hipStream_t s) {
+    const int NS = a.Ppad / 32;
+    if (!dg_small_supported(a.Ppad, a.KD) || a.nsplit != (NS == 5 ? 2 : 1)) return hipErrorInvalidValue;
+    const int njob = a.mat ? 1 : a.T + (a.depth ? 1 : 0);
+    const int per = njob * a.nsplit;
+    const int grid = ((a.B + 7) / 8) * 8 * per;
+    const int smem = small_smem(NS);
+    auto go = [&](auto kern) -> hipError_t {
+        const hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SM_THREADS), smem, s, a);
+        return hipGetLastError();
+    };
+#define DG_SM_CASE(NS_)                                                                                  \
+    if (NS == NS_) {                                                                                     \
+        if (a.KD == 96) return a.pointwise ? go(k_corr_small<NS_, 6, true>) : go(k_corr_small<NS_, 6, false>); \
+        return a.pointwise ? go(k_corr_small<NS_, 8, true>) : go(k_corr_small<NS_, 8, false>);          \
+    }
+    DG_SM_CASE(1) DG_SM_CASE(2) DG_SM_CASE(3) DG_SM_CASE(4) DG_SM_CASE(5)
+#undef DG_SM_CASE
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// sample() (src/modules.py:822-825: grid_sample, bilinear, padding_mode='border', align_corners=True, coordinates transposed) of
+// channel-last fp32 maps into rows [image][position][K4].  One block = 8 positions of one (job, image); 32 lanes per position walk
+// the channels four at a time.  Tap arithmetic as in k_plane_sample / k_gather_norm (the same operations in the same order).
+__global__ __launch_bounds__(256) void k_gather_rows(const DgGatherRowsArgs a) {
+    const int job = blockIdx.z, n = blockIdx.y, p = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (p >= a.P) return;
+    const int K4 = a.K4[job], hh = a.h[job], ww = a.w[job];
+    const int ii = p / a.S, j = p - ii * a.S;
+    const float* cc = a.coords[job] + (((size_t)n * a.S + j) * a.Sh + ii) * 2;
+    float x = ((cc[0] + 1.f) / 2.f) * (float)(ww - 1);
+    float y = ((cc[1] + 1.f) / 2.f) * (float)(hh - 1);
+    x = fminf(fmaxf(x, 0.f), (float)(ww - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(hh - 1));
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool inx = x0 + 1 <= ww - 1, iny = y0 + 1 <= hh - 1;
+    const float w00 = wy0 * wx0, w01 = inx ? wy0 * wx1 : 0.f, w10 = iny ? wy1 * wx0 : 0.f, w11 = (inx && iny) ? wy1 * wx1 : 0.f;
+    const int pix = y0 * ww + x0, dx = inx ? 1 : 0, dy = iny ? ww : 0;
+    const int img = a.srcidx[job] ? (int)a.srcidx[job][n] : n;
+    const float* base = a.src[job] + (size_t)img * hh * ww * K4;
+    const float* t00 = base + (size_t)pix * K4;
+    const float* t01 = base + (size_t)(pix + dx) * K4;
+    const float* t10 = base + (size_t)(pix + dy) * K4;
+    const float* t11 = base + (size_t)(pix + dy + dx) * K4;
+    float* out = a.rows[job] + ((size_t)n * a.P + p) * K4;
+    for (int k = 4 * l; k < K4; k += 128) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(t00 + k), a1 = *reinterpret_cast<const f32x4*>(t01 + k);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(t10 + k), a3 = *reinterpret_cast<const f32x4*>(t11 + k);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float acc = a0[e] * w00;
+            acc = fmaf(a1[e], w01, acc);
+            acc = fmaf(a2[e], w10, acc);
+            acc = fmaf(a3[e], w11, acc);
+            o[e] = acc;
+        }
+        *reinterpret_cast<f32x4*>(out + k) = o;
+    }
+}
+
+hipError_t dg_launch_gather_rows(const DgGatherRowsArgs& a, hipStream_t s) {
+    if (a.njobs < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_rows, dim3((a.P + 7) / 8, a.B, a.njobs), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

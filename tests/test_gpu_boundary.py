@@ -180,6 +180,50 @@ def test_headline_width_reference_vectors(case, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fpn2048_none", "fpn2048_fps"])
+def test_feature_pyramid_real_shapes_reference_vectors(case, dev):
+    """FeaturePyramidNet's REAL output shapes (src/modules.py:732-766): low_res_feats (B,2048,7,7) next to code (B,32,56,56) -
+    refused until round 5 (C <= 768).  Vectors from the imported reference (tests/golden/make_round5_fixtures.py): the
+    reference's torch.rand coordinates at feature_samples = 11, and depth_sampling = "fps" (pooled to the 7 x 7 FEATURE map) at 6 -
+    there the coordinates come from the library's own sampler and must equal the reference's.  The fused small-grid kernel streams
+    the 2048 channels in chunks of 64 (dg_small.hip); the maps differ in size, so the rows come from k_gather_rows."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from oracle import depthg_oracle as O
+    fx = load_golden_seeded(f"forward_{case}.npz")
+    cfg = cfg_from_fixture(fx, dg_outputs="full")
+    T = lambda a: torch.from_numpy(a).to(dev)
+    code, code_pos = T(fx["code"]).requires_grad_(True), T(fx["code_pos"]).requires_grad_(True)
+    c1, c2 = T(fx["coords1"]), T(fx["coords2"])
+    if case.endswith("_fps"):
+        S = int(cfg.feature_samples)
+        got1 = ops.fps_coords(T(fx["depth"]), (7, 7), S)
+        got2 = ops.fps_coords(T(fx["depth_pos"]), (7, 7), S)
+        assert torch.equal(got1, c1) and torch.equal(got2, c2)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), c1, c2,
+                                                       T(fx["perms"]))
+    total = O.total_loss(cfg, out)
+    total.backward()
+    errs = {k: _relerr(out[i].mean(), fx[k]) for i, k in ((0, "pos_intra_loss"), (2, "pos_inter_loss"), (4, "neg_inter_loss_mean"),
+                                                          (6, "depth_feat_loss"))}
+    errs["total"] = _relerr(total, fx["total"])
+    print(case, {k: f"{v:.2e}" for k, v in errs.items()})
+    # (small grids: P = 121 / 36 positions, B = 2 - the means are sums of 3e4 / 2.6e3 elements with bf16 feature operands; the small
+    #  fixtures of test_gpu_parity.py carry 2e-3 for the same reason)
+    for k, v in errs.items():
+        assert v < 2e-3, (k, v)
+    sub = int(fx["sub"])
+    for i, k, tol in ((1, "pos_intra_cd", 2e-5), (3, "pos_inter_cd", 2e-5), (5, "neg_inter_cd", 2e-5), (4, "neg_inter_loss", 4e-3)):
+        assert np.abs(out[i].detach().reshape(-1)[::sub].cpu().numpy() - fx[k]).max() < tol, k
+    for got, want, name in ((code.grad, fx["grad_code"], "code"), (code_pos.grad, fx["grad_code_pos"], "code_pos")):
+        assert tuple(got.shape) == (2, 32, 56, 56)
+        got, want = got.cpu().double(), torch.from_numpy(want).double()
+        rel = float((got - want).norm() / want.norm())
+        worst = float((got - want).abs().max() / want.abs().max())
+        print(case, name, f"grad rel-l2 {rel:.2e} worst {worst:.2e}")
+        assert rel < 5e-3 and worst < 2e-2, (name, rel, worst)
+
+
+@pytest.mark.gpu
 def test_headline_full_batch_correlated_features_vs_oracle(dev):
     """The headline at B = 32 on CORRELATED features (a common component 1.5 x the noise in every position, the generator of the
     `corr_feats` fixture: real backbone features share a strong mean direction).  The negative term's mean is then a

@@ -335,11 +335,16 @@ def test_error_paths(dev):
     with pytest.raises(RuntimeError):        # CPU tensors: no fallback path
         loss.forward_with(f.cpu(), f.cpu(), c.cpu(), c.cpu(), torch.ones(2, 1, 16, 16), torch.zeros(2, 4, 4, 2),
                           torch.zeros(2, 4, 4, 2), [torch.zeros(2, dtype=torch.long)] * 5)
-    big = torch.randn(1, 1024, 4, 4, device=dev)
-    with pytest.raises(RuntimeError, match="not supported"):
-        loss.forward_with(big, big, c[:1, :, :4, :4], c[:1, :, :4, :4], torch.ones(1, 1, 16, 16, device=dev),
-                          torch.zeros(1, 4, 4, 2, device=dev), torch.zeros(1, 4, 4, 2, device=dev),
-                          [torch.zeros(1, dtype=torch.long, device=dev)] * 5)
+    # more than 768 feature channels: fine on sample grids of <= 160 positions (the fused small-grid kernel streams the channels),
+    # refused with a message on larger grids, whose kernels hold whole channel vectors
+    big = torch.randn(1, 1024, 16, 16, device=dev)
+    cbig = torch.randn(1, 8, 16, 16, device=dev)
+    loss.forward_with(big, big, cbig, cbig, torch.ones(1, 1, 16, 16, device=dev), torch.zeros(1, 4, 4, 2, device=dev),
+                      torch.zeros(1, 4, 4, 2, device=dev), [torch.zeros(1, dtype=torch.long, device=dev)] * 5)
+    loss16 = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=16))
+    with pytest.raises(RuntimeError, match="at most 160 positions"):
+        loss16.forward_with(big, big, cbig, cbig, torch.ones(1, 1, 16, 16, device=dev), torch.zeros(1, 16, 16, 2, device=dev),
+                            torch.zeros(1, 16, 16, 2, device=dev), [torch.zeros(1, dtype=torch.long, device=dev)] * 5)
 
 
 def test_super_perms_kernel(dev):

@@ -32,7 +32,10 @@ def test_descriptor_validation_and_workspace():
     assert 0 < small < big < 2 ** 31
     shared = ops.workspace_bytes(ops.make_desc(32, 384, 70, 28, 28, 28, 5, **{**kw, "shared_coords": True}))
     assert shared < big
-    for bad in (dict(C=769), dict(D=129), dict(n_neg=9), dict(B=0)):
+    # (C > 768: legal on sample grids of <= 160 positions since round 5 - the fused small-grid kernel streams the channels - and
+    #  still refused on larger grids)
+    assert ops.workspace_bytes(ops.make_desc(2, 2048, 32, 7, 7, 11, 5, **{**kw, "code_hw": (56, 56)})) > 0
+    for bad in (dict(C=769, S=14), dict(C=8193), dict(D=129), dict(n_neg=9), dict(B=0)):
         args = dict(B=2, C=64, D=70, h=14, w=14, S=11, n_neg=5)
         args.update(bad)
         with pytest.raises(RuntimeError):

@@ -142,7 +142,7 @@ def test_forward_fps_coords_regenerated(case):
     assert np.array_equal(c2.numpy(), fx["coords2"])
 
 
-@pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident"])
+@pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident", "fpn2048_none", "fpn2048_fps"])
 def test_forward_headline_width_against_reference(case):
     """The headline width (C=384, D=70, 28x28, S=28) at B=2, vectors from the imported reference with its own torch.rand
     coordinates (`rand`) and on the pixel-centre grid (`ident`); inputs re-drawn from the stored seed."""
@@ -151,6 +151,9 @@ def test_forward_headline_width_against_reference(case):
     cfg = cfg_from_fixture(fx)
     code = T(fx["code"]).requires_grad_(True)
     code_pos = T(fx["code_pos"]).requires_grad_(True)
+    if case.endswith("_fps"):        # (round 5: FeaturePyramidNet's real shapes, (B,2048,7,7) next to (B,32,56,56)) the oracle's own FPS
+        c1, c2 = O.draw_coords(cfg, T(fx["feats"]), T(fx["feats_pos"]), T(fx["depth"]), T(fx["depth_pos"]))
+        assert np.array_equal(c1.numpy(), fx["coords1"]) and np.array_equal(c2.numpy(), fx["coords2"])
     out = O.forward(cfg, T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]), T(fx["depth_pos"]),
                     coords1=T(fx["coords1"]), coords2=T(fx["coords2"]), perms=[T(p) for p in fx["perms"]])
     for i, k in ((0, "pos_intra_loss"), (2, "pos_inter_loss"), (6, "depth_feat_loss")):
