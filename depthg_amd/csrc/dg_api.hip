@@ -422,6 +422,9 @@ static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, DgSmallAr
     a.xop = ws + p.op[0]; a.xinv = F32(p.inv[0]); a.blob_bytes = bl.bytes; a.blob_off_c = bl.off_c;
     a.wtot[0] = d->w_intra; a.wtot[1] = d->w_inter; a.wtot[2] = d->w_neg; a.wtot[3] = d->w_depth;
     a.nsplit = p.nsplit;
+#ifdef DG_DEVTOOLS
+    { static const int dbg = [] { const char* e = getenv("DG_SMALL_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
+#endif
 }
 
 // sampled rows of every operand (the reference's sample(), src/modules.py:822-825, of feats / code at coords1 / coords2 and of the

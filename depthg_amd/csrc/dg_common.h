@@ -438,6 +438,7 @@ struct DgSmallArgs {
     float* out_cd;                        // [B][P][P] or null
     float* out_loss;
     int32_t mat_t, mat;
+    int32_t debug;                        // developer: 1 = block 0 prints its phase stamps (DG_SMALL_DEBUG=1)
 };
 
 struct DgGatherRowsArgs {   // k_gather_rows: sample() of channel-last maps into fp32 rows (code maps of another size, maps beyond the LDS)

@@ -4,7 +4,7 @@
 //
 // k_corr_small: ONE launch per call.  A block owns (image n, pair-set t[, half of the stationary tiles]) of helper()
 // (src/modules.py:1231-1254) or the depth term (:1256-1278) and reads the SAMPLED fp32 rows of its two operands once:
-//   phase 1  the feature rows stream through LDS in chunks of 128 channels (fp32 -> bf16 on the way, squared norms accumulated beside
+//   phase 1  the feature rows stream through LDS in chunks of 64 channels (fp32 -> bf16 on the way, squared norms accumulated beside
 //            them), fd_raw = <a_p, b_q> of the un-normalised rows on the bf16 MFMA, one accumulator tile per (R tile, S tile) held in
 //            registers for the whole block; norm() (:789-790) is applied to the finished tiles as 1/|a_p| * 1/|b_q|;
 //   phase 2  the code rows are normalised in fp32 and split into fp16 hi + lo parts; cd = hi.hi + hi.lo + lo.hi in one accumulator
@@ -30,9 +30,10 @@ typedef int v4i_s __attribute__((ext_vector_type(4)));
 
 #define SM_THREADS 256
 
-// LDS images, all in 256-byte rows with granule (16 B) g of row r at slot g ^ (r & 15): the 16 lanes of one ds_read_b128 pass (16
-// consecutive rows, one granule) cover all 64 banks.  Feature chunk: [row][128 bf16]; code: [row][<= 128 fp16]; -G: [S position][R
-// position] fp16.
+// LDS images.  Feature chunk: [row][64 bf16] = 128-byte rows, granule (16 B) g of row r at slot g ^ ((r >> 1) & 7): the 16 lanes of
+// one ds_read_b128 pass (16 consecutive rows, one granule) cover all 64 banks.  Code: [row][<= 128 fp16] in 256-byte rows, slot
+// g ^ (r & 15).  G: [S position][R position] fp16 in 256-byte rows, same swizzle.
+__device__ __forceinline__ uint32_t sm_f(int row, int g) { return (uint32_t)row * 128u + (uint32_t)((g ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ uint32_t sm_c(int row, int g) { return (uint32_t)row * 256u + (uint32_t)((g ^ (row & 15)) << 4); }
 
 // 1.0 where g != 0 (the clamp mask back out of the stored -G: the epilogue never stores an exact zero for an element that is on)
@@ -53,17 +54,12 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     constexpr int NRM = NS == 5 ? 3 : NS;          // most stationary tiles of one block (5 tiles: blocks of 3 and 2)
     constexpr int NDF = NKD / 2;                   // 32-channel groups of a gradient tile row
     constexpr int KD = NKD * 16;
-    constexpr int NJ = NRM + NS;                   // loader passes: 256 threads = one tile of 32 rows x 8 lanes
-    constexpr int NSUB = NS >= 4 ? 1 : 2;          // 64-channel pieces per chunk (the staging registers of a 128-channel chunk and the
-                                                   // code rows held beside them do not fit next to 4-5 accumulator tiles)
-    constexpr int KC = 64 * NSUB;
-    // phase 1: two buffers of [R tiles | S tiles][32 rows][128 bf16]; phase 2: code images + the -G image (256-byte rows all)
-    constexpr uint32_t FBUF = NJ * 32 * 256, FS_OFF = NRM * 32 * 256;
-    constexpr uint32_t XH = 0, YH = NRM * 32 * 256, YL = YH + NS * 32 * 256, GB = YL + NS * 32 * 256; // (XL = GB until the epilogues)
-    static_assert(2 * FBUF <= GB + NS * 32 * 256, "phase 1 fits the phase-2 image");
+    constexpr int NJ = NRM + NS;                   // loader passes: 256 threads = one tile of 32 rows x 8 granules
+    constexpr uint32_t FR0 = 0, FRB = NRM * 32 * 128, FS0 = 2 * FRB, FSB = NS * 32 * 128;            // phase 1
+    constexpr uint32_t XH = 0, YH = NRM * 32 * 256, YL = YH + NS * 32 * 256, GB = YL + NS * 32 * 256; // phase 2 (XL = GB until the epilogues)
+    static_assert(FS0 + 2 * FSB <= GB + NS * 32 * 256, "phase 1 fits the phase-2 image");
     extern __shared__ __attribute__((aligned(16))) char sm[];
-    __shared__ __attribute__((aligned(16))) float invF[NJ * 32], invC[NJ * 32];
-    __shared__ float red[4 * 4];
+    __shared__ float invF[NJ * 32], invC[NJ * 32], red[4 * 4];
     __shared__ int last_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -86,19 +82,11 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int NR = nsplit == 1 ? NS : (sp == 0 ? 3 : 2);
     const bool grad = a.grad != 0 && !a.mat;
     const int opS = depth_job ? 0 : t;
-#ifdef DG_DEVTOOLS
-    unsigned long long stp[8];
-    int nstp = 0;
-#define SM_STAMP() do { if (a.debug == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stp[nstp++] = wall_clock64(); } } while (0)
-#else
-#define SM_STAMP() do {} while (0)
-#endif
-    SM_STAMP();
 
-    // ---- loader geometry: pass j = stationary tile j (j < NR) or streamed tile j - NR; thread = (row of the tile, lane of 8 channels)
+    // ---- loader geometry: pass j = stationary tile j (j < NR) or streamed tile j - NR; thread = (row of the tile, granule of 8 channels)
     const int row32 = tid >> 3, gran = tid & 7;
     auto pass_pos = [&](int j) { return j < NR ? (rt0 + j) * 32 + row32 : (j - NR) * 32 + row32; };
-    auto pass_row = [&](int j) { return (j < NR ? j : NRM + (j - NR)) * 32 + row32; };        // row of the LDS images, index into invF / invC
+    auto pass_idx = [&](int j) { return (j < NR ? j : NRM + (j - NR)) * 32 + row32; };        // index into invF / invC, LDS row = the same
 
     f32x16 acc[NS];
 #pragma unroll
@@ -106,43 +94,111 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[st][i] = 0.f;
 
-    // (the lambdas below capture copies, never `a` itself: a by-reference capture of the kernel argument makes hipcc copy the whole
-    //  struct to scratch in every thread)
+    // (the lambdas below capture these copies, never `a` itself: a by-reference capture of the kernel argument makes hipcc copy the
+    //  whole struct to scratch in every thread)
     const float* const rowsC_R = a.rowsC[0];
     const float* const rowsC_S = a.rowsC[opS];
     const int D4 = a.D4;
-
-    // ---- the code rows: requested before the first feature chunk and normalised while that chunk is on its way (EARLY), kept as fp16
-    //      hi + 2048 (x - hi) in registers until the LDS is free of feature chunks.  With 4 or 5 streamed tiles the registers do not
-    //      take the code rows beside the staging of a feature chunk: there they are requested under the LAST chunk's MFMAs.
-    constexpr bool EARLY = NS <= 3;
-    f16x8 chi[2][NJ], clo[2][NJ];
-    f32x4 vc[2][NJ][2];
-    auto load_code = [&]() {
+    f32x4 vc[2][NJ][2];                            // the code rows (two chunks of 64 channels), loaded under the last feature chunk
+    auto issue_code = [&]() {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool live = j < NR + NS;
             const int pos = live ? pass_pos(j) : 0;
             const float* src = (j < NR ? rowsC_R : rowsC_S) + ((size_t)n * P + (pos < P ? pos : 0)) * D4;
-            // (every load is issued unconditionally from a clamped address and zeroed afterwards: a load under a condition becomes
-            //  a branch with its own s_waitcnt vmcnt(0) - the loads of a pass then run one memory latency after the other)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int k = c * 64 + gran * 8 + 4 * u;
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + (k < D4 ? k : D4 - 4));
-                    const bool use = live && pos < P && k < D4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) vc[c][j][u][e] = use ? t4[e] : 0.f;
+                    vc[c][j][u] = (live && pos < P && k < D4) ? *reinterpret_cast<const f32x4*>(src + k) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
         }
     };
-    const bool write_x = grad && t == 0;           // the backward tail's copy of operand 0's normalised code (C part) and inverse norms
-    char* const xop = a.xop;
-    float* const xinv = a.xinv;
-    const int blob_bytes = a.blob_bytes, blob_off_c = a.blob_off_c, Ppad = a.Ppad;
-    auto norm_code = [&]() {
+
+    if (!depth_job) {
+        const int C4 = a.C4, nch = (C4 + 63) >> 6;
+        const float* srcp[NJ];
+        bool ok[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool live = j < NR + NS;
+            const int pos = live ? pass_pos(j) : 0;
+            ok[j] = live && pos < P;
+            srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4 + gran * 8;
+        }
+        f32x4 v[NJ][2];
+        float ss[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
+        auto issue = [&](int ch) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = ch * 64 + gran * 8 + 4 * u;
+                    v[j][u] = (ok[j] && k < C4) ? *reinterpret_cast<const f32x4*>(srcp[j] + ch * 64 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j >= NR + NS) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[j][u][e];
+                        ss[j] = fmaf(x, x, ss[j]);
+                        o[4 * u + e] = (__bf16)x;
+                    }
+                const uint32_t at = j < NR ? FR0 + buf * FRB + sm_f(j * 32 + row32, gran) : FS0 + buf * FSB + sm_f((j - NR) * 32 + row32, gran);
+                *reinterpret_cast<bf16x8*>(sm + at) = o;
+            }
+        };
+        auto mfma_chunk = [&](int buf) {
+            if (wid < NR) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + FR0 + buf * FRB + sm_f(wid * 32 + r, 2 * ks + h));
+#pragma unroll
+                    for (int st = 0; st < NS; ++st) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sm + FS0 + buf * FSB + sm_f(st * 32 + r, 2 * ks + h));
+                        acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[st], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        issue(0);
+        stash(0);
+        __syncthreads();
+        // chunk ch + 1 is in flight (registers) while chunk ch is multiplied; the last chunk has the code rows in flight instead
+        // (peeled: the 144 registers of the code rows are live only there, where the feature staging registers are dead)
+#pragma unroll 1
+        for (int ch = 0; ch + 1 < nch; ++ch) {
+            const int buf = ch & 1;
+            issue(ch + 1);
+            mfma_chunk(buf);
+            stash(buf ^ 1);
+            __syncthreads();
+        }
+        issue_code();
+        mfma_chunk((nch - 1) & 1);
+        __syncthreads();
+        // 1 / max(|row|, eps) of the feature rows (norm(), src/modules.py:789-790), from the fp32 values
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float s = ss[j];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (j < NR + NS && gran == 0) invF[pass_idx(j)] = ok[j] ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
+        }
+    } else {
+        issue_code();
+    }
+
+    // ---- code rows: normalise in fp32, split into fp16 hi + 2048 (x - hi), LDS images for the cd chain
+    {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (j >= NR + NS) continue;
@@ -157,145 +213,34 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     for (int e = 0; e < 4; ++e) s = fmaf(vc[c][j][u][e], vc[c][j][u][e], s);
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             const float inv = okc ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
-            if (gran == 0) invC[pass_row(j)] = inv;
+            const int idx = pass_idx(j);
+            if (gran == 0) invC[idx] = inv;
             const bool isR = j < NR;
-#ifdef DG_DEVTOOLS
-            if (a.debug == 2 && n == 0 && t == 1 && j == NR && row32 == 20)
-                printf("row 20 gran %d: s %.9g inv %.9g v %.9g %.9g %.9g %.9g | %.9g %.9g %.9g %.9g\n", gran, s, inv, vc[0][j][0][0], vc[0][j][0][1],
-                       vc[0][j][0][2], vc[0][j][0][3], vc[0][j][1][0], vc[0][j][1][1], vc[0][j][1][2], vc[0][j][1][3]);
-#endif
+            const int lrow = isR ? j * 32 + row32 : (j - NR) * 32 + row32;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float xn[8];
+                const int g = c * 8 + gran;
+                if (g >= KD / 8) continue;
+                f16x8 hi, lo;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        xn[4 * u + e] = vc[c][j][u][e] * inv;
-                        chi[c][j][4 * u + e] = (_Float16)xn[4 * u + e];
+                        const float x = vc[c][j][u][e] * inv;
+                        const _Float16 xh = (_Float16)x;
+                        hi[4 * u + e] = xh;
+                        lo[4 * u + e] = (_Float16)((x - (float)xh) * 2048.f);
                     }
-                // lo is formed from the hi BITS that are stored: hipcc otherwise converts the same value twice, once per use, with two
-                // different instructions whose results differ at exact ties - hi from one rounding, lo from the other, 2.4e-4 off
-                // (found against the reference fixture at C = 2048: one code row in 242 carried such an element)
-                {
-                    v4i_s hb = __builtin_bit_cast(v4i_s, chi[c][j]);
-                    asm volatile("" : "+v"(hb));
-                    chi[c][j] = __builtin_bit_cast(f16x8, hb);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) clo[c][j][e] = (_Float16)((xn[e] - (float)chi[c][j][e]) * 2048.f);
-                const int g = c * 8 + gran;
-                if (isR && write_x && g < KD / 8)
-                    *reinterpret_cast<f16x8*>(xop + ((size_t)n * NT + rt0 + j) * blob_bytes + blob_off_c + (g * 32 + row32) * 16) = chi[c][j];
+                *reinterpret_cast<f16x8*>(sm + (isR ? XH : YH) + sm_c(lrow, g)) = hi;
+                *reinterpret_cast<f16x8*>(sm + (isR ? GB : YL) + sm_c(lrow, g)) = lo;
+                // the backward tail applies norm()'s backward to the stationary-side tiles once, from operand 0's C part and inverse norms
+                if (isR && grad && t == 0 && g < a.KD / 8)
+                    *reinterpret_cast<f16x8*>(a.xop + ((size_t)n * NT + rt0 + j) * a.blob_bytes + a.blob_off_c + (g * 32 + row32) * 16) = hi;
             }
-            if (isR && write_x && gran == 0) xinv[(size_t)n * Ppad + pos] = inv;
-        }
-    };
-    if (depth_job) { load_code(); norm_code(); }
-
-    if (!depth_job) {
-        const int C4 = a.C4, nch = (C4 + KC - 1) / KC;
-        const float* srcp[NJ];
-        bool ok[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool live = j < NR + NS;
-            const int pos = live ? pass_pos(j) : 0;
-            ok[j] = live && pos < P;
-            srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4;
-        }
-        f32x4 v[NJ][2 * NSUB];
-        float ss[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
-        auto issue = [&](int ch) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int u = 0; u < 2 * NSUB; ++u) {
-                    const int k = ch * KC + (u >> 1) * 64 + gran * 8 + 4 * (u & 1);
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(srcp[j] + (k < C4 ? k : C4 - 4));     // (unconditional: see above)
-                    const bool use = ok[j] && k < C4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][u][e] = use ? t4[e] : 0.f;
-                }
-        };
-        auto stash = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j >= NR + NS) continue;
-#pragma unroll
-                for (int c = 0; c < NSUB; ++c) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = v[j][2 * c + u][e];
-                            ss[j] = fmaf(x, x, ss[j]);
-                            o[4 * u + e] = (__bf16)x;
-                        }
-                    *reinterpret_cast<bf16x8*>(sm + buf * FBUF + sm_c(pass_row(j), c * 8 + gran)) = o;
-                }
-            }
-        };
-        auto mfma_chunk = [&](int buf) {
-            if (wid < NR) {
-#pragma unroll
-                for (int ks = 0; ks < 4 * NSUB; ++ks) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + sm_c(wid * 32 + r, 2 * ks + h));
-#pragma unroll
-                    for (int st = 0; st < NS; ++st) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + FS_OFF + sm_c(st * 32 + r, 2 * ks + h));
-                        acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[st], 0, 0, 0);
-                    }
-                }
-            }
-        };
-        issue(0);
-        if (EARLY) load_code();                    // (behind the first chunk's loads: one memory latency for both)
-        stash(0);
-        __syncthreads();
-        if (EARLY) norm_code();                    // (the chunk's staging registers are free again)
-        // chunk ch + 1 (KC channels of every row) is in flight in registers while chunk ch is multiplied
-#pragma unroll 1
-        for (int ch = 0; ch + 1 < nch; ++ch) {
-            const int buf = ch & 1;
-            issue(ch + 1);
-            mfma_chunk(buf);
-            stash(buf ^ 1);
-            __syncthreads();
-        }
-        if (!EARLY) load_code();
-        mfma_chunk((nch - 1) & 1);
-        if (!EARLY) norm_code();
-        // 1 / max(|row|, eps) of the feature rows (norm(), src/modules.py:789-790), from the fp32 values
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            float s = ss[j];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-            if (j < NR + NS && gran == 0) invF[pass_row(j)] = ok[j] ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
-        }
-        __syncthreads();                           // every wave is done with the feature chunks
-    }
-    SM_STAMP();
-
-    // ---- the code images: [row][<= 128 fp16], hi and lo, stationary (X) and streamed (Y) rows
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (j >= NR + NS) continue;
-        const bool isR = j < NR;
-        const int lrow = isR ? j * 32 + row32 : (j - NR) * 32 + row32;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int g = c * 8 + gran;
-            if (g >= KD / 8) continue;
-            *reinterpret_cast<f16x8*>(sm + (isR ? XH : YH) + sm_c(lrow, g)) = chi[c][j];
-            *reinterpret_cast<f16x8*>(sm + (isR ? GB : YL) + sm_c(lrow, g)) = clo[c][j];
+            if (isR && grad && t == 0 && gran == 0) a.xinv[(size_t)n * a.Ppad + pos] = inv;
         }
     }
     __syncthreads();
-    SM_STAMP();
 
     // ---- phase 2a: per stationary tile (wave) and streamed tile: cd, epilogue, -G to LDS, stationary-side gradient
     const bool active = wid < NR;
@@ -304,32 +249,6 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int ks = 0; ks < NKD; ++ks) xl[ks] = *reinterpret_cast<const f16x8*>(sm + GB + sm_c(wid * 32 + r, 2 * ks + h));
     }
-    // selector fragments: B operand of the MFMA that brings 32 channels of 32 code rows into accumulator layout (rows in registers,
-    // channel on the lane) - the layout of the gradient tiles, and, packed eight registers at a time, the B operand of the
-    // gradient products (k <-> position in accumulator order): an exact transposition on the matrix core instead of sixty-four
-    // 2-byte LDS gathers per tile
-    f16x8 sel[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sel[kk][j] = (16 * kk + 8 * h + j == r) ? (_Float16)1.f : (_Float16)0.f;
-    auto tacc = [&](uint32_t base, int row0, int f) {
-        f32x16 z;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) z[i] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const f16x8 af = *reinterpret_cast<const f16x8*>(sm + base + sm_c(row0 + r, 4 * f + 2 * kk + h));
-            z = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, sel[kk], z, 0, 0, 0);
-        }
-        return z;
-    };
-    auto pack8 = [&](const f32x16& z, int q) {
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16)z[8 * q + j];
-        return o;
-    };
     __syncthreads();                               // XL has been read by its wave: the region becomes the -G image
 
     f32x16 dR1[NDF], dR2[PW ? NDF : 1];
@@ -338,47 +257,29 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dR1[f][i] = 0.f; if (PW) dR2[f][i] = 0.f; }
     float L1 = 0.f, L2 = 0.f, sfd = 0.f, csum = 0.f;
-    // (everything the tile loop reads from the kernel argument is copied to registers here: a scalar load inside the loop waits
-    //  with lgkmcnt(0), i.e. for every LDS read in flight as well)
-    const bool mat = a.mat != 0;
-    float* const out_cd = a.out_cd;
-    float* const out_loss = a.out_loss;
-    const float lo = a.lo, hi = a.hi;
-    const float shift = depth_job ? a.shift_depth : a.shift[t];
-    const int pr = (rt0 + wid) * 32 + r;
-    const bool rvalid = active && pr < P;
-    if (depth_job) {
-        // the depth term as a helper() whose fd is the rank-1 product of the depth indicators (dd = nz_p nz_q, src/modules.py:1273):
-        // "fd_raw" = 1 with the indicators in the roles of the inverse norms - the tile loop below has no branch on the job kind
-        for (int i = tid; i < NS * 32; i += SM_THREADS) invF[NRM * 32 + i] = a.nz[(size_t)n * a.Ppad + i];
-#pragma unroll
-        for (int st = 0; st < NS; ++st)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[st][i] = 1.f;
-        __syncthreads();
-    }
-    const float iFr = !active ? 0.f : (depth_job ? (rvalid ? a.nz[(size_t)n * a.Ppad + pr] : 0.f) : invF[wid * 32 + r]);
-    const float om_mat = (mat && PW && !depth_job) ? a.om[t] : 0.f;
     if (active) {
+        const int pr = (rt0 + wid) * 32 + r;
+        const bool rvalid = pr < P;
+        const float iFr = depth_job ? 0.f : invF[wid * 32 + r];
+        const float nzr = (depth_job && rvalid) ? a.nz[(size_t)n * a.Ppad + pr] : 0.f;
+        const float shift = depth_job ? a.shift_depth : a.shift[t];
+        const float lo = a.lo, hi = a.hi;
         float rm = 0.f;
         if (PW && !depth_job) {
             float rs = 0.f;
 #pragma unroll
             for (int st = 0; st < NS; ++st)
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    const f32x4 iv = *reinterpret_cast<const f32x4*>(&invF[(NRM + st) * 32 + 8 * i4 + 4 * h]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rs = fmaf(acc[st][4 * i4 + e], iv[e], rs);
-                }
+                for (int i = 0; i < 16; ++i) rs = fmaf(acc[st][i], invF[(NRM + st) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h], rs);
             rs *= iFr;
             rs += __shfl_xor(rs, 32, 64);
             rm = rs / (float)P;
         }
-        const float esub = rm + shift;               // e = fd - rowmean - shift
+        const float om_mat = (a.mat && PW && !depth_job) ? a.om[t] : 0.f;
+        const int nkc = (a.D + 15) >> 4;
 #pragma unroll 1
         for (int st = 0; st < NS; ++st) {
-            // (a rolled loop: unrolled, hipcc hoists the loads of every tile to the top and runs out of registers; the tile's
+            // (a rolled loop: unrolled, hipcc hoists the gathers of every tile to the top and runs out of registers; the tile's
             //  accumulator is picked out of the register file with selects)
             f32x16 fdt = acc[0];
 #pragma unroll
@@ -389,65 +290,48 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
             for (int i = 0; i < 16; ++i) cdv[i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < NKD; ++ks) {       // (channels D .. KD-1 are zero in every image: no guard, no branch)
-                const f16x8 yh = *reinterpret_cast<const f16x8*>(sm + YH + sm_c(st * 32 + r, 2 * ks + h));
-                const f16x8 yl = *reinterpret_cast<const f16x8*>(sm + YL + sm_c(st * 32 + r, 2 * ks + h));
-                const f16x8 xh = *reinterpret_cast<const f16x8*>(sm + XH + sm_c(wid * 32 + r, 2 * ks + h));
-                const f16x8 xs = xh * (_Float16)2048.f;                                    // exact (|x| <= 1)
-#ifdef DG_DEVTOOLS
-                if (a.debug == 2 && n == 0 && t == 1 && wid == 0 && st == 0 && (lane == 20 || lane == 52) && ks < 2)
-                    printf("2a lane %d ks %d yh %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f  yl %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", lane, ks,
-                           (float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3], (float)yh[4], (float)yh[5], (float)yh[6], (float)yh[7],
-                           (float)yl[0], (float)yl[1], (float)yl[2], (float)yl[3], (float)yl[4], (float)yl[5], (float)yl[6], (float)yl[7]);
-#endif
-                cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xs, cdv, 0, 0, 0);
-                cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yl, xh, cdv, 0, 0, 0);
-                cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xl[ks], cdv, 0, 0, 0);
-            }
-            // the tile's 1 / |b_q| (depth term: nz_q): element i of a lane = position (i & 3) + 8 (i >> 2) + 4 h
-            float iFs[16];
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 iv = *reinterpret_cast<const f32x4*>(&invF[(NRM + st) * 32 + 8 * i4 + 4 * h]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) iFs[4 * i4 + e] = iv[e];
+            for (int ks = 0; ks < NKD; ++ks) {
+                if (ks < nkc) {
+                    const f16x8 yh = *reinterpret_cast<const f16x8*>(sm + YH + sm_c(st * 32 + r, 2 * ks + h));
+                    const f16x8 yl = *reinterpret_cast<const f16x8*>(sm + YL + sm_c(st * 32 + r, 2 * ks + h));
+                    const f16x8 xh = *reinterpret_cast<const f16x8*>(sm + XH + sm_c(wid * 32 + r, 2 * ks + h));
+                    const f16x8 xs = xh * (_Float16)2048.f;                                    // exact (|x| <= 1)
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xs, cdv, 0, 0, 0);
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yl, xh, cdv, 0, 0, 0);
+                    cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xl[ks], cdv, 0, 0, 0);
+                }
             }
             uint16_t gh[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int sl = (i & 3) + 8 * (i >> 2) + 4 * h, s = st * 32 + sl;
                 const bool valid = rvalid && s < P;
-                const float fdn = fdt[i] * iFr * iFs[i];
-                const float e = fdn - esub;
+                float e, fdn = 0.f, ddv = 0.f;
+                if (depth_job) {
+                    ddv = nzr * a.nz[(size_t)n * a.Ppad + (s < a.Ppad ? s : 0)];
+                    e = ddv - shift;
+                } else {
+                    fdn = fdt[i] * iFr * invF[(NRM + st) * 32 + sl];
+                    e = (PW ? fdn - rm : fdn) - shift;
+                }
                 const float cd = cdv[i] * (1.f / 2048.f);
-                const float cl = valid ? fminf(fmaxf(cd, lo), hi) : 0.f;
-                L1 = fmaf(cl, e, L1);
-                L2 += cl;
-                sfd += valid ? fdn : 0.f;
-                csum += valid ? cd : 0.f;
+                const float cl = fminf(fmaxf(cd, lo), hi);
+                if (valid) { L1 = fmaf(cl, e, L1); L2 += cl; sfd += fdn; csum += cd; }
                 const bool on = valid && cd >= lo && cd <= hi;
                 const _Float16 g16 = (_Float16)(on ? e : 0.f);
                 uint16_t hb = __builtin_bit_cast(uint16_t, g16);
-                if (PW) hb = (on && (hb & 0x7fffu) == 0) ? (uint16_t)1 : hb;                  // an element that is on never stores an exact zero
+                if (PW && on && (hb & 0x7fffu) == 0) hb = 1;                                  // an element that is on never stores an exact zero
                 gh[i] = hb;
-            }
-            if (mat) {       // dg_corr_materialize: the un-reduced tensors (ONE uniform branch per tile: the values are formed again)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (rvalid && s < P) {
-                        const float fdn = fdt[i] * iFr * iFs[i], cd = cdv[i] * (1.f / 2048.f);
-                        const size_t o = ((size_t)n * P + pr) * P + s;
-                        if (out_cd) out_cd[o] = depth_job ? fdn : cd;
-                        if (out_loss) out_loss[o] = -fminf(fmaxf(cd, lo), hi) * (fdn - esub + om_mat);
-                    }
+                if (a.mat && valid) {
+                    const size_t o = ((size_t)n * P + pr) * P + s;
+                    if (a.out_cd) a.out_cd[o] = depth_job ? ddv : cd;
+                    if (a.out_loss) a.out_loss[o] = -cl * (e + om_mat);
                 }
             }
             if (grad) {
-                f16x8 ga[2], gm[2];
+                f16x8 ga[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i >> 3][i & 7] = __builtin_bit_cast(_Float16, gh[i]);
-                if (PW) { gm[0] = sm_mask_of(ga[0]); gm[1] = sm_mask_of(ga[1]); }
                 if (!depth_job) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -455,16 +339,21 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         *reinterpret_cast<uint16_t*>(sm + GB + sm_c(s, wid * 4 + (r >> 3)) + (r & 7) * 2) = gh[i];
                     }
                 }
-                // dR[r][:] += sum_s G[s][r] y[s][:]: the accumulator tile is the A operand (k <-> s in accumulator order), the B operand
-                // is the streamed tile's code transposed on the matrix core
+                // dR[r][:] += sum_s G[s][r] y[s][:]: the accumulator tile is the A operand (k <-> s in accumulator order), B gathers y
 #pragma unroll
-                for (int f = 0; f < NDF; ++f) {
-                    const f32x16 yt = tacc(YH, st * 32, f);
+                for (int q = 0; q < 2; ++q) {
+                    f16x8 gm;
+                    if (PW) gm = sm_mask_of(ga[q]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f16x8 b = pack8(yt, q);
+                    for (int f = 0; f < NDF; ++f) {
+                        f16x8 b;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int s = st * 32 + 16 * q + 8 * (j >> 2) + 4 * h + (j & 3), d = 32 * f + r;
+                            b[j] = *reinterpret_cast<const _Float16*>(sm + YH + sm_c(s, d >> 3) + (d & 7) * 2);
+                        }
                         dR1[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[q], b, dR1[f], 0, 0, 0);
-                        if (PW) dR2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm[q], b, dR2[f], 0, 0, 0);
+                        if (PW) dR2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm, b, dR2[f], 0, 0, 0);
                     }
                 }
             }
@@ -482,7 +371,6 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
         }
     }
-    SM_STAMP();
     // block partial sums (fixed order: butterfly inside the wave, waves 0..3 in turn)
     {
         float v4[4] = {L1, L2, sfd, csum};
@@ -508,60 +396,48 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int f = 0; f < NDF; ++f)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { dS1[f][i] = 0.f; if (PW) dS2[f][i] = 0.f; }
-#pragma unroll 1
-            for (int rt = 0; rt < NR; ++rt) {
-                // A = row s of the -G image, k <-> stationary position in accumulator order: two 8-byte runs per k-step
-                f16x8 af[2], am[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f16x4 a0 = *reinterpret_cast<const f16x4*>(sm + GB + sm_c(st * 32 + r, rt * 4 + 2 * q) + 8 * h);
-                    const f16x4 a1 = *reinterpret_cast<const f16x4*>(sm + GB + sm_c(st * 32 + r, rt * 4 + 2 * q + 1) + 8 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { af[q][e] = a0[e]; af[q][4 + e] = a1[e]; }
-                    if (PW) am[q] = sm_mask_of(af[q]);
-                }
+            for (int rk = 0; rk < 2 * NR; ++rk) {
+                const f16x8 af = *reinterpret_cast<const f16x8*>(sm + GB + sm_c(st * 32 + r, 2 * rk + h));
+                f16x8 am;
+                if (PW) am = sm_mask_of(af);
 #pragma unroll
                 for (int f = 0; f < NDF; ++f) {
-                    const f32x16 xt = tacc(XH, rt * 32, f);
+                    f16x8 b;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f16x8 b = pack8(xt, q);
-                        dS1[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q], b, dS1[f], 0, 0, 0);
-                        if (PW) dS2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am[q], b, dS2[f], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) {
+                        const int rr = 16 * rk + 8 * h + j, d = 32 * f + r;
+                        b[j] = *reinterpret_cast<const _Float16*>(sm + XH + sm_c(rr, d >> 3) + (d & 7) * 2);
                     }
+                    dS1[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b, dS1[f], 0, 0, 0);
+                    if (PW) dS2[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, b, dS2[f], 0, 0, 0);
                 }
             }
-            // norm() backward with the streamed rows y (hi + lo, brought into accumulator layout like the products): d = inv (g - y <g, y>);
-            // element i of a lane = position (i&3) + 8 (i>>2) + 4 h of the tile, channel 32 f + r: the dot product runs over the 32
-            // lanes of the half wave
-            f32x16 yv[NDF];
-#pragma unroll
-            for (int f = 0; f < NDF; ++f) {
-                const f32x16 yh = tacc(YH, st * 32, f), yl = tacc(YL, st * 32, f);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) yv[f][i] = fmaf(yl[i], 1.f / 2048.f, yh[i]);
-            }
+            // norm() backward with the streamed rows y (hi + lo): d = inv (g - y <g, y>), element i of a lane = position
+            // (i&3) + 8 (i>>2) + 4 h of the tile, channel 32 f + r: the dot product runs over the 32 lanes of the half wave
             float* o1 = a.dRB[t][sp] + (((size_t)n * NT + st) * NDF) * 1024 + lane * 4;
             float* o2 = PW ? a.dRB2[t][sp] + (((size_t)n * NT + st) * NDF) * 1024 + lane * 4 : nullptr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 iv4 = *reinterpret_cast<const f32x4*>(&invC[(NRM + st) * 32 + 8 * g + 4 * h]);
                 f32x4 w1[NDF], w2[PW ? NDF : 1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * g + e;
-                    float d1 = 0.f, d2 = 0.f;
+                    const int i = 4 * g + e, sl = (i & 3) + 8 * (i >> 2) + 4 * h, s = st * 32 + sl;
+                    float yv[NDF], d1 = 0.f, d2 = 0.f;
 #pragma unroll
                     for (int f = 0; f < NDF; ++f) {
-                        d1 = fmaf(dS1[f][i], yv[f][i], d1);
-                        if (PW) d2 = fmaf(dS2[f][i], yv[f][i], d2);
+                        const int d = 32 * f + r;
+                        const uint32_t at = sm_c(s, d >> 3) + (d & 7) * 2;
+                        yv[f] = (float)*reinterpret_cast<const _Float16*>(sm + YH + at) + (float)*reinterpret_cast<const _Float16*>(sm + YL + at) * (1.f / 2048.f);
+                        d1 = fmaf(dS1[f][i], yv[f], d1);
+                        if (PW) d2 = fmaf(dS2[f][i], yv[f], d2);
                     }
                     d1 = half_sum(d1);
                     if (PW) d2 = half_sum(d2);
+                    const float iv = invC[(NRM + st) * 32 + sl];
 #pragma unroll
                     for (int f = 0; f < NDF; ++f) {
-                        w1[f][e] = iv4[e] * (dS1[f][i] - yv[f][i] * d1);
-                        if (PW) w2[f][e] = iv4[e] * (dS2[f][i] - yv[f][i] * d2);
+                        w1[f][e] = iv * (dS1[f][i] - yv[f] * d1);
+                        if (PW) w2[f][e] = iv * (dS2[f][i] - yv[f] * d2);
                     }
                 }
 #pragma unroll
@@ -573,14 +449,6 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     }
 
-    SM_STAMP();
-#ifdef DG_DEVTOOLS
-    if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {
-        // wall_clock64 ticks at 100 MHz: 10 ns per tick
-        printf("k_corr_small block 0 (NS %d NKD %d PW %d): code + feats %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
-               NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3]);
-    }
-#endif
     // ---- the block that finishes last reduces the partial sums of the call into the output scalars (and old_mean_t for the backward)
     if (tid == 0) {
         __threadfence();

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #ifdef DG_DEVTOOLS
     unsigned long long stp[8];
     int nstp = 0;
-#define SM_STAMP() do { if (a.debug == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stp[nstp++] = wall_clock64(); } } while (0)
+#define SM_STAMP() do { if (a.debug) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stp[nstp++] = wall_clock64(); } } while (0)
 #else
 #define SM_STAMP() do {} while (0)
 #endif
@@ -131,10 +131,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int k = c * 64 + gran * 8 + 4 * u;
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + (k < D4 ? k : D4 - 4));
-                    const bool use = live && pos < P && k < D4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) vc[c][j][u][e] = use ? t4[e] : 0.f;
+                    vc[c][j][u] = (live && pos < P && k < D4) ? *reinterpret_cast<const f32x4*>(src + k) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
         }
     };
@@ -159,31 +156,17 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             const float inv = okc ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
             if (gran == 0) invC[pass_row(j)] = inv;
             const bool isR = j < NR;
-#ifdef DG_DEVTOOLS
-            if (a.debug == 2 && n == 0 && t == 1 && j == NR && row32 == 20)
-                printf("row 20 gran %d: s %.9g inv %.9g v %.9g %.9g %.9g %.9g | %.9g %.9g %.9g %.9g\n", gran, s, inv, vc[0][j][0][0], vc[0][j][0][1],
-                       vc[0][j][0][2], vc[0][j][0][3], vc[0][j][1][0], vc[0][j][1][1], vc[0][j][1][2], vc[0][j][1][3]);
-#endif
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float xn[8];
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        xn[4 * u + e] = vc[c][j][u][e] * inv;
-                        chi[c][j][4 * u + e] = (_Float16)xn[4 * u + e];
+                        const float x = vc[c][j][u][e] * inv;
+                        const _Float16 xh = (_Float16)x;
+                        chi[c][j][4 * u + e] = xh;
+                        clo[c][j][4 * u + e] = (_Float16)((x - (float)xh) * 2048.f);
                     }
-                // lo is formed from the hi BITS that are stored: hipcc otherwise converts the same value twice, once per use, with two
-                // different instructions whose results differ at exact ties - hi from one rounding, lo from the other, 2.4e-4 off
-                // (found against the reference fixture at C = 2048: one code row in 242 carried such an element)
-                {
-                    v4i_s hb = __builtin_bit_cast(v4i_s, chi[c][j]);
-                    asm volatile("" : "+v"(hb));
-                    chi[c][j] = __builtin_bit_cast(f16x8, hb);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) clo[c][j][e] = (_Float16)((xn[e] - (float)chi[c][j][e]) * 2048.f);
                 const int g = c * 8 + gran;
                 if (isR && write_x && g < KD / 8)
                     *reinterpret_cast<f16x8*>(xop + ((size_t)n * NT + rt0 + j) * blob_bytes + blob_off_c + (g * 32 + row32) * 16) = chi[c][j];
@@ -394,12 +377,6 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const f16x8 yl = *reinterpret_cast<const f16x8*>(sm + YL + sm_c(st * 32 + r, 2 * ks + h));
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(sm + XH + sm_c(wid * 32 + r, 2 * ks + h));
                 const f16x8 xs = xh * (_Float16)2048.f;                                    // exact (|x| <= 1)
-#ifdef DG_DEVTOOLS
-                if (a.debug == 2 && n == 0 && t == 1 && wid == 0 && st == 0 && (lane == 20 || lane == 52) && ks < 2)
-                    printf("2a lane %d ks %d yh %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f  yl %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", lane, ks,
-                           (float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3], (float)yh[4], (float)yh[5], (float)yh[6], (float)yh[7],
-                           (float)yl[0], (float)yl[1], (float)yl[2], (float)yl[3], (float)yl[4], (float)yl[5], (float)yl[6], (float)yl[7]);
-#endif
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xs, cdv, 0, 0, 0);
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yl, xh, cdv, 0, 0, 0);
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xl[ks], cdv, 0, 0, 0);
@@ -575,7 +552,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
     SM_STAMP();
 #ifdef DG_DEVTOOLS
-    if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {
+    if (a.debug && blockIdx.x == 0 && tid == 0) {
         // wall_clock64 ticks at 100 MHz: 10 ns per tick
         printf("k_corr_small block 0 (NS %d NKD %d PW %d): code + feats %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
                NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3]);

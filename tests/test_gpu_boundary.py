@@ -210,7 +210,7 @@ def test_feature_pyramid_real_shapes_reference_vectors(case, dev):
     # (small grids: P = 121 / 36 positions, B = 2 - the means are sums of 3e4 / 2.6e3 elements with bf16 feature operands; the small
     #  fixtures of test_gpu_parity.py carry 2e-3 for the same reason)
     for k, v in errs.items():
-        assert v < 2e-3, (k, v)
+        assert v < 2e-4, (k, v)          # measured 8e-8 .. 5.7e-5
     sub = int(fx["sub"])
     for i, k, tol in ((1, "pos_intra_cd", 2e-5), (3, "pos_inter_cd", 2e-5), (5, "neg_inter_cd", 2e-5), (4, "neg_inter_loss", 4e-3)):
         assert np.abs(out[i].detach().reshape(-1)[::sub].cpu().numpy() - fx[k]).max() < tol, k
@@ -220,7 +220,9 @@ def test_feature_pyramid_real_shapes_reference_vectors(case, dev):
         rel = float((got - want).norm() / want.norm())
         worst = float((got - want).abs().max() / want.abs().max())
         print(case, name, f"grad rel-l2 {rel:.2e} worst {worst:.2e}")
-        assert rel < 5e-3 and worst < 2e-2, (name, rel, worst)
+        # measured 3e-4 (code: exact clamp masks, fp32-grade cd) and 1.7e-3 (code_pos: only the inter pair-set's streamed side
+        # reaches it - a heavily cancelling sum of fp16 -G entries)
+        assert rel < (1e-3 if name == "code" else 4e-3) and worst < 1e-2, (name, rel, worst)
 
 
 @pytest.mark.gpu
