@@ -428,8 +428,8 @@ static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, DgSmallAr
 }
 
 // sampled rows of every operand (the reference's sample(), src/modules.py:822-825, of feats / code at coords1 / coords2 and of the
-// negatives' permuted maps, :1323-1343) -> the fused kernel.  Launches: the draw + depth indicators + tap records + ticket word, the
-// sampler, the fused kernel.
+// negatives' permuted maps, :1323-1343) -> the fused kernel.  Launches: the draw + depth indicators + tap records, the sampler, the
+// fused kernel, its one-wave finish.
 static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                          const float* orig_code, const float* orig_code_pos, const float* depth, const float* coords1,
                          const float* coords2, const int64_t* perms, const DrawArgs* draw, float* out_scalars, char* ws,
@@ -445,7 +445,6 @@ static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* o
         if (p.depth) { q.depth = depth; q.nz = F32(p.nz); q.nzsum = F32(p.nzsum); q.dH = desc->depth_h; q.dW = desc->depth_w; }
         if (p.grad && (size_t)p.hc * p.wc <= 4096 && p.P <= 65535) { q.coords1 = coords1; q.coords2 = coords2; q.taps = ws + p.taps; }
         q.B = p.B; q.h = p.hc; q.w = p.wc; q.S = p.S; q.Sh = p.Sh; q.P = p.P; q.Ppad = p.Ppad;
-        q.zero_word = a.ticket;
         if (p.B > 8192 && q.count > 0) return fail(DG_ERR_UNSUPPORTED, "B=%d too large for the in-call draw", p.B);
         DG_HIP(dg_launch_pre_general(q, stream));
     }

@@ -15,9 +15,9 @@
 // old_mean (fd.mean() over the WHOLE batch, :1237) is not known inside a block.  Everything is linear in it:
 //   loss sum  = sum clamp(cd) (fd' - shift) + old_mean * sum clamp(cd)               fd' = fd - rowmean
 //   gradient  = [mask (fd' - shift)] . y     + old_mean * [mask] . y
-// so a pointwise block emits both terms (the second set of gradient tiles costs MFMAs and bytes, no launch and no grid barrier);
-// the block that finishes last (ticket) reduces the partial sums, forms old_mean_t and the output scalars and leaves old_mean_t in
-// `om`, which the backward tail multiplies into the weight of the second set (DgScatterSrc.dfac).
+// so a pointwise block emits both terms (the second set of gradient tiles costs MFMAs and bytes, no grid barrier); a one-wave
+// launch behind the kernel (k_small_finish) reduces the partial sums, forms old_mean_t and the output scalars and leaves old_mean_t
+// in `om`, which the backward tail multiplies into the weight of the second set (DgScatterSrc.dfac).
 // Gradient tiles, partial sums and the operand-0 C part / inverse norms are written in the formats the existing backward tail
 // (dg_post.hip k_grad_combine / k_scatter_small) reads.
 //
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     extern __shared__ __attribute__((aligned(16))) char sm[];
     __shared__ __attribute__((aligned(16))) float invF[NJ * 32], invC[NJ * 32];
     __shared__ float red[4 * 4];
-    __shared__ int last_flag;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +86,12 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const bool grad = a.grad != 0 && !a.mat;
     const int opS = depth_job ? 0 : t;
 #ifdef DG_DEVTOOLS
-    unsigned long long stp[8];
+    const int abl = a.debug >> 4;          // developer timing ablations (results invalid): 1 no phase 2b, 2 no gradient work in 2a, 4 one feature chunk, 8 no tile loop
+#else
+    constexpr int abl = 0;
+#endif
+#ifdef DG_DEVTOOLS
+    unsigned long long stp[12];
     int nstp = 0;
 #define SM_STAMP() do { if (a.debug == 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stp[nstp++] = wall_clock64(); } } while (0)
 #else
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     if (depth_job) { load_code(); norm_code(); }
 
     if (!depth_job) {
-        const int C4 = a.C4, nch = (C4 + KC - 1) / KC;
+        const int C4 = a.C4, nch = (abl & 4) ? 1 : (C4 + KC - 1) / KC;
         const float* srcp[NJ];
         bool ok[NJ];
 #pragma unroll
@@ -252,10 +256,14 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
             }
         };
+        SM_STAMP();
         issue(0);
+        SM_STAMP();
         if (EARLY) load_code();                    // (behind the first chunk's loads: one memory latency for both)
         stash(0);
+        SM_STAMP();
         __syncthreads();
+        SM_STAMP();
         if (EARLY) norm_code();                    // (the chunk's staging registers are free again)
         // chunk ch + 1 (KC channels of every row) is in flight in registers while chunk ch is multiplied
 #pragma unroll 1
@@ -266,7 +274,9 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             stash(buf ^ 1);
             __syncthreads();
         }
+        SM_STAMP();
         if (!EARLY) load_code();
+        SM_STAMP();
         mfma_chunk((nch - 1) & 1);
         if (!EARLY) norm_code();
         // 1 / max(|row|, eps) of the feature rows (norm(), src/modules.py:789-790), from the fp32 values
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
         const float esub = rm + shift;               // e = fd - rowmean - shift
 #pragma unroll 1
-        for (int st = 0; st < NS; ++st) {
+        for (int st = 0; st < ((abl & 8) ? 0 : NS); ++st) {
             // (a rolled loop: unrolled, hipcc hoists the loads of every tile to the top and runs out of registers; the tile's
             //  accumulator is picked out of the register file with selects)
             f32x16 fdt = acc[0];
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     }
                 }
             }
-            if (grad) {
+            if (grad && !(abl & 2)) {
                 f16x8 ga[2], gm[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i >> 3][i & 7] = __builtin_bit_cast(_Float16, gh[i]);
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
 
     // ---- phase 2b: d/d(streamed code) = G x over this block's stationary tiles, normalisation backward, final tiles
-    if (grad && !depth_job) {
+    if (grad && !depth_job && !(abl & 1)) {
         for (int st = wid; st < NS; st += 4) {
             f32x16 dS1[NDF], dS2[PW ? NDF : 1];
 #pragma unroll
@@ -577,32 +587,52 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #ifdef DG_DEVTOOLS
     if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {
         // wall_clock64 ticks at 100 MHz: 10 ns per tick
-        printf("k_corr_small block 0 (NS %d NKD %d PW %d): code + feats %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
-               NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3]);
+        printf("k_corr_small block 0 (NS %d NKD %d PW %d): setup %llu, chunk 0 loads %llu, stash %llu, barrier %llu, chunk loop %llu, code loads %llu, "
+               "last mfma + norm %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
+               NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4], stp[6] - stp[5], stp[7] - stp[6],
+               stp[8] - stp[7], stp[9] - stp[8], stp[10] - stp[9]);
     }
 #endif
-    // ---- the block that finishes last reduces the partial sums of the call into the output scalars (and old_mean_t for the backward)
-    if (tid == 0) {
-        __threadfence();
-        last_flag = atomicAdd(a.ticket, 1u) == (unsigned)(B * per) - 1u;
+}
+
+// The partial sums of the call -> the output scalars, old_mean_t for the backward.  Its own one-wave launch: a last-block ticket inside
+// k_corr_small needs a device-scope release fence per block (the blocks sit on eight XCDs whose L2s are not coherent with each
+// other), and every one of those fences writes the XCD's whole dirty L2 back - the gradient tiles the kernel has just stored:
+// 35 of the launch's 51 us at config 2.
+__global__ __launch_bounds__(64) void k_small_finish(const DgSmallArgs a) {
+    // eight lanes per job (pair-set or depth term): lane (job = lane >> 3, sub = lane & 7) sums the partials sub, sub + 8, ... in double
+    // (fixed order), three butterfly steps finish the job; jobs 8 .. 10 (more than six negatives) take a second round
+    __shared__ double jobsum[DG_MAX_NEG + 3][4];
+    const int lane = threadIdx.x, B = a.B, P = a.P;
+    const int njob = a.T + (a.depth ? 1 : 0), nb = B * a.nsplit;
+    for (int j0 = 0; j0 < njob; j0 += 8) {
+        const int tt = j0 + (lane >> 3), sub = lane & 7;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (tt < njob)
+            for (int i = sub; i < nb; i += 8) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(a.part + ((size_t)tt * nb + i) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s4[k] += (double)q4[k];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s4[k] += __shfl_xor(s4[k], 1, 64); s4[k] += __shfl_xor(s4[k], 2, 64); s4[k] += __shfl_xor(s4[k], 4, 64);
+            if (sub == 0 && tt < njob) jobsum[tt][k] = s4[k];
+        }
+    }
+    double m = 0.0;
+    if (a.depth && a.nzsum) {                  // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
+        for (int i = lane; i < B; i += 64) { const double s = a.nzsum[i]; m += s * s; }
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
     }
     __syncthreads();
-    if (last_flag && wid == 0) {
-        __threadfence();
+    if (lane == 0) {
         double accv[DG_OUT_COUNT];
 #pragma unroll
         for (int i = 0; i < DG_OUT_COUNT; ++i) accv[i] = 0.0;
         const double numel = (double)B * P * P;
-        const int nb = B * nsplit;
         for (int tt = 0; tt < njob; ++tt) {
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            const volatile float* pp = a.part + (size_t)tt * nb * 4;
-            for (int i = lane; i < nb; i += 64)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s4[k] += (double)pp[i * 4 + k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                for (int o = 32; o > 0; o >>= 1) s4[k] += __shfl_xor(s4[k], o, 64);
+            const double* s4 = jobsum[tt];
             if (tt < a.T) {
                 const double om = a.pointwise ? s4[2] / numel : 0.0;
                 const double l = s4[0] + om * s4[1];
@@ -610,26 +640,17 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const double scale = tt < 2 ? 1.0 / numel : 1.0 / (numel * (a.T - 2));
                 accv[slot] += -l * scale;
                 accv[DG_OUT_CD_INTRA + (tt < 2 ? tt : 2)] += s4[3] * scale;
-                if (lane == 0) a.om[tt] = (float)om;
+                a.om[tt] = (float)om;
             } else {
                 accv[DG_OUT_LOSS_DEPTH] += -s4[0] / numel;
             }
         }
-        if (a.depth && a.nzsum) {                  // mean(dd) = mean_n (sum_p nz[n][p])^2 / P^2
-            double m = 0.0;
-            for (int i = lane; i < B; i += 64) { const double s = a.nzsum[i]; m += s * s; }
-            for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
-            accv[DG_OUT_DD] = m / numel;
-        }
-        if (lane == 0) {
-            accv[DG_OUT_TOTAL] = 0.0;
+        if (a.depth && a.nzsum) accv[DG_OUT_DD] = m / numel;
+        accv[DG_OUT_TOTAL] = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) accv[DG_OUT_TOTAL] += (double)a.wtot[i] * (double)(float)accv[i];
+        for (int i = 0; i < 4; ++i) accv[DG_OUT_TOTAL] += (double)a.wtot[i] * (double)(float)accv[i];
 #pragma unroll
-            for (int i = 0; i < DG_OUT_COUNT; ++i) a.out[i] = (float)accv[i];
-            *a.ticket = 0u;                        // ready for the next launch (re-launches of a recorded step included)
-            __threadfence();
-        }
+        for (int i = 0; i < DG_OUT_COUNT; ++i) a.out[i] = (float)accv[i];
     }
 }
 
@@ -649,9 +670,12 @@ hipError_t dg_launch_corr_small(const DgSmallArgs& a, hipStream_t s) {
     const int grid = ((a.B + 7) / 8) * 8 * per;
     const int smem = small_smem(NS);
     auto go = [&](auto kern) -> hipError_t {
-        const hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SM_THREADS), smem, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess || a.mat) return e;
+        hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(64), 0, s, a);
         return hipGetLastError();
     };
 #define DG_SM_CASE(NS_)                                                                                  \

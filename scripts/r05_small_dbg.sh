@@ -1,5 +1,5 @@
 #!/bin/bash
-for c in C2 C3 C4shard; do
+for c in C2 C3; do
   echo "== $c"
-  DG_SMALL_DEBUG=1 DEPTHG_LIB=$PWD/depthg_amd/lib/libdepthg_dev.so python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --eager --clock-warmup-s 0.05 2>&1 | grep "k_corr_small block" | tail -3
+  DG_SMALL_DEBUG=1 DEPTHG_LIB=$PWD/depthg_amd/lib/libdepthg_dev.so python bench.py --config $c --steps 30 --warmup 5 --no-cpu-baseline --eager --clock-warmup-s 0.5 2>&1 | grep "k_corr_small block" | tail -3
 done
