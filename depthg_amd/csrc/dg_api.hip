@@ -48,7 +48,7 @@ struct Plan {
     // the fused small-grid path (dg_small.hip): sampled rows -> ONE launch
     bool small;
     int nsplit;                             // blocks per (image, pair-set): 2 when the image has 5 tiles
-    size_t dRA2[DG_MAX_NEG + 2], dRBs[DG_MAX_NEG + 2], dRB2[DG_MAX_NEG + 2][2], part4, om;
+    size_t dRA2[DG_MAX_NEG + 2], dRBs[DG_MAX_NEG + 2], dRB2[DG_MAX_NEG + 2][2], dRBm[DG_MAX_NEG + 2][2], part4, om;
     size_t total;
 };
 
@@ -155,7 +155,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         for (int t = 0; t < p.T; ++t) {
             p.dRA2[t] = take(two ? gt : 0);
             p.dRBs[t] = take(p.small && p.grad && p.nsplit == 2 ? gt : 0);
-            for (int k = 0; k < 2; ++k) p.dRB2[t][k] = take(two && k < p.nsplit ? gt : 0);
+            for (int k = 0; k < 2; ++k) { p.dRB2[t][k] = take(two && k < p.nsplit ? gt : 0); p.dRBm[t][k] = take(two && k < p.nsplit ? gt : 0); }
         }
         p.part4 = take(p.small ? (size_t)(p.T + 1) * B * p.nsplit * 16 : 0);
         p.om = take(p.small ? (size_t)(p.T + 1) * 4 : 0);
@@ -837,12 +837,26 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
             const int64_t* route = t >= 2 ? perms + (size_t)(t - 2) * p.B : nullptr;
             const int csel = t == 0 ? 0 : 1, dest = t == 1 ? 1 : 0;
             add(p.dRA[t], nullptr, gi, 0, ft, 0, 1);
-            add(p.dRB[t], route, gi, csel, ft, dest, 0);
-            if (p.nsplit == 2) add(p.dRBs[t], route, gi, csel, ft, dest, 0);
-            if (p.pointwise) {
+            if (!p.pointwise) {
+                add(p.dRB[t], route, gi, csel, ft, dest, 0);
+                if (p.nsplit == 2) add(p.dRBs[t], route, gi, csel, ft, dest, 0);
+            } else {
                 const float* om = F32(p.om) + t;
                 add(p.dRA2[t], nullptr, gi, 0, ft, 0, 1); s.src[n - 1].dfac = om;
-                for (int k = 0; k < p.nsplit; ++k) { add(p.dRB2[t][k], route, gi, csel, ft, dest, 0); s.src[n - 1].dfac = om; }
+                // the final (streamed-side) sets: first term + old_mean_t x second term, merged by extra slices of the combine launch
+                // in front of the adjoint launch that reads the result - routed sources are what that launch's time scales with.
+                // (direct final sources - intra, inter - are read by the combine launch itself: those keep both terms)
+                for (int k = 0; k < p.nsplit; ++k) {
+                    const size_t first = k == 0 ? p.dRB[t] : p.dRBs[t];
+                    if (route) {
+                        s.axo[s.naxpy] = F32(p.dRBm[t][k]); s.axd[s.naxpy] = F32(first); s.axs[s.naxpy] = F32(p.dRB2[t][k]); s.axf[s.naxpy] = om;
+                        ++s.naxpy;
+                        add(p.dRBm[t][k], route, gi, csel, ft, dest, 0);
+                    } else {
+                        add(first, route, gi, csel, ft, dest, 0);
+                        add(p.dRB2[t][k], route, gi, csel, ft, dest, 0); s.src[n - 1].dfac = om;
+                    }
+                }
             }
         }
     } else {

@@ -598,6 +598,14 @@ struct DgScatterArgs {
     int8_t craw[2][DG_MAX_SCATTER / 2], cfin[2][DG_MAX_SCATTER / 2];
     int8_t ncraw[2], ncfin[2];
     int32_t taps_ready;    // 1: the forward built the tap records (dg_launch_pre_general)
+    // extra z slices of the k_grad_combine launch (general coordinates): axo[j] = axd[j] + axf[j][0] * axs[j], tile by tile - the fused
+    // small-grid path merges the old_mean term of every final source into ONE buffer here, so that the adjoint launch behind it walks
+    // as many routed sources as without `pointwise` (dg_small.hip).  The inputs stay as they are: a second backward sees the same.
+    int32_t naxpy;
+    float* axo[2 * (DG_MAX_NEG + 2)];
+    const float* axd[2 * (DG_MAX_NEG + 2)];
+    const float* axs[2 * (DG_MAX_NEG + 2)];
+    const float* axf[2 * (DG_MAX_NEG + 2)];
 };
 
 #ifdef __HIPCC__

@@ -41,6 +41,21 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, DP = NDF * 32;
     const int d = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (dest >= 2) {       // an axpy slice (DgScatterArgs.naxpy): this block's tile of job dest - 2, one channel group per wave
+        const int j = dest - 2;
+        const size_t off = ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + d * 1024 + lane * 4;
+        const float f = a.axf[j][0];
+        f32x4 x[4], y[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { x[g] = *reinterpret_cast<const f32x4*>(a.axs[j] + off + g * 256); y[g] = *reinterpret_cast<const f32x4*>(a.axd[j] + off + g * 256); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[g][e] = fmaf(f, x[g][e], y[g][e]);
+            *reinterpret_cast<f32x4*>(a.axo[j] + off + g * 256) = y[g];
+        }
+        return;
+    }
     __shared__ __attribute__((aligned(16))) char xs[NDF][DG_XROWS_LDS];
     __shared__ float part[NDF][32];
     DG_LOAD_GS(a, gs)
@@ -679,8 +694,9 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
             }
         }
 #endif
-        if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid, dim3(192), 0, s, ac);
-        else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid, dim3(256), 0, s, ac);
+        const dim3 cgrid2(a.Ppad / 32, a.B, 2 + a.naxpy);
+        if (a.DP == 96) hipLaunchKernelGGL(k_grad_combine<3>, cgrid2, dim3(192), 0, s, ac);
+        else if (a.DP == 128) hipLaunchKernelGGL(k_grad_combine<4>, cgrid2, dim3(256), 0, s, ac);
         else return hipErrorInvalidValue;
     }
     const int HW = a.h * a.w;
