@@ -86,7 +86,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const bool grad = a.grad != 0 && !a.mat;
     const int opS = depth_job ? 0 : t;
 #ifdef DG_DEVTOOLS
-    const int abl = a.debug >> 4;          // developer timing ablations (results invalid): 1 no phase 2b, 2 no gradient work in 2a, 4 one feature chunk, 8 no tile loop
+    const int abl = a.debug >> 4;          // developer timing ablations (results invalid): 1 no phase 2b, 2 no gradient work in 2a, 4 one feature chunk
 #else
     constexpr int abl = 0;
 #endif
@@ -195,90 +195,86 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (isR && write_x && gran == 0) xinv[(size_t)n * Ppad + pos] = inv;
         }
     };
-    if (depth_job) { load_code(); norm_code(); }
-
-    if (!depth_job) {
-        const int C4 = a.C4, nch = (abl & 4) ? 1 : (C4 + KC - 1) / KC;
-        const float* srcp[NJ];
-        bool ok[NJ];
+    // (ONE call site per piece of straight-line code below - every copy of the loader or of the normalisation is a kilobyte of
+    //  instructions, and the kernel has to stay inside the 64-KB instruction cache it shares with the neighbouring CU)
+    const int C4 = a.C4, nch = depth_job ? 0 : ((abl & 4) ? 1 : (C4 + KC - 1) / KC);
+    const float* srcp[NJ];
+    bool ok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const bool live = j < NR + NS;
+        const int pos = live ? pass_pos(j) : 0;
+        ok[j] = live && pos < P && !depth_job;
+        srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4;
+    }
+    f32x4 v[NJ][2 * NSUB];
+    float ss[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
+    auto issue = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int u = 0; u < 2 * NSUB; ++u) {
+                const int k = ch * KC + (u >> 1) * 64 + gran * 8 + 4 * (u & 1);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(srcp[j] + (k < C4 ? k : C4 - 4));     // (unconditional: see load_code)
+                const bool use = ok[j] && k < C4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[j][u][e] = use ? t4[e] : 0.f;
+            }
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const bool live = j < NR + NS;
-            const int pos = live ? pass_pos(j) : 0;
-            ok[j] = live && pos < P;
-            srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4;
-        }
-        f32x4 v[NJ][2 * NSUB];
-        float ss[NJ];
+            if (j >= NR + NS) continue;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
-        auto issue = [&](int ch) {
+            for (int c = 0; c < NSUB; ++c) {
+                bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int u = 0; u < 2 * NSUB; ++u) {
-                    const int k = ch * KC + (u >> 1) * 64 + gran * 8 + 4 * (u & 1);
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(srcp[j] + (k < C4 ? k : C4 - 4));     // (unconditional: see above)
-                    const bool use = ok[j] && k < C4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][u][e] = use ? t4[e] : 0.f;
-                }
-        };
-        auto stash = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j >= NR + NS) continue;
-#pragma unroll
-                for (int c = 0; c < NSUB; ++c) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = v[j][2 * c + u][e];
-                            ss[j] = fmaf(x, x, ss[j]);
-                            o[4 * u + e] = (__bf16)x;
-                        }
-                    *reinterpret_cast<bf16x8*>(sm + buf * FBUF + sm_c(pass_row(j), c * 8 + gran)) = o;
-                }
-            }
-        };
-        auto mfma_chunk = [&](int buf) {
-            if (wid < NR) {
-#pragma unroll
-                for (int ks = 0; ks < 4 * NSUB; ++ks) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + sm_c(wid * 32 + r, 2 * ks + h));
-#pragma unroll
-                    for (int st = 0; st < NS; ++st) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + FS_OFF + sm_c(st * 32 + r, 2 * ks + h));
-                        acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[st], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[j][2 * c + u][e];
+                        ss[j] = fmaf(x, x, ss[j]);
+                        o[4 * u + e] = (__bf16)x;
                     }
+                *reinterpret_cast<bf16x8*>(sm + buf * FBUF + sm_c(pass_row(j), c * 8 + gran)) = o;
+            }
+        }
+    };
+    auto mfma_chunk = [&](int buf) {
+        if (wid < NR) {
+#pragma unroll
+            for (int ks = 0; ks < 4 * NSUB; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + sm_c(wid * 32 + r, 2 * ks + h));
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + FS_OFF + sm_c(st * 32 + r, 2 * ks + h));
+                    acc[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[st], 0, 0, 0);
                 }
             }
-        };
-        SM_STAMP();
-        issue(0);
-        SM_STAMP();
-        if (EARLY) load_code();                    // (behind the first chunk's loads: one memory latency for both)
-        stash(0);
-        SM_STAMP();
-        __syncthreads();
-        SM_STAMP();
-        if (EARLY) norm_code();                    // (the chunk's staging registers are free again)
-        // chunk ch + 1 (KC channels of every row) is in flight in registers while chunk ch is multiplied
-#pragma unroll 1
-        for (int ch = 0; ch + 1 < nch; ++ch) {
-            const int buf = ch & 1;
-            issue(ch + 1);
-            mfma_chunk(buf);
-            stash(buf ^ 1);
-            __syncthreads();
         }
-        SM_STAMP();
-        if (!EARLY) load_code();
-        SM_STAMP();
-        mfma_chunk((nch - 1) & 1);
-        if (!EARLY) norm_code();
+    };
+    SM_STAMP();
+    if (!depth_job) issue(0);
+    if (EARLY && !depth_job) load_code();          // (behind the first chunk's loads: one memory latency for both)
+    // chunk ch + 1 (KC channels of every row) is in flight in registers while chunk ch is multiplied; buffer ch & 1 was last read two
+    // iterations ago, in front of the previous iteration's barrier
+#pragma unroll 1
+    for (int ch = 0; ch + 1 < nch; ++ch) {
+        stash(ch & 1);
+        __syncthreads();
+        issue(ch + 1);
+        mfma_chunk(ch & 1);
+    }
+    // the last chunk, peeled: with 4-5 accumulator tiles the code rows' registers fit only here, where the staging registers die
+    // (kept live around the loop they spill: 100-140 registers to scratch)
+    if (nch > 0) { stash((nch - 1) & 1); __syncthreads(); }
+    if (!EARLY || depth_job) load_code();
+    if (nch > 0) mfma_chunk((nch - 1) & 1);
+    SM_STAMP();
+    norm_code();
+    if (!depth_job) {
         // 1 / max(|row|, eps) of the feature rows (norm(), src/modules.py:789-790), from the fp32 values
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -286,8 +282,8 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
             if (j < NR + NS && gran == 0) invF[pass_row(j)] = ok[j] ? 1.f / fmaxf(sqrtf(s), DG_EPS_NORM) : 0.f;
         }
-        __syncthreads();                           // every wave is done with the feature chunks
     }
+    __syncthreads();                               // every wave is done with the feature chunks
     SM_STAMP();
 
     // ---- the code images: [row][<= 128 fp16], hi and lo, stationary (X) and streamed (Y) rows
@@ -386,10 +382,11 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             rm = rs / (float)P;
         }
         const float esub = rm + shift;               // e = fd - rowmean - shift
+        if (PW && !depth_job) sfd = (h == 0 && rvalid) ? rm * (float)P : 0.f;      // sum fd of this lane's row (both halves hold it): old_mean's share
 #pragma unroll 1
-        for (int st = 0; st < ((abl & 8) ? 0 : NS); ++st) {
-            // (a rolled loop: unrolled, hipcc hoists the loads of every tile to the top and runs out of registers; the tile's
-            //  accumulator is picked out of the register file with selects)
+        for (int st = 0; st < NS; ++st) {
+            // (a rolled loop - unrolled, the kernel outgrows the 64-KB instruction cache and is slower: 47.5 -> 50.9 us at config 3;
+            //  the tile's accumulator is picked out of the register file with selects)
             f32x16 fdt = acc[0];
 #pragma unroll
             for (int k = 1; k < NS; ++k)
@@ -404,49 +401,60 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const f16x8 yl = *reinterpret_cast<const f16x8*>(sm + YL + sm_c(st * 32 + r, 2 * ks + h));
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(sm + XH + sm_c(wid * 32 + r, 2 * ks + h));
                 const f16x8 xs = xh * (_Float16)2048.f;                                    // exact (|x| <= 1)
-#ifdef DG_DEVTOOLS
-                if (a.debug == 2 && n == 0 && t == 1 && wid == 0 && st == 0 && (lane == 20 || lane == 52) && ks < 2)
-                    printf("2a lane %d ks %d yh %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f  yl %.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", lane, ks,
-                           (float)yh[0], (float)yh[1], (float)yh[2], (float)yh[3], (float)yh[4], (float)yh[5], (float)yh[6], (float)yh[7],
-                           (float)yl[0], (float)yl[1], (float)yl[2], (float)yl[3], (float)yl[4], (float)yl[5], (float)yl[6], (float)yl[7]);
-#endif
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xs, cdv, 0, 0, 0);
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yl, xh, cdv, 0, 0, 0);
                 cdv = __builtin_amdgcn_mfma_f32_32x32x16_f16(yh, xl[ks], cdv, 0, 0, 0);
             }
-            // the tile's 1 / |b_q| (depth term: nz_q): element i of a lane = position (i & 3) + 8 (i >> 2) + 4 h
+            // the tile's 1 / |b_q| (depth term: nz_q) times this lane's 1 / |a_p|: element i of a lane = position (i & 3) + 8 (i >> 2) + 4 h
             float iFs[16];
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 const f32x4 iv = *reinterpret_cast<const f32x4*>(&invF[(NRM + st) * 32 + 8 * i4 + 4 * h]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) iFs[4 * i4 + e] = iv[e];
+                for (int e = 0; e < 4; ++e) iFs[4 * i4 + e] = iv[e] * iFr;
+            }
+            // Epilogue on pairs of elements.  Padded positions need no select in the sums: their code rows are zero, so cd = 0 and
+            // clamp(cd) = 0 there (lo <= 0 <= hi); only the mask - which is ON at cd = 0 - has to know them.
+            uint32_t gw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float e2[2];
+                uint32_t m2 = 0u;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * j + u, s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float fdn = fdt[i] * iFs[i];
+                    const float e = fdn - esub;
+                    const float cd = cdv[i] * (1.f / 2048.f);
+                    const float cl = __builtin_amdgcn_fmed3f(cd, lo, hi);
+                    L1 = fmaf(cl, e, L1);
+                    L2 += cl;
+                    csum += cd;
+                    const bool on = rvalid && s < P && cd >= lo && cd <= hi;
+                    e2[u] = e;
+                    m2 |= on ? (u ? 0xffff0000u : 0x0000ffffu) : 0u;
+                }
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                h2_t hv;
+                hv[0] = (_Float16)e2[0]; hv[1] = (_Float16)e2[1];
+                uint32_t hw2 = __builtin_bit_cast(uint32_t, hv);
+                if (PW) {        // an element that is on never stores an exact zero (the mask is read back out of -G): |g| = max(|g|, 2^-24)
+                    const uint32_t ab = hw2 & 0x7fff7fffu;
+                    typedef unsigned short u2_t __attribute__((ext_vector_type(2)));
+                    const u2_t mx = __builtin_elementwise_max(__builtin_bit_cast(u2_t, ab), u2_t{1, 1});
+                    hw2 = (hw2 & 0x80008000u) | __builtin_bit_cast(uint32_t, mx);
+                }
+                gw[j] = hw2 & m2;
             }
             uint16_t gh[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const bool valid = rvalid && s < P;
-                const float fdn = fdt[i] * iFr * iFs[i];
-                const float e = fdn - esub;
-                const float cd = cdv[i] * (1.f / 2048.f);
-                const float cl = valid ? fminf(fmaxf(cd, lo), hi) : 0.f;
-                L1 = fmaf(cl, e, L1);
-                L2 += cl;
-                sfd += valid ? fdn : 0.f;
-                csum += valid ? cd : 0.f;
-                const bool on = valid && cd >= lo && cd <= hi;
-                const _Float16 g16 = (_Float16)(on ? e : 0.f);
-                uint16_t hb = __builtin_bit_cast(uint16_t, g16);
-                if (PW) hb = (on && (hb & 0x7fffu) == 0) ? (uint16_t)1 : hb;                  // an element that is on never stores an exact zero
-                gh[i] = hb;
-            }
+            for (int j = 0; j < 8; ++j) { gh[2 * j] = (uint16_t)(gw[j] & 0xffffu); gh[2 * j + 1] = (uint16_t)(gw[j] >> 16); }
             if (mat) {       // dg_corr_materialize: the un-reduced tensors (ONE uniform branch per tile: the values are formed again)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int s = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     if (rvalid && s < P) {
-                        const float fdn = fdt[i] * iFr * iFs[i], cd = cdv[i] * (1.f / 2048.f);
+                        const float fdn = fdt[i] * iFs[i], cd = cdv[i] * (1.f / 2048.f);
                         const size_t o = ((size_t)n * P + pr) * P + s;
                         if (out_cd) out_cd[o] = depth_job ? fdn : cd;
                         if (out_loss) out_loss[o] = -fminf(fmaxf(cd, lo), hi) * (fdn - esub + om_mat);
@@ -587,10 +595,8 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #ifdef DG_DEVTOOLS
     if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {
         // wall_clock64 ticks at 100 MHz: 10 ns per tick
-        printf("k_corr_small block 0 (NS %d NKD %d PW %d): setup %llu, chunk 0 loads %llu, stash %llu, barrier %llu, chunk loop %llu, code loads %llu, "
-               "last mfma + norm %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
-               NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4], stp[6] - stp[5], stp[7] - stp[6],
-               stp[8] - stp[7], stp[9] - stp[8], stp[10] - stp[9]);
+        printf("k_corr_small block 0 (NS %d NKD %d PW %d): setup %llu, chunk loop %llu, norm %llu, code images %llu, phase 2a %llu, phase 2b %llu  [x10 ns]\n",
+               NS, NKD, (int)PW, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2], stp[4] - stp[3], stp[5] - stp[4], stp[6] - stp[5]);
     }
 #endif
 }
