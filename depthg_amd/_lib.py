@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 113                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 114                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
@@ -19,7 +19,8 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_corr_backward_total", "dg_corr_main_kernel_name",
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
            "dg_head_backward_pair", "dg_cluster_lookup_forward",
-           "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities"]
+           "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities",
+           "dg_prof_main_span"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -124,6 +125,8 @@ def load():
     lib.dg_super_perms_seeded.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32, vp, vp]
     lib.dg_super_perms_state.restype = ctypes.c_int
     lib.dg_super_perms_state.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
+    lib.dg_prof_main_span.restype = ctypes.c_int
+    lib.dg_prof_main_span.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -25,6 +25,10 @@ static int fail(int code, const char* fmt, ...) {
 extern "C" int dg_version(void) { return DG_VERSION; }
 extern "C" const char* dg_last_error(void) { return g_err; }
 
+// ---- measurement aid: the fused correlation launch's execution span (include/depthg_corr.h dg_prof_main_span)
+static unsigned long long* g_prof_span = nullptr;
+extern "C" int dg_prof_main_span(void* span) { g_prof_span = static_cast<unsigned long long*>(span); return DG_OK; }
+
 // ---- workspace plan
 static inline size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -224,6 +228,7 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
     clamp_bounds(d, a.lo, a.hi);
     a.inv_BP = 1.0f / ((float)p.B * (float)p.P);
     a.dummy = ws + p.op[0];
+    a.span = g_prof_span;
 }
 
 // k_gs jobs: one per pair-set; the producing job of the G tiles is helper_job(t) of the fused launch (R = operand 1,
@@ -422,6 +427,7 @@ static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, DgSmallAr
     a.xop = ws + p.op[0]; a.xinv = F32(p.inv[0]); a.blob_bytes = bl.bytes; a.blob_off_c = bl.off_c;
     a.wtot[0] = d->w_intra; a.wtot[1] = d->w_inter; a.wtot[2] = d->w_neg; a.wtot[3] = d->w_depth;
     a.nsplit = p.nsplit;
+    a.span = g_prof_span;
 #ifdef DG_DEVTOOLS
     { static const int dbg = [] { const char* e = getenv("DG_SMALL_DEBUG"); return e ? atoi(e) : 0; }(); a.debug = dbg; }
 #endif
@@ -484,6 +490,7 @@ static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* o
         DG_HIP(dg_launch_gather_rows(g, stream));
     }
     DG_HIP(dg_launch_corr_small(a, stream));
+    DG_HIP(dg_launch_small_finish(a, stream));
     return DG_OK;
 }
 struct FeatKeep { const float* keep[2]; float scale; };      // deferred Dropout2d of the two feature maps (dg_corr_forward_masked)
@@ -904,7 +911,7 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     if (p.small) {          // the fused small-grid kernel again, on the rows (and old_mean_t) the forward left in the workspace
         DgSmallArgs m;
         small_args(p, desc, ws, m);
-        m.mat = 1; m.mat_t = which; m.out_cd = out_cd; m.out_loss = out_loss; m.grad = 0;
+        m.mat = 1; m.mat_t = which; m.out_cd = out_cd; m.out_loss = out_loss; m.grad = 0; m.span = nullptr;
         DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
         return DG_OK;
     }
@@ -934,7 +941,7 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
         DgSmallArgs m;
         small_args(p, desc, static_cast<char*>(workspace), m);
         m.out = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.scratch_out);
-        DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
+        DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));        // (the kernel alone: what the roofline leg times)
         return DG_OK;
     }
     DgCorrArgs a;

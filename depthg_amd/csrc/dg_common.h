@@ -169,6 +169,16 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 #endif
 
+#ifdef __HIPCC__
+// dg_prof_main_span: one thread per workgroup stamps the launch's span (constant 100-MHz clock)
+__device__ __forceinline__ void dg_span_enter(unsigned long long* span) {
+    if (span) __hip_atomic_fetch_min(&span[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void dg_span_exit(unsigned long long* span) {
+    if (span) __hip_atomic_fetch_max(&span[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // job kinds of the fused correlation kernel
 enum { DG_JOB_HELPER = 0, DG_JOB_DEPTH = 1 };
 
@@ -219,6 +229,7 @@ struct DgCorrArgs {
     int32_t debug;        // developer ablation bits (0 in production)
     uint32_t* wctr;       // k_corr2's persistent workgroups: [0..7] items handed out so far per XCD (beyond each workgroup's first), [8]
                           // workgroups that have left; all zero at launch (k_colmean) and again when the last workgroup leaves; null: static walk
+    unsigned long long* span;   // measurement aid (dg_prof_main_span): [0] min of the workgroups' entry times, [1] max of their exit times; or null
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
     // ragged last row blocks grouped by streamed operand (dg_corr2.hip; lists written by k_group_ragged); gr_list null: off
@@ -439,6 +450,7 @@ struct DgSmallArgs {
     float* out_loss;
     int32_t mat_t, mat;
     int32_t debug;                        // developer: 1 = block 0 prints its phase stamps (DG_SMALL_DEBUG=1)
+    unsigned long long* span;             // measurement aid (dg_prof_main_span) or null
 };
 
 struct DgGatherRowsArgs {   // k_gather_rows: sample() of channel-last maps into fp32 rows (code maps of another size, maps beyond the LDS)
@@ -712,7 +724,8 @@ hipError_t dg_launch_topk_rows(const float* vals, long long rows, long long cols
                                long long* out_idx, float* out_val, hipStream_t s);
 hipError_t dg_launch_pre_general(const struct DgPreArgs& a, hipStream_t s);
 bool dg_small_supported(int Ppad, int KD);
-hipError_t dg_launch_corr_small(const struct DgSmallArgs& a, hipStream_t s);
+hipError_t dg_launch_corr_small(const struct DgSmallArgs& a, hipStream_t s);       // the fused kernel; the call's scalars need ...
+hipError_t dg_launch_small_finish(const struct DgSmallArgs& a, hipStream_t s);     // ... this one-wave launch behind it
 hipError_t dg_launch_gather_rows(const struct DgGatherRowsArgs& a, hipStream_t s);
 hipError_t dg_launch_lhp_points(const float* depth, int B, int H, int W, int h, int w, float factor, float* points, hipStream_t s);
 hipError_t dg_launch_lhp_propagate(bool backward, const float* src, const float* points, float* stats, int B, int D, int P,

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     // and passed on through LDS at the item's end; an item that turns out to be served by a group asks and waits on the spot.
     __shared__ int next_item_s;
     int next_orig = 0;
+    if (threadIdx.x == 0) dg_span_enter(args_k.span);
     for (int orig = blockIdx.x; orig < nitems; orig = next_orig) {
     unsigned taken = 0;                 // (thread 0) items of this XCD handed out before this request
     // (pointer and mode re-derived per item from the kernel arguments: two scalar registers less across the tile loops)
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #endif
     advance();
     }       // (next work item)
+    if (threadIdx.x == 0) dg_span_exit(args_k.span);
     // the last workgroup to leave puts the counters back to zero (a re-launch on the same workspace - dg_corr_relaunch_main - finds
     // them as k_colmean left them for this one)
     if (DYN && threadIdx.x == 0) {

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int xk = (int)blockIdx.x >> 3;
     const int n = ((int)blockIdx.x & 7) + 8 * (xk / per);
     if (n >= B) return;
+    if (tid == 0) dg_span_enter(a.span);
     const int jj = xk % per;
     const int sp = jj % nsplit;
     int t = jj / nsplit;
@@ -591,6 +592,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     }
 
+    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg_span_exit(a.span); }
     SM_STAMP();
 #ifdef DG_DEVTOOLS
     if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {
@@ -676,12 +678,9 @@ hipError_t dg_launch_corr_small(const DgSmallArgs& a, hipStream_t s) {
     const int grid = ((a.B + 7) / 8) * 8 * per;
     const int smem = small_smem(NS);
     auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        const hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(SM_THREADS), smem, s, a);
-        e = hipGetLastError();
-        if (e != hipSuccess || a.mat) return e;
-        hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(64), 0, s, a);
         return hipGetLastError();
     };
 #define DG_SM_CASE(NS_)                                                                                  \
@@ -692,6 +691,11 @@ hipError_t dg_launch_corr_small(const DgSmallArgs& a, hipStream_t s) {
     DG_SM_CASE(1) DG_SM_CASE(2) DG_SM_CASE(3) DG_SM_CASE(4) DG_SM_CASE(5)
 #undef DG_SM_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t dg_launch_small_finish(const DgSmallArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -460,6 +460,30 @@ def corr_relaunch_main(desc, perms, workspace):
     _lib.check(rc, "dg_corr_relaunch_main")
 
 
+class MainKernelTimer:
+    """Measurement aid (bench.py): the execution span of the fused correlation launch INSIDE the step, hipGraph replays included
+    (dg_prof_main_span): while armed, every workgroup of that kernel stamps its entry / exit time (the GPU's constant 100-MHz
+    clock) into two device words with atomic min / max.  `reset()` in front of a step (an asynchronous fill on the current
+    stream), `last_ms()` behind it: the interval a kernel trace reports for the launch, minus the dispatch ramp."""
+
+    def __init__(self, device):
+        self.span = torch.zeros(2, dtype=torch.int64, device=device)
+        self._init = torch.tensor([-1, 0], dtype=torch.int64, device=device)       # {UINT64_MAX, 0}
+
+    def arm(self, on=True):
+        _lib.check(_lib.load().dg_prof_main_span(_ptr(self.span) if on else None), "dg_prof_main_span")
+
+    def reset(self):
+        self.span.copy_(self._init, non_blocking=True)
+
+    def last_ms(self):
+        torch.cuda.synchronize()
+        t0, t1 = (int(v) for v in self.span.tolist())
+        if t0 < 0 or t1 <= 0:                      # nothing stamped
+            return float("nan")
+        return (t1 - t0) * 1e-5                    # 10-ns ticks -> ms
+
+
 def corr_main_kernel_name(desc):
     """Which kernel the fused correlation launch of `desc` runs ("k_corr2" / "k_corr_main"), from the library's own predicate."""
     name = _lib.load().dg_corr_main_kernel_name(ctypes.byref(desc))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 113   /* 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 114   /* 114: dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -439,6 +439,16 @@ int dg_probe_ce_backward(const float* logits, const int64_t* label, const float*
 /* Measurement aid: name of the kernel the fused correlation launch of this descriptor runs ("k_corr2": the one-wave-per-SIMD
  * form of dg_corr2.hip, "k_corr_main": the general form), decided by the same predicate the launch uses; NULL on a bad desc. */
 const char* dg_corr_main_kernel_name(const dg_corr_desc* desc);
+
+/*
+ * Measurement aid (bench.py roofline leg): the execution span of the fused correlation launch INSIDE the step, hipGraph replays
+ * included.  `span` = device pointer to two uint64 (or NULL: off): every workgroup of the fused kernel of every later dg_corr_forward*
+ * call of this process takes min(span[0], entry time) and max(span[1], exit time) with device-scope atomics; times are the GPU's
+ * constant 100-MHz wall clock (s_memrealtime: 10 ns per tick).  The caller sets {UINT64_MAX, 0} in front of the step it wants to
+ * read (e.g. a memset on the launch stream) and reads (span[1] - span[0]) x 10 ns behind it - the interval a kernel trace reports
+ * for the launch, minus the dispatch ramp.  Nothing in the product path depends on it.
+ */
+int dg_prof_main_span(void* span);
 
 /*
  * Measurement aid (bench.py roofline leg): re-launch only the fused correlation kernel on the operands a
