@@ -20,7 +20,7 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
            "dg_head_backward_pair", "dg_cluster_lookup_forward",
            "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities",
-           "dg_prof_main_span"]
+           "dg_prof_main_span", "dg_corr_materialize_shared"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -89,6 +89,8 @@ def load():
     lib.dg_corr_backward_total.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.dg_corr_materialize.restype = ctypes.c_int
     lib.dg_corr_materialize.argtypes = [cp, ctypes.c_int32, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_corr_materialize_shared.restype = ctypes.c_int
+    lib.dg_corr_materialize_shared.argtypes = [cp, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_corr_relaunch_main.restype = ctypes.c_int
     lib.dg_corr_relaunch_main.argtypes = [cp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_fps_workspace_bytes.restype = ctypes.c_size_t

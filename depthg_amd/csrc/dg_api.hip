@@ -52,7 +52,7 @@ struct Plan {
     // the fused small-grid path (dg_small.hip): sampled rows -> ONE launch
     bool small;
     int nsplit;                             // blocks per (image, pair-set): 2 when the image has 5 tiles
-    size_t dRA2[DG_MAX_NEG + 2], dRBs[DG_MAX_NEG + 2], dRB2[DG_MAX_NEG + 2][2], dRBm[DG_MAX_NEG + 2][2], part4, om;
+    size_t dRA2[DG_MAX_NEG + 2], dRBs[DG_MAX_NEG + 2], dRB2[DG_MAX_NEG + 2][2], dRBm[DG_MAX_NEG + 2], part4, om;
     size_t total;
 };
 
@@ -159,7 +159,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         for (int t = 0; t < p.T; ++t) {
             p.dRA2[t] = take(two ? gt : 0);
             p.dRBs[t] = take(p.small && p.grad && p.nsplit == 2 ? gt : 0);
-            for (int k = 0; k < 2; ++k) { p.dRB2[t][k] = take(two && k < p.nsplit ? gt : 0); p.dRBm[t][k] = take(two && k < p.nsplit ? gt : 0); }
+            for (int k = 0; k < 2; ++k) p.dRB2[t][k] = take(two && k < p.nsplit ? gt : 0);
+            p.dRBm[t] = take(p.small && p.grad && t >= 2 && (p.pointwise || p.nsplit == 2) ? gt : 0);
         }
         p.part4 = take(p.small ? (size_t)(p.T + 1) * B * p.nsplit * 16 : 0);
         p.om = take(p.small ? (size_t)(p.T + 1) * 4 : 0);
@@ -844,25 +845,22 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
             const int64_t* route = t >= 2 ? perms + (size_t)(t - 2) * p.B : nullptr;
             const int csel = t == 0 ? 0 : 1, dest = t == 1 ? 1 : 0;
             add(p.dRA[t], nullptr, gi, 0, ft, 0, 1);
-            if (!p.pointwise) {
-                add(p.dRB[t], route, gi, csel, ft, dest, 0);
-                if (p.nsplit == 2) add(p.dRBs[t], route, gi, csel, ft, dest, 0);
+            const float* om = p.pointwise ? F32(p.om) + t : nullptr;
+            if (p.pointwise) { add(p.dRA2[t], nullptr, gi, 0, ft, 0, 1); s.src[n - 1].dfac = om; }
+            // the streamed-side (final) tiles: one set per half of the stationary tiles, with `pointwise` the old_mean terms on top.
+            // ROUTED sources (the negatives) are merged into one buffer each by extra slices of the combine launch, in front of the
+            // adjoint launch that reads the result - routed sources are what that launch's time scales with.  Direct ones (intra,
+            // inter) are read by the combine launch itself: those keep their terms.
+            if (route && (p.pointwise || p.nsplit == 2)) {
+                const int j = s.naxpy++;
+                s.axo[j] = F32(p.dRBm[t]); s.axd[j] = F32(p.dRB[t]); s.axd2[j] = p.nsplit == 2 ? F32(p.dRBs[t]) : nullptr;
+                s.axs[j] = p.pointwise ? F32(p.dRB2[t][0]) : nullptr; s.axs2[j] = (p.pointwise && p.nsplit == 2) ? F32(p.dRB2[t][1]) : nullptr;
+                s.axf[j] = om;
+                add(p.dRBm[t], route, gi, csel, ft, dest, 0);
             } else {
-                const float* om = F32(p.om) + t;
-                add(p.dRA2[t], nullptr, gi, 0, ft, 0, 1); s.src[n - 1].dfac = om;
-                // the final (streamed-side) sets: first term + old_mean_t x second term, merged by extra slices of the combine launch
-                // in front of the adjoint launch that reads the result - routed sources are what that launch's time scales with.
-                // (direct final sources - intra, inter - are read by the combine launch itself: those keep both terms)
                 for (int k = 0; k < p.nsplit; ++k) {
-                    const size_t first = k == 0 ? p.dRB[t] : p.dRBs[t];
-                    if (route) {
-                        s.axo[s.naxpy] = F32(p.dRBm[t][k]); s.axd[s.naxpy] = F32(first); s.axs[s.naxpy] = F32(p.dRB2[t][k]); s.axf[s.naxpy] = om;
-                        ++s.naxpy;
-                        add(p.dRBm[t][k], route, gi, csel, ft, dest, 0);
-                    } else {
-                        add(first, route, gi, csel, ft, dest, 0);
-                        add(p.dRB2[t][k], route, gi, csel, ft, dest, 0); s.src[n - 1].dfac = om;
-                    }
+                    add(k == 0 ? p.dRB[t] : p.dRBs[t], route, gi, csel, ft, dest, 0);
+                    if (p.pointwise) { add(p.dRB2[t][k], route, gi, csel, ft, dest, 0); s.src[n - 1].dfac = om; }
                 }
             }
         }
@@ -896,8 +894,21 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     return DG_OK;
 }
 
+static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64_t* perms, float* out_cd, float* out_loss,
+                            void* workspace, size_t workspace_bytes, dg_stream_t stream_);
+
 extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, float* out_cd, float* out_loss,
                                    void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    return materialize_impl(desc, which, nullptr, out_cd, out_loss, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_corr_materialize_shared(const dg_corr_desc* desc, int32_t which, const int64_t* perms, float* out_cd, float* out_loss,
+                                          void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    return materialize_impl(desc, which, perms, out_cd, out_loss, workspace, workspace_bytes, stream_);
+}
+
+static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64_t* perms, float* out_cd, float* out_loss,
+                            void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     Plan p;
     int rc = make_plan(desc, p);
     if (rc != DG_OK) return rc;
@@ -905,7 +916,8 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     if (workspace_bytes < p.total) return fail(DG_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, p.total);
     if (which < -1 || which >= p.T) return fail(DG_ERR_INVALID, "which=%d outside [-1,%d)", which, p.T);
     if (which == -1 && !p.depth) return fail(DG_ERR_INVALID, "depth term not enabled in descriptor");
-    if (which >= 2 && p.shared) return fail(DG_ERR_UNSUPPORTED, "materialising negatives needs the perms; not available with DG_SHARED_COORDS");
+    if (which >= 2 && p.shared && !perms)
+        return fail(DG_ERR_INVALID, "materialising a negative of a DG_SHARED_COORDS call needs its batch maps: dg_corr_materialize_shared");
     if (!out_cd && !out_loss) return DG_OK;
     char* ws = static_cast<char*>(workspace);
     if (p.small) {          // the fused small-grid kernel again, on the rows (and old_mean_t) the forward left in the workspace
@@ -918,7 +930,7 @@ extern "C" int dg_corr_materialize(const dg_corr_desc* desc, int32_t which, floa
     DgCorrArgs a;
     corr_args_base(p, desc, ws, a);
     // stationary = operand 2 (on MFMA lanes) -> the stores of one accumulator register are contiguous along q
-    DgJob j = which == -1 ? depth_job(p, desc, ws) : helper_job(p, desc, ws, which, true, nullptr);
+    DgJob j = which == -1 ? depth_job(p, desc, ws) : helper_job(p, desc, ws, which, true, perms);
     j.center_on_lane = 0;
     j.out_cd = out_cd; j.out_loss = out_loss; j.part = nullptr; j.dR = nullptr;
     a.jobs[0] = j; a.njobs = 1;

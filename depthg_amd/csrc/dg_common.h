@@ -610,14 +610,17 @@ struct DgScatterArgs {
     int8_t craw[2][DG_MAX_SCATTER / 2], cfin[2][DG_MAX_SCATTER / 2];
     int8_t ncraw[2], ncfin[2];
     int32_t taps_ready;    // 1: the forward built the tap records (dg_launch_pre_general)
-    // extra z slices of the k_grad_combine launch (general coordinates): axo[j] = axd[j] + axf[j][0] * axs[j], tile by tile - the fused
-    // small-grid path merges the old_mean term of every final source into ONE buffer here, so that the adjoint launch behind it walks
-    // as many routed sources as without `pointwise` (dg_small.hip).  The inputs stay as they are: a second backward sees the same.
+    // extra z slices of the k_grad_combine launch (general coordinates): axo[j] = axd[j] + axd2[j] + axf[j][0] * (axs[j] + axs2[j]), tile
+    // by tile (null terms are left out) - the fused small-grid path merges the two halves of every ROUTED streamed-side source and
+    // their old_mean terms into ONE buffer here, so that the adjoint launch behind it walks one routed source per negative whatever
+    // the grid (dg_small.hip).  The inputs stay as they are: a second backward sees the same.
     int32_t naxpy;
-    float* axo[2 * (DG_MAX_NEG + 2)];
-    const float* axd[2 * (DG_MAX_NEG + 2)];
-    const float* axs[2 * (DG_MAX_NEG + 2)];
-    const float* axf[2 * (DG_MAX_NEG + 2)];
+    float* axo[DG_MAX_NEG + 2];
+    const float* axd[DG_MAX_NEG + 2];
+    const float* axd2[DG_MAX_NEG + 2];
+    const float* axs[DG_MAX_NEG + 2];
+    const float* axs2[DG_MAX_NEG + 2];
+    const float* axf[DG_MAX_NEG + 2];
 };
 
 #ifdef __HIPCC__

@@ -44,14 +44,22 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
     if (dest >= 2) {       // an axpy slice (DgScatterArgs.naxpy): this block's tile of job dest - 2, one channel group per wave
         const int j = dest - 2;
         const size_t off = ((size_t)n * (a.Ppad >> 5) + rt) * (32 * DP) + d * 1024 + lane * 4;
-        const float f = a.axf[j][0];
-        f32x4 x[4], y[4];
+        const float f = a.axf[j] ? a.axf[j][0] : 0.f;
+        const float* const d2 = a.axd2[j];
+        const float* const s1 = a.axs[j];
+        const float* const s2 = a.axs2[j];
+        f32x4 y[4], y2[4], x[4], x2[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { x[g] = *reinterpret_cast<const f32x4*>(a.axs[j] + off + g * 256); y[g] = *reinterpret_cast<const f32x4*>(a.axd[j] + off + g * 256); }
+        for (int g = 0; g < 4; ++g) {
+            y[g] = *reinterpret_cast<const f32x4*>(a.axd[j] + off + g * 256);
+            y2[g] = d2 ? *reinterpret_cast<const f32x4*>(d2 + off + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            x[g] = s1 ? *reinterpret_cast<const f32x4*>(s1 + off + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            x2[g] = s2 ? *reinterpret_cast<const f32x4*>(s2 + off + g * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[g][e] = fmaf(f, x[g][e], y[g][e]);
+            for (int e = 0; e < 4; ++e) y[g][e] = fmaf(f, x[g][e] + x2[g][e], y[g][e] + y2[g][e]);
             *reinterpret_cast<f32x4*>(a.axo[j] + off + g * 256) = y[g];
         }
         return;

@@ -336,13 +336,13 @@ class ContrastiveCorrelationLoss(nn.Module):
         if mode != "full":
             raise ValueError(f"cfg.dg_outputs must be 'full' or 'reduced', got {mode!r}")
         # reference-shaped outputs (src/modules.py:1352-1367); cd tensors carry no gradient (the caller only logs them)
-        if shared_coords and N > 0:
-            raise RuntimeError("depthg_amd: dg_outputs='full' is not available with the shared dense grid; use 'reduced'")
+        # (on the shared dense grid the negatives' operands are the anchors' operand read through the batch maps: the maps go along;
+        #  a 28 x 28 tensor is 78.7 MB per pair-set at B = 32 - the reference materialises them on every step, here only when asked)
         intra_cd, _ = ops.corr_materialize(desc, 0, ws)
         inter_cd, _ = ops.corr_materialize(desc, 1, ws)
         neg_cd, neg_loss = [], []
         for k in range(N):
-            c, l = ops.corr_materialize(desc, 2 + k, ws, want_cd=True, want_loss=True)
+            c, l = ops.corr_materialize(desc, 2 + k, ws, want_cd=True, want_loss=True, perms=perms_t)
             neg_cd.append(c)
             neg_loss.append(l)
         if N > 0:

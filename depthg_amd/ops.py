@@ -185,16 +185,18 @@ def corr_backward_total(desc, grad_total, coords1, coords2, perms, workspace, sh
     return g_code, g_code_pos
 
 
-def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False):
+def corr_materialize(desc, which, workspace, want_cd=True, want_loss=False, perms=None):
+    """The un-reduced (B,S,S,S,S) tensors of pair-set `which` (-1: the depth term's dd) from the operands the forward left in
+    `workspace`.  `perms`: the forward's (n_neg, B) batch maps - needed for the negatives of a shared-coordinates (dense grid) call."""
     lib = _lib.load()
     dev = workspace.device
     sh = 1 if (desc.flags & _lib.DG_LINE_GRID) else desc.S
     shape = (desc.B, sh, desc.S, sh, desc.S)
     cd = _empty(shape, torch.float32, dev) if want_cd else None
     loss = _empty(shape, torch.float32, dev) if want_loss else None
-    rc = lib.dg_corr_materialize(ctypes.byref(desc), int(which), _ptr(cd), _ptr(loss), _ptr(workspace),
-                                 workspace.numel(), _stream(dev))
-    _lib.check(rc, "dg_corr_materialize")
+    rc = lib.dg_corr_materialize_shared(ctypes.byref(desc), int(which), _ptr(perms), _ptr(cd), _ptr(loss), _ptr(workspace),
+                                        workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_materialize_shared")
     return cd, loss
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 114   /* 114: dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 114   /* 114: dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -203,6 +203,15 @@ int dg_corr_backward_total(const dg_corr_desc* desc,
 int dg_corr_materialize(const dg_corr_desc* desc, int32_t which,
                         float* out_cd, float* out_loss,
                         void* workspace, size_t workspace_bytes, dg_stream_t stream);
+
+/*
+ * dg_corr_materialize for calls with DG_SHARED_COORDS (the dense identity grid), where the negatives' operands are the anchors'
+ * operand read through their batch maps: `perms` = the (n_neg, B) maps the forward used (dg_corr_forward's argument or what
+ * dg_corr_forward_draw wrote).  The reference returns these tensors on every grid (src/modules.py:1352-1367; `hist_freq` steps of
+ * src/train_segmentation.py histogram them).  Without DG_SHARED_COORDS it is dg_corr_materialize (perms may be NULL).
+ */
+int dg_corr_materialize_shared(const dg_corr_desc* desc, int32_t which, const int64_t* perms, float* out_cd, float* out_loss,
+                               void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * Depth-guided sample locations (replaces farthest_point_sampling_depth, src/modules.py:999-1037,
