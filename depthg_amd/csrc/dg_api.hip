@@ -406,14 +406,14 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
 struct DrawArgs { int64_t* out; uint64_t seed; unsigned long long* state; };
 
 // ---- the fused small-grid path (dg_small.hip)
-static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, DgSmallArgs& a) {
+static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, const int64_t* perms, DgSmallArgs& a) {
     memset(&a, 0, sizeof(a));
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     for (int o = 0; o < p.nops; ++o) { a.rowsF[o] = F32(p.rows_f[o]); a.rowsC[o] = F32(p.rows_c[o]); }
     a.T = p.T; a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.C4 = p.C4; a.D = p.D; a.D4 = p.D4; a.KD = p.KD;
     a.pointwise = p.pointwise ? 1 : 0; a.depth = p.depth ? 1 : 0; a.grad = p.grad ? 1 : 0;
     clamp_bounds(d, a.lo, a.hi);
-    for (int t = 0; t < p.T; ++t) a.shift[t] = shift_of(d, t);
+    for (int t = 0; t < p.T; ++t) { a.shift[t] = shift_of(d, t); a.opS[t] = op_of(p, t); a.sidx[t] = map_of(p, t, perms); }
     a.shift_depth = d->shift_depth;
     a.nz = F32(p.nz); a.nzsum = F32(p.nzsum);
     for (int t = 0; t <= p.T; ++t) a.dRA[t] = F32(p.dRA[t]);
@@ -443,7 +443,7 @@ static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* o
                          hipStream_t stream) {
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     DgSmallArgs a;
-    small_args(p, desc, ws, a);
+    small_args(p, desc, ws, perms, a);
     a.out = out_scalars;
     {
         DgPreArgs q;
@@ -922,7 +922,7 @@ static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64
     char* ws = static_cast<char*>(workspace);
     if (p.small) {          // the fused small-grid kernel again, on the rows (and old_mean_t) the forward left in the workspace
         DgSmallArgs m;
-        small_args(p, desc, ws, m);
+        small_args(p, desc, ws, perms, m);
         m.mat = 1; m.mat_t = which; m.out_cd = out_cd; m.out_loss = out_loss; m.grad = 0; m.span = nullptr;
         DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
         return DG_OK;
@@ -951,7 +951,7 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     if (p.small) {
         // (the scalars of the re-launch go to the workspace's scratch vector: the call's own outputs are not touched)
         DgSmallArgs m;
-        small_args(p, desc, static_cast<char*>(workspace), m);
+        small_args(p, desc, static_cast<char*>(workspace), perms, m);
         m.out = reinterpret_cast<float*>(static_cast<char*>(workspace) + p.scratch_out);
         DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));        // (the kernel alone: what the roofline leg times)
         return DG_OK;

@@ -425,7 +425,9 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 struct DgSmallArgs {
     const float* rowsF[DG_MAX_NEG + 2];   // [operand][B][P][C4] sampled feature rows (k_plane_sample / k_gather_rows), channels C..C4-1 zero
     const float* rowsC[DG_MAX_NEG + 2];   // [operand][B][P][D4] sampled code rows
-    int32_t T, B, P, Ppad, C4, D, D4, KD; // T pair-sets (operand of pair-set t = t); KD in {96, 128}: padded code width of the gradient tiles
+    int32_t T, B, P, Ppad, C4, D, D4, KD; // T pair-sets; KD in {96, 128}: padded code width of the gradient tiles
+    int32_t opS[DG_MAX_NEG + 2];          // streamed operand of pair-set t (t itself; with DG_SHARED_COORDS the negatives stream operand 0 ...
+    const int64_t* sidx[DG_MAX_NEG + 2];  // ... of image sidx[t][n] - the batch map - instead of image n; null: image n)
     int32_t pointwise, depth, grad;
     float lo, hi;                         // clamp bounds
     float shift[DG_MAX_NEG + 2], shift_depth;

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int rt0 = sp == 0 ? 0 : 3;
     const int NR = nsplit == 1 ? NS : (sp == 0 ? 3 : 2);
     const bool grad = a.grad != 0 && !a.mat;
-    const int opS = depth_job ? 0 : t;
+    const int opS = depth_job ? 0 : a.opS[t];
+    const int nS = (!depth_job && a.sidx[t]) ? (int)a.sidx[t][n] : n;       // image whose rows the streamed operand is (shared coordinates: the batch map)
 #ifdef DG_DEVTOOLS
     const int abl = a.debug >> 4;          // developer timing ablations (results invalid): 1 no phase 2b, 2 no gradient work in 2a, 4 one feature chunk
 #else
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int j = 0; j < NJ; ++j) {
             const bool live = j < NR + NS;
             const int pos = live ? pass_pos(j) : 0;
-            const float* src = (j < NR ? rowsC_R : rowsC_S) + ((size_t)n * P + (pos < P ? pos : 0)) * D4;
+            const float* src = (j < NR ? rowsC_R : rowsC_S) + ((size_t)(j < NR ? n : nS) * P + (pos < P ? pos : 0)) * D4;
             // (every load is issued unconditionally from a clamped address and zeroed afterwards: a load under a condition becomes
             //  a branch with its own s_waitcnt vmcnt(0) - the loads of a pass then run one memory latency after the other)
 #pragma unroll
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const bool live = j < NR + NS;
         const int pos = live ? pass_pos(j) : 0;
         ok[j] = live && pos < P && !depth_job;
-        srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)n * P + (ok[j] ? pos : 0)) * C4;
+        srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)(j < NR ? n : nS) * P + (ok[j] ? pos : 0)) * C4;
     }
     f32x4 v[NJ][2 * NSUB];
     float ss[NJ];

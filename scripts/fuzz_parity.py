@@ -135,6 +135,8 @@ def one(seed):
 t0 = time.time()
 counts = {}
 for s in range(seed0, seed0 + n_cases):
+    if os.environ.get("FUZZ_TRACE"):      # (a GPU fault kills the process: name the case first)
+        print("seed", s, flush=True)
     try:
         status, desc = one(s)
     except Exception as e:  # noqa: BLE001

@@ -133,3 +133,35 @@ def test_dense_grids_without_padded_positions(B, D, hw, N, dev):
     for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
         rel = float((got.cpu() - want).norm() / want.norm())
         assert rel < 2.1e-2, (name, rel)
+
+
+@pytest.mark.parametrize("B,C,D,hw,S,N,line", [(5, 100, 33, 12, 6, 3, False), (3, 64, 90, 9, 11, 2, False), (4, 48, 16, 10, 8, 2, True)])
+def test_small_grid_with_shared_coordinates(B, C, D, hw, S, N, line, dev):
+    """DG_SHARED_COORDS without the identity grid (ONE sample grid for every image and both coordinate sets: two operands, the
+    negatives read operand 0 through their batch maps) on sample grids of <= 160 positions - the fused small-grid kernel then
+    takes the streamed rows of a negative from image perm[n] of operand 0.  (Round 5's first version indexed an operand per
+    pair-set there and faulted; the randomized sweep found it, no committed test did.)  Also the S x 1 line grid."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(9000 + 10 * B + S)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 3 * hw, 3 * hw), generator=g).float()
+    d[:, :, :4, :5] = 0.0
+    S2 = 1 if line else S
+    c1 = (torch.rand(1, S, S2, 2, generator=g) * 2.2 - 1.1).expand(B, S, S2, 2).contiguous()
+    perms = [torch.randint(0, B, (B,), generator=g) for _ in range(N)]          # duplicates and fixed points allowed (quirk Q6)
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced")
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c1, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c1.to(dev),
+                                                       [p.to(dev) for p in perms], shared_coords=True)
+    O.total_loss(cfg, out).backward()
+    torch.cuda.synchronize()
+    for i in range(len(ref)):
+        _relclose(out[i].mean(), ref[i].mean(), 3e-3, 2e-5, f"tuple[{i}]")
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        rel = float((got.cpu() - want).norm() / want.norm())
+        assert rel < 5e-3, (name, rel)          # (exact clamp masks on this path: 4e-4 .. 2e-3 measured)
