@@ -115,7 +115,9 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     p.rows = !p.ident && same_maps && (size_t)p.nops * p.P <= 2 * HW && HW <= 1024 && B <= 32767;
     for (int i = 0; i < 2; ++i) { p.nhwc_f[i] = take(p.rows ? 0 : B * HW * p.C4 * 4); p.nhwc_c[i] = take(p.rows ? 0 : B * HWc * p.D4 * 4); }
     const bool want_rows = p.rows || p.small;      // (the fused small-grid kernel reads sampled rows whichever sampler wrote them)
-    for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(want_rows ? B * p.P * p.C4 * 4 : 0); p.rows_c[i] = take(want_rows ? B * p.P * p.D4 * 4 : 0); }
+    // (the fused small-grid kernel takes bf16 feature rows of up(C, 128) channels - whole chunks; the multi-launch path fp32 rows of C4)
+    const size_t frow = p.small ? (size_t)up(p.C, 128) * 2 : (size_t)p.C4 * 4;
+    for (int i = 0; i < p.nops; ++i) { p.rows_f[i] = take(want_rows ? B * p.P * frow : 0); p.rows_c[i] = take(want_rows ? B * p.P * p.D4 * 4 : 0); }
     for (int i = 0; i < p.nops; ++i) {
         p.op[i] = take(B * (p.Ppad / 32) * (size_t)p.blob);
         p.inv[i] = take(B * p.Ppad * 4);
@@ -410,7 +412,7 @@ static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, const int
     memset(&a, 0, sizeof(a));
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     for (int o = 0; o < p.nops; ++o) { a.rowsF[o] = F32(p.rows_f[o]); a.rowsC[o] = F32(p.rows_c[o]); }
-    a.T = p.T; a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.C4 = p.C4; a.D = p.D; a.D4 = p.D4; a.KD = p.KD;
+    a.T = p.T; a.B = p.B; a.P = p.P; a.Ppad = p.Ppad; a.C4 = (int)up(p.C, 128); a.D = p.D; a.D4 = p.D4; a.KD = p.KD;
     a.pointwise = p.pointwise ? 1 : 0; a.depth = p.depth ? 1 : 0; a.grad = p.grad ? 1 : 0;
     clamp_bounds(d, a.lo, a.hi);
     for (int t = 0; t < p.T; ++t) { a.shift[t] = shift_of(d, t); a.opS[t] = op_of(p, t); a.sidx[t] = map_of(p, t, perms); }
@@ -459,7 +461,8 @@ static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* o
         DgPlaneArgs t;
         memset(&t, 0, sizeof(t));
         t.src[0] = orig_feats; t.src[1] = orig_feats_pos; t.src[2] = orig_code; t.src[3] = orig_code_pos;
-        t.K[0] = t.K[1] = p.C; t.K4[0] = t.K4[1] = p.C4; t.K[2] = t.K[3] = p.D; t.K4[2] = t.K4[3] = p.D4;
+        t.K[0] = t.K[1] = p.C; t.K4[0] = t.K4[1] = (int)up(p.C, 128); t.K[2] = t.K[3] = p.D; t.K4[2] = t.K4[3] = p.D4;
+        t.feats_bf16 = 1;
         for (int o = 0; o < p.nops; ++o) { t.rows[o][0] = F32(p.rows_f[o]); t.rows[o][1] = F32(p.rows_c[o]); }
         t.coords1 = coords1; t.coords2 = coords2; t.perms = perms;
         t.nops = p.nops; t.B = p.B; t.h = p.h; t.w = p.w; t.S = p.S; t.Sh = p.Sh; t.P = p.P;
@@ -483,9 +486,9 @@ static int forward_small(const Plan& p, const dg_corr_desc* desc, const float* o
             const float* coords = o == 0 ? coords1 : coords2;
             const int64_t* idx = o >= 2 ? perms + (size_t)(o - 2) * p.B : nullptr;
             g.src[nj] = F32(p.nhwc_f[srcsel]); g.coords[nj] = coords; g.srcidx[nj] = idx; g.rows[nj] = F32(p.rows_f[o]);
-            g.K4[nj] = p.C4; g.h[nj] = p.h; g.w[nj] = p.w; ++nj;
+            g.K4[nj] = p.C4; g.Kout[nj] = (int)up(p.C, 128); g.as_bf16[nj] = 1; g.h[nj] = p.h; g.w[nj] = p.w; ++nj;
             g.src[nj] = F32(p.nhwc_c[srcsel]); g.coords[nj] = coords; g.srcidx[nj] = idx; g.rows[nj] = F32(p.rows_c[o]);
-            g.K4[nj] = p.D4; g.h[nj] = p.hc; g.w[nj] = p.wc; ++nj;
+            g.K4[nj] = p.D4; g.Kout[nj] = p.D4; g.as_bf16[nj] = 0; g.h[nj] = p.hc; g.w[nj] = p.wc; ++nj;
         }
         g.njobs = nj; g.B = p.B; g.S = p.S; g.Sh = p.Sh; g.P = p.P;
         DG_HIP(dg_launch_gather_rows(g, stream));

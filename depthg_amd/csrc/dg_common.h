@@ -321,6 +321,7 @@ struct DgPlaneArgs {        // k_plane_sample: sample() of all operands straight
     const int64_t* perms;    // [nops - 2][B] batch maps of the negatives (operand o >= 2 of image n reads image perms[o-2][n])
     int32_t nops, B, h, w, S, Sh, P;
     int32_t tap_consumers;   // (set by the launcher) consumers whose tap table is held in LDS together
+    int32_t feats_bf16;      // 1: rows[.][0] are bf16 (B, P, K4) - the fused small-grid kernel's input (K4 then a multiple of 8)
 };
 
 #ifdef __HIPCC__
@@ -423,7 +424,7 @@ __device__ __forceinline__ void depth_nz_image(const float* __restrict__ depth, 
 // means, exact clamp masks, the correlation and the streamed-side gradient: a block owns one (image, pair-set[, half of the
 // stationary tiles]) and reads the SAMPLED fp32 rows of its two operands once.
 struct DgSmallArgs {
-    const float* rowsF[DG_MAX_NEG + 2];   // [operand][B][P][C4] sampled feature rows (k_plane_sample / k_gather_rows), channels C..C4-1 zero
+    const void* rowsF[DG_MAX_NEG + 2];    // [operand][B][P][C4] sampled feature rows, bf16 (k_plane_sample / k_gather_rows), C4 a multiple of 128 (whole chunks), channels C..C4-1 zero
     const float* rowsC[DG_MAX_NEG + 2];   // [operand][B][P][D4] sampled code rows
     int32_t T, B, P, Ppad, C4, D, D4, KD; // T pair-sets; KD in {96, 128}: padded code width of the gradient tiles
     int32_t opS[DG_MAX_NEG + 2];          // streamed operand of pair-set t (t itself; with DG_SHARED_COORDS the negatives stream operand 0 ...
@@ -459,8 +460,9 @@ struct DgGatherRowsArgs {   // k_gather_rows: sample() of channel-last maps into
     const float* src[2 * (DG_MAX_NEG + 2)];      // NHWC fp32 [B][h*w][K4]
     const float* coords[2 * (DG_MAX_NEG + 2)];   // [B][S][Sh][2]
     const int64_t* srcidx[2 * (DG_MAX_NEG + 2)]; // batch map or null
-    float* rows[2 * (DG_MAX_NEG + 2)];           // [B][P][K4]
+    void* rows[2 * (DG_MAX_NEG + 2)];            // [B][P][Kout]: fp32, or bf16 when as_bf16 (Kout then a multiple of 8, padding zeroed)
     int32_t K4[2 * (DG_MAX_NEG + 2)], h[2 * (DG_MAX_NEG + 2)], w[2 * (DG_MAX_NEG + 2)];
+    int32_t Kout[2 * (DG_MAX_NEG + 2)], as_bf16[2 * (DG_MAX_NEG + 2)];
     int32_t njobs, B, S, Sh, P;
 };
 

@@ -445,7 +445,21 @@ __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArg
                 float* rows = a.rows[o][kind] + ((size_t)n * a.P + ps) * K4 + k0 + c;
                 const float* tt = taps + ((size_t)e * a.P + ps) * 8;
                 const int rstep = PSTEP * K4;
-                if (chan) {
+                if (chan && kind == 0 && a.feats_bf16) {
+                    // feature rows for the fused small-grid kernel (dg_small.hip): bf16 - half the bytes written here and read there;
+                    // that kernel multiplies bf16 rows anyway and takes its norms from the values it multiplies
+                    __bf16* rows16 = reinterpret_cast<__bf16*>(a.rows[o][0]) + ((size_t)n * a.P + ps) * K4 + k0 + c;
+#pragma unroll 2
+                    for (int p = ps; p < a.P; p += PSTEP, tt += PSTEP * 8, rows16 += rstep) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(tt);
+                        const v4i_pl ix = *reinterpret_cast<const v4i_pl*>(tt + 4);
+                        float acc = plane[ix[0]] * w[0];
+                        acc = fmaf(plane[ix[1]], w[1], acc);
+                        acc = fmaf(plane[ix[2]], w[2], acc);
+                        acc = fmaf(plane[ix[3]], w[3], acc);
+                        *rows16 = (__bf16)acc;
+                    }
+                } else if (chan) {
 #pragma unroll 2
                     for (int p = ps; p < a.P; p += PSTEP, tt += PSTEP * 8, rows += rstep) {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(tt);

@@ -4,8 +4,8 @@
 //
 // k_corr_small: ONE launch per call.  A block owns (image n, pair-set t[, half of the stationary tiles]) of helper()
 // (src/modules.py:1231-1254) or the depth term (:1256-1278) and reads the SAMPLED fp32 rows of its two operands once:
-//   phase 1  the feature rows stream through LDS in chunks of 128 channels (fp32 -> bf16 on the way, squared norms accumulated beside
-//            them), fd_raw = <a_p, b_q> of the un-normalised rows on the bf16 MFMA, one accumulator tile per (R tile, S tile) held in
+//   phase 1  the feature rows (bf16 from the sampler) stream through LDS in chunks of 128 channels, their squared norms accumulated
+//            beside them, fd_raw = <a_p, b_q> of the un-normalised rows on the bf16 MFMA, one accumulator tile per (R tile, S tile) held in
 //            registers for the whole block; norm() (:789-790) is applied to the finished tiles as 1/|a_p| * 1/|b_q|;
 //   phase 2  the code rows are normalised in fp32 and split into fp16 hi + lo parts; cd = hi.hi + hi.lo + lo.hi in one accumulator
 //            (fp32-grade: the clamp mask 1[lo <= cd <= hi] is exact, for zero_clamp AND stabalize); pointwise centering from the
@@ -54,9 +54,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     constexpr int NDF = NKD / 2;                   // 32-channel groups of a gradient tile row
     constexpr int KD = NKD * 16;
     constexpr int NJ = NRM + NS;                   // loader passes: 256 threads = one tile of 32 rows x 8 lanes
-    constexpr int NSUB = NS >= 4 ? 1 : 2;          // 64-channel pieces per chunk (the staging registers of a 128-channel chunk and the
-                                                   // code rows held beside them do not fit next to 4-5 accumulator tiles)
-    constexpr int KC = 64 * NSUB;
+    constexpr int KC = 128;                        // channels per feature chunk: a 256-byte LDS row, two 16-byte pieces per thread and row
     // phase 1: two buffers of [R tiles | S tiles][32 rows][128 bf16]; phase 2: code images + the -G image (256-byte rows all)
     constexpr uint32_t FBUF = NJ * 32 * 256, FS_OFF = NRM * 32 * 256;
     constexpr uint32_t XH = 0, YH = NRM * 32 * 256, YL = YH + NS * 32 * 256, GB = YL + NS * 32 * 256; // (XL = GB until the epilogues)
@@ -200,16 +198,18 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // (ONE call site per piece of straight-line code below - every copy of the loader or of the normalisation is a kilobyte of
     //  instructions, and the kernel has to stay inside the 64-KB instruction cache it shares with the neighbouring CU)
     const int C4 = a.C4, nch = depth_job ? 0 : ((abl & 4) ? 1 : (C4 + KC - 1) / KC);
-    const float* srcp[NJ];
+    const __bf16* srcp[NJ];
     bool ok[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const bool live = j < NR + NS;
         const int pos = live ? pass_pos(j) : 0;
         ok[j] = live && pos < P && !depth_job;
-        srcp[j] = a.rowsF[j < NR ? 0 : opS] + ((size_t)(j < NR ? n : nS) * P + (ok[j] ? pos : 0)) * C4;
+        srcp[j] = static_cast<const __bf16*>(a.rowsF[j < NR ? 0 : opS]) + ((size_t)(j < NR ? n : nS) * P + (ok[j] ? pos : 0)) * C4;
     }
-    f32x4 v[NJ][2 * NSUB];
+    // The feature rows arrive as bf16 (the sampler's output): a chunk goes to LDS as it is, and the squared norms are taken from the
+    // values that are multiplied.  Piece u of a thread = channels 64 u + 8 gran .. + 7 of its row.
+    v4i_s v[NJ][2];
     float ss[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) ss[j] = 0.f;
@@ -217,12 +217,11 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int u = 0; u < 2 * NSUB; ++u) {
-                const int k = ch * KC + (u >> 1) * 64 + gran * 8 + 4 * (u & 1);
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(srcp[j] + (k < C4 ? k : C4 - 4));     // (unconditional: see load_code)
-                const bool use = ok[j] && k < C4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[j][u][e] = use ? t4[e] : 0.f;
+            for (int u = 0; u < 2; ++u) {
+                // (no select at all: the rows are a whole number of chunks long - the sampler zero-fills the channels past C - and a
+                //  padded position reads position 0's finite values, which its zero inverse norm and the epilogue's validity mask
+                //  keep out of every result)
+                v[j][u] = *reinterpret_cast<const v4i_s*>(srcp[j] + ch * KC + 64 * u + gran * 8);
             }
     };
     auto stash = [&](int buf) {
@@ -230,24 +229,21 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         for (int j = 0; j < NJ; ++j) {
             if (j >= NR + NS) continue;
 #pragma unroll
-            for (int c = 0; c < NSUB; ++c) {
-                bf16x8 o;
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = v[j][2 * c + u][e];
-                        ss[j] = fmaf(x, x, ss[j]);
-                        o[4 * u + e] = (__bf16)x;
-                    }
-                *reinterpret_cast<bf16x8*>(sm + buf * FBUF + sm_c(pass_row(j), c * 8 + gran)) = o;
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __builtin_bit_cast(float, v[j][u][e] << 16), x1 = __builtin_bit_cast(float, v[j][u][e] & (int)0xffff0000);
+                    ss[j] = fmaf(x0, x0, ss[j]);
+                    ss[j] = fmaf(x1, x1, ss[j]);
+                }
+                *reinterpret_cast<v4i_s*>(sm + buf * FBUF + sm_c(pass_row(j), u * 8 + gran)) = v[j][u];
             }
         }
     };
     auto mfma_chunk = [&](int buf) {
         if (wid < NR) {
 #pragma unroll
-            for (int ks = 0; ks < 4 * NSUB; ++ks) {
+            for (int ks = 0; ks < 8; ++ks) {
                 const bf16x8 bf = *reinterpret_cast<const bf16x8*>(sm + buf * FBUF + sm_c(wid * 32 + r, 2 * ks + h));
 #pragma unroll
                 for (int st = 0; st < NS; ++st) {
@@ -725,20 +721,32 @@ __global__ __launch_bounds__(256) void k_gather_rows(const DgGatherRowsArgs a) {
     const float* t01 = base + (size_t)(pix + dx) * K4;
     const float* t10 = base + (size_t)(pix + dy) * K4;
     const float* t11 = base + (size_t)(pix + dy + dx) * K4;
-    float* out = a.rows[job] + ((size_t)n * a.P + p) * K4;
-    for (int k = 4 * l; k < K4; k += 128) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(t00 + k), a1 = *reinterpret_cast<const f32x4*>(t01 + k);
-        const f32x4 a2 = *reinterpret_cast<const f32x4*>(t10 + k), a3 = *reinterpret_cast<const f32x4*>(t11 + k);
-        f32x4 o;
+    const int Kout = a.Kout[job];
+    const bool as16 = a.as_bf16[job] != 0;
+    float* out = static_cast<float*>(a.rows[job]) + ((size_t)n * a.P + p) * Kout;
+    __bf16* out16 = static_cast<__bf16*>(a.rows[job]) + ((size_t)n * a.P + p) * Kout;
+    for (int k = 4 * l; k < Kout; k += 128) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (k < K4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(t00 + k), a1 = *reinterpret_cast<const f32x4*>(t01 + k);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(t10 + k), a3 = *reinterpret_cast<const f32x4*>(t11 + k);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float acc = a0[e] * w00;
-            acc = fmaf(a1[e], w01, acc);
-            acc = fmaf(a2[e], w10, acc);
-            acc = fmaf(a3[e], w11, acc);
-            o[e] = acc;
+            for (int e = 0; e < 4; ++e) {
+                float acc = a0[e] * w00;
+                acc = fmaf(a1[e], w01, acc);
+                acc = fmaf(a2[e], w10, acc);
+                acc = fmaf(a3[e], w11, acc);
+                o[e] = acc;
+            }
         }
-        *reinterpret_cast<f32x4*>(out + k) = o;
+        if (as16) {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (__bf16)o[e];
+            *reinterpret_cast<bf16x4*>(out16 + k) = ob;
+        } else {
+            *reinterpret_cast<f32x4*>(out + k) = o;
+        }
     }
 }
 
