@@ -232,9 +232,10 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float x0 = __builtin_bit_cast(float, v[j][u][e] << 16), x1 = __builtin_bit_cast(float, v[j][u][e] & (int)0xffff0000);
-                    ss[j] = fmaf(x0, x0, ss[j]);
-                    ss[j] = fmaf(x1, x1, ss[j]);
+                    // both squares of a dword in one instruction.  (As asm: through __builtin_amdgcn_fdot2_f32_bf16 on a bit-cast
+                    //  vector element hipcc 7.2 emitted all four instructions on element 0 - every norm wrong, 70 tests red)
+                    const int w = v[j][u][e];
+                    asm("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(ss[j]) : "v"(w));
                 }
                 *reinterpret_cast<v4i_s*>(sm + buf * FBUF + sm_c(pass_row(j), u * 8 + gran)) = v[j][u];
             }
