@@ -2,7 +2,7 @@
 """Copies the round's evidence from gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/
 and writes profiles/<tag>_SUMMARY.md.  usage: scripts/make_profile_summary.py r02"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, f"{tag}_kernel_stats.csv"), dst)
@@ -34,7 +34,9 @@ m = [v for k, v in pm.items() if kname in k][0]
 avg = [float(r["AverageNs"]) / 1e3 for r in rows if kname in r["Name"]][0]
 o += [f"\n(`{kname}` has extra calls: `bench.py`'s roofline leg re-launches it 23 times alone.  Sum of the other kernels' averages: {tail:.0f} µs.)\n",
       f"## Dominant kernel: `{kname}`\n",
-      f"* plain run: {b['roofline']['kernel_ms']*1e3:.1f} µs per launch (HIP events, 20 launches) -> {b['roofline']['achieved']} TFLOP/s = "
+      f"* plain run: {b['roofline']['kernel_ms']*1e3:.1f} µs per launch ({b['roofline'].get('kernel_ms_method', 'HIP events').split(';')[0]}; "
+      f"min {b['roofline'].get('kernel_ms_min')} / max {b['roofline'].get('kernel_ms_max')} ms; differential {b['roofline'].get('kernel_ms_diff')} ms, "
+      f"back-to-back re-launches {b['roofline'].get('kernel_ms_loop')} ms) -> {b['roofline']['achieved']} TFLOP/s = "
       f"{100*b['roofline']['frac']:.1f} % of the 2.5 PFLOP/s dense bf16 peak, on {b['roofline']['algorithmic_gflop_per_launch']} algorithmic GFLOP per launch.",
       f"* under rocprofv3: average {avg:.1f} µs (kernel-trace); the bench line inside the same run: {br['roofline']['kernel_ms']*1e3:.1f} µs "
       f"({br['roofline']['achieved']} TFLOP/s).",
@@ -61,6 +63,23 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
         name += " (`--steps 20 --warmup 5`, the driver's command line)"
     o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
              f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
+# per-kernel tables of the small-grid configurations (kernel trace of `bench.py --config <c> --steps 50`)
+for c in ("C2", "C3", "C4shard"):
+    f = os.path.join(src, f"{tag}_kernel_stats_{c}.csv")
+    if not os.path.exists(f):
+        continue
+    shutil.copy(f, dst)
+    o += [f"\n## Kernels of one {c} step (`{tag}_kernel_stats_{c}.csv`)\n", "| kernel | calls | avg µs |\n|---|---|---|"]
+    tot = 0.0
+    for r in csv.DictReader(open(f)):
+        if float(r["Percentage"]) > 0.3:
+            o.append(f"| `{r['Name'].split('(')[0][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} |")
+            if "k_corr_small" not in r["Name"] or True:
+                tot += float(r["AverageNs"]) / 1e3
+    o.append(f"\n(sum of the averages: {tot:.0f} µs)")
+for extra in (f"{tag}_kernel_stats_headline.csv", f"{tag}_gputests.txt"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), dst)
 if os.path.exists(os.path.join(src, f"{tag}_parity.md")):
     shutil.copy(os.path.join(src, f"{tag}_parity.md"), dst)
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
