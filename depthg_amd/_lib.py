@@ -102,7 +102,7 @@ def load():
     lib.dg_rand_keep_state.restype = ctypes.c_int
     lib.dg_rand_keep_state.argtypes = [vp, ctypes.c_int64, ctypes.c_float, vp, vp]
     lib.dg_fps_coords_pair.restype = ctypes.c_int
-    lib.dg_fps_coords_pair.argtypes = [vp, vp] + [ctypes.c_int32] * 6 + [vp, vp, vp]
+    lib.dg_fps_coords_pair.argtypes = [vp, vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
     lib.dg_super_perms.restype = ctypes.c_int
     lib.dg_super_perms.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, vp, vp]
     lib.dg_salience_coords.restype = ctypes.c_int

@@ -1133,12 +1133,14 @@ extern "C" int dg_lhp_map_backward(int32_t mode, const float* grad_out, const fl
 }
 
 extern "C" size_t dg_fps_workspace_bytes(int32_t B, int32_t h, int32_t w) {
-    (void)B; (void)h; (void)w;
-    return 256;   // the sampler keeps its state in LDS; a token workspace keeps the call shape uniform
+    // the pooled depth maps of B images (adaptive_avg_pool2d to the feature map, written by a launch over the whole chip in front of
+    // the sampler); the sampler itself keeps its state in LDS
+    if (B < 1 || h < 1 || w < 1) return 256;
+    return (size_t)B * h * w * 4 + 256;
 }
 
 static int fps_entry(const float* depth, const float* depth_b, int32_t Ba, int32_t B, int32_t depth_h, int32_t depth_w, int32_t h,
-                     int32_t w, int32_t S, float* out_coords, int32_t* out_inds, dg_stream_t stream_) {
+                     int32_t w, int32_t S, float* out_coords, int32_t* out_inds, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     if (!depth || !out_coords || (Ba < B && !depth_b)) return fail(DG_ERR_INVALID, "null pointer");
     if (B < 1 || Ba < 1 || h < 1 || w < 1 || S < 1 || depth_h < h || depth_w < w) return fail(DG_ERR_INVALID, "bad FPS dimensions");
     if (S * S > h * w) return fail(DG_ERR_INVALID, "cannot sample %d points from a %dx%d map", S * S, h, w);
@@ -1147,20 +1149,22 @@ static int fps_entry(const float* depth, const float* depth_b, int32_t Ba, int32
     const uint32_t bits = 0x404f54cbu;
     float factor;
     memcpy(&factor, &bits, 4);
-    DG_HIP(dg_launch_fps(depth, depth_b, Ba, B, depth_h, depth_w, h, w, S, factor, out_coords, out_inds, static_cast<hipStream_t>(stream_)));
+    // (a workspace that is missing or too small is not an error: the sampler then pools inside its own blocks, one image per CU)
+    float* pooled = (workspace && workspace_bytes >= (size_t)B * h * w * 4) ? static_cast<float*>(workspace) : nullptr;
+    DG_HIP(dg_launch_fps(depth, depth_b, Ba, B, depth_h, depth_w, h, w, S, factor, out_coords, out_inds, pooled, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 
 extern "C" int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_w, int32_t h, int32_t w,
                              int32_t S, float* out_coords, int32_t* out_inds, void* workspace, size_t workspace_bytes,
                              dg_stream_t stream_) {
-    (void)workspace; (void)workspace_bytes;
-    return fps_entry(depth, nullptr, B, B, depth_h, depth_w, h, w, S, out_coords, out_inds, stream_);
+    return fps_entry(depth, nullptr, B, B, depth_h, depth_w, h, w, S, out_coords, out_inds, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int dg_fps_coords_pair(const float* depth, const float* depth_pos, int32_t B, int32_t depth_h, int32_t depth_w,
-                                  int32_t h, int32_t w, int32_t S, float* out_coords, int32_t* out_inds, dg_stream_t stream_) {
-    return fps_entry(depth, depth_pos, B, 2 * B, depth_h, depth_w, h, w, S, out_coords, out_inds, stream_);
+                                  int32_t h, int32_t w, int32_t S, float* out_coords, int32_t* out_inds, void* workspace,
+                                  size_t workspace_bytes, dg_stream_t stream_) {
+    return fps_entry(depth, depth_pos, B, 2 * B, depth_h, depth_w, h, w, S, out_coords, out_inds, workspace, workspace_bytes, stream_);
 }
 
 // ---- the segmentation head and the probes (dg_head.hip, dg_probe.hip)

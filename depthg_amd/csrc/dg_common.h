@@ -744,7 +744,7 @@ hipError_t dg_launch_lhp_map_bwd(int mode, const float* g, const float* map, con
 hipError_t dg_launch_rand_coords_state(unsigned long long* state, float* out, int n, hipStream_t s, float keep_p = -1.f);
 // (B images in all; the first Ba from `depth`, the rest from `depth_b`)
 hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B, int H, int W, int h, int w, int S, float factor,
-                         float* out_coords, int32_t* out_inds, hipStream_t s);
+                         float* out_coords, int32_t* out_inds, float* pooled_ws, hipStream_t s);
 
 // ---- the segmentation head (dg_head.hip; DinoFeaturizer's cluster1 / cluster2, src/modules.py:75-88, 122-137)
 struct DgHeadFwdArgs {

@@ -851,7 +851,7 @@ template <int NPT>       // points per thread (even): h*w <= NPT * FPS_THREADS
 __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restrict__ depth, const float* __restrict__ depth_b, int Ba,
                                                             int H, int W, int h, int w,
                                                             int S, float factor, int stage_floats, float* __restrict__ out_coords,
-                                                            int32_t* __restrict__ out_inds) {
+                                                            int32_t* __restrict__ out_inds, const float* __restrict__ pooled) {
     constexpr int NP2 = NPT / 2;
     static_assert(NPT % 2 == 0, "points are updated in pairs");
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -874,7 +874,27 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
     fps2 qx[NP2], qy[NP2], qz[NP2], qd[NP2];
 #pragma unroll
     for (int k = 0; k < NPT; ++k) { qx[k >> 1][k & 1] = 0.f; qy[k >> 1][k & 1] = 0.f; qz[k >> 1][k & 1] = 0.f; qd[k >> 1][k & 1] = -1.f; }
-    {
+    if (pooled) {
+        // the pooled map comes from k_pool_depth (a launch over the whole chip in front of this one: one block per image streaming
+        // its 200-KB depth map through one CU was 15 of this launch's 62 us): depth2points only
+        const float* pd = pooled + (size_t)n * HW;
+        float dvs[NPT];
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) { const int idx = tid + FPS_THREADS * k; dvs[k] = idx < HW ? pd[idx] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int idx = tid + FPS_THREADS * k;
+            const int i = idx / w, j = idx - i * w;
+            if (idx < HW) {
+                const float dv = dvs[k];
+                const float fd = __fmul_rn(factor, dv);
+                qy[k >> 1][k & 1] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)i, (float)h / 2.0f)), (float)h);
+                qx[k >> 1][k & 1] = __fdiv_rn(__fmul_rn(fd, __fsub_rn((float)j, (float)w / 2.0f)), (float)w);
+                qz[k >> 1][k & 1] = __fmul_rn(-dv, 5.0f);
+                qd[k >> 1][k & 1] = __builtin_inff();
+            }
+        }
+    } else {
         float* stage = reinterpret_cast<float*>(selbits + nwords + ((4 - ((nsel + nwords) & 3)) & 3));     // 16-byte aligned
         const int max_rows = stage_floats / W;                      // image rows that fit the staging buffer
         const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(d) & 15) == 0);
@@ -1003,8 +1023,37 @@ __global__ __launch_bounds__(FPS_THREADS) void k_fps_coords(const float* __restr
     }
 }
 
+// adaptive_avg_pool2d of the depth maps to the feature map (src/modules.py:1003), one block per (pooled row, image): the image rows
+// of the row's windows go through LDS (coalesced), one thread per output pixel sums its window in the operator's order
+// (fps_pool_lds: the same function the sampler's in-kernel pooling uses - the pooled values have the same bits).
+__global__ __launch_bounds__(256) void k_pool_depth(const float* __restrict__ depth, const float* __restrict__ depth_b, int Ba, int H, int W,
+                                                    int h, int w, float* __restrict__ pooled) {
+    extern __shared__ __attribute__((aligned(16))) float st[];
+    const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float* d = n < Ba ? depth + (size_t)n * H * W : depth_b + (size_t)(n - Ba) * H * W;
+    const int ys = (i * H) / h, ye = ((i + 1) * H + h - 1) / h, nfl = (ye - ys) * W;
+    const float* src = d + (size_t)ys * W;
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+        for (int q = tid; q < (nfl >> 2); q += 256) reinterpret_cast<f32x4*>(st)[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src) + q);
+    } else {
+        for (int q = tid; q < nfl; q += 256) st[q] = src[q];
+    }
+    __syncthreads();
+    for (int j = tid; j < w; j += 256) pooled[((size_t)n * h + i) * w + j] = fps_pool_lds(st, ys, H, W, h, w, i, j);
+}
+
 hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B, int H, int W, int h, int w, int S, float factor,
-                         float* out_coords, int32_t* out_inds, hipStream_t s) {
+                         float* out_coords, int32_t* out_inds, float* pooled_ws, hipStream_t s) {
+    if (pooled_ws) {
+        const int win_rows = (H + h - 1) / h + 1;
+        if ((size_t)win_rows * W * 4 <= 64 * 1024) {
+            hipLaunchKernelGGL(k_pool_depth, dim3(h, B), dim3(256), win_rows * W * 4, s, depth, depth_b, Ba, H, W, h, w, pooled_ws);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        } else {
+            pooled_ws = nullptr;
+        }
+    }
     // LDS: selection order, selected-set mask, then the staging buffer for bands of the depth map: at least the image rows
     // of one pooled row, at most 128 KB
     const int head = (S * S + (h * w + 31) / 32 + 3) / 4 * 16;
@@ -1019,7 +1068,8 @@ hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, depth_b, Ba, H, W, h, w, S, factor, stage_floats, out_coords, out_inds);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(FPS_THREADS), smem, s, depth, depth_b, Ba, H, W, h, w, S, factor, stage_floats, out_coords, out_inds,
+                           (const float*)pooled_ws);
         return hipGetLastError();
     };
     if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);

@@ -228,7 +228,8 @@ def fps_coords_pair(depth, depth_pos, feat_hw, n_samples):
     h, w = int(feat_hw[0]), int(feat_hw[1])
     S = int(n_samples)
     coords = _empty((2 * B, S, S, 2), torch.float32, depth.device)
-    rc = lib.dg_fps_coords_pair(_ptr(depth), _ptr(depth_pos), B, H, W, h, w, S, _ptr(coords), None, _stream(depth.device))
+    ws = _empty((lib.dg_fps_workspace_bytes(2 * B, h, w)), torch.uint8, depth.device)      # the pooled depth maps of both calls
+    rc = lib.dg_fps_coords_pair(_ptr(depth), _ptr(depth_pos), B, H, W, h, w, S, _ptr(coords), None, _ptr(ws), ws.numel(), _stream(depth.device))
     _lib.check(rc, "dg_fps_coords_pair")
     return coords
 

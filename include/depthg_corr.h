@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 114   /* 114: dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 114   /* 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -233,7 +233,8 @@ int dg_fps_coords(const float* depth, int32_t B, int32_t depth_h, int32_t depth_
  * depth, depth_pos : fp32 (B,1,depth_h,depth_w) each;  out_coords (2B,S,S,2): [0,B) from depth, [B,2B) from depth_pos;
  * out_inds int32 (2B,S*S) or NULL.  (version 110) */
 int dg_fps_coords_pair(const float* depth, const float* depth_pos, int32_t B, int32_t depth_h, int32_t depth_w,
-                       int32_t h, int32_t w, int32_t S, float* out_coords, int32_t* out_inds, dg_stream_t stream);
+                       int32_t h, int32_t w, int32_t S, float* out_coords, int32_t* out_inds,
+                       void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * Salience-guided sample locations (replaces sample_nonzero_locations, src/modules.py:1191-1204, the cfg.use_salience
