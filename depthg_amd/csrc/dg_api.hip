@@ -47,6 +47,7 @@ struct Plan {
     size_t ticket;                          // the depth blocks' ticket of the k_gs launch
     size_t maskbits[DG_MAX_NEG + 2];        // exact clamp masks of the pair-sets (k_cd_mask), xmask: in use on a small sample grid,
     bool xmask, xmask_dense;                // xmask_dense: on the dense identity grid (DG_EXACT_MASKS)
+    bool fold;                              // the intra pair-set's streamed-side gradient is formed in the fused kernel (dg_corr2.hip FOLD)
     size_t clo[2];                          // ... with pointwise: the parts of the normalised code the fp16 C parts drop (k_cd_mask3)
     size_t gr_list, gr_count, gr_rank;      // consumer lists of the grouped ragged row blocks (dg_corr2.hip)
     // the fused small-grid path (dg_small.hip): sampled rows -> ONE launch
@@ -57,6 +58,7 @@ struct Plan {
 };
 
 // developer A/B: DG_SMALL_PATH=0 keeps the multi-launch small-grid path of rounds 2-4 (needs C <= 768)
+#define FOLD_STASH_OFF (5 * 1024)        // k_corr2<24, 6, 5>: code k-step 5 of the C part (channels 80 .. 95: padding for D <= 80)
 static bool small_path_enabled() {
     static const bool on = [] { const char* e = getenv("DG_SMALL_PATH"); return !(e && e[0] == '0'); }();
     return on;
@@ -135,7 +137,7 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     for (int i = 0; i < 2; ++i) p.comb[i] = take(B * p.Ppad * p.KD * 4);
     p.scratch_out = take(DG_OUT_COUNT * 4);
     p.taps = take(2 * B * dg_taps_record_bytes(p.hc * p.wc, p.P));     // the adjoint of sample() scatters into the CODE maps
-    for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;
+    for (int t = 0; t < p.T; ++t) p.gbuf[t] = p.grad ? take(B * (size_t)(p.Ppad / 32) * (p.Ppad / 32) * 2048) : 0;     // (gbuf[0]: 4 KiB would do with p.fold, which is decided below)
     p.ticket = take(256);
     // exact clamp masks: gradient passes of the zero_clamp recipe on small sample grids (fp32 sampled rows exist, <= 8 tiles, the
     // one-wave-per-SIMD form of k_corr_main)
@@ -151,6 +153,13 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         return fail(DG_ERR_UNSUPPORTED, "DG_EXACT_MASKS: exact clamp masks exist on small sample grids (always on there) and on the dense "
                                         "identity grid with C <= 384 (padded to 384), D <= 80, P >= 160, B <= 64, zero_clamp without stabalize");
     for (int t = 0; t < p.T; ++t) p.maskbits[t] = take((p.xmask || p.xmask_dense) ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
+    // FOLD: gradient passes of the pointwise recipe that k_corr2 runs (the conditions of dg_corr2_supported, which forward_impl
+    // re-checks) without exact mask words; DG_FOLD_INTRA=0 keeps the k_gs job (developer A/B)
+    {
+        static const bool fold_on = [] { const char* e = getenv("DG_FOLD_INTRA"); return !(e && e[0] == '0'); }();
+        p.fold = fold_on && p.grad && p.pointwise && !p.small && p.KF == 384 && p.KD == 96 && p.D <= 80 && (d->flags & DG_ZERO_CLAMP) &&
+                 !(d->flags & DG_STABALIZE) && p.Ppad >= 160 && p.B <= 64 && !p.xmask && !p.xmask_dense;
+    }
     for (int i = 0; i < 2; ++i) p.clo[i] = take((p.xmask_dense && p.pointwise) ? B * (size_t)(p.Ppad / 32) * p.KD * 64 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
     p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
@@ -306,7 +315,8 @@ struct SideRegion {
 // depth term) instead of reading 1/7 of the G tiles again.  With `pointwise` -G is NOT symmetric: the reference centres fd by its
 // ROW means only (fd -= fd.mean([3, 4]), src/modules.py:1238-1239), -G[p][q] - -G[q][p] = mask (rowmean_q - rowmean_p) - invisible
 // on i.i.d. features, 1e-2 of the gradient on the FPS recipes (the test with exact masks caught it).
-static bool intra_is_symmetric(const Plan& p) { return !p.pointwise; }
+// (p.fold: with `pointwise` k_corr2 forms G + G^T in its own accumulator, dg_corr2.hip FOLD - the same consequence for the launches)
+static bool intra_is_symmetric(const Plan& p) { return !p.pointwise || p.fold; }
 static void build_gs_jobs(const Plan& p, char* ws, const int64_t* perms, DgGsArgs& g) {
     memset(&g, 0, sizeof(g));
     const int t0 = intra_is_symmetric(p) ? 1 : 0;
@@ -338,6 +348,7 @@ static int build_corr_jobs(const Plan& p, const dg_corr_desc* desc, char* ws, co
         j.part = F32(p.part[t]);
         j.dR = p.grad ? F32(p.dRA[t]) : nullptr;
         j.Gout = p.grad ? reinterpret_cast<uint16_t*>(ws + p.gbuf[t]) : nullptr;
+        j.fold = (p.fold && t == 0) ? 1 : 0;
         j.maskbits = (p.xmask || p.xmask_dense) ? reinterpret_cast<const uint32_t*>(ws + p.maskbits[t]) : nullptr;
         j.slot_loss = t < 2 ? t : DG_OUT_LOSS_NEG;
         j.slot_cd = t < 2 ? DG_OUT_CD_INTRA + t : DG_OUT_CD_NEG;
@@ -401,6 +412,7 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
     if (p.grad && njA > 0) {
         const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // the pair-set jobs, one launch
         if (e != hipErrorNotSupported) return e;
+        if (p.fold) return hipErrorInvalidValue;          // (the plan folded the intra pair-set for a kernel that does not run)
     }
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);
 }
@@ -731,6 +743,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             r.ncs = 2;
             for (int o = 0; o < 2; ++o) { r.cs_part[o] = F32(p.ccolpart[o]); r.cs_out[o] = F32(p.csum[o]); }
         }
+        if (p.fold) { r.stash = ws + p.op[0]; r.stash_off = FOLD_STASH_OFF; }
         DG_HIP(dg_launch_rowmean(r, stream));
     }
 
@@ -930,6 +943,11 @@ static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64
         DG_HIP(dg_launch_corr_small(m, static_cast<hipStream_t>(stream_)));
         return DG_OK;
     }
+    // (a gradient pass with k_corr2's FOLD left the intra row means in the padding of the operand-1 blobs' C part: k_corr_main's
+    //  un-reduced forms multiply all of it)
+    if (p.pointwise && p.KF == 384 && p.KD == 96 && p.D <= 80)
+        DG_HIP(dg_launch_clear_stash(ws + p.op[0], p.B, p.Ppad / 32, (size_t)p.blob, (int)DgBlob(p.KF, p.KD).off_c + FOLD_STASH_OFF,
+                                     static_cast<hipStream_t>(stream_)));
     DgCorrArgs a;
     corr_args_base(p, desc, ws, a);
     // stationary = operand 2 (on MFMA lanes) -> the stores of one accumulator register are contiguous along q

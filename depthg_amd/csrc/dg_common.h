@@ -210,6 +210,7 @@ struct DgJob {
     int32_t slot_loss;       // output scalar the loss sum of this job adds to (DG_OUT_*; -1 none)   } copied into
     int32_t slot_cd;         // ... the cd sum                                                        } DgFinishArgs
     float fin_scale;         // 1/numel of the tensor the job contributes to                         } by the host
+    int32_t fold;            // k_corr2 FOLD: the intra pair-set's streamed-side gradient is formed in the fused kernel (no G tiles read)
 };
 
 #define DG_MAX_JOBS 12      // pair-sets (<= DG_MAX_NEG + 2) + the depth job
@@ -571,6 +572,8 @@ struct DgRowmeanArgs {
     DgRowmeanJob jobs[DG_MAX_NEG + 2];
     int32_t njobs, B, P, Ppad, KF, KD;
     const float* abar;           // [B][KF] mean normalised feats of operand 1
+    char* stash;                 // non-null: k_corr2 FOLD - job 0's row means r also go, as -r / 2 in an fp16 pair (hi, 2048 lo), into k = 0, 1
+    int32_t stash_off;           //   of position p's granule of the operand-1 blobs' C part, k-step stash_off / 1024 (all channel padding)
     const float* cs_part[2];     // ncs > 0: block x == Ppad/32 + 1 of an image also reduces the code column sums of the dense
     float* cs_out[2];            //          operands (csum[o][n][d] = sum_tiles ccolpart[o][n][tile][d]), see DgDenseArgs.code_split
     int32_t ncs;
@@ -717,6 +720,7 @@ hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
+hipError_t dg_launch_clear_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
 hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long long* state, int count, int B, int64_t* out, hipStream_t s);
 hipError_t dg_launch_salience_coords(const float* sal, int B, int H, int W, int n, const float* u_sel, const float* u_fb,

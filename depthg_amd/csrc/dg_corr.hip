@@ -750,6 +750,10 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t
     const char* Rb = img + (size_t)(act ? rtile : 0) * BL::BYTES + BL::OFF_C;
 #pragma unroll
     for (int k = 0; k < NKD; ++k) Rc[k] = *reinterpret_cast<const v4i*>(Rb + ((2 * k + h) * 32 + r) * 16);
+    // (k-steps that are all channel padding: zero HERE - with k_corr2's FOLD the operand-1 blobs carry the intra row means in
+    //  the first such k-step of the C part, dg_corr2.hip; a zero stationary fragment makes the product blind to it)
+#pragma unroll
+    for (int k = 0; k < NKD; ++k) if (16 * k >= a.D) Rc[k] = v4i{0, 0, 0, 0};
     const float nz_lane = act ? nz[rtile * 32 + r] : 0.f;
     const float c0 = -a.dep_shift;
     f32x16 acc[NDF];

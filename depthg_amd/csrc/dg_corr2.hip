@@ -195,11 +195,20 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 }
 
 // NKF feature k-steps (C = 16 NKF), KD = 16 NKD padded code width, NKC code k-steps that are not all padding
-template <int NKF, int NKD, int NKC, bool XM = false, bool DYN = false>      // DYN: the dynamic walk (many items per workgroup), below
+// FOLD (round 5): the intra pair-set's streamed-side gradient is formed HERE, with no G tiles and no k_gs job.  Intra streams the
+// stationary operand's own image; fd, cd and the clamp mask are symmetric in (p, q), only the centering by ROW means is not:
+// -G[p][q] = m (fd + c0 - r_p).  d/dc of both sides is (G + G^T) y with (G + G^T)[p][q] = 2 m (fd + c0 - r_p / 2 - r_q / 2) =: 2 m Z -
+// ONE product with the tile the wave holds anyway, if the accumulator holds Z instead of fd + c0 - r_p.  The lane's half (r_p / 2)
+// goes into the chain's start value; the streamed position's half rides in the chain as ONE more MFMA: the S tile's unused code
+// k-step NKC (channels 16 NKC .. of the zero padding, KD > 16 NKC) carries -r_q / 2 as an fp16 pair (hi, 2048 lo) in k = 0, 1
+// (k_rowmean writes it), the B fragment is the constant (1, 2^-11, 0 ...).  The loss sums come out of the gradient tiles
+// (sum <x_p, dR_p>) and stay right: sum m cd (r_q - r_p) = 0 by symmetry.  The host doubles the tile's weight (dg_api.hip).
+template <int NKF, int NKD, int NKC, bool XM = false, bool DYN = false, bool FOLD = false>      // DYN: the dynamic walk (many items per workgroup), below
 __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     using BL = BlobT<NKF, NKD>;
     constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
-    constexpr int BUF = BL::BYTES, NS = NKF + NKC, PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+    constexpr int BUF = BL::BYTES, NS = NKF + NKC + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+    static_assert(!FOLD || (NKC < NKD && !XM), "FOLD needs a spare code k-step in the blob; not combined with the exact-mask form");
     constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
     static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
@@ -380,6 +389,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #pragma unroll
     for (int f = 0; f < RF; ++f) { dRp[f] = args.jobs[fj[f]].dR; partp[f] = args.jobs[fj[f]].part; }
     (void)n_first;
+    bool fo[RF];                                          // FOLD: this fragment's pair-set is folded (wave-uniform)
+#pragma unroll
+    for (int f = 0; f < RF; ++f) fo[f] = FOLD && args.jobs[fj[f]].fold != 0;
 
     // ---- small per-block inputs first (their latency runs under the 270 KB that follow): the B per-image sums of the row means
     //      (m0), this lane's row means, the streamed operand's code column sums.  asm loads: hipcc would wait for a load it knows
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
             const DgJob& jf = args.jobs[fj[f]];
             float c0 = -jf.shift;
             if (jf.rvec) c0 += wave_sum_dpp(lane < args.B ? rimg_v[f] : 0.f) * args.inv_BP;      // (B <= 64 images per call of this form)
-            const float cl = jf.rvec ? c0 - rvec_v[f] : c0;
+            const float cl = jf.rvec ? c0 - (fo[f] ? 0.5f * rvec_v[f] : rvec_v[f]) : c0;
             const float2 two = make_float2(cl, cl);
             c0pair[f] = __builtin_bit_cast(double, two);
             asm volatile("" : "+v"(c0pair[f]));
@@ -544,19 +556,29 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     v4i_t* gbase[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f)
-        gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + ((size_t)fn[f] * ntiles * ntiles + (act[f] ? ft[f] : 0)) * 128 + lane;
+        gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + (fo[f] ? (size_t)0 : ((size_t)fn[f] * ntiles * ntiles + (act[f] ? ft[f] : 0)) * 128) + lane;
     const size_t gstep = (size_t)ntiles * 128;
+    // (a folded fragment has no reader for its G tiles; its stores stay in the instruction stream - the counted vmcnt waits of the
+    //  tile barrier count them - but all go to the first 2 KiB of the pair-set's buffer with the default cache policy: L2 traffic)
+    size_t gstepb[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f) gstepb[f] = fo[f] ? (size_t)0 : gstep * sizeof(v4i_t);
     // running store pointers (the tile index times the tile stride as 64-bit scalar multiplies in front of every store cost three
     // s_mul and two adds each): gp[0] points at S tile t, gp[1] at S tile t - 1 (fragment 1 runs one phase behind)
-    uintptr_t gp[RF] = {reinterpret_cast<uintptr_t>(gbase[0]), reinterpret_cast<uintptr_t>(gbase[1]) - gstep * sizeof(v4i_t)};
+    uintptr_t gp[RF] = {reinterpret_cast<uintptr_t>(gbase[0]), reinterpret_cast<uintptr_t>(gbase[1]) - gstepb[1]};
     auto g_store = [&](const int f, const int sp, int t) {
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
         (void)t;
         v4i_t* g = reinterpret_cast<v4i_t*>(gp[f]) + 64 * sp;
         // (non-temporal: with the default cache policy on these stores / k_gs's loads the step is 1-6 % slower, profiles/r03_SUMMARY.md)
-        asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
+        if (FOLD && __builtin_expect(fo[f], 0)) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(g), "v"(ga[f][sp]) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
     };
+    // FOLD: the B fragment of the extra chain step - k = 0: 1, k = 1: 2^-11 (lanes of half 0 hold k 0..7), zero for a fragment that is
+    // not folded.  It borrows ga[f][0]: free between the gradient product that read it and the next epilogue of the fragment.
+    const int fold_w = h == 0 ? 0x10003C00 : 0;
+
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
     uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + C2_RED_BYTES);
@@ -597,8 +619,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     //         -- counted vmcnt + the one workgroup barrier of the tile --
     //     C   dR_0 += G_0^T ScP (t), 6 MFMAs     gaps: first fragments of tile t+1, fd initialisation of fragment 0
     // (tile 0: the "previous" fragment-1 state is all-zero G and zero B fragments; only its G store is skipped)
+    // (FOLD: every chain of the launch runs the extra step - with a zero B fragment where the fragment is not folded.  Two forms of
+    //  the tile loop, chosen per block, were tried: hipcc then parks values in accumulator registers at the join - the audit of
+    //  tests/test_host_cpu.py fails - for 4 us of MFMA time.)
     auto run = [&](auto A0, auto A1) {
-        constexpr bool ACT0 = A0.value, ACT1 = A1.value;
+        constexpr bool ACT0 = A0.value, ACT1 = A1.value, FRUN = FOLD;
         constexpr int TOT = ACT1 ? 2 * NS : NS;
         constexpr int BP0 = ACT1 ? 2 * NS - 9 : TOT;            // first MFMA index whose gap carries a gradient-B read (phase B gaps NS-9 ..)
         constexpr int MM = XM ? (ACT0 ? 1 : 0) + (ACT1 ? 1 : 0) : 0;       // mask-word pieces per tile
@@ -621,6 +646,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 if constexpr (st == 0) mfma_fd8_from<f * NKF>(Yf[f], ra[idx % PF], c0splat[f]);
                 else if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
                 else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
+                else if constexpr (FRUN && st == NS - 1) mfma_h8(Yf[f], ra[idx % PF], ga[f][0]);      // Z: the streamed position's half of the centering
                 else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
                 if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
             };
@@ -640,6 +666,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                     constexpr int k = (st - 10) / 2;
                     if constexpr (((st - 10) & 1) == 0) dma_setup<k * 4096>(dst2, dma_voff, dtmp); else dma_go(dtmp, sb2);
                 }
+                if constexpr (FRUN && ACT0 && st == NS - 3) ga[0][0] = v4i_t{fo[0] ? fold_w : 0, 0, 0, 0};
                 if constexpr (ACT1 && st == NS - 1) { if (t > 0) g_store(1, 0, t - 1); }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -670,6 +697,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                     if constexpr (st >= 2 && st < 10) epi_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, st - 2>{});
                     if constexpr (st == 11) g_store(0, 0, t);
                     if constexpr (st == 13) g_store(0, 1, t);
+                    if constexpr (FRUN && ACT1 && st == 16) ga[1][0] = v4i_t{fo[1] ? fold_w : 0, 0, 0, 0};
                     if constexpr (st >= NS - 9 && st < NS - 9 + 2 * NDF) {      // B fragments of the gradient products (shared by both fragments)
                         constexpr int q = st - (NS - 9), sp = q / NDF, d = q % NDF;
                         lds_rd<d * 512 + sp * (2 * KD * 16)>(bP[q], vp);
@@ -721,7 +749,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
             STAMP(t, 5);
             bcur = bnext;
 #pragma unroll
-            for (int f = 0; f < RF; ++f) { gp[f] += gstep * sizeof(v4i_t); asm volatile("" : "+v"(gp[f])); }
+            for (int f = 0; f < RF; ++f) { gp[f] += gstepb[f]; asm volatile("" : "+v"(gp[f])); }
         }
         // ---- tail: fragment 1 of the last tile (epilogue, G store, gradient product)
         if constexpr (ACT1) {
@@ -942,7 +970,10 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
     const int smem = 4 * BL::BYTES + C2_RED_BYTES;
     const int g0 = dg_corr2_launch_grid(args);
     const bool dyn0 = dg_corr2_dynamic_walk(args, g0);
-    auto kern = dyn0 ? k_corr2<24, 6, 5, false, true> : k_corr2<24, 6, 5, false, false>;
+    bool fold = false;
+    for (int j = 0; j < args.njobs; ++j) fold = fold || args.jobs[j].fold != 0;
+    auto kern = fold ? (dyn0 ? k_corr2<24, 6, 5, false, true, true> : k_corr2<24, 6, 5, false, false, true>)
+                     : (dyn0 ? k_corr2<24, 6, 5, false, true> : k_corr2<24, 6, 5, false, false>);
     hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
     if (e != hipSuccess) return e;
 #if defined(DG_DEVTOOLS) && defined(C2_STAMPS)

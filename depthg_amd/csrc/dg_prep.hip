@@ -1119,7 +1119,23 @@ __global__ __launch_bounds__(64 * ROWMEAN_WAVES) void k_rowmean(const DgRowmeanA
         const float v = acc[i] + __shfl(acc[i], (lane + 16) & 63, 64);
         const int p = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (has && !lo) J.rvec[(size_t)n * a.Ppad + p] = p < a.P ? v : 0.f;
+        if (a.stash && has && !lo && jb == 0) {
+            // k_corr2 FOLD (dg_corr2.hip): -r_p / 2 as hi + lo' / 2048 (hi = fp16(x), lo' = fp16(2048 (x - hi)): 22 bits, no subnormal
+            // operand) in k = 0, 1 of position p's granule of the C part's first all-padding k-step; the other k stay zero
+            const float x = p < a.P ? -0.5f * v : 0.f;
+            const _Float16 xh = (_Float16)x, xl = (_Float16)((x - (float)xh) * 2048.f);
+            const uint32_t word = (uint32_t)__builtin_bit_cast(unsigned short, xh) | ((uint32_t)__builtin_bit_cast(unsigned short, xl) << 16);
+            *reinterpret_cast<uint32_t*>(a.stash + ((size_t)n * nt + tile) * L.bytes + L.off_c + a.stash_off + (p & 31) * 16) = word;
+        }
     }
+}
+// the words above back to zero (dg_corr_materialize: k_corr_main's un-reduced forms multiply every code k-step of the blob)
+__global__ __launch_bounds__(64) void k_clear_stash(char* blobs, size_t blob_bytes, int off) {
+    if (threadIdx.x < 32) *reinterpret_cast<uint32_t*>(blobs + (size_t)blockIdx.x * blob_bytes + off + threadIdx.x * 16) = 0u;
+}
+hipError_t dg_launch_clear_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, hipStream_t s) {
+    hipLaunchKernelGGL(k_clear_stash, dim3(B * ntiles), dim3(64), 0, s, blobs, blob_bytes, off);
+    return hipGetLastError();
 }
 
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s) {
