@@ -525,3 +525,45 @@ def test_fused_kernel_walks_give_the_same_bits():
         line = [l for l in r.stdout.splitlines() if l.startswith("WALK")][-1]
         seen[walk] = line
     assert seen["static"] == seen["dynamic"], seen
+
+
+_FOLD_CHILD = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+import bench
+from depthg_amd import ContrastiveCorrelationLoss
+dev = torch.device("cuda:0")
+conf = bench.CONFIGS["headline"]; H = dict(conf["H"]); H["B"] = 8
+cfg = bench.make_cfg(conf)
+f, fp, c, cp, d, dp = bench.synth_inputs(H["B"], 91, dev, H)
+c.requires_grad_(True); cp.requires_grad_(True)
+torch.manual_seed(5)
+lf = ContrastiveCorrelationLoss(cfg)
+lf(f, fp, None, None, c, cp, d, dp)
+lf.total.backward()
+torch.cuda.synchronize()
+torch.save(dict(s=lf.last_scalars.cpu(), g=c.grad.cpu(), gp=cp.grad.cpu()), sys.argv[1])
+print("FOLD done")
+"""
+
+
+def test_intra_fold_matches_the_g_tile_route(tmp_path):
+    """k_corr2's FOLD forms the intra pair-set's streamed-side code gradient in its own accumulator (G + G^T through one more chain
+    step that carries the streamed position's half of the row-mean centering) instead of storing G tiles for a k_gs job
+    (src/modules.py:1236-1254: helper(feats, feats, code, code)).  Both routes on the same inputs (DG_FOLD_INTRA, read once per
+    process): scalars to 1e-6 relative, gradients to 2e-4 of their norm - the two differ by fp16 rounding of different tiles
+    (G and G^T against G + G^T), not by anything systematic; grad_code_pos (no intra term) bit for bit."""
+    import torch
+    out = {}
+    for fold in ("1", "0"):
+        path = str(tmp_path / f"fold{fold}.pt")
+        env = dict(os.environ, DG_FOLD_INTRA=fold)
+        r = subprocess.run([sys.executable, "-c", _FOLD_CHILD.format(root=ROOT), path], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "FOLD done" in r.stdout, r.stderr[-3000:]
+        out[fold] = torch.load(path)
+    a, b = out["1"], out["0"]
+    assert torch.allclose(a["s"], b["s"], rtol=1e-6, atol=1e-9), (a["s"], b["s"])
+    rel = float((a["g"] - b["g"]).norm() / b["g"].norm())
+    assert rel < 2e-4, rel
+    assert float((a["g"] - b["g"]).abs().max()) > 0.0                     # (the two routes really are different code paths)
+    assert torch.equal(a["gp"], b["gp"])
