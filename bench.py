@@ -586,6 +586,13 @@ def main():
                    + ("replayed" if graph_mode else "host-launched") + " step, last of 20 back-to-back steps, mean of 16 samples"
                    if in_step else "HIP events: [step + 1 extra launch] - [step], 5 x 20 iterations, median (no span stamps were read)")
     step_gf, main_gf, gs_gf = algorithmic_gflop(H["B"], H["S"] ** 2, H["C"], H["D"], H["n_neg"])
+    # k_corr2's FOLD: the fused launch also forms the intra pair-set's streamed-side gradient (one correlation with K = D of the
+    # reference's work, by symmetry and one extra MFMA per chain) - that share moves from the k_gs launch to this one
+    intra_folded = ops.corr_intra_folded(desc)
+    if intra_folded:
+        share = 2.0 * H["B"] * (H["S"] ** 2) ** 2 * H["D"] / 1e9
+        main_gf += share
+        gs_gf -= share
     achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # which kernel that launch is: the library's own predicate (dg_corr_main_kernel_name), not a copy of it
     kname = ops.corr_main_kernel_name(desc)
@@ -610,7 +617,8 @@ def main():
                 "kernel_ms_diff": round(kern_ms_diff, 4), "kernel_ms_loop": round(kern_ms_loop, 4),
                 "kernel_ms_method": kern_method + "; kernel_ms_diff: [step + 1 extra launch] - [step], 5 x 20 iterations, median; "
                                     "kernel_ms_loop: 20 back-to-back re-launches",
-                "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2)}
+                "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2),
+                "intra_folded": bool(intra_folded)}
 
     if rank == 0:
         line = {

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 114                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 115                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 
@@ -16,7 +16,7 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_corr_materialize", "dg_corr_relaunch_main", "dg_fps_workspace_bytes", "dg_fps_coords", "dg_fps_coords_pair", "dg_rand_coords_state", "dg_rand_keep_state", "dg_super_perms",
            "dg_salience_coords", "dg_simple_depth_coords", "dg_confusion_update", "dg_topk_rows", "dg_lhp_forward", "dg_lhp_backward", "dg_super_perms_seeded", "dg_super_perms_state",
            "dg_lhp_map_forward", "dg_lhp_map_backward", "dg_corr_forward_draw", "dg_corr_forward_masked",
-           "dg_corr_backward_total", "dg_corr_main_kernel_name",
+           "dg_corr_backward_total", "dg_corr_main_kernel_name", "dg_corr_intra_folded",
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
            "dg_head_backward_pair", "dg_cluster_lookup_forward",
            "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities",
@@ -83,6 +83,8 @@ def load():
     lib.dg_probe_ce_backward.argtypes = [vp] * 4 + [i32] * 6 + [vp] * 2
     lib.dg_corr_main_kernel_name.restype = ctypes.c_char_p
     lib.dg_corr_main_kernel_name.argtypes = [cp]
+    lib.dg_corr_intra_folded.restype = ctypes.c_int
+    lib.dg_corr_intra_folded.argtypes = [cp]
     lib.dg_corr_backward.restype = ctypes.c_int
     lib.dg_corr_backward.argtypes = [cp] + [vp] * 7 + [ctypes.c_size_t, vp]
     lib.dg_corr_backward_total.restype = ctypes.c_int

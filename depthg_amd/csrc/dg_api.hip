@@ -984,6 +984,12 @@ extern "C" int dg_corr_relaunch_main(const dg_corr_desc* desc, const int64_t* pe
     return DG_OK;
 }
 
+extern "C" int dg_corr_intra_folded(const dg_corr_desc* desc) {
+    Plan p;
+    if (make_plan(desc, p) != DG_OK) return -1;
+    return p.fold ? 1 : 0;
+}
+
 extern "C" const char* dg_corr_main_kernel_name(const dg_corr_desc* desc) {
     Plan p;
     if (make_plan(desc, p) != DG_OK) return nullptr;

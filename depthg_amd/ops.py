@@ -487,6 +487,14 @@ class MainKernelTimer:
         return (t1 - t0) * 1e-5                    # 10-ns ticks -> ms
 
 
+def corr_intra_folded(desc):
+    """True when the fused correlation launch of `desc` also forms the intra pair-set's streamed-side gradient (k_corr2's FOLD)."""
+    rc = _lib.load().dg_corr_intra_folded(ctypes.byref(desc))
+    if rc < 0:
+        _lib.check(-1, "dg_corr_intra_folded")
+    return rc == 1
+
+
 def corr_main_kernel_name(desc):
     """Which kernel the fused correlation launch of `desc` runs ("k_corr2" / "k_corr_main"), from the library's own predicate."""
     name = _lib.load().dg_corr_main_kernel_name(ctypes.byref(desc))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 114   /* 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 115   /* 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -449,6 +449,12 @@ int dg_probe_ce_backward(const float* logits, const int64_t* label, const float*
 /* Measurement aid: name of the kernel the fused correlation launch of this descriptor runs ("k_corr2": the one-wave-per-SIMD
  * form of dg_corr2.hip, "k_corr_main": the general form), decided by the same predicate the launch uses; NULL on a bad desc. */
 const char* dg_corr_main_kernel_name(const dg_corr_desc* desc);
+
+/* Measurement aid: 1 when the fused correlation launch of this descriptor also forms the intra pair-set's streamed-side code
+ * gradient (k_corr2's FOLD: helper(feats, feats, code, code) of src/modules.py:1236-1254 is symmetric up to its row-mean centering;
+ * DESIGN.md section 4.1) - that share of the algorithmic work then belongs to the fused launch, not to k_gs; 0 otherwise; -1 on a
+ * bad desc.  (DG_FOLD_INTRA=0 in the environment switches the fold off.) */
+int dg_corr_intra_folded(const dg_corr_desc* desc);
 
 /*
  * Measurement aid (bench.py roofline leg): the execution span of the fused correlation launch INSIDE the step, hipGraph replays
