@@ -810,7 +810,10 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t
             }
         }
         if (t + 1 < ntiles) fetch(t + 1);                 // in flight during this tile's arithmetic
-        __syncthreads();                                   // tile t is in buffer t & 1; everybody is done with the other one
+        // tile t is in buffer t & 1; everybody is done with the other one.  (An LDS-only barrier: __syncthreads() is also a fence of
+        // global memory - hipcc puts s_waitcnt vmcnt(0) in front of it, i.e. it waited for the loads just issued, and every tile of
+        // the block cost a whole memory latency: found in round 5, dg_prep.hip k_cd_mask3 had the same)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const char* tile = smem + (t & 1) * TILE;
         if (act) {
             f32x16 yc = f32x16{};
