@@ -176,7 +176,10 @@ def test_headline_width_reference_vectors(case, dev):
         rel = float((got - want).norm() / want.norm())
         worst = float((got - want).abs().max() / want.abs().max())
         print(case, name, f"grad rel-l2 {rel:.2e} worst {worst:.2e}")
-        assert rel < 3e-2 and worst < 0.2, (name, rel, worst)
+        # (measured: random coordinates, 784 positions on the blob path - 4.7e-3 /
+        #  6.1e-3, worst 1.1e-2; the identity grid 1.35e-2 / 1.2e-2, worst 5.7e-2: clamp-mask flips of the fp16 cd)
+        lim = (2e-2, 1e-1) if "ident" in case else (1.2e-2, 3e-2)
+        assert rel < lim[0] and worst < lim[1], (name, rel, worst)
 
 
 @pytest.mark.gpu

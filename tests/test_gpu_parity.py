@@ -63,7 +63,7 @@ def test_golden_forward_backward(case, dev):
     if cfg.depth_feat_correlation_loss:
         _relclose(out[6], fx["depth_feat_loss"], RT, AT, "depth_feat_loss")
         _relclose(out[7].mean(), fx["depth_feat_cd_mean"], 1e-6, 1e-7, "dd mean")
-    _relclose(total, fx["total"], 5e-3, 1e-5, "total")
+    _relclose(total, fx["total"], 2e-3, 1e-5, "total")           # (measured <= 9.6e-4 over the cases: scripts/print_golden_errors.py)
     sub = int(fx["sub"])
     pick = (lambda t: t.detach().cpu().numpy()) if bool(fx["store_full"]) else \
         (lambda t: t.detach().reshape(-1)[::sub].cpu().numpy())
@@ -78,7 +78,9 @@ def test_golden_forward_backward(case, dev):
         want = want.astype(np.float64)
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
         cos = (got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want))
-        tol = 3e-3 if not cfg.zero_clamp else 3e-2
+        # (measured, scripts/print_golden_errors.py: <= 2.3e-3 on the sample grids - exact clamp masks of the fused small-grid kernel -,
+        #  4.6e-3 at D = 100; the bound was 3e-2 while these grids still took fp16 masks)
+        tol = 3e-3 if not cfg.zero_clamp else 8e-3
         assert rel < tol and cos > 0.9995, f"{name}: rel-l2 {rel:.3e} cos {cos:.6f}"
 
 
