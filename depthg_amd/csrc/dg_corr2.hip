@@ -777,7 +777,13 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
     asm volatile("" : "+v"(Yc[1]));
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[3] = wall_clock64(); }
+    // (e[13], e[14]: the shader clock - s_memtime - at the two ends of the tile loop, next to the 100-MHz wall clock in e[3], e[4]:
+    //  cycles / wall time = the clock this CU HELD while it ran the loop, scripts/held_clock.py)
+    if (args.blocklog && threadIdx.x == 0) {
+        unsigned long long* e = args.blocklog + (size_t)orig * 16; unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+        e[3] = wall_clock64(); e[13] = tm;
+    }
 #endif
     request();
     if (act[1]) run(std::true_type{}, std::true_type{});
@@ -786,7 +792,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // no LDS-DMA piece may outlive the workgroup's LDS allocation
     BSTAMP(2);
 #ifdef C2_BLOCKLOG
-    if (args.blocklog && threadIdx.x == 0) { unsigned long long* e = args.blocklog + (size_t)orig * 16; e[4] = wall_clock64(); }
+    if (args.blocklog && threadIdx.x == 0) {
+        unsigned long long* e = args.blocklog + (size_t)orig * 16; unsigned long long tm;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) :: "memory");
+        e[4] = wall_clock64(); e[14] = tm;
+    }
 #endif
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
