@@ -799,7 +799,8 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // FPS.  One block per image.  All arithmetic is IEEE fp32 with the reference's operation order and
 // no fused multiply-add, so that the selected set is bit-identical to numpy's for the same depth.
-#define FPS_THREADS 256
+#define FPS_THREADS 512      // (8 waves: 2 points per thread at 28 x 28 - the packed fp32 distance update issues at ~8 cycles per
+                             //  instruction, so halving the points per thread buys more than the wider barrier costs: 47 -> 42 us, round 5)
 // (wave-wide reductions below: DPP row operations - inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then the row
 //  totals are carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3); lane 63 holds the result)
 // Pooled depth of output pixel (i, j) from image rows staged in LDS (`st` holds rows ybase.. of the depth map, W floats
@@ -1072,6 +1073,7 @@ hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B
                            (const float*)pooled_ws);
         return hipGetLastError();
     };
+    if (h * w <= 2 * FPS_THREADS) return launch(k_fps_coords<2>);
     if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);
     if (h * w <= 8 * FPS_THREADS) return launch(k_fps_coords<8>);
     return launch(k_fps_coords<16>);
