@@ -1075,8 +1075,8 @@ hipError_t dg_launch_fps(const float* depth, const float* depth_b, int Ba, int B
     };
     if (h * w <= 2 * FPS_THREADS) return launch(k_fps_coords<2>);
     if (h * w <= 4 * FPS_THREADS) return launch(k_fps_coords<4>);
-    if (h * w <= 8 * FPS_THREADS) return launch(k_fps_coords<8>);
-    return launch(k_fps_coords<16>);
+    if (h * w <= 8 * FPS_THREADS) return launch(k_fps_coords<8>);        // (4096 pixels: the sampler's limit, dg_api.hip fps_entry)
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------
