@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--exact-masks", action="store_true",
                     help="cfg.dg_exact_masks: the clamp mask 1[cd >= 0] from fp32 dot products instead of the fp16 cd of the MFMA "
                          "chain (gradient error 1.4e-2 -> below 2e-3 relative L2; dense ViT-S grids; the default is the fast path)")
-    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph", "twocalls", "torchmasks", "writefeats"], default="", help=argparse.SUPPRESS)
+    ap.add_argument("--ablate", choices=["", "noexchange", "onegraph", "streamwait", "twocalls", "torchmasks", "writefeats"], default="", help=argparse.SUPPRESS)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the collective path even with one rank (self-test)")
     args = ap.parse_args()
@@ -461,7 +461,8 @@ def main():
                 return compute(buckets[k])
         # (--ablate: timing experiments only - where the N > 1 schedule's extra time goes)
         sched = DoubleBufferedExchange(buckets, run_kernels, comm, even_if_alone=args.force_dist,
-                                       exchange=args.ablate != "noexchange", alternate=args.ablate != "onegraph")
+                                       exchange=args.ablate != "noexchange", alternate=args.ablate != "onegraph",
+                                       host_wait=args.ablate != "streamwait")
         step = sched.step
 
     def sync():

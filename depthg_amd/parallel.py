@@ -97,11 +97,18 @@ class GradBucket:
             self.allreduce_mean_(even_if_alone=even_if_alone)
             self._exchange_done = stream.record_event()
 
-    def wait_exchange(self):
-        """Current stream waits for the last `exchange_on` (no host block)."""
+    def wait_exchange(self, host: bool = False):
+        """Order the last `exchange_on` in front of what comes next.  host=False: the current stream waits for it (no host block).
+        host=True: the HOST waits for it - no packet in the compute stream's queue.  A cross-stream wait in front of every replayed
+        step costs that stream ~10 us although the event it names completed long before (round 5, one rank, `--force-dist`: 0.327 ->
+        0.317 ms); the collective of two steps ago is done by the time the host, which runs ahead of the GPU, gets here, so the host
+        wait only bounds the run-ahead to the two buckets."""
         ev = getattr(self, "_exchange_done", None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            if host:
+                ev.synchronize()
+            else:
+                torch.cuda.current_stream().wait_event(ev)
 
     def wait(self):
         """Make the current stream wait for an outstanding async all-reduce (no host block)."""
@@ -116,8 +123,9 @@ class DoubleBufferedExchange:
     two gradient buckets used alternately, so that step i + 1 fills the other buffer while step i's all-reduce is in flight on
     the side stream.  Per step, in this order:
 
-        1. `wait_exchange` of bucket k = i mod 2  - the collective that read this buffer two steps ago (long done; it keeps the
-                                                    order between that collective and the refill explicit on the compute stream)
+        1. `wait_exchange` of bucket k = i mod 2  - the collective that read this buffer two steps ago (long done); the HOST waits
+                                                    (`host_wait`, the default on GPU buckets): the refill must not overtake that
+                                                    collective, and a wait packet in the compute stream's queue costs ~10 us per step
         2. `compute(k)`                           - the step's kernels; they end by filling bucket k (a hipGraph replay in bench.py)
         3. `exchange_on(comm)` of bucket k        - the all-reduce on the side stream, behind everything enqueued so far
 
@@ -126,10 +134,10 @@ class DoubleBufferedExchange:
     timed region ends.  Every rank must call `step()` the same number of times.  `trace` (when given a list) records the calls -
     the CPU tests drive this class over gloo with a stub `compute`."""
 
-    def __init__(self, buckets, compute, comm_stream=None, even_if_alone=False, exchange=True, alternate=True, trace=None):
+    def __init__(self, buckets, compute, comm_stream=None, even_if_alone=False, exchange=True, alternate=True, trace=None, host_wait=True):
         assert len(buckets) == 2
         self.buckets, self.compute, self.comm = buckets, compute, comm_stream
-        self.even_if_alone, self.exchange, self.alternate = even_if_alone, exchange, alternate
+        self.even_if_alone, self.exchange, self.alternate, self.host_wait = even_if_alone, exchange, alternate, host_wait
         self.count, self.trace = 0, trace
 
     def _note(self, what, k):
@@ -139,7 +147,7 @@ class DoubleBufferedExchange:
     def step(self):
         k = (self.count & 1) if self.alternate else 0
         self._note("wait", k)
-        self.buckets[k].wait_exchange()
+        self.buckets[k].wait_exchange(host=self.host_wait)
         self._note("compute", k)
         out = self.compute(k)
         if self.exchange:
