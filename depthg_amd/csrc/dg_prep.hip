@@ -324,8 +324,22 @@ template <int CH>         // channels per block (32 or 16: smaller planes, more 
 __global__ __launch_bounds__(PLANE_THREADS) void k_plane_sample(const DgPlaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pl[];          // [CH][HW + 1], then the tap table [consumers][P][8]
     __shared__ short l_o[(DG_MAX_NEG + 2) * 64 + 2], l_n[(DG_MAX_NEG + 2) * 64 + 2];
-    const int tid = threadIdx.x, HW = a.h * a.w, b = blockIdx.y;
-    int m = 0, gy = blockIdx.x;
+    // XCD-aware block order: the dispatcher deals consecutive blocks round-robin over the 8 XCDs, each with its own L2.  A block writes
+    // 64-byte pieces (32 channels) of its consumers' rows; the other half of each 128-byte line comes from the NEXT channel group of
+    // the same image - on another XCD in dispatch order, so the halves never met in an L2 and went to memory as partial lines (82 MB
+    // written for 52 MB of rows at config 3).  Logical block index = XCD-major: neighbours in (image, channel group) order share an XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        // (measured, three alternating runs each: config 3 (B = 32) 0.1694 -> 0.1673 ms and its WRITE_SIZE 82 -> 52 MB, config 2 (B = 16)
+        //  0.1579 -> 0.1574, the config-4 shard (B = 8: one image per XCD) 0.1733 -> 0.1760 - so from two images per XCD on)
+        if ((total & 7) == 0 && gridDim.y >= 16) {
+            const int lin = by * gridDim.x + bx, logical = (lin & 7) * (total >> 3) + (lin >> 3);
+            by = logical / (int)gridDim.x; bx = logical - by * (int)gridDim.x;
+        }
+    }
+    const int tid = threadIdx.x, HW = a.h * a.w, b = by;
+    int m = 0, gy = bx;
     while (m < 3 && gy >= (a.K4[m] + CH - 1) / CH) { gy -= (a.K4[m] + CH - 1) / CH; ++m; }
     const int K = a.K[m], K4 = a.K4[m], k0 = gy * CH, kind = m >> 1, pos_map = m & 1;
     const float* __restrict__ src = a.src[m] + ((size_t)b * K + k0) * HW;
