@@ -63,6 +63,7 @@ CONFIGS = {
 }
 HEAD_GRAD_ELEMS = 201_740          # cluster1 (26,950) + cluster2 (174,790) parameters, reference src/modules.py:75-88
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16/f16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_CLOCK_GHZ = 2.4               # ... which is 256 CUs x 4 SIMDs x 1024 flop/cycle at this shader clock
 
 
 def make_cfg(conf, **over):
@@ -203,15 +204,62 @@ def _free_port():
         return s.getsockname()[1]
 
 
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def count_gpus_sysfs(root=KFD_NODES, environ=None):
+    """GPUs of this node WITHOUT touching the HIP / HSA runtime: the KFD topology nodes with SIMDs (CPU nodes have `simd_count 0`),
+    capped by a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list.  None when the topology cannot be read (no amdgpu driver, a
+    container without /sys/class/kfd): the caller then lets the ranks themselves fail on a missing device."""
+    environ = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(root))
+    except OSError:
+        return None
+    have = 0
+    for nd in nodes:
+        try:
+            with open(os.path.join(root, nd, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            have += 1
+    for key in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = environ.get(key)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
+def profiler_preloaded(environ=None):
+    """True under rocprofv3 / rocprof: its preloaded tool library has initialised the GPU before this program started, so this
+    process must not act as a launcher of further GPU processes (the ranks have to be profiled directly)."""
+    environ = os.environ if environ is None else environ
+    if "rocprof" in environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_TOOL")) for k in environ)
+
+
 def spawn_ranks(n, argv):
     """`--gpus N` (N > 1) with WORLD_SIZE unset: start the N ranks as a CHILD `python -m torch.distributed.run` (one process per
-    GPU, rendezvous on 127.0.0.1) from this parent, which has made no GPU call (torch.cuda.device_count() does not initialise the
-    device on this image; nothing here re-execs an initialised process).  Rank 0's JSON line is relayed as the last line of
-    stdout.  Non-zero exit when the node has fewer than N GPUs, when a rank fails, or when the line was not produced by N ranks."""
+    GPU, rendezvous on 127.0.0.1) from this parent, which makes no GPU call at all: the devices are counted from the KFD topology in
+    sysfs (count_gpus_sysfs), not through the runtime, and nothing here re-execs an initialised process.  Refused (exit 6) under a
+    profiler's preload, which has initialised the GPU already: profile the ranks, not the launcher.  Rank 0's JSON line is relayed
+    as the last line of stdout.  Non-zero exit when the node has fewer than N GPUs, when a rank fails, or when the line was not
+    produced by N ranks."""
     dry = bool(os.environ.get("DG_BENCH_DRYRUN"))
-    have = torch.cuda.device_count()
-    if have < n and not dry:
-        print(f"[bench] --gpus {n}: this node shows {have} GPU(s); not running a {n}-GPU line on fewer devices", file=sys.stderr)
+    if profiler_preloaded() and not dry:
+        print(f"[bench] --gpus {n} under a profiler preload (rocprofv3): the GPU is already initialised in this process, which "
+              f"must not start further GPU processes.  Profile a rank instead: rocprofv3 ... -- python3 -m torch.distributed.run "
+              f"--nproc-per-node {n} ... bench.py --gpus {n} is also a launcher hop; run one rank with --force-dist", file=sys.stderr)
+        return 6
+    have = count_gpus_sysfs()
+    if have is None and not os.path.exists("/dev/kfd"):
+        have = 0                               # no KFD topology and no compute device node: there is no GPU to run on
+    if have is not None and have < n and not dry:
+        print(f"[bench] --gpus {n}: this node shows {have} GPU(s) in {KFD_NODES}; not running a {n}-GPU line on fewer devices",
+              file=sys.stderr)
         return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -241,21 +289,46 @@ def spawn_ranks(n, argv):
 
 
 def dryrun_rank(args, world, rank):
-    """DG_BENCH_DRYRUN=1 (tests/test_dp_gloo.py, no GPU): the rank rendezvous over gloo, counts its peers with an all-reduce and
-    rank 0 prints a line of the usual shape with no measurement in it - what is checked is the launch path, not the step."""
+    """DG_BENCH_DRYRUN=1 (tests/test_dp_gloo.py, no GPU): the ranks rendezvous over gloo and drive the N > 1 step schedule itself
+    (depthg_amd.parallel.DoubleBufferedExchange, CPU buckets, a stub in place of the step's kernels) the way main() does: a
+    warm-up of a DIFFERENT length on every rank with no collective in it, then exactly --steps steps with one all-reduce each.
+    Rank 0 prints a line of the usual shape with no measurement in it - what is checked is the launch path and that the
+    collectives of the timed steps pair up, not the step."""
     import torch.distributed as dist
+    from depthg_amd.parallel import DoubleBufferedExchange, GradBucket
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     one = torch.ones(1)
     dist.all_reduce(one)
+    buckets = [GradBucket(64, "cpu", dist) for _ in range(2)]
+    sched = None
+
+    def stub(k):
+        buckets[k].flat.fill_(float(1000 * rank + sched.count))      # "this step's gradients": names (rank, step)
+        return sched.count
+
+    sched = DoubleBufferedExchange(buckets, stub, comm_stream=None)
+    warm_calls = 3 + 2 * rank + args.warmup                          # unequal on purpose (main(): time-based, so it differs too)
+    for _ in range(warm_calls):
+        sched.warm()
+    dist.barrier()
+    ok = True
+    for i in range(args.steps):
+        sched.step()
+        want = 1000.0 * (world - 1) / 2.0 + i                        # mean over the ranks of 1000 r + i
+        ok = ok and abs(float(buckets[i & 1].flat[0]) - want) < 1e-3
+    sched.drain()
+    flags = [None] * world
+    dist.all_gather_object(flags, (warm_calls, bool(ok)))
     if rank == 0:
         print(json.dumps({"metric": "dry run: no step was timed", "value": None, "unit": "steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dryrun": True,
+                          "warm_calls_by_rank": [f[0] for f in flags], "steps_paired_on_every_rank": all(f[1] for f in flags),
                           "config": {"name": args.config, "ranks_seen": int(one.item()), "parallelism": f"dp{world}"}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    return 0
+    return 0 if all(f[1] for f in flags) else 7
 
 
 def main():
@@ -321,8 +394,9 @@ def main():
     H = conf["H"]
     # the fused correlation kernel's workgroups stamp their entry / exit times (dg_prof_main_span) - also inside the replayed hipGraph,
     # so the roofline leg below reads the kernel's execution span INSIDE steps, what a kernel trace shows, not a re-launch beside them
+    # (the timed steps run WITHOUT the stamps: the timer is armed only for a second recording of the step, made behind the timed
+    #  region, that the roofline leg replays - the pointer in force at capture time is baked into a hipGraph)
     ktimer = ops.MainKernelTimer(dev)
-    ktimer.arm(True)
     # ONE schedule for every N: the compute part of the step is replayed from a hipGraph (the eager step's Python side, 0.2 ms,
     # plus the collective's, 0.05-0.14 ms, would make the host the limit of a 0.3-ms step); N > 1 adds the collective on a side
     # stream and nothing else.  --eager / --sync-allreduce opt out (the JSON line says which schedule ran).
@@ -529,6 +603,18 @@ def main():
             dist_diag["drain_ms"] = round((time.perf_counter() - t_d) * 1e3, 4)      # host wait for the tail: last collectives + barrier
             stall = sum(a.elapsed_time(b) for a, b in evs) / nprobe
             dist_diag["exchange_wait_ms"] = round(stall, 5)
+            # the SAME K steps with the collective on the compute stream, which waits for it right away (what --sync-allreduce
+            # times, here with the replayed step): the overlapped `value` above hides the collective under the next step's kernels,
+            # this figure has all of it on the critical path - a real training step lies between the two
+            t_s = time.perf_counter()
+            for _ in range(args.steps):
+                run_kernels(0)
+                buckets[0].allreduce_mean_(even_if_alone=args.force_dist)
+            sync()
+            t_sync = torch.tensor([time.perf_counter() - t_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_sync, op=dist.ReduceOp.MAX)
+            dist_diag["ms_per_step_sync_allreduce"] = round(float(t_sync) / args.steps * 1e3, 4)
+            dist_diag["value_sync_allreduce"] = round(world * args.steps / float(t_sync), 2)
     if use_dist:
         # a rank that fell back to the host-launched step is named on the line whichever rank it was (rank 0 prints)
         notes = [None] * world
@@ -573,14 +659,24 @@ def main():
     # the kernel inside the step: `reps` back-to-back steps, the span stamps reset in front of the LAST one and read behind it; 16 such
     # samples, mean and spread.  This is the figure the committed rocprofv3 kernel trace of the same command reports as the kernel's
     # average (minus the dispatch ramp) - `frac` is quoted on it.
-    in_step = []
+    ktimer.arm(True)
+    probe_graph = capture_or_die(compute) if graph_mode else None       # (kept alive to the end of main(): it writes to ktimer.span)
+    probe = (lambda: probe_graph[0].replay()) if probe_graph is not None else compute
+    in_step, held = [], []
     for _ in range(16):
         for _ in range(reps - 1):
-            warm()
+            probe()
         ktimer.reset()
-        warm()
-        in_step.append(ktimer.last_ms())
+        probe()
+        ms, ghz = ktimer.last()
+        in_step.append(ms)
+        held.append(ghz)
+    # the same 20 steps with and without the stamps (what the instrumentation costs the step; the timed region above ran without)
+    t_probe = timed(probe)
     ktimer.arm(False)
+    t_plain = timed(warm)
+    held = [v for v in held if v == v and v > 0.0]
+    held_ghz = sum(held) / len(held) if held else None
     in_step = [v for v in in_step if v == v and v > 0.0]
     kern_ms = sum(in_step) / len(in_step) if in_step else kern_ms_diff
     kern_method = ("span of the kernel's workgroups (entry / exit stamps of the GPU's 100-MHz clock, atomic min / max) inside the "
@@ -619,7 +715,15 @@ def main():
                 "kernel_ms_method": kern_method + "; kernel_ms_diff: [step + 1 extra launch] - [step], 5 x 20 iterations, median; "
                                     "kernel_ms_loop: 20 back-to-back re-launches",
                 "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2),
-                "intra_folded": bool(intra_folded)}
+                "intra_folded": bool(intra_folded),
+                # the shader clock the kernel's CUs held while they ran it (sum of the workgroups' s_memtime cycles / sum of their
+                # 100-MHz wall ticks, same 16 in-step samples as kernel_ms) and the fraction of the peak AT THAT CLOCK: the
+                # 2.5-PFLOP/s peak is 1024 SIMDs x 1024 flop/cycle at 2.4 GHz.  Box-to-box differences of `frac` with equal
+                # cycles per launch are differences of this clock (power management), not of the kernel
+                "held_clock_ghz": round(held_ghz, 4) if held_ghz else None,
+                "frac_at_held_clock": round(achieved / PEAK_BF16_TFLOPS * PEAK_CLOCK_GHZ / held_ghz, 4) if held_ghz else None,
+                "kernel_mcycles": round(kern_ms * 1e-3 * held_ghz * 1e9 / 1e6, 3) if held_ghz else None,
+                "stamps_cost_ms_per_step": round(t_probe - t_plain, 5)}
 
     if rank == 0:
         line = {

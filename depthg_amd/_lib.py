@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 115                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 116                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS = (1 << i for i in range(9))
 

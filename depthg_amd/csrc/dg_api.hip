@@ -64,6 +64,7 @@ static bool small_path_enabled() {
     return on;
 }
 
+static void clamp_bounds(const dg_corr_desc* d, float& lo, float& hi);
 static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (!d) return fail(DG_ERR_INVALID, "null descriptor");
     if (d->B < 1 || d->C < 1 || d->D < 1 || d->h < 1 || d->w < 1 || d->S < 1)
@@ -153,12 +154,14 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         return fail(DG_ERR_UNSUPPORTED, "DG_EXACT_MASKS: exact clamp masks exist on small sample grids (always on there) and on the dense "
                                         "identity grid with C <= 384 (padded to 384), D <= 80, P >= 160, B <= 64, zero_clamp without stabalize");
     for (int t = 0; t < p.T; ++t) p.maskbits[t] = take((p.xmask || p.xmask_dense) ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
-    // FOLD: gradient passes of the pointwise recipe that k_corr2 runs (the conditions of dg_corr2_supported, which forward_impl
-    // re-checks) without exact mask words; DG_FOLD_INTRA=0 keeps the k_gs job (developer A/B)
+    // FOLD: gradient passes of the pointwise recipe that k_corr2 runs (dg_corr2_shape_supported: the launcher's own predicate; the
+    // job-level conditions - stationary = operand 1, G tiles wanted, no batch map on R - hold for every gradient pass) without exact mask words; DG_FOLD_INTRA=0 keeps the k_gs job (developer A/B)
     {
         static const bool fold_on = [] { const char* e = getenv("DG_FOLD_INTRA"); return !(e && e[0] == '0'); }();
-        p.fold = fold_on && p.grad && p.pointwise && !p.small && p.KF == 384 && p.KD == 96 && p.D <= 80 && (d->flags & DG_ZERO_CLAMP) &&
-                 !(d->flags & DG_STABALIZE) && p.Ppad >= 160 && p.B <= 64 && !p.xmask && !p.xmask_dense;
+        float lo, hi;
+        clamp_bounds(d, lo, hi);
+        p.fold = fold_on && p.grad && p.pointwise && !p.small && dg_corr2_shape_supported(p.KF, p.KD, p.D, lo, hi, p.Ppad, p.B) &&
+                 !p.xmask && !p.xmask_dense;
     }
     for (int i = 0; i < 2; ++i) p.clo[i] = take((p.xmask_dense && p.pointwise) ? B * (size_t)(p.Ppad / 32) * p.KD * 64 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
@@ -944,10 +947,11 @@ static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64
         return DG_OK;
     }
     // (a gradient pass with k_corr2's FOLD left the intra row means in the padding of the operand-1 blobs' C part: k_corr_main's
-    //  un-reduced forms multiply all of it)
-    if (p.pointwise && p.KF == 384 && p.KD == 96 && p.D <= 80)
-        DG_HIP(dg_launch_clear_stash(ws + p.op[0], p.B, p.Ppad / 32, (size_t)p.blob, (int)DgBlob(p.KF, p.KD).off_c + FOLD_STASH_OFF,
-                                     static_cast<hipStream_t>(stream_)));
+    //  un-reduced forms multiply all of it.  Cleared for this launch and written back behind it, from the row means that are still in
+    //  the workspace: the workspace stays what the forward prepared - dg_corr_relaunch_main remains valid.)
+    const int stash_off = (int)DgBlob(p.KF, p.KD).off_c + FOLD_STASH_OFF;
+    if (p.fold)
+        DG_HIP(dg_launch_set_stash(ws + p.op[0], p.B, p.Ppad / 32, (size_t)p.blob, stash_off, nullptr, p.P, p.Ppad, static_cast<hipStream_t>(stream_)));
     DgCorrArgs a;
     corr_args_base(p, desc, ws, a);
     // stationary = operand 2 (on MFMA lanes) -> the stores of one accumulator register are contiguous along q
@@ -957,6 +961,9 @@ static int materialize_impl(const dg_corr_desc* desc, int32_t which, const int64
     a.jobs[0] = j; a.njobs = 1;
     a.pos_w = p.ident ? p.w : 0;
     DG_HIP(dg_launch_corr(a, p.KF, p.KD, p.rf, 2, static_cast<hipStream_t>(stream_)));
+    if (p.fold)
+        DG_HIP(dg_launch_set_stash(ws + p.op[0], p.B, p.Ppad / 32, (size_t)p.blob, stash_off, reinterpret_cast<const float*>(ws + p.rvec[0]),
+                                   p.P, p.Ppad, static_cast<hipStream_t>(stream_)));
     return DG_OK;
 }
 

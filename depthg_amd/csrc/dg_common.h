@@ -170,12 +170,28 @@ __device__ __forceinline__ float half_sum(float v) {
 #endif
 
 #ifdef __HIPCC__
-// dg_prof_main_span: one thread per workgroup stamps the launch's span (constant 100-MHz clock)
-__device__ __forceinline__ void dg_span_enter(unsigned long long* span) {
-    if (span) __hip_atomic_fetch_min(&span[0], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// dg_prof_main_span: one thread per workgroup stamps the launch's span (constant 100-MHz clock) and adds its own lifetime in
+// shader cycles (s_memtime) and in wall ticks to two running sums: sum of cycles / sum of ticks = the clock the CUs HELD while
+// they ran the kernel (span[2] / span[3] x 0.1 GHz).  `keep` = two 64-bit words of the workgroup's LDS (the entry stamps wait
+// there: no register lives across the kernel for them).
+__device__ __forceinline__ void dg_span_enter(unsigned long long* span, unsigned long long* keep) {
+    if (span) {
+        const unsigned long long w = (unsigned long long)wall_clock64();
+        unsigned long long c;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) :: "memory");
+        keep[0] = w; keep[1] = c;
+        __hip_atomic_fetch_min(&span[0], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-__device__ __forceinline__ void dg_span_exit(unsigned long long* span) {
-    if (span) __hip_atomic_fetch_max(&span[1], (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void dg_span_exit(unsigned long long* span, const unsigned long long* keep) {
+    if (span) {
+        const unsigned long long w = (unsigned long long)wall_clock64();
+        unsigned long long c;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) :: "memory");
+        __hip_atomic_fetch_max(&span[1], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&span[2], c - keep[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&span[3], w - keep[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 #endif
 
@@ -230,7 +246,7 @@ struct DgCorrArgs {
     int32_t debug;        // developer ablation bits (0 in production)
     uint32_t* wctr;       // k_corr2's persistent workgroups: [0..7] items handed out so far per XCD (beyond each workgroup's first), [8]
                           // workgroups that have left; all zero at launch (k_colmean) and again when the last workgroup leaves; null: static walk
-    unsigned long long* span;   // measurement aid (dg_prof_main_span): [0] min of the workgroups' entry times, [1] max of their exit times; or null
+    unsigned long long* span;   // measurement aid (dg_prof_main_span): [0] min of the workgroups' entry times, [1] max of their exit times, [2] / [3] sums of their lifetimes in shader cycles / wall ticks; or null
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
     // ragged last row blocks grouped by streamed operand (dg_corr2.hip; lists written by k_group_ragged); gr_list null: off
@@ -696,6 +712,7 @@ inline hipError_t dg_set_max_smem(const void* kern, int bytes) {
 hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, int mode, hipStream_t stream);
 hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
 bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD);
+bool dg_corr2_shape_supported(int KF, int KD, int D, float lo, float hi, int Ppad, int B);
 hipError_t dg_launch_gs(const struct DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t s, bool depth_only = false);   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
@@ -720,7 +737,7 @@ hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);
 hipError_t dg_launch_colmean(const DgColmeanArgs& a, hipStream_t s);
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s);
 hipError_t dg_launch_rowmean(const DgRowmeanArgs& a, hipStream_t s);
-hipError_t dg_launch_clear_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, hipStream_t s);
+hipError_t dg_launch_set_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, const float* rvec, int P, int Ppad, hipStream_t s);
 hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s);
 hipError_t dg_launch_super_perms(const float* keys, uint64_t seed, unsigned long long* state, int count, int B, int64_t* out, hipStream_t s);
 hipError_t dg_launch_salience_coords(const float* sal, int B, int H, int W, int n, const float* u_sel, const float* u_fb,

@@ -685,11 +685,12 @@ __global__ __launch_bounds__(NWAVES * 64) void k_corr_main(const DgCorrArgs args
     const DgJob& job = args.jobs[jid];
     if ((DG_DBG(args.debug) & 16777216) && rb == args.nrb - 1 && args.nrb > 1) return;     // (ablation: skip the last row block)
     if ((DG_DBG(args.debug) & 134217728) && job.kind == DG_JOB_DEPTH) return;               // (ablation: skip the depth job)
-    if (!MAT && threadIdx.x == 0) dg_span_enter(args.span);
+    __shared__ unsigned long long span_keep[2];
+    if (!MAT && threadIdx.x == 0) dg_span_enter(args.span, span_keep);
     if (job.kind == DG_JOB_DEPTH) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_DEPTH, NKC>(args, job, n, rb, smem);
     else if (job.center_on_lane == 0) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_ROW, NKC>(args, job, n, rb, smem);
     else if (!MAT) corr_body<NKF, NKD, NWAVES, RF, GRAD, MAT, SIMPLE, KIND_LANE, NKC>(args, job, n, rb, smem);
-    if (!MAT && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg_span_exit(args.span); }
+    if (!MAT && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg_span_exit(args.span, span_keep); }
 }
 
 // ---- k_gs: gradient w.r.t. the streamed operand's code from the stored G tiles ---------------------------------

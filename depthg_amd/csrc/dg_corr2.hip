@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     // of the item the request stood in front of every load of the block's start in the in-order vmcnt queue: +3 % on the kernel)
     // and passed on through LDS at the item's end; an item that turns out to be served by a group asks and waits on the spot.
     __shared__ int next_item_s;
+    __shared__ unsigned long long span_keep[2];          // (dg_prof_main_span: thread 0's entry stamps)
     int next_orig = 0;
-    if (threadIdx.x == 0) dg_span_enter(args_k.span);
+    if (threadIdx.x == 0) dg_span_enter(args_k.span, span_keep);
     for (int orig = blockIdx.x; orig < nitems; orig = next_orig) {
     unsigned taken = 0;                 // (thread 0) items of this XCD handed out before this request
     // (pointer and mode re-derived per item from the kernel arguments: two scalar registers less across the tile loops)
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #endif
     advance();
     }       // (next work item)
-    if (threadIdx.x == 0) dg_span_exit(args_k.span);
+    if (threadIdx.x == 0) dg_span_exit(args_k.span, span_keep);
     // the last workgroup to leave puts the counters back to zero (a re-launch on the same workspace - dg_corr_relaunch_main - finds
     // them as k_colmean left them for this one)
     if (DYN && threadIdx.x == 0) {
@@ -948,12 +949,17 @@ static bool dg_corr2_dynamic_walk(const DgCorrArgs& args, int grid) {
 
 // Helper jobs (stationary = operand 1) of a gradient pass with clamp(cd) = cd * mask.  Returns hipErrorNotSupported for
 // shapes this form does not cover (the caller then uses k_corr_main).
-bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD) {
+// The shapes and clamp recipe this form covers - ONE predicate for the launcher below and for the host's plan (dg_api.hip decides
+// from it whether the intra pair-set may be folded: a second copy of these conditions there could drift from this one and turn a
+// fall-back to k_corr_main into a failed call)
+bool dg_corr2_shape_supported(int KF, int KD, int D, float lo, float hi, int Ppad, int B) {
 #ifdef C2_DISABLE          // (developer A/B: everything through k_corr_main)
     return false;
 #endif
-    if (!(KF == 384 && KD == 96 && args.D <= 80)) return false;
-    if (!(args.lo == 0.f && args.hi > 1e30f) || args.Ppad < 160 || args.B > 64) return false;
+    return KF == 384 && KD == 96 && D <= 80 && lo == 0.f && hi > 1e30f && Ppad >= 160 && B <= 64;
+}
+bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD) {
+    if (!dg_corr2_shape_supported(KF, KD, args.D, args.lo, args.hi, args.Ppad, args.B)) return false;
     for (int j = 0; j < args.njobs; ++j) {
         const DgJob& J = args.jobs[j];
         if (J.kind != DG_JOB_HELPER || !J.center_on_lane || !J.Gout || J.ridx) return false;

@@ -1146,12 +1146,22 @@ __global__ __launch_bounds__(64 * ROWMEAN_WAVES) void k_rowmean(const DgRowmeanA
         }
     }
 }
-// the words above back to zero (dg_corr_materialize: k_corr_main's un-reduced forms multiply every code k-step of the blob)
-__global__ __launch_bounds__(64) void k_clear_stash(char* blobs, size_t blob_bytes, int off) {
-    if (threadIdx.x < 32) *reinterpret_cast<uint32_t*>(blobs + (size_t)blockIdx.x * blob_bytes + off + threadIdx.x * 16) = 0u;
+// the words above back to zero (dg_corr_materialize: k_corr_main's un-reduced forms multiply every code k-step of the blob) - or,
+// with `rvec` (the intra pair-set's row means, still in the workspace), written again exactly as k_rowmean wrote them, so that the
+// workspace is what the forward left (dg_corr_relaunch_main after a dg_corr_materialize)
+__global__ __launch_bounds__(64) void k_set_stash(char* blobs, size_t blob_bytes, int off, const float* rvec, int ntiles, int P, int Ppad) {
+    if (threadIdx.x >= 32) return;
+    uint32_t word = 0u;
+    if (rvec) {
+        const int n = (int)blockIdx.x / ntiles, tile = (int)blockIdx.x - n * ntiles, p = tile * 32 + (int)threadIdx.x;
+        const float x = p < P ? -0.5f * rvec[(size_t)n * Ppad + p] : 0.f;
+        const _Float16 xh = (_Float16)x, xl = (_Float16)((x - (float)xh) * 2048.f);
+        word = (uint32_t)__builtin_bit_cast(unsigned short, xh) | ((uint32_t)__builtin_bit_cast(unsigned short, xl) << 16);
+    }
+    *reinterpret_cast<uint32_t*>(blobs + (size_t)blockIdx.x * blob_bytes + off + threadIdx.x * 16) = word;
 }
-hipError_t dg_launch_clear_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, hipStream_t s) {
-    hipLaunchKernelGGL(k_clear_stash, dim3(B * ntiles), dim3(64), 0, s, blobs, blob_bytes, off);
+hipError_t dg_launch_set_stash(char* blobs, int B, int ntiles, size_t blob_bytes, int off, const float* rvec, int P, int Ppad, hipStream_t s) {
+    hipLaunchKernelGGL(k_set_stash, dim3(B * ntiles), dim3(64), 0, s, blobs, blob_bytes, off, rvec, ntiles, P, Ppad);
     return hipGetLastError();
 }
 

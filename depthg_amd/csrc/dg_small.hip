@@ -74,7 +74,8 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int xk = (int)blockIdx.x >> 3;
     const int n = ((int)blockIdx.x & 7) + 8 * (xk / per);
     if (n >= B) return;
-    if (tid == 0) dg_span_enter(a.span);
+    __shared__ unsigned long long span_keep[2];
+    if (tid == 0) dg_span_enter(a.span, span_keep);
     const int jj = xk % per;
     const int sp = jj % nsplit;
     int t = jj / nsplit;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(SM_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     }
 
-    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg_span_exit(a.span); }
+    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dg_span_exit(a.span, span_keep); }
     SM_STAMP();
 #ifdef DG_DEVTOOLS
     if (a.debug == 1 && blockIdx.x == 0 && tid == 0) {

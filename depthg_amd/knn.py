@@ -26,18 +26,14 @@ def nns_path(data_dir, model_type, dataset_name, image_set, crop_type, res):
     return os.path.join(data_dir, "nns", "nns_{}_{}_{}_{}_{}.npz".format(model_type, dataset_name, image_set, crop_type, res))
 
 
-def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int = 64, engine: str = "hip") -> torch.Tensor:
+def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int = 64) -> torch.Tensor:
     """(n, F) L2-normalised features on the GPU -> int64 (n, k) on the CPU, row i = the k most similar images of i in
     decreasing similarity.  Slices like the reference: `step = n // n_batches` query rows per similarity matrix
-    (src/precompute_knns.py:101-112), so the peak scratch is `step x n` floats.  `engine`: "hip" = dg_knn_similarities (fp32 MFMA,
-    the library's own contraction: 75 TFLOP/s on a 775 x 49,629 x 384 slice), "rocblas" = torch.matmul (the vendor GEMM: 105 TFLOP/s
-    on the same slice; the whole cocostuff-sized table takes 52 against 45 ms - scripts/knn_time.py).
-    Why the slower engine is the default: its fp32 dot products run in a fixed k order that this library owns, so the table - and
-    with it every positive pick of a training run - has the same bits on every ROCm release, where the vendor GEMM's split of K is
-    free to change; near-ties (the fixtures' smallest gap is 8e-8) are the only rows that can differ.  The job is offline and
-    one-shot: 7 ms.  Pass engine="rocblas" when only speed matters."""
-    if engine not in ("hip", "rocblas"):
-        raise ValueError(f"engine must be 'hip' or 'rocblas', got {engine!r}")
+    (src/precompute_knns.py:101-112), so the peak scratch is `step x n` floats.  The similarities come from dg_knn_similarities
+    (fp32 MFMA, the library's own contraction; 75 TFLOP/s on a 775 x 49,629 x 384 slice): its fp32 dot products run in a fixed k
+    order that this library owns, so the table - and with it every positive pick of a training run - has the same bits on every
+    ROCm release.  (The vendor GEMM is 15 % faster on the one-shot offline job, 45 against 52 ms for a cocostuff-sized table; it is
+    timed beside this path in scripts/knn_time.py and is not a backend of the product.)"""
     if not normed_feats.is_cuda:
         raise RuntimeError(f"depthg_amd: `normed_feats` must live on the GPU (got {normed_feats.device}); there is no CPU path")
     x = normed_feats.detach().to(torch.float32).contiguous()
@@ -45,8 +41,7 @@ def nearest_neighbors(normed_feats: torch.Tensor, k: int = NNS_K, n_batches: int
     step = max(n // int(n_batches), 1)
     out = []
     for i in range(0, n, step):
-        # einsum("nf,mf->nm"), src/precompute_knns.py:106-108
-        sims = ops.knn_similarities(x[i:i + step], x) if engine == "hip" else torch.matmul(x[i:i + step], x.t())
+        sims = ops.knn_similarities(x[i:i + step], x)           # einsum("nf,mf->nm"), src/precompute_knns.py:106-108
         out.append(ops.topk_rows(sims, k).cpu())
         del sims
     return torch.cat(out, dim=0)

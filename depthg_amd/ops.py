@@ -466,12 +466,14 @@ def corr_relaunch_main(desc, perms, workspace):
 class MainKernelTimer:
     """Measurement aid (bench.py): the execution span of the fused correlation launch INSIDE the step, hipGraph replays included
     (dg_prof_main_span): while armed, every workgroup of that kernel stamps its entry / exit time (the GPU's constant 100-MHz
-    clock) into two device words with atomic min / max.  `reset()` in front of a step (an asynchronous fill on the current
-    stream), `last_ms()` behind it: the interval a kernel trace reports for the launch, minus the dispatch ramp."""
+    clock) into two device words with atomic min / max and adds its lifetime in shader cycles / wall ticks to two more.
+    `reset()` in front of a step (an asynchronous copy on the current stream), `last_ms()` / `last()` behind it: the interval a
+    kernel trace reports for the launch, minus the dispatch ramp, and the clock the kernel's CUs held.  A hipGraph captured while
+    the timer is armed keeps writing to `span` at every replay: keep the timer alive as long as such a graph."""
 
     def __init__(self, device):
-        self.span = torch.zeros(2, dtype=torch.int64, device=device)
-        self._init = torch.tensor([-1, 0], dtype=torch.int64, device=device)       # {UINT64_MAX, 0}
+        self.span = torch.zeros(4, dtype=torch.int64, device=device)
+        self._init = torch.tensor([-1, 0, 0, 0], dtype=torch.int64, device=device)       # {UINT64_MAX, 0, 0, 0}
 
     def arm(self, on=True):
         _lib.check(_lib.load().dg_prof_main_span(_ptr(self.span) if on else None), "dg_prof_main_span")
@@ -479,12 +481,17 @@ class MainKernelTimer:
     def reset(self):
         self.span.copy_(self._init, non_blocking=True)
 
-    def last_ms(self):
+    def last(self):
+        """(span in ms, held shader clock in GHz) of the launches since the last reset; (nan, nan) when nothing was stamped."""
         torch.cuda.synchronize()
-        t0, t1 = (int(v) for v in self.span.tolist())
+        t0, t1, cyc, ticks = (int(v) for v in self.span.tolist())
         if t0 < 0 or t1 <= 0:                      # nothing stamped
-            return float("nan")
-        return (t1 - t0) * 1e-5                    # 10-ns ticks -> ms
+            return float("nan"), float("nan")
+        ghz = cyc / ticks * 0.1 if ticks > 0 else float("nan")      # cycles per 10-ns tick
+        return (t1 - t0) * 1e-5, ghz               # 10-ns ticks -> ms
+
+    def last_ms(self):
+        return self.last()[0]
 
 
 def corr_intra_folded(desc):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 115   /* 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 116   /* 116: dg_prof_main_span takes FOUR words (+ the workgroups' lifetimes in shader cycles and wall ticks: the clock the CUs held); 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -458,11 +458,15 @@ int dg_corr_intra_folded(const dg_corr_desc* desc);
 
 /*
  * Measurement aid (bench.py roofline leg): the execution span of the fused correlation launch INSIDE the step, hipGraph replays
- * included.  `span` = device pointer to two uint64 (or NULL: off): every workgroup of the fused kernel of every later dg_corr_forward*
- * call of this process takes min(span[0], entry time) and max(span[1], exit time) with device-scope atomics; times are the GPU's
- * constant 100-MHz wall clock (s_memrealtime: 10 ns per tick).  The caller sets {UINT64_MAX, 0} in front of the step it wants to
- * read (e.g. a memset on the launch stream) and reads (span[1] - span[0]) x 10 ns behind it - the interval a kernel trace reports
- * for the launch, minus the dispatch ramp.  Nothing in the product path depends on it.
+ * included, and the shader clock its CUs held.  `span` = device pointer to FOUR uint64 (or NULL: off).  Every workgroup of the fused
+ * kernel of every later dg_corr_forward* call of this process takes min(span[0], entry time) and max(span[1], exit time) and adds its
+ * own lifetime to span[2] (shader cycles, s_memtime) and span[3] (ticks of the GPU's constant 100-MHz wall clock, s_memrealtime:
+ * 10 ns per tick), all with device-scope atomics.  The caller sets {UINT64_MAX, 0, 0, 0} in front of the step it wants to read (e.g.
+ * a copy on the launch stream) and reads behind it: (span[1] - span[0]) x 10 ns = the interval a kernel trace reports for the
+ * launch, minus the dispatch ramp; span[2] / span[3] x 0.1 = the clock in GHz the kernel's CUs held on average.  Nothing in the
+ * product path depends on it.  LIFETIME: the pointer in force when a launch is RECORDED is what the launch uses - a hipGraph captured
+ * while a span was set writes to it at every replay, so the four words must outlive every such graph (or the graph must be dropped
+ * first); capture the graphs you time with the span off (NULL) and a separate one with it on for the measurement.
  */
 int dg_prof_main_span(void* span);
 

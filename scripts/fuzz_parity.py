@@ -67,7 +67,8 @@ def one(seed):
         perms = [torch.randint(0, B, (B,), generator=g) for _ in range(N)]
     else:
         perms = [O.super_perm(B, g) for _ in range(N)]
-    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="full" if full else "reduced", dg_dense_grid=dense, **flags)
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="full" if full else "reduced", dg_dense_grid=dense,
+                        dg_small_identity_blobs=bool(os.environ.get("DG_FUZZ_BLOBS")), **flags)   # DG_FUZZ_BLOBS=1: dense grids of <= 160 positions on the blob kernels (the route until round 6)
     if dense:
         c1 = c2 = O.identity_coords(B, h)
         kw = dict(shared_coords=True, identity_grid=True)

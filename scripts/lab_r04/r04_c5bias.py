@@ -2,7 +2,7 @@
 """developer aid (round 4): signed error of the loss means against the oracle on dense grids of growing size, B = 2, for the library
 named by DEPTHG_LIB - where does config 5's 8e-5 come from?   python scripts/r04_c5bias.py [S ...]"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from depthg_amd import ContrastiveCorrelationLoss

@@ -1,6 +1,6 @@
 """developer check of k_corr_small's cd precision: materialised cd tensors against the oracle's fp32 / an fp64 recomputation"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from depthg_amd import ContrastiveCorrelationLoss
 from oracle import depthg_oracle as O

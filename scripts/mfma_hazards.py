@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static audit of MFMA result hazards in hipcc's generated assembly (tests/test_host_cpu.py runs it on dg_corr2.hip).
+"""Static audit of MFMA (and dot-product) result hazards in hipcc's generated assembly (tests/test_host_cpu.py runs it on
+dg_corr2.hip; the dot rule on dg_small.hip, the only other file with an arithmetic instruction in inline asm).
 
 Why: every MFMA of k_corr2 is `asm volatile` with literal register operands, so hipcc's hazard recogniser does not know that the
 destination registers of such an instruction are not readable for a number of wait states.  Round 4 found a compiler-generated
@@ -162,6 +163,47 @@ def audit(asm_text, kernel=None, required=REQUIRED):
     return bad, {"mfma": n_mfma, "instructions": len(ins), "closest_touch_wait_states": min_seen}
 
 
+DOT_REQUIRED = 3
+
+
+def audit_dots(asm_text, kernel=None, required=DOT_REQUIRED):
+    """The other hazard an inline-asm statement can hide from hipcc (GCNHazardRecognizer's DotWriteDifferentVALURead / -Write on
+    gfx940+): the result of a v_dot* instruction may be touched by an instruction of ANOTHER opcode only `required` wait states
+    later; the same opcode accumulating into it (SrcC == vDst) needs none.  dg_small.hip's squared norms are asm `v_dot2c_f32_bf16`
+    (the builtin was miscompiled): the compiler pads its own dot instructions, not these.
+    -> (violations as (dot Ins, offending Ins, wait states), number of dot instructions seen)"""
+    ins, labels = parse(asm_text, kernel)
+    bad, ndot = [], 0
+    for M in ins:
+        if not M.mnem.startswith("v_dot"):
+            continue
+        ndot += 1
+        dst = regs_of(M.ops[0]) if M.ops else set()
+        stack, seen = [(M.idx + 1, 1)], set()
+        while stack:
+            i, t = stack.pop()
+            while i < len(ins) and t < required:
+                J = ins[i]
+                if (i, t) in seen:
+                    break
+                seen.add((i, t))
+                touch = J.touch if not J.is_mfma else (J.dst | J.ab | J.c)
+                if touch & dst:
+                    if J.mnem == M.mnem and regs_of(J.ops[0]) == dst:
+                        break                               # the same dot accumulating on: its own walk covers the registers
+                    bad.append((M, J, t))
+                t += J.wait
+                if J.kind == "end":
+                    break
+                if J.kind == "branch":
+                    i = labels.get(J.target, len(ins))
+                    continue
+                if J.kind == "cbranch" and J.target in labels:
+                    stack.append((labels[J.target], t))
+                i += 1
+    return bad, ndot
+
+
 def main():
     text = open(sys.argv[1]).read()
     bad, stats = audit(text, sys.argv[2] if len(sys.argv) > 2 else None)
@@ -169,7 +211,11 @@ def main():
     for M, J, t in bad[:40]:
         print(f"line {J.line_no}: `{J.text}` touches the result of line {M.line_no} `{M.text}` after {t} wait states (< {REQUIRED})")
     print(f"{len(bad)} violation(s)")
-    return 1 if bad else 0
+    dbad, ndot = audit_dots(text, sys.argv[2] if len(sys.argv) > 2 else None)
+    for M, J, t in dbad[:40]:
+        print(f"line {J.line_no}: `{J.text}` touches the result of line {M.line_no} `{M.text}` after {t} wait states (< {DOT_REQUIRED})")
+    print(f"{ndot} dot instruction(s), {len(dbad)} violation(s)")
+    return 1 if (bad or dbad) else 0
 
 
 if __name__ == "__main__":

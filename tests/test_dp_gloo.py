@@ -296,6 +296,40 @@ def test_bench_gpus_n_spawns_n_ranks_by_itself():
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["config"]["parallelism"] == "dp2"
 
 
+@pytest.mark.timeout(300)
+def test_bench_four_rank_dry_run_with_unequal_warmups():
+    """World 4: the schedule class driven by bench.py's own rank code over gloo, every rank with another warm-up count (no collective
+    in there), then the same number of steps - each step's bucket must be the mean over the FOUR ranks of that step's pattern."""
+    import json
+    r = _run_bench(["--gpus", "4", "--steps", "5", "--warmup", "2"], {"DG_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 4 and line["config"]["ranks_seen"] == 4
+    assert len(set(line["warm_calls_by_rank"])) == 4 and line["steps_paired_on_every_rank"] is True
+
+
+def test_device_count_comes_from_sysfs_not_from_the_runtime(tmp_path):
+    """spawn_ranks' parent must not touch HIP: GPUs are the KFD topology nodes with SIMDs; a visible-devices list caps the count;
+    an unreadable topology gives None; a profiler preload is recognised from the environment."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert bench.count_gpus_sysfs(str(tmp_path), {}) == 3
+    assert bench.count_gpus_sysfs(str(tmp_path), {"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert bench.count_gpus_sysfs(str(tmp_path / "missing"), {}) is None
+    assert bench.profiler_preloaded({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert bench.profiler_preloaded({"ROCPROFILER_LIBRARY_CTOR": "1"}) and not bench.profiler_preloaded({"PATH": "/usr/bin"})
+    src = open(os.path.join(root, "bench.py")).read()
+    body = src[src.index("def spawn_ranks"):src.index("def dryrun_rank")]
+    assert "torch.cuda" not in body.split('"""')[2]            # (the code behind the docstring)
+
+
 def test_bench_refuses_a_line_for_more_gpus_than_ranks():
     # a launcher that made ONE rank for --gpus 2: no line, non-zero exit (round 4's bench printed n_gpus: 1 and exited 0)
     r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "DG_BENCH_DRYRUN": "1"})

@@ -53,7 +53,7 @@ def _relclose(got, want, rtol, atol, what):
 def test_golden_forward_backward(case, dev):
     fx = load_golden(f"forward_{case}.npz")
     cfg, out, total, g_code, g_code_pos = _run_fixture(fx, dev)
-    RT, AT = 2e-3, 1e-5
+    RT, AT = 1e-3, 1e-5          # (measured <= 9.6e-4 over the cases, near-cancelling means included: scripts/print_golden_errors.py)
     _relclose(out[0], fx["pos_intra_loss"], RT, AT, "pos_intra_loss")
     _relclose(out[2], fx["pos_inter_loss"], RT, AT, "pos_inter_loss")
     _relclose(out[4].mean(), fx["neg_inter_loss_mean"], RT, AT, "neg_inter_loss.mean")
@@ -63,7 +63,7 @@ def test_golden_forward_backward(case, dev):
     if cfg.depth_feat_correlation_loss:
         _relclose(out[6], fx["depth_feat_loss"], RT, AT, "depth_feat_loss")
         _relclose(out[7].mean(), fx["depth_feat_cd_mean"], 1e-6, 1e-7, "dd mean")
-    _relclose(total, fx["total"], 2e-3, 1e-5, "total")           # (measured <= 9.6e-4 over the cases: scripts/print_golden_errors.py)
+    _relclose(total, fx["total"], RT, AT, "total")
     sub = int(fx["sub"])
     pick = (lambda t: t.detach().cpu().numpy()) if bool(fx["store_full"]) else \
         (lambda t: t.detach().reshape(-1)[::sub].cpu().numpy())
@@ -651,16 +651,15 @@ def test_topk_rows_kernel(dev):
         ops.topk_rows(m.to(dev), 65)
 
 
-@pytest.mark.parametrize("engine", ["hip", "rocblas"])
 @pytest.mark.parametrize("name", ["small", "wide"])
-def test_nearest_neighbors_table(name, engine, dev):
-    """knn.nearest_neighbors (similarity slice on the fp32 MFMA - dg_knn_similarities - or by the vendor GEMM, then dg_topk_rows)
+def test_nearest_neighbors_table(name, dev):
+    """knn.nearest_neighbors (similarity slice on the fp32 MFMA - dg_knn_similarities - then dg_topk_rows)
     against the table the reference's calls produce on the same features: identical except where two similarities are closer
     than the float32 rounding of the two GEMMs (5e-6)."""
     from depthg_amd import knn
     fx = load_golden("knn.npz")
     feats = torch.from_numpy(fx[f"{name}_feats"])
-    got = knn.nearest_neighbors(feats.to(dev), k=30, n_batches=int(fx[f"{name}_nbatches"]), engine=engine)
+    got = knn.nearest_neighbors(feats.to(dev), k=30, n_batches=int(fx[f"{name}_nbatches"]))
     want = torch.from_numpy(fx[f"{name}_nns"])
     assert got.shape == want.shape and got.dtype == torch.int64 and not got.is_cuda
     sims = feats.double() @ feats.double().t()
