@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <optional>
 
 // ---- error reporting
 static thread_local char g_err[512] = "";
@@ -155,13 +156,13 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
                                         "identity grid with C <= 384 (padded to 384), D <= 80, P >= 160, B <= 64, zero_clamp without stabalize");
     for (int t = 0; t < p.T; ++t) p.maskbits[t] = take((p.xmask || p.xmask_dense) ? B * (size_t)(p.Ppad / 32) * p.Ppad * 4 : 0);
     // FOLD: gradient passes of the pointwise recipe that k_corr2 runs (dg_corr2_shape_supported: the launcher's own predicate; the
-    // job-level conditions - stationary = operand 1, G tiles wanted, no batch map on R - hold for every gradient pass) without exact mask words; DG_FOLD_INTRA=0 keeps the k_gs job (developer A/B)
+    // job-level conditions - stationary = operand 1, G tiles wanted, no batch map on R - hold for every gradient pass); DG_FOLD_INTRA=0 keeps the k_gs job (developer A/B)
     {
         static const bool fold_on = [] { const char* e = getenv("DG_FOLD_INTRA"); return !(e && e[0] == '0'); }();
         float lo, hi;
         clamp_bounds(d, lo, hi);
         p.fold = fold_on && p.grad && p.pointwise && !p.small && dg_corr2_shape_supported(p.KF, p.KD, p.D, lo, hi, p.Ppad, p.B) &&
-                 !p.xmask && !p.xmask_dense;
+                 !p.xmask;          // (with the dense grid's exact mask words too, since round 6: k_corr2<.., XM, .., FOLD>)
     }
     for (int i = 0; i < 2; ++i) p.clo[i] = take((p.xmask_dense && p.pointwise) ? B * (size_t)(p.Ppad / 32) * p.KD * 64 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
@@ -251,7 +252,7 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
 // A second stream of the library's own (one per device, created on the first call that is not being captured into a graph) for the
 // launches that may run beside each other inside one call; null while none exists and the caller's stream is capturing (creating
 // one there is not a capturable operation: the call then launches in sequence).
-struct SideStream { hipStream_t s; hipEvent_t fork, join; std::mutex use; };
+struct SideStream { hipStream_t s; hipEvent_t fork, join, mid[2]; std::mutex use; };
 static SideStream* side_stream_for(hipStream_t caller) {
     static std::mutex mu;
     static std::map<int, SideStream> table;
@@ -263,15 +264,17 @@ static SideStream* side_stream_for(hipStream_t caller) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(caller, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
     hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};       // fork, join, two hand-overs from the side stream in mid-region
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-        if (fork) (void)hipEventDestroy(fork);          // nothing half-made stays behind: the call launches in sequence instead
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (int i = 0; i < 4; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);      // nothing half-made stays behind: the call launches in sequence instead
         (void)hipStreamDestroy(s);
         return nullptr;
     }
     SideStream& ss = table[dev];        // (std::map nodes do not move: the pointer stays valid; std::mutex is not copyable)
-    ss.s = s; ss.fork = fork; ss.join = join;
+    ss.s = s; ss.fork = ev[0]; ss.join = ev[1]; ss.mid[0] = ev[2]; ss.mid[1] = ev[3];
     return &ss;
 }
 
@@ -297,10 +300,17 @@ struct SideRegion {
         forked = e == hipSuccess;
         return e;
     }
+    void reset() { forked = join_recorded = joined = false; }         // (after a join: the region may fork again)
     hipError_t record_join() {
         hipError_t e = hipEventRecord(side->join, side->s);
         join_recorded = e == hipSuccess;
         return e;
+    }
+    // hand-over i in mid-region: everything launched on the side stream so far is ordered in front of what the caller launches next
+    hipError_t hand_over(int i) {
+        hipError_t e = hipEventRecord(side->mid[i], side->s);
+        if (e != hipSuccess) return e;
+        return hipStreamWaitEvent(caller, side->mid[i], 0);
     }
     hipError_t join() {
         if (!forked || joined) return hipSuccess;
@@ -421,6 +431,12 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
 }
 
 struct DrawArgs { int64_t* out; uint64_t seed; unsigned long long* state; };
+
+// (DG_SPLIT_MASKS=0: the exact-mask chain of the dense grid in sequence on the caller's stream, developer A/B)
+static bool split_masks_enabled() {
+    static const bool on = [] { const char* e = getenv("DG_SPLIT_MASKS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 // ---- the fused small-grid path (dg_small.hip)
 static void small_args(const Plan& p, const dg_corr_desc* d, char* ws, const int64_t* perms, DgSmallArgs& a) {
@@ -573,6 +589,15 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
     char* ws = static_cast<char*>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
 
+    // Exact clamp masks on the dense grid (round 6): the mask words depend on the code maps and the batch maps only, so their chain
+    // (code norms + draw -> code operands -> k_cd_mask3) runs on the library's side stream BESIDE the feature side of the preparation
+    // (k_prep_dense's feats, k_colmean, k_rowmean) instead of in front of the fused kernel: the same launches split by role, joined
+    // in front of the fused kernel.  Without a side stream (first call inside a capture) everything runs in sequence as before.
+    // (the region object - it holds the side stream's lock - exists only on calls that use it; the k_gs launches below re-use it)
+    std::optional<SideRegion> side_region;
+    if (p.xmask_dense && p.ident && split_masks_enabled()) side_region.emplace(stream);
+    const bool split = side_region && static_cast<bool>(*side_region) && p.pointwise;
+    SideRegion* const sidep = side_region ? &*side_region : nullptr;      // (only touched under `split`)
     DgPreArgs pre_late;
     memset(&pre_late, 0, sizeof(pre_late));
     // 1.+2. operands.  Identity grid: one launch builds both feats and both code operands straight from NCHW (+ the
@@ -589,6 +614,14 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
         if (fk) { g.fkeep[0] = fk->keep[0]; g.fkeep[1] = fk->keep[1]; g.fscale = fk->scale; }
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
+        if (split) {
+            // the code roles (norms) and the draw on the side stream - the chain code norms -> code operands -> mask words hangs
+            // off them and runs beside the feature operands, their means and the row means
+            DgDenseArgs gs = g;
+            gs.roles = 2 | 8; g.roles = 1 | 4;
+            DG_HIP(sidep->fork());
+            DG_HIP(dg_launch_prep_dense(gs, sidep->stream()));
+        }
         DG_HIP(dg_launch_prep_dense(g, stream));
         if (p.xmask_dense && !p.pointwise) {
             // exact clamp masks without `pointwise` (the code operands are then built by k_prep_dense itself, without the parts the
@@ -717,6 +750,12 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             c.dc.B = p.B; c.dc.D = p.D; c.dc.KF = p.KF; c.dc.KD = p.KD; c.dc.h = p.h; c.dc.w = p.w; c.dc.P = p.P; c.dc.Ppad = p.Ppad;
             if (p.xmask_dense) { c.dc.clo[0] = ws + p.clo[0]; c.dc.clo[1] = ws + p.clo[1]; }
         }
+        if (split) {
+            DgColmeanArgs cs = c;
+            cs.zsel = 1; c.zsel = 2;
+            DG_HIP(sidep->hand_over(0));                        // the draw (and the norms): the consumer lists below read the batch maps
+            DG_HIP(dg_launch_colmean(cs, sidep->stream()));     // code operands (+ what the fp16 C parts drop)
+        }
         DG_HIP(dg_launch_colmean(c, stream));
     }
     if (p.xmask_dense && p.pointwise) {
@@ -730,7 +769,14 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         }
         const DgBlob bl(p.KF, p.KD);
         m.T = p.T; m.B = p.B; m.Ppad = p.Ppad; m.blob_bytes = bl.bytes; m.off_c = bl.off_c; m.KD = p.KD;
-        DG_HIP(dg_launch_cd_mask3(m, stream));
+        if (split) {
+            DG_HIP(sidep->hand_over(1));                        // the code operands: k_rowmean reduces their column sums and writes FOLD's
+                                                              // stash into the padding they zeroed
+            DG_HIP(dg_launch_cd_mask3(m, sidep->stream()));
+            DG_HIP(sidep->record_join());
+        } else {
+            DG_HIP(dg_launch_cd_mask3(m, stream));
+        }
     }
     if (p.pointwise) {
         DgRowmeanArgs r;
@@ -751,6 +797,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
     }
 
     // 4. fused correlation passes
+    if (split) DG_HIP(sidep->join());                           // the mask words
     DG_HIP(launch_main(p, a, njA, depth_index, stream));
 
     // 5. scalar outputs: the partial sums are reduced by the next launch (k_gs on a gradient pass)
@@ -790,7 +837,9 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             // bytes, the 128 depth blocks by a latency chain on half the CUs (one behind the other: 76 + 52 us)
             DgGsArgs gstream = g;
             gstream.dep_blocks = 0; gstream.fin.out = nullptr;
-            SideRegion side(stream);
+            if (!side_region) side_region.emplace(stream);
+            SideRegion& side = *side_region;
+            side.reset();                                     // (a second fork .. join of the same region object)
             if (side) {
                 DG_HIP(side.fork());
                 DG_HIP(dg_launch_gs(g, dep_maskbits, side.stream(), true));

@@ -507,6 +507,8 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     // 1 / 0 of source o or null, the kept channels scaled by fscale = 1/(1-p) - the product the producer would have written
     const float* fkeep[2];
     float fscale;
+    int32_t roles;           // 0: every role; else a mask of the roles THIS launch runs - 1 feats, 2 code, 4 depth indicators, 8 the draw
+                             // (the launch split in two that run on two streams: dg_api.hip, exact clamp masks on the dense grid)
 };
 
 // Code operands of the identity grid from whole channel planes (extra blocks of the k_colmean launch, after the norms of
@@ -573,6 +575,8 @@ struct DgColmeanArgs {      // bbar[o][n][k] = (1/P) sum_groups colpart[o][n][gr
     unsigned int* zero_words9;         // nine words this launch sets to 0 (DgCorrArgs.wctr), or null
     DgGroupArgs gr;                    // gr.nkeys > 0: blockIdx.z == 2 writes the consumer lists of k_corr2's grouped ragged blocks
     DgDenseCodeArgs dc;                // dc.B > 0: blockIdx.z == 3 builds the dense code operands (and blockIdx.z == 1 is the k_rowmean launch's)
+    int32_t zsel;                      // 0: every role; 1: only the dense code operands (blockIdx.z == 3); 2: every role but them - the launch
+                                       //    split in two that run on two streams (dg_api.hip, exact clamp masks on the dense grid)
 };
 
 struct DgRowmeanJob {

@@ -207,13 +207,19 @@ template <int NKF, int NKD, int NKC, bool XM = false, bool DYN = false, bool FOL
 __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     using BL = BlobT<NKF, NKD>;
     constexpr int RF = 2, NW = 4, KD = BL::KD, NDF = KD / 32, DP = KD;
-    constexpr int BUF = BL::BYTES, NS = NKF + NKC + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
-    static_assert(!FOLD || (NKC < NKD && !XM), "FOLD needs a spare code k-step in the blob; not combined with the exact-mask form");
+    // chain steps per fragment and tile: the NKF feature k-steps, the NKC code k-steps - NOT in the exact-mask form (round 6): its mask
+    // comes from the words of k_cd_mask3 and G = m (fd'' - shift) needs no cd; the loss and cd sums come out of the gradient tiles and
+    // the column sums as ever, so the fp16 cd chain was 10 dead MFMAs of 70 per tile - and FOLD's one extra step
+    constexpr int BUF = BL::BYTES, NS = NKF + (XM ? 0 : NKC) + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+    static_assert(!FOLD || NKC < NKD, "FOLD needs a spare code k-step in the blob");
     constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
     static_assert(BL::CHUNKS % NW == 0, "tile chunks must split evenly over the waves");
     static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
-    static_assert(10 + 2 * PIECES <= NS && NS >= 26 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
+    // phase-A gaps: 0, 1 mask words, 2..9 the epilogue halves of fragment 1, then the DMA pieces of tile t + 3 - each in two halves over
+    // two neighbouring gaps where the chain is long enough (SPLIT_DMA), whole in one gap otherwise (the exact-mask form's short chain)
+    constexpr bool SPLIT_DMA = 10 + 2 * PIECES <= NS;
+    static_assert(10 + PIECES <= NS - 3 && NS >= 22 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] tiles, red[8][4]
     declare_agprs();
 #ifdef C2_STAMPS
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     auto rd_step = [&](auto ST, v4i_t& d) {               // A fragment of chain step ST (feature k-steps, then code k-steps)
         constexpr int st = ST.value;
         if constexpr (st < NKF) { if constexpr (st & 1) lds_rd<(st >> 1) * 2048>(d, va1); else lds_rd<(st >> 1) * 2048>(d, va0); }
-        else lds_rd<(st - NKF) * 1024>(d, vc);
+        else lds_rd<(XM ? NKC : st - NKF) * 1024>(d, vc);          // (XM: the only step behind the feature steps is FOLD's, code k-step NKC)
     };
 
     acc_t Yf[RF], Yc[RF];
@@ -543,10 +549,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         auto& YcL = Yc;                      // (named outside the asm operand below: clang captures it for the generic lambda only so)
         if constexpr (XM) {
             ga[f][j >> 2][j & 3] = epi2m<j>(yf[2 * j], yf[2 * j + 1], wsh[f], lo16);
-            // (the mask comes from the words, so the cd chain's result is dead here and hipcc hands its registers to address
-            //  arithmetic as soon as 11 wait states behind the chain's last asm MFMA - whose late write-back it knows nothing about.
-            //  Keep them reserved until the epilogue, as in the form that reads them: scripts/mfma_hazards.py audits the rule)
-            if constexpr (j == 7) asm volatile("" :: "v"(YcL[f]));
+            (void)YcL;                       // (no cd chain in this form: the mask comes from the words)
         } else {
             const f32x16 yc = __builtin_bit_cast(f32x16, Yc[f]);
             ga[f][j >> 2][j & 3] = epi2(yf[2 * j], yf[2 * j + 1], yc[2 * j], yc[2 * j + 1], perm_sel);
@@ -646,8 +649,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 }
                 if constexpr (st == 0) mfma_fd8_from<f * NKF>(Yf[f], ra[idx % PF], c0splat[f]);
                 else if constexpr (st < NKF) mfma_fd8<f * NKF + st>(Yf[f], ra[idx % PF]);
-                else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
                 else if constexpr (FRUN && st == NS - 1) mfma_h8(Yf[f], ra[idx % PF], ga[f][0]);      // Z: the streamed position's half of the centering
+                else if constexpr (st == NKF) mfma_h80(Yc[f], ra[idx % PF], Rc[f][0]);
                 else mfma_h8(Yc[f], ra[idx % PF], Rc[f][st - NKF]);
                 if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
             };
@@ -663,10 +666,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 if constexpr (XM && ACT0 && st == 0) mask_issue(0, t + 3);
                 if constexpr (XM && ACT1 && st == 1) { mask_issue(1, t + 2); mask_prep(wsh[1], mwB, msh); }
                 if constexpr (ACT1 && st >= 2 && st < 10) epi1_half(std::integral_constant<int, st - 2>{});
-                if constexpr (st >= 10 && st < 10 + 2 * PIECES) {           // piece k: M0 + offset in gap 10 + 2k, the load in gap 11 + 2k
+                if constexpr (SPLIT_DMA && st >= 10 && st < 10 + 2 * PIECES) {           // piece k: M0 + offset in gap 10 + 2k, the load in gap 11 + 2k
                     constexpr int k = (st - 10) / 2;
                     if constexpr (((st - 10) & 1) == 0) dma_setup<k * 4096>(dst2, dma_voff, dtmp); else dma_go(dtmp, sb2);
                 }
+                if constexpr (!SPLIT_DMA && st >= 10 && st < 10 + PIECES) dma_piece<(st - 10) * 4096>(dst2, dma_voff, sb2);
                 if constexpr (FRUN && ACT0 && st == NS - 3) ga[0][0] = v4i_t{fo[0] ? fold_w : 0, 0, 0, 0};
                 if constexpr (ACT1 && st == NS - 1) { if (t > 0) g_store(1, 0, t - 1); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -772,11 +776,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(dRv[0]), "+v"(dRv[1]));
     };
     // "previous tile" state of fragment 1 in front of tile 0: cd = -1 everywhere (mask off, G = 0), zero gradient B fragments
+    // (XM: the word of that state, mwB, starts as zero - every element off)
+    if constexpr (!XM) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) Yc[1][i] = __builtin_bit_cast(double, make_float2(-1.f, -1.f));
+        for (int i = 0; i < 8; ++i) Yc[1][i] = __builtin_bit_cast(double, make_float2(-1.f, -1.f));
+        asm volatile("" : "+v"(Yc[1]));
+    }
 #pragma unroll
     for (int q = 0; q < 2 * NDF; ++q) bP[q] = v4i_t{0, 0, 0, 0};
-    asm volatile("" : "+v"(Yc[1]));
 #ifdef C2_BLOCKLOG
     // (e[13], e[14]: the shader clock - s_memtime - at the two ends of the tile loop, next to the 100-MHz wall clock in e[3], e[4]:
     //  cycles / wall time = the clock this CU HELD while it ran the loop, scripts/held_clock.py)
@@ -977,7 +984,10 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
         const int smem_x = 4 * BL::BYTES + C2_RED_BYTES + 4 * 2 * 4 * 256;
         const int gx = dg_corr2_launch_grid(args);
         const bool dynx = dg_corr2_dynamic_walk(args, gx);
-        auto kx = dynx ? k_corr2<24, 6, 5, true, true> : k_corr2<24, 6, 5, true, false>;
+        bool foldx = false;
+        for (int j = 0; j < args.njobs; ++j) foldx = foldx || args.jobs[j].fold != 0;
+        auto kx = foldx ? (dynx ? k_corr2<24, 6, 5, true, true, true> : k_corr2<24, 6, 5, true, false, true>)
+                        : (dynx ? k_corr2<24, 6, 5, true, true> : k_corr2<24, 6, 5, true, false>);
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
         hipLaunchKernelGGL(kx, dim3(gx), dim3(256), smem_x, stream, args);

@@ -934,10 +934,12 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     const int gx = a.Ppad / 32;                          // blocks per (image, role): one per tile (>= what the code roles need: launcher)
     const int nz = a.depth ? 5 : 4;                      // image-major: every XCD gets whole images, all roles
     const int x = bid % gx, z = (bid / gx) % nz, n = bid / (gx * nz);
+    const int roles = a.roles ? a.roles : 15;
     if (n >= a.B) {                                      // the trailing blocks: the negatives' batch maps of this step
-        dg_super_perm_row(nullptr, a.draw_seed, a.draw_state, a.B, a.draw_out, bid - gx * nz * a.B, a.draw_count, sl);
+        if (roles & 8) dg_super_perm_row(nullptr, a.draw_seed, a.draw_state, a.B, a.draw_out, bid - gx * nz * a.B, a.draw_count, sl);
         return;
     }
+    if (!(roles & (z < 2 ? 1 : (z < 4 ? 2 : 4)))) return;         // (a role of the other launch of a split call)
     if (z < 2) {
         if (!(DG_DBG(a.debug) & 1)) prep_dense_feats<MAXU, FK>(a, sl, x, n, z);
     } else if (z < 4) {
@@ -1011,6 +1013,7 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
     if (a.zero_word && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     if (a.zero_words9 && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x < 9) a.zero_words9[threadIdx.x] = 0u;
     auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) { colsum_reduce(part, n, ngroups, K, scale, out); };
+    if (a.zsel == 1 ? blockIdx.z != 3 : (a.zsel == 2 && blockIdx.z == 3)) return;      // (one half of a split launch)
     if (blockIdx.z == 3) {                                // dense code operands from channel planes: y = operand * (KD / 8) + channel group
         const int GD = a.dc.KD / 8;
         if ((int)blockIdx.y < 2 * GD) dense_code_planes(a.dc, cm_smem, n, (int)blockIdx.y / GD, (int)blockIdx.y % GD);

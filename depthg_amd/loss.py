@@ -262,6 +262,9 @@ class ContrastiveCorrelationLoss(nn.Module):
             orig_feats, orig_feats_pos, feat_keep = self._unwrap_deferred(orig_feats, orig_feats_pos)
         if not _checked:
             self._check_maps(orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth)
+        if identity_grid and tuple(orig_code.shape[-2:]) != tuple(orig_feats.shape[-2:]):
+            raise ValueError(f"depthg_amd: the identity grid needs code maps of the feature maps' size, got "
+                             f"{orig_code.shape[-2]}x{orig_code.shape[-1]} against {orig_feats.shape[-2]}x{orig_feats.shape[-1]}")
         if identity_grid and int(cfg.feature_samples) ** 2 <= SMALL_GRID_POSITIONS and not getattr(cfg, "dg_small_identity_blobs", False):
             # Dense grids of at most 160 positions (7 x 7 ... 12 x 12) do NOT take the identity-grid launches: the identity
             # coordinates go through the sampler like any others (what the reference does with them) and the fused small-grid kernel
@@ -285,8 +288,6 @@ class ContrastiveCorrelationLoss(nn.Module):
         B, C, h, w = orig_feats.shape
         D, hc, wc = orig_code.shape[1:]
         same_maps = (hc, wc) == (h, w)
-        if identity_grid and not same_maps:
-            raise ValueError(f"depthg_amd: the identity grid needs code maps of the feature maps' size, got {hc}x{wc} against {h}x{w}")
         S, N = int(cfg.feature_samples), int(cfg.neg_samples)
         if tuple(coords1.shape) != tuple(coords2.shape) or tuple(coords1.shape) not in ((B, S, S, 2), (B, S, 1, 2)):
             raise ValueError(f"depthg_amd: coords must both be (B,S,S,2) or (B,S,1,2) with B={B}, S={S}; got "

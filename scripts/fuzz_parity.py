@@ -114,7 +114,7 @@ def one(seed):
             continue
         rel = float((got.cpu() - want).norm() / want.norm())
         # (D == 1: the normalised code is +-1 and its gradient vanishes identically - both sides hold rounding noise only)
-        tiny = float(got.abs().max()) < 1e-7 and float(want.abs().max()) < (1e-6 if D == 1 else 1e-7)      # (the oracle's noise reached 1.4e-7 at D = 1)
+        tiny = max(float(got.abs().max()), float(want.abs().max())) < (1e-6 if D == 1 else 1e-7)      # (noise at D = 1: the oracle's reached 1.4e-7, the fused small-grid kernel's 1.6e-7 - seed 9053 of the edge sweep)
         if rel > 4e-2 and not tiny:
             # what a failure is made of: the elements of the oracle's cd within 1e-3 of a clamp threshold (the fp16 cd of the
             # fused kernels may clamp those the other way: on a grid of a few positions ONE such element is percents of the
