@@ -690,9 +690,15 @@ def main():
         share = 2.0 * H["B"] * (H["S"] ** 2) ** 2 * H["D"] / 1e9
         main_gf += share
         gs_gf -= share
-    achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # which kernel that launch is: the library's own predicate (dg_corr_main_kernel_name), not a copy of it
     kname = ops.corr_main_kernel_name(desc)
+    # exact clamp masks on the dense grid: k_corr2's exact-mask form has NO cd chain (round 6) - the mask words come from k_cd_mask3,
+    # which forms every cd in split fp16 (three times the MFMAs of the chain) - so the (2 + n) code correlations of the forward are
+    # not the fused launch's work any more: they leave its algorithmic flops (nothing is credited for k_cd_mask3's recomputation)
+    cd_outside = bool(args.exact_masks) and kname == "k_corr2" and H["S"] ** 2 > 160
+    if cd_outside:
+        main_gf -= (2 + H["n_neg"]) * 2.0 * H["B"] * (H["S"] ** 2) ** 2 * H["D"] / 1e9
+    achieved = main_gf / 1e3 / (kern_ms / 1e3)   # TFLOP/s of the fused kernel alone
     # HBM bytes per launch of that kernel: counters cannot be read from inside a run, so this is the figure of the committed PMC
     # passes of THIS round (scripts/profile_round.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) - null when there is none
     traffic, traffic_source = None, None
@@ -715,7 +721,7 @@ def main():
                 "kernel_ms_method": kern_method + "; kernel_ms_diff: [step + 1 extra launch] - [step], 5 x 20 iterations, median; "
                                     "kernel_ms_loop: 20 back-to-back re-launches",
                 "algorithmic_gflop_per_launch": round(main_gf, 2), "algorithmic_gflop_per_step": round(step_gf, 2),
-                "intra_folded": bool(intra_folded),
+                "intra_folded": bool(intra_folded), "cd_in_mask_kernel": cd_outside,
                 # the shader clock the kernel's CUs held while they ran it (sum of the workgroups' s_memtime cycles / sum of their
                 # 100-MHz wall ticks, same 16 in-step samples as kernel_ms) and the fraction of the peak AT THAT CLOCK: the
                 # 2.5-PFLOP/s peak is 1024 SIMDs x 1024 flop/cycle at 2.4 GHz.  Box-to-box differences of `frac` with equal
