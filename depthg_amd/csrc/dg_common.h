@@ -735,6 +735,7 @@ struct DgCdMask3Args {
     const int64_t* sidx[DG_MAX_NEG + 2];     // batch map of the streamed operand (null: identity)
     uint32_t* bits[DG_MAX_NEG + 2];          // [B][Ppad/32][Ppad] out (the format of DgCdMaskArgs.bits)
     int32_t T, B, Ppad, blob_bytes, off_c, KD;
+    int32_t nsplit;                          // parts the walk over the S tiles is split in (0: the launcher decides)
 };
 hipError_t dg_launch_cd_mask3(const DgCdMask3Args& a, hipStream_t s);
 hipError_t dg_launch_plane_sample(const DgPlaneArgs& a, hipStream_t s);

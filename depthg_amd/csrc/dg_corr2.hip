@@ -210,7 +210,12 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     // chain steps per fragment and tile: the NKF feature k-steps, the NKC code k-steps - NOT in the exact-mask form (round 6): its mask
     // comes from the words of k_cd_mask3 and G = m (fd'' - shift) needs no cd; the loss and cd sums come out of the gradient tiles and
     // the column sums as ever, so the fp16 cd chain was 10 dead MFMAs of 70 per tile - and FOLD's one extra step
-    constexpr int BUF = BL::BYTES, NS = NKF + (XM ? 0 : NKC) + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+#ifdef C2_XM_KEEP_CD        // (developer A/B: the exact-mask form with its dead cd chain, as until round 5)
+    constexpr bool NOCD = false;
+#else
+    constexpr bool NOCD = XM;
+#endif
+    constexpr int BUF = BL::BYTES, NS = NKF + (NOCD ? 0 : NKC) + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
     static_assert(!FOLD || NKC < NKD, "FOLD needs a spare code k-step in the blob");
     constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
@@ -218,7 +223,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     static_assert(ADR + RF * 2 * 16 <= 256 && NDF == 3, "accumulator-file plan: Rf + four gradient accumulators");
     // phase-A gaps: 0, 1 mask words, 2..9 the epilogue halves of fragment 1, then the DMA pieces of tile t + 3 - each in two halves over
     // two neighbouring gaps where the chain is long enough (SPLIT_DMA), whole in one gap otherwise (the exact-mask form's short chain)
+#ifdef C2_FORCE_SINGLE_DMA  // (developer A/B)
+    constexpr bool SPLIT_DMA = false;
+#else
     constexpr bool SPLIT_DMA = 10 + 2 * PIECES <= NS;
+#endif
     static_assert(10 + PIECES <= NS - 3 && NS >= 22 && NS > PF, "phase-A gaps for the epilogue halves and the DMA pieces / phase-B gaps");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][BUF] tiles, red[8][4]
     declare_agprs();
@@ -432,18 +441,26 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         });
     };
     load_rfrag(std::integral_constant<int, 0>{});
+    // (NOCD - the exact-mask form, which has no cd chain: these fragments are needed at the block end only, and are loaded THERE by
+    //  ordinary loads.  As asm loads up here with no reader inside the loop, hipcc - for which an asm statement's output exists the
+    //  moment the statement ends - copied them to other registers before they had landed: NaN loss sums, round 6.)
     v4i_t Rc[RF][NKC];                                    // B operands of the cd chain: granule 2k + h of row r
+    const char* rc_lane[RF];                              // (NOCD: this lane's address of granule h, kept in a vector register pair - as
+                                                          //  scalar pointers across the tile loop they spilled into VGPR lanes)
+#pragma unroll
+    for (int f = 0; f < RF; ++f) { rc_lane[f] = Rblob[f] + BL::OFF_C + (h * 32 + r) * 16; if constexpr (NOCD) asm volatile("" : "+v"(rc_lane[f])); }
 #pragma unroll
     for (int f = 0; f < RF; ++f)
 #pragma unroll
-        for (int k = 0; k < NKC; ++k)
+        for (int k = 0; k < (NOCD ? 0 : NKC); ++k)
             // (asm: a load hipcc knows about would make it wait for vmcnt at the first use INSIDE the tile loop - on every
             //  iteration, draining the DMA pipeline; these complete before the first tile's counted wait: they are older)
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rc[f][k]) : "v"(Rblob[f] + BL::OFF_C + ((2 * k + h) * 32 + r) * 16) : "memory");
     sfor<RF * 2 * 4>([&](auto I) { agpr_zero4<ADR + 4 * I.value>(); });
     // the streamed image: its batch-map entry has landed (it is the oldest load; younger: 2 RF small inputs, NKF + RF NKC fragment loads)
-    static_assert(2 * RF + NKF + RF * NKC == 38, "literal wait count below");
-    asm volatile("s_waitcnt vmcnt(38)" : "+v"(mS_ld) :: "memory");
+    static_assert(2 * RF + NKF + RF * NKC == 38, "literal wait counts below");
+    if constexpr (NOCD) asm volatile("s_waitcnt vmcnt(28)" : "+v"(mS_ld) :: "memory");       // (no code fragment loads)
+    else asm volatile("s_waitcnt vmcnt(38)" : "+v"(mS_ld) :: "memory");
     const int nS = __builtin_amdgcn_readfirstlane(sidx_p ? mS_ld : mS);
 #pragma unroll
     for (int d = 0; d < NDF; ++d) {
@@ -496,7 +513,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
     auto rd_step = [&](auto ST, v4i_t& d) {               // A fragment of chain step ST (feature k-steps, then code k-steps)
         constexpr int st = ST.value;
         if constexpr (st < NKF) { if constexpr (st & 1) lds_rd<(st >> 1) * 2048>(d, va1); else lds_rd<(st >> 1) * 2048>(d, va0); }
-        else lds_rd<(XM ? NKC : st - NKF) * 1024>(d, vc);          // (XM: the only step behind the feature steps is FOLD's, code k-step NKC)
+        else lds_rd<(NOCD ? NKC : st - NKF) * 1024>(d, vc);          // (XM: the only step behind the feature steps is FOLD's, code k-step NKC)
     };
 
     acc_t Yf[RF], Yc[RF];
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 
 
 #ifdef C2_STAMPS       // developer build: cycle stamps of one block's tile loop (make EXTRA="-DDG_DEVTOOLS -DC2_STAMPS", DG_STAMPS=<file>)
-    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + C2_RED_BYTES);
+    uint32_t* const st_lds = reinterpret_cast<uint32_t*>(smem + NBUF * BUF + C2_RED_BYTES + (XM ? 4 * 2 * 4 * 256 : 0));      // (XM: behind the mask-word ring)
     #ifndef C2_STAMP_N
 #define C2_STAMP_N 0
 #define C2_STAMP_J 0
@@ -809,6 +826,16 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 
     // ---- block end: raw gradient tiles (accumulator order, as k_corr_main) and the block's partial sums
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last gradient MFMAs have retired before their registers are read
+    if constexpr (NOCD) {                                       // (requested first: the gradient tiles' reads and stores run under their latency)
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+            for (int k = 0; k < NKC; ++k)
+                // (a GLOBAL-address-space load: through the generic pointer hipcc emitted flat_load_dwordx4 here and the fragments came
+                //  back wrong - NaN loss sums with correct gradients, round 6 - as they did from asm loads at the top of the block that
+                //  nothing inside the tile loop named; scripts/lab_r06_nan.py, profiles/r06_xm_block_end_loads.txt)
+                Rc[f][k] = *reinterpret_cast<const v4i_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(rc_lane[f] + k * 1024));
+    }
     float lsumf[RF] = {0.f, 0.f}, csumf[RF] = {0.f, 0.f};
     float* red = reinterpret_cast<float*>(smem + NBUF * BUF);      // [8 fragment slots][4]: loss sum, cd sum, pair-set, image
     sfor<RF>([&](auto FI) {
@@ -990,6 +1017,20 @@ hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t s
                         : (dynx ? k_corr2<24, 6, 5, true, true> : k_corr2<24, 6, 5, true, false>);
         hipError_t ex = dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x);
         if (ex != hipSuccess) return ex;
+#if defined(DG_DEVTOOLS) && defined(C2_STAMPS)
+        if (const char* stamp_file = getenv("DG_STAMPS")) {
+            static uint32_t* stamp_buf = nullptr;
+            if (!stamp_buf && hipMalloc(&stamp_buf, (4 * 25 * 6 + 16) * 4) != hipSuccess) return hipErrorOutOfMemory;
+            DgCorrArgs a2 = args;
+            a2.stamps = stamp_buf;
+            (void)dg_set_max_smem(reinterpret_cast<const void*>(kx), smem_x + (4 * 25 * 6 + 16) * 4);
+            hipLaunchKernelGGL(kx, dim3(gx), dim3(256), smem_x + (4 * 25 * 6 + 16) * 4, stream, a2);
+            uint32_t host[4 * 25 * 6 + 16];
+            if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(host, stamp_buf, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* fp = fopen(stamp_file, "wb")) { fwrite(host, 4, 4 * 25 * 6 + 16, fp); fclose(fp); }
+            return hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL(kx, dim3(gx), dim3(256), smem_x, stream, args);
         return hipGetLastError();
     }

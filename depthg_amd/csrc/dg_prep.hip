@@ -509,15 +509,24 @@ __global__ __launch_bounds__(256) void k_cd_mask(const DgCdMaskArgs a) {
 // word one v_alignbit each (first version: a compare, a select and an or per element - the launch was bound by its VALU count).
 // Output: the word format of k_cd_mask (bit i of word (S tile, R position) = S position 32 tile + i).
 typedef int v4i_m3 __attribute__((ext_vector_type(4)));
-template <int NKC>
-__global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
+// W = waves (R tiles) per block: a divisor of the tile count where there is one in 5..8 (25 tiles = 5 x 5, 98 = 14 x 7): with eight
+// waves and 25 tiles every fourth block ran ONE wave through the whole walk (round 5: 78 us for 33 us of MFMAs at the headline).
+template <int NKC, int W>
+__global__ __launch_bounds__(64 * W) void k_cd_mask3(const DgCdMask3Args a) {
+    constexpr int NT = 64 * W;
     using v4i = v4i_m3;
     constexpr int HB = 2 * NKC * 512;                    // bytes of the hi (or lo) rows of one tile that the chain reads
     constexpr int NPC = 2 * HB / 16;                     // 16-byte pieces of one staged tile (hi then lo)
     __shared__ __attribute__((aligned(16))) char buf[2][2 * HB];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
     const int nt = a.Ppad >> 5, n = blockIdx.y, t = blockIdx.z;
-    const int rt = blockIdx.x * 8 + wid;
+    // blockIdx.x = (group of W R tiles) * nsplit + part: a block walks the S tiles [s0, s1) of its part (nsplit > 1: shorter blocks, so
+    // that the launch's last round of blocks is not half empty - 1120 blocks of 25 tiles on 768 block slots at the headline)
+    const int nsplit = a.nsplit > 0 ? a.nsplit : 1;
+    const int rgrp = (int)blockIdx.x / nsplit, part = (int)blockIdx.x - rgrp * nsplit;
+    const int per = (nt + nsplit - 1) / nsplit, s0 = part * per, s1 = min(nt, s0 + per);
+    if (s0 >= s1) return;
+    const int rt = rgrp * W + wid;
     const bool act = rt < nt;
     const int nS = a.sidx[t] ? (int)a.sidx[t][n] : n;
     const size_t lo_tile = (size_t)a.KD * 64;            // bytes of one tile's lo part
@@ -545,19 +554,19 @@ __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
         return pc < HB / 16 ? sh + (size_t)st * a.blob_bytes + pc * 16 : sl + (size_t)st * lo_tile + (pc - HB / 16) * 16;
     };
     auto fetch = [&](int st, v4i& p0, v4i& p1) {
-        const int sc = st < nt ? st : nt - 1;                      // (past the end: a harmless re-load)
+        const int sc = st < s1 ? st : s1 - 1;                      // (past the end: a harmless re-load)
         p0 = *reinterpret_cast<const v4i*>(piece_src(sc, tid));
-        if (tid + 512 < NPC) p1 = *reinterpret_cast<const v4i*>(piece_src(sc, tid + 512));
+        if (tid + NT < NPC) p1 = *reinterpret_cast<const v4i*>(piece_src(sc, tid + NT));
     };
     auto stash = [&](int b, const v4i& p0, const v4i& p1) {
         *reinterpret_cast<v4i*>(buf[b] + tid * 16) = p0;
-        if (tid + 512 < NPC) *reinterpret_cast<v4i*>(buf[b] + (tid + 512) * 16) = p1;
+        if (tid + NT < NPC) *reinterpret_cast<v4i*>(buf[b] + (tid + NT) * 16) = p1;
     };
-    static_assert(NPC <= 1024, "two pieces per thread");
+    static_assert(NPC <= 2 * NT, "two pieces per thread");
     uint32_t* const out = a.bits[t] + (size_t)n * nt * a.Ppad + (act ? rt : 0) * 32 + r;
     auto compute = [&](int st) {
         if (!act) return;
-        const char* tile = buf[st & 1];
+        const char* tile = buf[(st - s0) & 1];
         f32x16 a0 = f32x16{};
 #pragma unroll
         for (int k = 0; k < NKC; ++k) {
@@ -577,30 +586,46 @@ __global__ __launch_bounds__(512) void k_cd_mask3(const DgCdMask3Args a) {
         word |= (uint32_t)__shfl_xor((int)word, 32);
         if (h == 0) out[(size_t)st * a.Ppad] = word;
     };
-    fetch(0, sa0, sa1);
+    fetch(s0, sa0, sa1);
     stash(0, sa0, sa1);
-    fetch(1, sa0, sa1);
-    fetch(2, sb0, sb1);
+    fetch(s0 + 1, sa0, sa1);
+    fetch(s0 + 2, sb0, sb1);
     // (LDS-only barriers: __syncthreads() is also a fence of global memory - s_waitcnt vmcnt(0) in front of it - and so waited for
     //  the two tiles of look-ahead at every tile: 80 us for 33 us of MFMAs at the headline)
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    for (int st = 0; st < nt; st += 2) {
+    for (int st = s0; st < s1; st += 2) {
         // buf[0]: tile st; (sa): tile st + 1; (sb): tile st + 2
         lds_barrier();
         compute(st);
         stash(1, sa0, sa1);
         fetch(st + 3, sa0, sa1);
-        if (st + 1 >= nt) break;
+        if (st + 1 >= s1) break;
         lds_barrier();
         compute(st + 1);
         stash(0, sb0, sb1);
         fetch(st + 4, sb0, sb1);
     }
 }
-hipError_t dg_launch_cd_mask3(const DgCdMask3Args& a, hipStream_t s) {
-    if (a.KD != 96) return hipErrorInvalidValue;
-    const int nt = a.Ppad / 32;
-    hipLaunchKernelGGL(k_cd_mask3<5>, dim3((nt + 7) / 8, a.B, a.T), dim3(512), 0, s, a);
+hipError_t dg_launch_cd_mask3(const DgCdMask3Args& a_in, hipStream_t s) {
+    if (a_in.KD != 96) return hipErrorInvalidValue;
+    const int nt = a_in.Ppad / 32;
+    // (W = 8 and one part measured fastest at the headline - 80.5 us against 90 with W = 5 and two parts, round 6: the staging of the
+    //  S tiles per R tile, not the idle waves of the last block, sets the pace; the other forms stay selectable in developer builds)
+    int w = 8;
+    DgCdMask3Args a = a_in;
+    if (a.nsplit <= 0) a.nsplit = 1;
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_MASK3_SPLIT")) a.nsplit = atoi(e);
+    if (const char* e = getenv("DG_MASK3_W")) w = atoi(e);
+    if (w < 5 || w > 8) w = 8;
+#endif
+    const dim3 grid(((nt + w - 1) / w) * a.nsplit, a.B, a.T);
+    switch (w) {
+        case 5: hipLaunchKernelGGL((k_cd_mask3<5, 5>), grid, dim3(320), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((k_cd_mask3<5, 6>), grid, dim3(384), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((k_cd_mask3<5, 7>), grid, dim3(448), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_cd_mask3<5, 8>), grid, dim3(512), 0, s, a); break;
+    }
     return hipGetLastError();
 }
 
