@@ -63,6 +63,7 @@ CONFIGS = {
 }
 HEAD_GRAD_ELEMS = 201_740          # cluster1 (26,950) + cluster2 (174,790) parameters, reference src/modules.py:75-88
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16/f16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0             # HBM3E peak of MI355X (same guide)
 PEAK_CLOCK_GHZ = 2.4               # ... which is 256 CUs x 4 SIMDs x 1024 flop/cycle at this shader clock
 
 
@@ -731,6 +732,20 @@ def main():
                 "kernel_mcycles": round(kern_ms * 1e-3 * held_ghz * 1e9 / 1e6, 3) if held_ghz else None,
                 "stamps_cost_ms_per_step": round(t_probe - t_plain, 5)}
 
+    if H["S"] ** 2 <= 160:
+        # Sample grids of <= 160 positions (configs 2-4: every recipe the reference ships): the step is a few MB of MFMA work behind
+        # samplers that read the whole maps - bytes and launch latencies, not flops.  The yardstick is HBM: the bytes that MUST move
+        # (the four maps and the depth maps read once, the two code gradients written once) over the step time, against 8 TB/s.  The
+        # fused kernel's MFMA figures stay on the line as `mfma_*` (they say how little of the step the contraction is).
+        nmaps = H["B"] * H["h"] * H["w"] * 4.0
+        depth_b = H["B"] * float(H["depth_hw"]) ** 2 * 4.0
+        compulsory = 2 * nmaps * H["C"] + 2 * nmaps * H["D"] + 2 * nmaps * H["D"] + (2 if conf["sampling"] == "fps" else 1) * depth_b
+        hbm = compulsory / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(hbm, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(hbm / PEAK_HBM_GBPS, 4),
+                    "traffic": None, "compulsory_bytes_per_step": int(compulsory),
+                    "what": "compulsory bytes of one step (feats + code maps and the depth maps read once, d/d code and d/d code_pos written "
+                            "once) / ms_per_step; the step's kernels also write and re-read the sampled rows (a design choice, not counted)",
+                    "mfma": roofline}
     if rank == 0:
         line = {
             "metric": "correlation-loss steps/sec at B=32,C=384,28x28 (fwd+bwd, per-GPU batch 32)" if args.config == "headline"

@@ -1037,7 +1037,8 @@ __global__ __launch_bounds__(256) void k_colmean(const DgColmeanArgs a) {
     const int n = blockIdx.x, o = blockIdx.y;
     if (a.zero_word && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x == 0) *a.zero_word = 0u;
     if (a.zero_words9 && n == 0 && o == 0 && blockIdx.z == 0 && threadIdx.x < 9) a.zero_words9[threadIdx.x] = 0u;
-    auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) { colsum_reduce(part, n, ngroups, K, scale, out); };
+    // (always_inline: out of line, the lambda's pointers lose their address space - flat loads, tests/test_host_cpu.py audits it)
+    auto reduce = [&](const float* part, int ngroups, int K, float scale, float* out) __attribute__((always_inline)) { colsum_reduce(part, n, ngroups, K, scale, out); };
     if (a.zsel == 1 ? blockIdx.z != 3 : (a.zsel == 2 && blockIdx.z == 3)) return;      // (one half of a split launch)
     if (blockIdx.z == 3) {                                // dense code operands from channel planes: y = operand * (KD / 8) + channel group
         const int GD = a.dc.KD / 8;
