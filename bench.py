@@ -704,9 +704,8 @@ def main():
     # passes of THIS round (scripts/profile_round.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) - null when there is none
     traffic, traffic_source = None, None
     if args.config == "headline":
-        src = os.path.join("profiles", "r05_pmc_per_launch.json")
-        if not os.path.exists(os.path.join(ROOT, src)):
-            src = os.path.join("profiles", "r04_pmc_per_launch.json")
+        src = next((c for c in (os.path.join("profiles", f"r0{r}_pmc_per_launch.json") for r in (6, 5, 4))
+                    if os.path.exists(os.path.join(ROOT, c))), os.path.join("profiles", "r04_pmc_per_launch.json"))
         try:
             pmc = json.load(open(os.path.join(ROOT, src)))
             for name, vals in pmc.items():

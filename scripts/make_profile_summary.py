@@ -2,7 +2,7 @@
 """Copies the round's evidence from gpurun_out/<tag>/ (written by scripts/profile_round.sh on the GPU box) into profiles/
 and writes profiles/<tag>_SUMMARY.md.  usage: scripts/make_profile_summary.py r02"""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, f"{tag}_kernel_stats.csv"), dst)
@@ -37,14 +37,17 @@ o += [f"\n(`{kname}` has extra calls: `bench.py`'s roofline leg re-launches it 2
       f"* plain run: {b['roofline']['kernel_ms']*1e3:.1f} µs per launch ({b['roofline'].get('kernel_ms_method', 'HIP events').split(';')[0]}; "
       f"min {b['roofline'].get('kernel_ms_min')} / max {b['roofline'].get('kernel_ms_max')} ms; differential {b['roofline'].get('kernel_ms_diff')} ms, "
       f"back-to-back re-launches {b['roofline'].get('kernel_ms_loop')} ms) -> {b['roofline']['achieved']} TFLOP/s = "
-      f"{100*b['roofline']['frac']:.1f} % of the 2.5 PFLOP/s dense bf16 peak, on {b['roofline']['algorithmic_gflop_per_launch']} algorithmic GFLOP per launch.",
+      f"{100*b['roofline']['frac']:.1f} % of the 2.5 PFLOP/s dense bf16 peak, on {b['roofline']['algorithmic_gflop_per_launch']} algorithmic GFLOP per launch; "
+      f"held shader clock {b['roofline'].get('held_clock_ghz')} GHz (sum of the workgroups' s_memtime cycles / sum of their wall ticks) -> "
+      f"{b['roofline'].get('frac_at_held_clock')} of the peak at that clock, {b['roofline'].get('kernel_mcycles')} M cycles per launch; the stamps cost the step "
+      f"{b['roofline'].get('stamps_cost_ms_per_step')} ms (the timed steps run without them).",
       f"* under rocprofv3: average {avg:.1f} µs (kernel-trace); the bench line inside the same run: {br['roofline']['kernel_ms']*1e3:.1f} µs "
       f"({br['roofline']['achieved']} TFLOP/s).",
       f"* HBM traffic per launch (PMC): FETCH_SIZE {m['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction) = {m['hbm_read_bytes_corrected']/1e6:.0f} MB read, "
-      f"WRITE_SIZE {m['WRITE_SIZE']:.0f} KiB = {m['hbm_write_bytes']/1e6:.0f} MB written (287 MB fp16 G tiles for k_gs + the raw gradient tiles), "
+      f"WRITE_SIZE {m['WRITE_SIZE']:.0f} KiB = {m['hbm_write_bytes']/1e6:.0f} MB written (fp16 G tiles of six pair-sets for k_gs + the raw gradient tiles), "
       f"total {m['hbm_traffic_bytes_per_launch']/1e6:.0f} MB = {m['hbm_traffic_bytes_per_launch']/(avg*1e-6)/1e12:.2f} TB/s during the kernel.",
       f"* SQ counters per launch: SQ_VALU_MFMA_BUSY_CYCLES {m['SQ_VALU_MFMA_BUSY_CYCLES']:.3g} (= MFMA instructions x 32 cycles; over 1024 SIMDs x the kernel's "
-      f"{avg:.0f} µs at the ~1.9 GHz it holds = {m['SQ_VALU_MFMA_BUSY_CYCLES']/(1024*avg*1e-6*1.9e9):.2f} of the SIMD-cycles), "
+      f"{avg:.0f} µs at the {b['roofline'].get('held_clock_ghz') or 1.9} GHz it holds = {m['SQ_VALU_MFMA_BUSY_CYCLES']/(1024*avg*1e-6*(b['roofline'].get('held_clock_ghz') or 1.9)*1e9):.2f} of the SIMD-cycles), "
       f"SQ_INSTS_VALU {m['SQ_INSTS_VALU']:.3g}, SQ_INSTS_LDS {m['SQ_INSTS_LDS']:.3g}, SQ_LDS_BANK_CONFLICT {m['SQ_LDS_BANK_CONFLICT']:.0f}, "
       f"SQ_WAVE_CYCLES {m['SQ_WAVE_CYCLES']:.3g}, SQ_WAIT_INST_ANY {m['SQ_WAIT_INST_ANY']:.3g}.",
       f"\n## Step\n\n{b['value']} steps/s ({b['ms_per_step']} ms per step) on one GPU; CPU restatement on {b['cpu_baseline']['cores']} host threads: "
@@ -61,8 +64,11 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
         name += " (`--exact-masks`: cfg.dg_exact_masks)"
     if "driver_args" in f:
         name += " (`--steps 20 --warmup 5`, the driver's command line)"
-    o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{c['roofline']['kernel']}` | {c['roofline']['kernel_ms']*1e3:.1f} | "
-             f"{c['roofline']['frac']} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
+    rf = c['roofline'].get('mfma', c['roofline'])          # (small sample grids report against HBM; their MFMA figures ride under 'mfma')
+    frac = (f"{rf['frac']} (HBM: {c['roofline']['achieved']} GB/s of compulsory bytes = {c['roofline']['frac']} of 8 TB/s)"
+            if c['roofline'].get('bound') == 'hbm' else f"{rf['frac']} at {rf.get('held_clock_ghz')} GHz held")
+    o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{rf['kernel']}` | {rf['kernel_ms']*1e3:.1f} | "
+             f"{frac} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
 # per-kernel tables of the small-grid configurations (kernel trace of `bench.py --config <c> --steps 50`)
 for c in ("C2", "C3", "C4shard"):
     f = os.path.join(src, f"{tag}_kernel_stats_{c}.csv")

@@ -2,7 +2,7 @@
 # Produces the per-round evidence kept under profiles/: kernel-trace stats of the bench command and the HBM-traffic
 # PMC passes of the fused kernel (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md "HBM").
 # usage (on the GPU box): scripts/profile_round.sh r03   (then, here: scripts/make_profile_summary.py r03)
-tag=${1:-r05}
+tag=${1:-r06}
 export TMPDIR=/tmp
 out=/root/repo/gpurun_out/$tag
 rm -rf $out

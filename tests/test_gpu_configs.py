@@ -470,7 +470,7 @@ def test_bench_line_of_the_multi_gpu_schedule():
     # one schedule at every N: the plain single-GPU line is the replayed step too; --eager is the explicit opt-out
     assert d["config"]["schedule"] == lines["--graph"]["config"]["schedule"] == "hipGraph replay"
     assert lines["--eager"]["config"]["schedule"] == "eager" and d["config"]["ranks_seen"] == 1
-    assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r04_pmc_per_launch.json", "profiles/r05_pmc_per_launch.json")
+    assert d["config"]["clock_warmup_steps"] >= 10 and lines["--graph"]["roofline"]["traffic_source"] in (None, "profiles/r04_pmc_per_launch.json", "profiles/r05_pmc_per_launch.json", "profiles/r06_pmc_per_launch.json")
 
 
 
