@@ -567,3 +567,73 @@ def test_intra_fold_matches_the_g_tile_route(tmp_path):
     assert rel < 2e-4, rel
     assert float((a["g"] - b["g"]).abs().max()) > 0.0                     # (the two routes really are different code paths)
     assert torch.equal(a["gp"], b["gp"])
+
+
+_XM_CHILD = r"""
+import sys, hashlib, torch
+sys.path.insert(0, {root!r})
+import bench
+from depthg_amd import ContrastiveCorrelationLoss
+dev = torch.device("cuda:0")
+conf = bench.CONFIGS["headline"]; H = dict(conf["H"]); H["B"] = 8
+cfg = bench.make_cfg(conf, dg_exact_masks=True)
+f, fp, c, cp, d, dp = bench.synth_inputs(H["B"], 93, dev, H)
+c.requires_grad_(True); cp.requires_grad_(True)
+torch.manual_seed(7)
+lf = ContrastiveCorrelationLoss(cfg)
+for _ in range(2):                     # (the second call runs with the library's side stream in place)
+    c.grad = None; cp.grad = None
+    torch.manual_seed(7)
+    lf(f, fp, None, None, c, cp, d, dp)
+    lf.total.backward()
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for t in (lf.last_scalars, c.grad, cp.grad):
+    h.update(t.detach().cpu().numpy().tobytes())
+print("XM", h.hexdigest(), [float(v) for v in lf.last_scalars[:4]])
+"""
+
+
+def test_exact_mask_chain_on_the_side_stream_gives_the_same_bits():
+    """cfg.dg_exact_masks on the dense grid: the chain code norms + draw -> code operands -> k_cd_mask3 runs on the library's side
+    stream beside the feature side of the preparation (round 6; the same launches split by role, two hand-over events and a join in
+    front of the fused kernel) or, with DG_SPLIT_MASKS=0, in sequence on the caller's stream.  A missing dependency between the two
+    streams would show as different bits: scalars and both gradients must be identical."""
+    seen = {}
+    for split in ("1", "0"):
+        env = dict(os.environ, DG_SPLIT_MASKS=split)
+        r = subprocess.run([sys.executable, "-c", _XM_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        seen[split] = [l for l in r.stdout.splitlines() if l.startswith("XM")][-1]
+    assert seen["1"] == seen["0"], seen
+    vals = [float(v) for v in seen["1"].split("[")[1].rstrip("]").split(",")]
+    assert all(v == v for v in vals), seen                      # (round 6's first build of the form returned NaN loss sums)
+
+
+def test_main_kernel_span_reports_the_held_clock(dev):
+    """dg_prof_main_span (C ABI 116): four words - first entry, last exit (100-MHz ticks) and the workgroups' summed lifetimes in shader
+    cycles and in ticks.  One headline-width forward: a span of 10 us .. 10 ms and a held clock between 0.5 and 3 GHz; after
+    arm(False) a further call leaves the words alone."""
+    import bench
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    conf = bench.CONFIGS["headline"]
+    H = dict(conf["H"]); H["B"] = 8
+    cfg = bench.make_cfg(conf)
+    f, fp, c, cp, d, dp = bench.synth_inputs(H["B"], 5, dev, H)
+    c.requires_grad_(True); cp.requires_grad_(True)
+    lf = ContrastiveCorrelationLoss(cfg)
+    timer = ops.MainKernelTimer(dev)
+    try:
+        timer.arm(True)
+        lf(f, fp, None, None, c, cp, d, dp)              # (first call: allocations, lazy initialisation)
+        timer.reset()
+        lf(f, fp, None, None, c, cp, d, dp)
+        ms, ghz = timer.last()
+        assert 0.01 < ms < 10.0 and 0.5 < ghz < 3.0, (ms, ghz)
+        timer.arm(False)
+        timer.reset()
+        lf(f, fp, None, None, c, cp, d, dp)
+        ms2, ghz2 = timer.last()
+        assert ms2 != ms2 and ghz2 != ghz2               # nan: nothing stamped
+    finally:
+        timer.arm(False)

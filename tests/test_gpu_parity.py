@@ -258,11 +258,15 @@ def test_headline_loss_vs_oracle_subset(dev):
         assert rel < 2e-2 and worst < 0.12, (name, float(rel), float(worst))
 
 
-def test_headline_full_batch_vs_oracle(dev):
+@pytest.mark.parametrize("exact", [False, True])
+def test_headline_full_batch_vs_oracle(exact, dev):
     """THE headline, whole: B=32, C=384, D=70, 28x28 dense grid, 5 negatives, depth term - bench.py's workload with its recipe
     scalars - against the CPU oracle (about two seconds on 16 host threads).  Loss means and the weighted total within the
     north_star tolerance of 1e-4 relative (measured 0 .. 4.4e-6, profiles/r03_parity.md); gradients at 1.5 x the measurement
-    (1.4e-2 relative L2; largest element error 2.9 % / 8.7 % of the largest element)."""
+    (1.4e-2 relative L2; largest element error 2.9 % / 8.7 % of the largest element).
+    exact: cfg.dg_exact_masks - the clamp masks 1[cd >= 0] (src/modules.py:1250-1252) from split-fp16 cd (k_cd_mask3), k_corr2's
+    exact-mask form (no cd chain, intra pair-set folded: round 6); measured 1.0e-3 / 2.2e-3 relative L2, 1.5 % / 3.4 % of the largest
+    element (profiles/r05_parity.md, unchanged by the new form) - bounds 3e-3 and 5e-2."""
     import os
     import bench
     from depthg_amd import ContrastiveCorrelationLoss
@@ -274,7 +278,7 @@ def test_headline_full_batch_vs_oracle(dev):
     f, fp, c, cp, d, dp = bench.synth_inputs(B, 1234, "cpu", H)
     g = torch.Generator().manual_seed(1235)
     perms = [O.super_perm(B, g) for _ in range(H["n_neg"])]
-    cfg = O.default_cfg(feature_samples=hw, neg_samples=H["n_neg"], dim=H["D"], dg_outputs="reduced", **conf["scal"])
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=H["n_neg"], dim=H["D"], dg_outputs="reduced", dg_exact_masks=exact, **conf["scal"])
     coords = O.identity_coords(B, hw)
     cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
     ref = O.forward(cfg, f, fp, cr, cpr, d, dp, coords1=coords, coords2=coords, perms=perms)
@@ -294,7 +298,7 @@ def test_headline_full_batch_vs_oracle(dev):
     for got, want, name in ((cg.grad.cpu(), cr.grad, "code"), (cpg.grad.cpu(), cpr.grad, "code_pos")):
         rel = (got - want).norm() / want.norm()
         worst = (got - want).abs().max() / want.abs().max()
-        assert rel < 2.1e-2 and worst < 0.13, (name, float(rel), float(worst))
+        assert (rel < 3e-3 and worst < 5e-2) if exact else (rel < 2.1e-2 and worst < 0.13), (name, float(rel), float(worst))
 
 
 def test_headline_width_without_clamp_gradient(dev):
