@@ -31,7 +31,7 @@
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 #define C2_RED_BYTES 256   // behind the tile buffers: the block-end reduction's [8 fragment slots][4] dwords + [8] output pointers
 #ifndef C2_PF
-#define C2_PF 4            // LDS fragment reads in flight ahead of the MFMA that consumes them
+#define C2_PF 8            // LDS fragment reads in flight ahead of the MFMA that consumes them (8, or 12 in developer builds of the exact-mask form)
 #endif
 
 template <class F, int... I>
@@ -161,6 +161,21 @@ __device__ __forceinline__ int epi2(const float y0, const float y1, const float 
     return o;
 }
 
+// The same in two halves for two neighbouring MFMA gaps (round 6: the epilogue of a fragment spread over 16 gaps, two instructions
+// each, instead of 8 gaps of four - a tile is bound by the issue of its non-MFMA instructions, and the gaps that held four VALU next
+// to a ring read and a counted wait ran over their MFMA's 32 cycles while others stood half empty)
+__device__ __forceinline__ void epi2_a(int& o, int& t, const float y0, const float y1, const float c0, const float c1, const uint32_t sel) {
+    asm volatile("v_perm_b32 %1, %5, %4, %6\n\t"
+                 "v_cvt_pk_f16_f32 %0, %2, %3"
+                 : "=&v"(o), "=&v"(t) : "v"(y0), "v"(y1), "v"(c0), "v"(c1), "s"(sel));
+}
+__device__ __forceinline__ int epi2_b(int o, int t) {
+    asm volatile("v_pk_ashrrev_i16 %1, 15, %1 op_sel_hi:[0,1]\n\t"
+                 "v_bfi_b32 %0, %1, 0, %0"
+                 : "+v"(o), "+v"(t));
+    return o;
+}
+
 // ---- exact clamp masks (XM): the mask 1[cd >= 0] of zero_clamp comes as one word per (S tile, R position) from a higher-precision
 // cd (k_cd_mask) instead of from the sign of the fp16 chain.  The words travel like the tiles: one 256-byte LDS-DMA piece per
 // fragment and tile into a four-slot ring three tiles ahead, read back by the lane that owns the R position.
@@ -182,6 +197,20 @@ template <int J> __device__ __forceinline__ int epi2m(const float y0, const floa
                  "v_bfi_b32 %1, %6, %1, %2\n\t"
                  "v_and_b32 %0, %0, %1"
                  : "=&v"(o), "=&v"(m0), "=&v"(m1) : "v"(y0), "v"(y1), "v"(wsh), "s"(lo16), "n"(B0), "n"(B0 + 1));
+    return o;
+}
+
+template <int J> __device__ __forceinline__ void epi2m_a(int& o, int& m0, int& m1, const float y0, const float y1, const uint32_t wsh) {
+    constexpr int B0 = 2 * (J & 1) + 8 * (J >> 1);
+    asm volatile("v_bfe_i32 %1, %5, %c6, 1\n\t"
+                 "v_bfe_i32 %2, %5, %c7, 1\n\t"
+                 "v_cvt_pk_f16_f32 %0, %3, %4"
+                 : "=&v"(o), "=&v"(m0), "=&v"(m1) : "v"(y0), "v"(y1), "v"(wsh), "n"(B0), "n"(B0 + 1));
+}
+__device__ __forceinline__ int epi2m_b(int o, int m0, int m1, const uint32_t lo16) {
+    asm volatile("v_bfi_b32 %1, %3, %1, %2\n\t"
+                 "v_and_b32 %0, %0, %1"
+                 : "+v"(o), "+v"(m0) : "v"(m1), "s"(lo16));
     return o;
 }
 
@@ -215,7 +244,8 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #else
     constexpr bool NOCD = XM;
 #endif
-    constexpr int BUF = BL::BYTES, NS = NKF + (NOCD ? 0 : NKC) + (FOLD ? 1 : 0), PF = 8, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+    constexpr int BUF = BL::BYTES, NS = NKF + (NOCD ? 0 : NKC) + (FOLD ? 1 : 0), PF = C2_PF, NBUF = 4;     // tiles are fetched NBUF - 1 ahead
+    static_assert(PF == 8 || PF == 12, "phase C issues the first PF reads of a tile over its six gaps");
     static_assert(!FOLD || NKC < NKD, "FOLD needs a spare code k-step in the blob");
     constexpr int PIECES = BL::CHUNKS / NW;                 // 1-KiB DMA pieces per wave and tile
     constexpr int ADR = RF * NKF * 4;                       // first accumulator register of the gradient accumulators
@@ -572,18 +602,43 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
             ga[f][j >> 2][j & 3] = epi2(yf[2 * j], yf[2 * j + 1], yc[2 * j], yc[2 * j + 1], perm_sel);
         }
     };
+    // half HH (0..15) of the epilogue of fragment f: pair HH >> 1, first half (mask source + fp16 pack) or second (mask applied)
+    int eo[RF] = {0, 0}, et[RF] = {0, 0}, eu[RF] = {0, 0};
+    auto epi_half = [&](auto F, auto HHc) {
+        constexpr int f = F.value, HH = HHc.value, j = HH >> 1;
+        if constexpr ((HH & 1) == 0) {
+            const f32x16 yf = __builtin_bit_cast(f32x16, Yf[f]);
+            if constexpr (XM) epi2m_a<j>(eo[f], et[f], eu[f], yf[2 * j], yf[2 * j + 1], wsh[f]);
+            else {
+                const f32x16 yc = __builtin_bit_cast(f32x16, Yc[f]);
+                epi2_a(eo[f], et[f], yf[2 * j], yf[2 * j + 1], yc[2 * j], yc[2 * j + 1], perm_sel);
+            }
+        } else {
+            if constexpr (XM) ga[f][j >> 2][j & 3] = epi2m_b(eo[f], et[f], eu[f], lo16);
+            else ga[f][j >> 2][j & 3] = epi2_b(eo[f], et[f]);
+        }
+    };
+    (void)epi_pair;
     // per-fragment base of the G tiles [image][S tile t][R tile]: resolved HERE - a kernel-argument (scalar) load inside the
     // tile loop would have to be waited for with lgkmcnt(0), i.e. together with every LDS read in flight
     v4i_t* gbase[RF];
 #pragma unroll
     for (int f = 0; f < RF; ++f)
+#ifdef C2_ABL_GSTORE      // (developer ablation, WRONG results: every G store of the launch into the same 2 KiB - what do the 246 MB of G writes cost the loop?)
+        gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + lane;
+#else
         gbase[f] = reinterpret_cast<v4i_t*>(args.jobs[fj[f]].Gout) + (fo[f] ? (size_t)0 : ((size_t)fn[f] * ntiles * ntiles + (act[f] ? ft[f] : 0)) * 128) + lane;
+#endif
     const size_t gstep = (size_t)ntiles * 128;
     // (a folded fragment has no reader for its G tiles; its stores stay in the instruction stream - the counted vmcnt waits of the
     //  tile barrier count them - but all go to the first 2 KiB of the pair-set's buffer with the default cache policy: L2 traffic)
     size_t gstepb[RF];
 #pragma unroll
+#ifdef C2_ABL_GSTORE
+    for (int f = 0; f < RF; ++f) gstepb[f] = 0;
+#else
     for (int f = 0; f < RF; ++f) gstepb[f] = fo[f] ? (size_t)0 : gstep * sizeof(v4i_t);
+#endif
     // running store pointers (the tile index times the tile stride as 64-bit scalar multiplies in front of every store cost three
     // s_mul and two adds each): gp[0] points at S tile t, gp[1] at S tile t - 1 (fragment 1 runs one phase behind)
     uintptr_t gp[RF] = {reinterpret_cast<uintptr_t>(gbase[0]), reinterpret_cast<uintptr_t>(gbase[1]) - gstepb[1]};
@@ -591,6 +646,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
         (void)t;
+#ifdef C2_ABL_NOGSTORE     // (developer ablation, WRONG results: no G store is issued)
+        return;
+#endif
         v4i_t* g = reinterpret_cast<v4i_t*>(gp[f]) + 64 * sp;
         // (non-temporal: with the default cache policy on these stores / k_gs's loads the step is 1-6 % slower, profiles/r03_SUMMARY.md)
         if (FOLD && __builtin_expect(fo[f], 0)) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(g), "v"(ga[f][sp]) : "memory");
@@ -648,7 +706,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         constexpr int TOT = ACT1 ? 2 * NS : NS;
         constexpr int BP0 = ACT1 ? 2 * NS - 9 : TOT;            // first MFMA index whose gap carries a gradient-B read (phase B gaps NS-9 ..)
         constexpr int MM = XM ? (ACT0 ? 1 : 0) + (ACT1 ? 1 : 0) : 0;       // mask-word pieces per tile
-        auto epi1_half = [&](auto HH) { epi_pair(std::integral_constant<int, 1>{}, HH); };   // pair HH (0..7) of the epilogue of fragment 1
+        auto epi1_half = [&](auto HH) { epi_half(std::integral_constant<int, 1>{}, HH); };   // half HH (0..15) of the epilogue of fragment 1
         auto dr1 = [&](auto Q) {
             constexpr int q = Q.value, sp = q / NDF, d = q % NDF;
             if constexpr (d < 2) mfma_h_acc<ADR + 32 + d * 16>(ga[1][sp], bP[q]); else mfma_h8(dRv[1], ga[1][sp], bP[q]);
@@ -672,7 +730,11 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 if constexpr (idx + PF < TOT) rd_step(std::integral_constant<int, (idx + PF) % NS>{}, ra[idx % PF]);
             };
             // DMA source / destination of tile t+3 (scalar)
+#ifdef C2_ABL_DMA         // (developer ablation, WRONG results: every tile of the loop is tile 0 of the streamed image - what does the arrival of the tiles cost?)
+            const int t2 = 0;
+#else
             const int t2 = t + 3 < ntiles ? t + 3 : 0;            // past the end: dummy pieces keep the counted waits uniform
+#endif
             const char* const sb2 = Sop_img + (size_t)t2 * BL::BYTES;
             const uint32_t dst2 = smem_a + bprev * BUF + wid * 1024;
             STAMP(t, 0);
@@ -682,12 +744,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 if constexpr (ACT0) chain_slot(ST, std::integral_constant<int, 0>{});
                 if constexpr (XM && ACT0 && st == 0) mask_issue(0, t + 3);
                 if constexpr (XM && ACT1 && st == 1) { mask_issue(1, t + 2); mask_prep(wsh[1], mwB, msh); }
-                if constexpr (ACT1 && st >= 2 && st < 10) epi1_half(std::integral_constant<int, st - 2>{});
+                if constexpr (ACT1 && st >= 2 && st < 18) epi1_half(std::integral_constant<int, st - 2>{});
+#ifndef C2_ABL_NODMA       // (developer ablation, WRONG results: no tile is fetched inside the loop - what does ISSUING the nine pieces cost?)
                 if constexpr (SPLIT_DMA && st >= 10 && st < 10 + 2 * PIECES) {           // piece k: M0 + offset in gap 10 + 2k, the load in gap 11 + 2k
                     constexpr int k = (st - 10) / 2;
                     if constexpr (((st - 10) & 1) == 0) dma_setup<k * 4096>(dst2, dma_voff, dtmp); else dma_go(dtmp, sb2);
                 }
                 if constexpr (!SPLIT_DMA && st >= 10 && st < 10 + PIECES) dma_piece<(st - 10) * 4096>(dst2, dma_voff, sb2);
+#endif
                 if constexpr (FRUN && ACT0 && st == NS - 3) ga[0][0] = v4i_t{fo[0] ? fold_w : 0, 0, 0, 0};
                 if constexpr (ACT1 && st == NS - 1) { if (t > 0) g_store(1, 0, t - 1); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -716,9 +780,9 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 if constexpr (ACT0 && !ACT1 && st == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
                 if constexpr (ACT0) {
                     if constexpr (XM && st == 1) mask_prep(wsh[0], mwA, msh);
-                    if constexpr (st >= 2 && st < 10) epi_pair(std::integral_constant<int, 0>{}, std::integral_constant<int, st - 2>{});
-                    if constexpr (st == 11) g_store(0, 0, t);
-                    if constexpr (st == 13) g_store(0, 1, t);
+                    if constexpr (st >= 2 && st < 18) epi_half(std::integral_constant<int, 0>{}, std::integral_constant<int, st - 2>{});
+                    if constexpr (st == 11) g_store(0, 0, t);             // (pairs 0..3 are complete behind gap 9)
+                    if constexpr (st == 19) g_store(0, 1, t);             // (pairs 4..7 behind gap 17)
                     if constexpr (FRUN && ACT1 && st == 16) ga[1][0] = v4i_t{fo[1] ? fold_w : 0, 0, 0, 0};
                     if constexpr (st >= NS - 9 && st < NS - 9 + 2 * NDF) {      // B fragments of the gradient products (shared by both fragments)
                         constexpr int q = st - (NS - 9), sp = q / NDF, d = q % NDF;
@@ -762,7 +826,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                         lds_rd32(mwA, mrd_a + (uint32_t)((t + 1) & 3) * 256);
                     }
                     // first PF fragments of tile t+1 (valid after the barrier), issued in index order (the counted waits rely on it)
-                    if constexpr (q < 2) { rd_step(std::integral_constant<int, 2 * q>{}, ra[2 * q]); rd_step(std::integral_constant<int, 2 * q + 1>{}, ra[2 * q + 1]); }
+                    if constexpr (PF == 12 || q < 2) { rd_step(std::integral_constant<int, 2 * q>{}, ra[2 * q]); rd_step(std::integral_constant<int, 2 * q + 1>{}, ra[2 * q + 1]); }
                     else rd_step(std::integral_constant<int, q + 2>{}, ra[q + 2]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -777,7 +841,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
         if constexpr (ACT1) {
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             if constexpr (XM) { wait_lgkm<0>(); mask_prep(wsh[1], mwB, msh); }
-            sfor<8>([&](auto HH) { epi1_half(HH); });
+            sfor<16>([&](auto HH) { epi1_half(HH); });
             g_store(1, 0, ntiles - 1); g_store(1, 1, ntiles - 1);
             asm volatile("s_nop 1" ::: "memory");
             sfor<2 * NDF>([&](auto Q) { dr1(Q); });
