@@ -47,6 +47,7 @@ struct Plan {
     size_t comb[2], scratch_out, taps, gbuf[DG_MAX_NEG + 2];
     size_t ticket;                          // the depth blocks' ticket of the k_gs launch
     size_t maskbits[DG_MAX_NEG + 2];        // exact clamp masks of the pair-sets (k_cd_mask), xmask: in use on a small sample grid,
+    bool half;                              // fp16 gradient tiles between k_corr2 / k_gs and k_combine_out (identity grid; DgScatterSrc.half)
     bool xmask, xmask_dense;                // xmask_dense: on the dense identity grid (DG_EXACT_MASKS)
     bool fold;                              // the intra pair-set's streamed-side gradient is formed in the fused kernel (dg_corr2.hip FOLD)
     size_t clo[2];                          // ... with pointwise: the parts of the normalised code the fp16 C parts drop (k_cd_mask3)
@@ -164,6 +165,17 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
         p.fold = fold_on && p.grad && p.pointwise && !p.small && dg_corr2_shape_supported(p.KF, p.KD, p.D, lo, hi, p.Ppad, p.B) &&
                  !p.xmask;          // (with the dense grid's exact mask words too, since round 6: k_corr2<.., XM, .., FOLD>)
     }
+    // fp16 gradient tiles (round 6): the identity grid's backward is ONE launch (k_combine_out) that reads the raw tiles of k_corr2 and the
+    // streamed-side tiles of k_gs once - 93 of the headline step's 1342 MB go with fp32 -> fp16 (both producers bounded: the raw tiles by
+    // construction, k_gs's by leaving the division by ||c|| to the consumer).  Where k_corr2 runs and k_combine_out will (its routed list
+    // holds n_neg x B entries at most 512); DG_HALF_TILES=0 keeps fp32 tiles (developer A/B)
+    {
+        static const bool half_on = [] { const char* e = getenv("DG_HALF_TILES"); return !(e && e[0] == '0'); }();
+        float lo, hi;
+        clamp_bounds(d, lo, hi);
+        p.half = half_on && p.ident && p.grad && !p.small && dg_corr2_shape_supported(p.KF, p.KD, p.D, lo, hi, p.Ppad, p.B) &&
+                 p.N * p.B <= 512 && p.S == p.h && p.S == p.w;
+    }
     for (int i = 0; i < 2; ++i) p.clo[i] = take((p.xmask_dense && p.pointwise) ? B * (size_t)(p.Ppad / 32) * p.KD * 64 : 0);
     p.gr_list = take((size_t)DG_MAX_JOBS * B * DG_GR_CAP * 4);
     p.gr_count = take((size_t)DG_MAX_JOBS * B * 4);
@@ -245,6 +257,7 @@ static void corr_args_base(const Plan& p, const dg_corr_desc* d, char* ws, DgCor
     a.inv_BP = 1.0f / ((float)p.B * (float)p.P);
     a.dummy = ws + p.op[0];
     a.span = g_prof_span;
+    a.half_tiles = p.half ? 1 : 0;
 }
 
 // k_gs jobs: one per pair-set; the producing job of the G tiles is helper_job(t) of the fused launch (R = operand 1,
@@ -425,7 +438,7 @@ static hipError_t launch_main(const Plan& p, const DgCorrArgs& a, int njA, int d
     if (p.grad && njA > 0) {
         const hipError_t e = dg_launch_corr2(a, p.KF, p.KD, stream);      // the pair-set jobs, one launch
         if (e != hipErrorNotSupported) return e;
-        if (p.fold) return hipErrorInvalidValue;          // (the plan folded the intra pair-set for a kernel that does not run)
+        if (p.fold || p.half) return hipErrorInvalidValue;          // (the plan folded the intra pair-set / asked for fp16 tiles of a kernel that does not run)
     }
     return dg_launch_corr(a, p.KF, p.KD, p.rf, p.grad ? 1 : 0, stream);
 }
@@ -844,14 +857,14 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
                 DG_HIP(side.fork());
                 DG_HIP(dg_launch_gs(g, dep_maskbits, side.stream(), true));
                 DG_HIP(side.record_join());
-                DG_HIP(dg_launch_gs(gstream, nullptr, stream));
+                DG_HIP(dg_launch_gs(gstream, nullptr, stream, false, p.half));
                 DG_HIP(side.join());
             } else {
-                DG_HIP(dg_launch_gs(gstream, nullptr, stream));
+                DG_HIP(dg_launch_gs(gstream, nullptr, stream, false, p.half));
                 DG_HIP(dg_launch_gs(g, dep_maskbits, stream, true));
             }
         } else {
-            DG_HIP(dg_launch_gs(g, dep_maskbits, stream));
+            DG_HIP(dg_launch_gs(g, dep_maskbits, stream, false, p.half));
         }
     } else {
         DG_HIP(dg_launch_finish(f, stream));
@@ -898,10 +911,11 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     const float f = (float)(-1.0 / ((double)p.B * p.P * p.P));
     const float fn = p.N > 0 ? f / (float)p.N : 0.f;
     int n = 0;
-    auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest, int raw) {
+    auto add = [&](size_t buf, const int64_t* route, int gidx, int csel, float factor, int dest, int raw, int half = 0) {
         s.src[n].buf = F32(buf); s.src[n].route = route; s.src[n].gidx = gidx; s.src[n].coords_sel = csel;
-        s.src[n].factor = factor; s.src[n].dest = dest; s.src[n].raw = raw; ++n;
+        s.src[n].factor = factor; s.src[n].dest = dest; s.src[n].raw = raw; s.src[n].half = half; ++n;
     };
+    const int hf = p.half ? 1 : 0;              // (the pair-sets' tiles of k_corr2 and k_gs; the depth term's stay fp32)
     // dRA[t]: the fused kernel's raw accumulator-order tiles (stationary operand = operand 1 for every pair-set);
     // dRB[t]: k_gs output, row-major, normalisation backward already applied
     if (p.small) {
@@ -933,13 +947,13 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
             }
         }
     } else {
-    if (intra_is_symmetric(p)) add(p.dRA[0], nullptr, 0, 0, 2.0f * f, 0, 1);      // -G symmetric: d/dc1 + d/dc2 = 2 d/dc1 (no k_gs job, build_gs_jobs)
-    else { add(p.dRA[0], nullptr, 0, 0, f, 0, 1); add(p.dRB[0], nullptr, 0, 0, f, 0, 0); }
-    add(p.dRA[1], nullptr, 1, 0, f, 0, 1);
-    add(p.dRB[1], nullptr, 1, 1, f, 1, 0);
+    if (intra_is_symmetric(p)) add(p.dRA[0], nullptr, 0, 0, 2.0f * f, 0, 1, hf);      // -G symmetric: d/dc1 + d/dc2 = 2 d/dc1 (no k_gs job, build_gs_jobs)
+    else { add(p.dRA[0], nullptr, 0, 0, f, 0, 1, hf); add(p.dRB[0], nullptr, 0, 0, f, 0, 0, hf); }
+    add(p.dRA[1], nullptr, 1, 0, f, 0, 1, hf);
+    add(p.dRB[1], nullptr, 1, 1, f, 1, 0, hf);
     for (int k = 0; k < p.N; ++k) {
-        add(p.dRA[2 + k], nullptr, 2, 0, fn, 0, 1);
-        add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0, 0);
+        add(p.dRA[2 + k], nullptr, 2, 0, fn, 0, 1, hf);
+        add(p.dRB[2 + k], perms + (size_t)k * p.B, 2, 1, fn, 0, 0, hf);
     }
     }
     if (p.depth) add(p.dRA[p.T], nullptr, 3, 0, 2.0f * f, 0, 1);   // dd and cd symmetric: d/dc1 + d/dc2 = 2 d/dc1
@@ -951,6 +965,9 @@ static int corr_backward_impl(const dg_corr_desc* desc, const float* grad_scalar
     {
         const DgBlob bl(p.KF, p.KD);
         s.xop = ws + p.op[0]; s.xinv = F32(p.inv[0]); s.blob_bytes = bl.bytes; s.blob_off_c = bl.off_c;
+        // (half, final sources: destination 0 = the code map behind operand 0 - the negatives' streamed operand on the shared grid -,
+        //  destination 1 = operand 1's)
+        s.xinv_dest[0] = F32(p.inv[0]); s.xinv_dest[1] = p.nops > 1 ? F32(p.inv[1]) : nullptr;
     }
     s.out[0] = grad_code; s.out[1] = grad_code_pos;
     s.B = p.B; s.D = p.D; s.DP = p.KD; s.h = p.hc; s.w = p.wc; s.S = p.S; s.Sh = p.Sh; s.P = p.P; s.Ppad = p.Ppad;     // (h, w): the code maps

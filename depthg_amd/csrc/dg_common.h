@@ -247,6 +247,7 @@ struct DgCorrArgs {
     uint32_t* wctr;       // k_corr2's persistent workgroups: [0..7] items handed out so far per XCD (beyond each workgroup's first), [8]
                           // workgroups that have left; all zero at launch (k_colmean) and again when the last workgroup leaves; null: static walk
     unsigned long long* span;   // measurement aid (dg_prof_main_span): [0] min of the workgroups' entry times, [1] max of their exit times, [2] / [3] sums of their lifetimes in shader cycles / wall ticks; or null
+    int32_t half_tiles;   // k_corr2: 1 = the raw gradient tiles (DgJob.dR) are written as fp16 (DgScatterSrc.half)
     uint32_t* stamps;     // developer timing stamps (null in production)
     unsigned long long* blocklog;   // developer block timeline: [block][8] = hw id, xcc id, 4 wall-clock stamps (null in production)
     // ragged last row blocks grouped by streamed operand (dg_corr2.hip; lists written by k_group_ragged); gr_list null: off
@@ -614,6 +615,10 @@ struct DgScatterSrc {
     int32_t raw;           // see buf
     const float* dfac;     // null, or a device scalar multiplied into the factor (the fused small-grid path: old_mean of the pair-set,
                            // which only the forward's last block knows - dg_small.hip)
+    int32_t half;          // 1 (identity grid, round 6): the tiles are fp16, [B][Ppad/32][DP/32][2][64][8] - accumulator elements 8s .. 8s+7 of
+                           // a lane in one 16-byte piece, the layout of the G tiles.  raw == 1: as above.  raw == 0: k_gs's output PROJECTED
+                           // (dx - x <x, dx>) but not yet divided by ||c||: the consumer multiplies by xinv_dest of the destination position
+                           // (bounded like the raw tiles whatever the norm of a code vector is: nothing can leave the fp16 range)
 };
 #define DG_MAX_SCATTER 48
 struct DgScatterArgs {
@@ -628,6 +633,7 @@ struct DgScatterArgs {
     char* taps;            // [2 coords sets][B] inverse tap records (dg_taps_record_bytes each)
     const char* xop;       // operand-1 blobs (C part = normalised code rows the raw sources refer to)
     const float* xinv;     // [B][Ppad] 1 / max(||code||, eps) of operand 1
+    const float* xinv_dest[2];   // ... of the operand whose code map destination 0 / 1 is (half, final sources; identity grid)
     int32_t blob_bytes, blob_off_c;
     float* out[2];         // grad_code, grad_code_pos  (B,D,h,w)
     int32_t B, D, DP, h, w, S, Sh, P, Ppad, DC;   // DC = channels per block (power of two <= 32)
@@ -636,6 +642,10 @@ struct DgScatterArgs {
     // (set by the launcher) the direct sources of k_grad_combine per destination, in source order: raw ones, then final ones
     int8_t craw[2][DG_MAX_SCATTER / 2], cfin[2][DG_MAX_SCATTER / 2];
     int8_t ncraw[2], ncfin[2];
+    // ... and those with fp16 tiles (DgScatterSrc.half), which the lists above then leave out (k_combine_out)
+    int8_t crawh[2][DG_MAX_SCATTER / 2], cfinh[2][DG_MAX_SCATTER / 2];
+    int8_t ncrawh[2], ncfinh[2];
+    int32_t routed_half;   // 1: every routed source has fp16 tiles (all or none: the launcher checks)
     int32_t taps_ready;    // 1: the forward built the tap records (dg_launch_pre_general)
     // extra z slices of the k_grad_combine launch (general coordinates): axo[j] = axd[j] + axd2[j] + axf[j][0] * (axs[j] + axs2[j]), tile
     // by tile (null terms are left out) - the fused small-grid path merges the two halves of every ROUTED streamed-side source and
@@ -717,7 +727,7 @@ hipError_t dg_launch_corr(const DgCorrArgs& args, int KF, int KD, int nwaves, in
 hipError_t dg_launch_corr2(const DgCorrArgs& args, int KF, int KD, hipStream_t stream);   // hipErrorNotSupported: use dg_launch_corr
 bool dg_corr2_supported(const DgCorrArgs& args, int KF, int KD);
 bool dg_corr2_shape_supported(int KF, int KD, int D, float lo, float hi, int Ppad, int B);
-hipError_t dg_launch_gs(const struct DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t s, bool depth_only = false);   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
+hipError_t dg_launch_gs(const struct DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t s, bool depth_only = false, bool half_out = false);   // half_out: DgScatterSrc.half tiles (KF = 384, KD = 96)   // dep_maskbits: exact clamp masks of the intra pair-set (DgJob.maskbits) or null
 hipError_t dg_launch_finish(const DgFinishArgs& a, hipStream_t stream);
 hipError_t dg_launch_transpose(const DgTransposeArgs& a, int B, hipStream_t s);
 hipError_t dg_launch_gather(const DgGatherArgs& a, int maxK, hipStream_t s);

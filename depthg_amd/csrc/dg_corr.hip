@@ -882,7 +882,7 @@ __device__ __forceinline__ void gs_depth_block(const DgGsArgs& a, const uint32_t
     }
 }
 
-template <int NKF, int NKD, bool XM>
+template <int NKF, int NKD, bool XM, bool HALF = false>      // HALF: the output as DgScatterSrc.half tiles (fp16, projected, not yet divided by ||c||)
 __device__ __forceinline__ void gs_body(const DgGsArgs& a, const uint32_t* dep_maskbits) {
     using BL = BlobT<NKF, NKD>;
     constexpr int KD = BL::KD, NDF = KD / 32, TS = GS_TS;
@@ -1022,6 +1022,25 @@ __device__ __forceinline__ void gs_body(const DgGsArgs& a, const uint32_t* dep_m
         for (int i = 0; i < 16; ++i) dot[i] = fmaf((float)x[f][i], acc[f][i], dot[i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) dot[i] = half_sum(dot[i]);
+    if constexpr (HALF) {
+        // fp16 tiles: (dx - x <x, dx>) - the division by ||c|| is the consumer's (k_combine_out), so that the stored value is bounded
+        // like dx itself whatever the norm of a code vector - in pieces of eight accumulator elements, [2][64][8] per channel group
+        _Float16* outh = reinterpret_cast<_Float16*>(J.dS) + ((size_t)n * ntS + st) * (32 * KD) + lane * 8;
+#pragma unroll
+        for (int f = 0; f < NDF; ++f)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = 8 * sp + e;
+                    const int pos = st * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    v[e] = (_Float16)(pos < a.P ? (acc[f][i] - (float)x[f][i] * dot[i]) : 0.f);
+                }
+                if (32 * f + r < a.D) *reinterpret_cast<f16x8*>(outh + f * 1024 + sp * 512) = v;
+            }
+        return;
+    }
     float inv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -1043,19 +1062,19 @@ __device__ __forceinline__ void gs_body(const DgGsArgs& a, const uint32_t* dep_m
         }
 }
 
-template <int NKF, int NKD>
-__global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) { gs_body<NKF, NKD, false>(a, nullptr); }
+template <int NKF, int NKD, bool HALF = false>
+__global__ __launch_bounds__((GS_CW + 1) * 64, 4) void k_gs(const DgGsArgs a) { gs_body<NKF, NKD, false, HALF>(a, nullptr); }
 // the same launch with the exact clamp masks of the intra pair-set in the depth term's blocks (small sample grids: k_cd_mask;
 // 256 registers per wave - see gs_depth_block).  Its own kernel and argument list: the plain one is at a register cliff where an
 // eight-byte longer argument block alone cost 9 us at the headline (13 instead of 9 spilled registers).
-template <int NKF, int NKD>
+template <int NKF, int NKD, bool HALF = false>
 __global__ __launch_bounds__((GS_CW + 1) * 64, 2) void k_gs_xm(const DgGsArgs a, const uint32_t* dep_maskbits) {
-    gs_body<NKF, NKD, true>(a, dep_maskbits);
+    gs_body<NKF, NKD, true, HALF>(a, dep_maskbits);
 }
 
 // depth_only: the depth term's blocks alone (DG_EXACT_MASKS on the dense grid: the G-stream blocks run as a launch of the plain
 // kernel with two blocks per CU, the depth blocks - which need the intra pair-set's mask words - as one of the 256-register form)
-hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream, bool depth_only) {
+hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStream_t stream, bool depth_only, bool half_out) {
     dim3 grid((depth_only ? 0 : ((a.Ppad / 32 + GS_CW - 1) / GS_CW) * a.njobs * a.B) + a.dep_blocks), block((GS_CW + 1) * 64);
     if (grid.x == 0) return hipSuccess;
     DgGsArgs a2 = a;
@@ -1063,6 +1082,15 @@ hipError_t dg_launch_gs(const DgGsArgs& a, const uint32_t* dep_maskbits, hipStre
     if (const char* dbg = getenv("DG_DEBUG")) a2.debug = atoi(dbg);   // developer ablation switches (timing only)
 #endif
     const int smem = GS_NB * 4 * a.KD * 16 + GS_CW * 32 * GS_TS;
+    if (half_out) {          // fp16 output tiles: the widths of k_corr2 only (the identity grid's plan asks for them there)
+        if (a.KF != 384 || a.KD != 96) return hipErrorInvalidValue;
+        const void* kern = dep_maskbits ? reinterpret_cast<const void*>(k_gs_xm<24, 6, true>) : reinterpret_cast<const void*>(k_gs<24, 6, true>);
+        hipError_t e = dg_set_max_smem(kern, smem);
+        if (e != hipSuccess) return e;
+        if (dep_maskbits) hipLaunchKernelGGL((k_gs_xm<24, 6, true>), grid, block, smem, stream, a2, dep_maskbits);
+        else hipLaunchKernelGGL((k_gs<24, 6, true>), grid, block, smem, stream, a2);
+        return hipGetLastError();
+    }
 #define DG_GS(NKF_, NKD_)                                                                                               \
     if (a.KF == NKF_ * 16 && a.KD == NKD_ * 16) {                                                                        \
         const void* kern = dep_maskbits ? reinterpret_cast<const void*>(k_gs_xm<NKF_, NKD_>)                             \

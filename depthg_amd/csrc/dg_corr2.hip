@@ -901,6 +901,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 Rc[f][k] = *reinterpret_cast<const v4i_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(rc_lane[f] + k * 1024));
     }
     float lsumf[RF] = {0.f, 0.f}, csumf[RF] = {0.f, 0.f};
+    const bool half_tiles = args.half_tiles != 0;
     float* red = reinterpret_cast<float*>(smem + NBUF * BUF);      // [8 fragment slots][4]: loss sum, cd sum, pair-set, image
     sfor<RF>([&](auto FI) {
         constexpr int f = FI.value;
@@ -928,10 +929,23 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
                 for (int i = 0; i < 16; ++i) v[i] = dv[i];
             }
             if (base && 32 * d + r < args.D) {
+                if (half_tiles) {
+                    // fp16 tiles (DgScatterSrc.half): elements 8s .. 8s+7 as one 16-byte piece, [2][64][8] per channel group - half the
+                    // bytes here and in k_combine_out, and two store instructions per group instead of four
+                    _Float16* hb = reinterpret_cast<_Float16*>(dRj) + ((size_t)fn[f] * ntiles + ft[f]) * (32 * DP) + d * 1024 + lane * 8;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
+                    for (int sp = 0; sp < 2; ++sp) {
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[8 * sp + e];
+                        __builtin_nontemporal_store(__builtin_bit_cast(v4i_t, o), reinterpret_cast<v4i_t*>(hb + sp * 512));
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(base + (d * 4 + g) * 256));
+                    }
                 }
             }
             // sum clamp(cd)(fd'' - shift) = sum_p <x_p, dR'_p>, sum cd = sum_p <x_p, sum_q y_q>   (dg_corr.hip "FOLD")

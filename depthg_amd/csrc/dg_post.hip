@@ -136,6 +136,9 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
 // bit-reproducible) and writes (B,D,h,w) directly: a tile's 32 positions are 32 consecutive pixels, so each channel row of the
 // tile is one 128-byte run (through a per-wave LDS stage, two channel rows per store instruction).  No combined-tile round trip,
 // no second launch.
+#ifndef COMB_HB
+#define COMB_HB 4          // fp16 tiles per batch of k_combine_out (two 16-byte loads each; 8: 176 registers, two waves per SIMD, 48 us against 34)
+#endif
 #define COMB_MAXROUTE 512      // (routed source, image) pairs a destination image can collect at worst: routed sources x B
 template <int NDF>
 __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a) {
@@ -172,7 +175,11 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
         if (hit) {
             const int o = base + __popcll(bal & ((1ull << lane) - 1));
             const DgScatterSrc& q = a.src[s];
-            if (o < COMB_MAXROUTE) { rl_p[o] = q.buf + (size_t)m * a.Ppad * a.DP; rl_w[o] = dg_src_factor(q) * dg_pick(gs, q.gidx); }
+            if (o < COMB_MAXROUTE) {
+                // (half tiles: the same element index, two bytes per element - the pointer stays a float* and is re-typed at the load)
+                rl_p[o] = q.half ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(q.buf) + (size_t)m * a.Ppad * a.DP) : q.buf + (size_t)m * a.Ppad * a.DP;
+                rl_w[o] = dg_src_factor(q) * dg_pick(gs, q.gidx);
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -190,7 +197,53 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    // fp16 tiles (DgScatterSrc.half): [2][64][8] per channel group - the lane's elements 8s .. 8s+7 in one 16-byte piece; final ones are
+    // projected but not yet divided by ||c||: 1 / ||c|| of the destination's own positions, loaded once
+    const size_t in_img_h = (size_t)rt * (32 * DP) + lane * 8 + (ok ? d * 1024 : 0);
+    constexpr int HB = COMB_HB;
+    float invd[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        invd[i] = (a.xinv_dest[dest] && rr < a.P) ? a.xinv_dest[dest][(size_t)n * a.Ppad + rr] : 0.f;
+    }
+    // up to eight half tiles at a time (HB: sixteen 16-byte loads in flight, what four fp32 tiles are), every load of the batch in flight before the first is used (one at a time the launch was
+    // bound by the latency of its loads: the fp32 form's 28 us came back as 24 instead of 17)
+    auto add_half4 = [&](const _Float16 __attribute__((address_space(1)))* const (&hb)[HB], const float (&sc)[HB], const bool raw) __attribute__((always_inline)) {
+        f16x8 t0[HB], t1[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            t0[u] = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(hb[u]);
+            t1[u] = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(hb[u] + ((ok && sc[u] != 0.f) ? 512 : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const bool use = ok && sc[u] != 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = fmaf(raw ? sc[u] : sc[u] * invd[e], use ? (float)t0[u][e] : 0.f, v[e]);
+                v[8 + e] = fmaf(raw ? sc[u] : sc[u] * invd[8 + e], use ? (float)t1[u][e] : 0.f, v[8 + e]);
+            }
+        }
+    };
+    const _Float16 __attribute__((address_space(1)))* const hdummy = reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.xinv));
+    auto add_sources_half = [&](const int8_t* list, const int nsrc_, const bool raw) __attribute__((always_inline)) {
+        for (int k0 = 0; k0 < nsrc_; k0 += HB) {
+            const _Float16 __attribute__((address_space(1)))* hb[HB];
+            float sc[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const bool live = k0 + u < nsrc_;
+                const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
+                sc[u] = live ? dg_src_factor(q) * dg_pick(gs, q.gidx) : 0.f;
+                hb[u] = sc[u] != 0.f ? reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(q.buf)) + (size_t)n * a.Ppad * DP + in_img_h
+                                     : hdummy;
+            }
+            add_half4(hb, sc, raw);
+        }
+    };
     auto add_sources = [&](const int8_t* list, const int nsrc_) __attribute__((always_inline)) {
+
         for (int k0 = 0; k0 < nsrc_; k0 += 4) {
             f32x4 t[4][4];
             float sc[4];
@@ -213,8 +266,9 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
             }
         }
     };
-    const int nraw = a.ncraw[dest];
-    add_sources(a.craw[dest], nraw);
+    const int nraw = a.ncraw[dest] + a.ncrawh[dest];
+    add_sources(a.craw[dest], a.ncraw[dest]);
+    add_sources_half(a.crawh[dest], a.ncrawh[dest], true);
     if (nraw > 0) {
         const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c + d * 2048;
         _Float16 x[1][16];
@@ -236,7 +290,21 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
         }
     }
     add_sources(a.cfin[dest], a.ncfin[dest]);
+    add_sources_half(a.cfinh[dest], a.ncfinh[dest], false);
     // ---- the routed images' tiles (k_gs output: final), four at a time
+    if (a.routed_half) {
+        for (int e0 = 0; e0 < cnt; e0 += HB) {
+            const _Float16 __attribute__((address_space(1)))* hb[HB];
+            float sc[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int e = min(e0 + k, cnt - 1);
+                sc[k] = e0 + k < cnt ? rl_w[e] : 0.f;
+                hb[k] = sc[k] != 0.f ? reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(rl_p[e])) + in_img_h : hdummy;
+            }
+            add_half4(hb, sc, false);
+        }
+    } else
     for (int e0 = 0; e0 < cnt; e0 += 4) {
         f32x4 u4[4][4];
         float sc[4];
@@ -679,13 +747,13 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
     DgScatterArgs ac = a;
     {
         for (int dest = 0; dest < 2; ++dest) {
-            ac.ncraw[dest] = ac.ncfin[dest] = 0;
+            ac.ncraw[dest] = ac.ncfin[dest] = ac.ncrawh[dest] = ac.ncfinh[dest] = 0;
             for (int i = 0; i < a.nsrc; ++i) {
                 const DgScatterSrc& q = a.src[i];
                 if (q.dest != dest || q.route != nullptr) continue;
-                int8_t& cnt = q.raw ? ac.ncraw[dest] : ac.ncfin[dest];
+                int8_t& cnt = q.half ? (q.raw ? ac.ncrawh[dest] : ac.ncfinh[dest]) : (q.raw ? ac.ncraw[dest] : ac.ncfin[dest]);
                 if (cnt >= DG_MAX_SCATTER / 2) return hipErrorInvalidValue;
-                (q.raw ? ac.craw[dest] : ac.cfin[dest])[cnt++] = (int8_t)i;
+                (q.half ? (q.raw ? ac.crawh[dest] : ac.cfinh[dest]) : (q.raw ? ac.craw[dest] : ac.cfin[dest]))[cnt++] = (int8_t)i;
             }
         }
         const dim3 cgrid(a.Ppad / 32, a.B, 2);
@@ -694,7 +762,14 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
             // identity grid: combine + routed negatives + (B,D,h,w) output in one launch
             int nrouted = 0;
             for (int i = 0; i < a.nsrc; ++i) nrouted += a.src[i].route != nullptr;
-            if (a.dense && a.S == a.h && a.S == a.w && nrouted * a.B <= COMB_MAXROUTE && (a.DP == 96 || a.DP == 128)) {
+            bool any_half = false;
+            int routed_h = 0;
+            for (int i = 0; i < a.nsrc; ++i) { any_half = any_half || a.src[i].half != 0; routed_h += (a.src[i].route != nullptr && a.src[i].half) ? 1 : 0; }
+            if (routed_h != 0 && routed_h != nrouted) return hipErrorInvalidValue;      // (fp16 tiles for every routed source or for none)
+            ac.routed_half = routed_h != 0 ? 1 : 0;
+            const bool one_launch = a.dense && a.S == a.h && a.S == a.w && nrouted * a.B <= COMB_MAXROUTE && (a.DP == 96 || a.DP == 128);
+            if (any_half && !one_launch) return hipErrorInvalidValue;      // (fp16 tiles are k_combine_out's: the plan asks for them only where it runs)
+            if (one_launch) {
                 // (the list holds the worst case - every routed image of every routed source pointing at one destination)
                 if (a.DP == 96) hipLaunchKernelGGL(k_combine_out<3>, cgrid, dim3(192), 0, s, ac);
                 else hipLaunchKernelGGL(k_combine_out<4>, cgrid, dim3(256), 0, s, ac);

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""developer aid (round 6): where two runs of the dense step differ bit-wise (fp16 gradient tiles)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from depthg_amd import ContrastiveCorrelationLoss
+from depthg_amd.loss import identity_coords
+from oracle import depthg_oracle as O
+dev = torch.device("cuda:0")
+B, C, D, hw = 8, 384, 70, 28
+g = torch.Generator().manual_seed(77)
+f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+c, cp = torch.randn(B, D, hw, hw, generator=g).to(dev), torch.randn(B, D, hw, hw, generator=g).to(dev)
+d = torch.randint(0, 256, (B, 1, 224, 224), generator=g).float().to(dev)
+perms = torch.stack([O.super_perm(B, g) for _ in range(5)]).to(dev)
+c1 = identity_coords(B, hw, dev)
+loss = ContrastiveCorrelationLoss(O.default_cfg(feature_samples=hw, dg_outputs="reduced"))
+runs = []
+for _ in range(4):
+    cg, cpg = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    loss.forward_with(f, fp, cg, cpg, d, c1, c1, perms, shared_coords=True, identity_grid=True)
+    loss.total.backward()
+    torch.cuda.synchronize()
+    runs.append((loss.scalars.detach().clone(), cg.grad.clone(), cpg.grad.clone()))
+for k in range(1, 4):
+    for name, a, b in zip(("scalars", "grad_code", "grad_code_pos"), runs[0], runs[k]):
+        diff = (a != b)
+        if diff.any():
+            idx = diff.nonzero()
+            print(f"run {k} {name}: {int(diff.sum())} of {a.numel()} differ; first {idx[:5].tolist()}; images {sorted(set(idx[:,0].tolist()))[:8] if idx.dim()>1 and idx.shape[1]>1 else ''}",
+                  "channels", sorted(set(idx[:,1].tolist()))[:12] if idx.dim() > 1 and idx.shape[1] > 1 else "", "max abs diff", float((a-b).abs().max()))
+        else:
+            print(f"run {k} {name}: identical")
