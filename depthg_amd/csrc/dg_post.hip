@@ -136,11 +136,17 @@ __global__ __launch_bounds__(64 * NDF) void k_grad_combine(const DgScatterArgs a
 // bit-reproducible) and writes (B,D,h,w) directly: a tile's 32 positions are 32 consecutive pixels, so each channel row of the
 // tile is one 128-byte run (through a per-wave LDS stage, two channel rows per store instruction).  No combined-tile round trip,
 // no second launch.
+#ifndef COMB_HB_HM
+#define COMB_HB_HM 4          // ... in half mode (6, 8: 176 registers, three instead of four-plus waves per SIMD: 44 us against 27.5)
+#endif
 #ifndef COMB_HB
 #define COMB_HB 4          // fp16 tiles per batch of k_combine_out (two 16-byte loads each; 8: 176 registers, two waves per SIMD, 48 us against 34)
 #endif
 #define COMB_MAXROUTE 512      // (routed source, image) pairs a destination image can collect at worst: routed sources x B
-template <int NDF>
+// HM (half mode: the call's pair-set tiles are fp16, only the depth term's are fp32): eight fp16 tiles and ONE fp32 tile per batch instead
+// of four and four - the block is a chain of load phases (ablations, experiments/r06.md 18.8: each costs 3-5 us of the launch), and
+// with every raw tile of a destination in one batch and every routed one in another there are four of them instead of seven
+template <int NDF, bool HM = false>
 __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a) {
     const int rt = blockIdx.x, n = blockIdx.y, dest = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, DP = NDF * 32;
@@ -154,8 +160,9 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
     DG_LOAD_GS(a, gs)
     // ---- routed list of (dest, n): every thread tests one (routed source, image) pair per round
     int nr = 0;
-    for (int s = 0; s < a.nsrc; ++s)
-        if (a.src[s].dest == dest && a.src[s].route != nullptr) { if (tid == 0) rsrc[nr] = s; ++nr; }
+    if (DG_DBG(a.debug) & 8) { if (dest == 1) return; }                   // (developer ablations, WRONG results: 8 no destination-1 blocks,
+    for (int s = 0; s < a.nsrc; ++s)                                       //  1 no routed sources, 2 no norm() backward, 4 no output)
+        if (a.src[s].dest == dest && a.src[s].route != nullptr && !(DG_DBG(a.debug) & 1)) { if (tid == 0) rsrc[nr] = s; ++nr; }
     if (tid == 0) rl_cnt = 0;
     __syncthreads();
     for (int i0 = 0; i0 < nr * a.B; i0 += 64 * NDF) {
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
     // fp16 tiles (DgScatterSrc.half): [2][64][8] per channel group - the lane's elements 8s .. 8s+7 in one 16-byte piece; final ones are
     // projected but not yet divided by ||c||: 1 / ||c|| of the destination's own positions, loaded once
     const size_t in_img_h = (size_t)rt * (32 * DP) + lane * 8 + (ok ? d * 1024 : 0);
-    constexpr int HB = COMB_HB;
+    constexpr int HB = HM ? COMB_HB_HM : COMB_HB, FB = HM ? 1 : 4;
     float invd[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -244,11 +251,11 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
     };
     auto add_sources = [&](const int8_t* list, const int nsrc_) __attribute__((always_inline)) {
 
-        for (int k0 = 0; k0 < nsrc_; k0 += 4) {
-            f32x4 t[4][4];
-            float sc[4];
+        for (int k0 = 0; k0 < nsrc_; k0 += FB) {
+            f32x4 t[FB][4];
+            float sc[FB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FB; ++u) {
                 const bool live = k0 + u < nsrc_;
                 const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
                 sc[u] = live ? dg_src_factor(q) * dg_pick(gs, q.gidx) : 0.f;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
                 for (int g = 0; g < 4; ++g) t[u][g] = *reinterpret_cast<const f32x4*>(base + (ok ? g * 256 : 0));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < FB; ++u) {
                 const bool use = ok && k0 + u < nsrc_;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
     const int nraw = a.ncraw[dest] + a.ncrawh[dest];
     add_sources(a.craw[dest], a.ncraw[dest]);
     add_sources_half(a.crawh[dest], a.ncrawh[dest], true);
-    if (nraw > 0) {
+    if (nraw > 0 && !(DG_DBG(a.debug) & 2)) {
         const char* xb = a.xop + ((size_t)n * (a.Ppad >> 5) + rt) * a.blob_bytes + a.blob_off_c + d * 2048;
         _Float16 x[1][16];
         dg_load_code_rows<1>(xb, xs[d], lane, x);
@@ -324,6 +331,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
                 for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaf(sc[k], ok ? u4[k][g][e] : 0.f, v[4 * g + e]);
     }
     // ---- out[dest][(n, channel, pixel)]: the wave's [32 channels][32 positions] tile through LDS, rows of 128 contiguous bytes
+    if (DG_DBG(a.debug) & 4) { if (v[0] == 1.2345f) a.out[dest][0] = v[1]; return; }
     float* st = stage[d];
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[r * 33 + (i & 3) + 8 * (i >> 2) + 4 * h] = v[i];
@@ -767,11 +775,15 @@ hipError_t dg_launch_scatter(const DgScatterArgs& a, hipStream_t s) {
             for (int i = 0; i < a.nsrc; ++i) { any_half = any_half || a.src[i].half != 0; routed_h += (a.src[i].route != nullptr && a.src[i].half) ? 1 : 0; }
             if (routed_h != 0 && routed_h != nrouted) return hipErrorInvalidValue;      // (fp16 tiles for every routed source or for none)
             ac.routed_half = routed_h != 0 ? 1 : 0;
+#ifdef DG_DEVTOOLS
+            if (const char* e = getenv("DG_COMB_DEBUG")) ac.debug = atoi(e);
+#endif
             const bool one_launch = a.dense && a.S == a.h && a.S == a.w && nrouted * a.B <= COMB_MAXROUTE && (a.DP == 96 || a.DP == 128);
             if (any_half && !one_launch) return hipErrorInvalidValue;      // (fp16 tiles are k_combine_out's: the plan asks for them only where it runs)
             if (one_launch) {
                 // (the list holds the worst case - every routed image of every routed source pointing at one destination)
-                if (a.DP == 96) hipLaunchKernelGGL(k_combine_out<3>, cgrid, dim3(192), 0, s, ac);
+                if (a.DP == 96 && any_half) hipLaunchKernelGGL((k_combine_out<3, true>), cgrid, dim3(192), 0, s, ac);
+                else if (a.DP == 96) hipLaunchKernelGGL(k_combine_out<3>, cgrid, dim3(192), 0, s, ac);
                 else hipLaunchKernelGGL(k_combine_out<4>, cgrid, dim3(256), 0, s, ac);
                 return hipGetLastError();
             }
