@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
             for (int k = 0; k < NKC; ++k)
                 // (a GLOBAL-address-space load: through the generic pointer hipcc emitted flat_load_dwordx4 here and the fragments came
                 //  back wrong - NaN loss sums with correct gradients, round 6 - as they did from asm loads at the top of the block that
-                //  nothing inside the tile loop named; scripts/lab_r06_nan.py, profiles/r06_xm_block_end_loads.txt)
+                //  nothing inside the tile loop named; scripts/lab_r06/lab_r06_nan.py, profiles/r06_xm_block_end_loads.txt)
                 Rc[f][k] = *reinterpret_cast<const v4i_t __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(rc_lane[f] + k * 1024));
     }
     float lsumf[RF] = {0.f, 0.f}, csumf[RF] = {0.f, 0.f};

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer aid (round 6): where the NaN of the exact-mask form comes from - scalars, gradient NaN counts, against the oracle."""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from depthg_amd import ContrastiveCorrelationLoss

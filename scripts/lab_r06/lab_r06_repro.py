@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """developer aid (round 6): where two runs of the dense step differ bit-wise (fp16 gradient tiles)."""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from depthg_amd import ContrastiveCorrelationLoss
 from depthg_amd.loss import identity_coords
