@@ -1272,7 +1272,13 @@ static int head_check(int32_t B, int32_t C, int32_t D, int32_t P) {
     return DG_OK;
 }
 static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P, int32_t M2 = 0) {     // (M2: a second product in the same launch)
-    const int tiles = ((M + 127) / 128 + (M2 + 127) / 128) * ((N + 127) / 128), steps = B * ((P + 31) / 32);
+    const int steps = B * ((P + 31) / 32);
+    if (dg_head_wgrad_one_pass(M, N, M2, P) && steps >= 8) {
+        // k_head_wgrad3: one block per CU and one round - the largest multiple of 8 splits whose blocks (channel tiles x splits) fit 256 CUs
+        const int s = (256 / ((N + 127) / 128)) & ~7;
+        return s > steps ? (steps & ~7) : s;              // (a multiple of 8 either way: what the launcher checks)
+    }
+    const int tiles = ((M + 127) / 128 + (M2 + 127) / 128) * ((N + 127) / 128);
 #ifndef HEAD_SPLIT_TARGET
     // about two blocks per CU; three when both featurizer passes of a step share the launch (1600 position steps at the headline:
     // 512 / 640 / 768 / 896 blocks gave 136 / 132 / 128 / 133 us for the two weight-gradient launches and their reduction)

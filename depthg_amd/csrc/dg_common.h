@@ -830,6 +830,7 @@ hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);
 hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s);
+bool dg_head_wgrad_one_pass(int M, int N, int M2, int P);      // the two products over the features as k_head_wgrad3 (one block = all rows x 128 channels)
 struct DgHeadReduceJob { const float* part; float* out; float* out2; int32_t n, splits; float scale; };
 struct DgHeadReduceArgs { DgHeadReduceJob jobs[6]; int32_t njobs; };
 hipError_t dg_launch_head_reduce(const DgHeadReduceArgs& a, hipStream_t s);

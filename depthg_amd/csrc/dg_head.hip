@@ -771,8 +771,193 @@ __global__ __launch_bounds__(256, 2) void k_head_wgrad2(const DgHeadWgradArgs a)
     else wgrad2_body<TA2, TB>(a, a.A2, a.dA2, a.keep_2, a.part2, a.M2, (tm - tm1) * 128, n0, split);
 }
 
+// Round 6: the two products that share the feature operand in ONE pass over it.  A block owns ALL rows of both products - 384 rows of
+// d hidden (bf16) and up to 128 rows of d code (fp32) = a 512-row tile - and 128 feature channels; its eight waves sit 4 x 2 on the
+// 512 x 128 tile (128 x 64 each: 128 accumulator registers).  The fp32 feature rows of a step are read ONCE per block, where
+// k_head_wgrad2 reads them once per 128-row tile: four times (308 of its 451 MB at the paired headline shape, 77 here).
+// One block per CU: nothing but the block's own look-ahead covers the memory round trip, and registers cannot (two sets of a step's
+// pieces spill).  So every operand goes global -> LDS by DMA (global_load_lds_dwordx4: no registers), NSTAGE - 1 steps ahead, as it
+// lies in memory - fp32 rows stay fp32 in LDS and are rounded to bf16 on the way into the fragments (the same rounding, later).
+// LDS image of a step (32 positions): rows of 64 (bf16) / 128 (fp32) bytes, the 16-byte pieces of a row XORed with row bits so that the
+// 16 rows one ds_read_b128 pass touches cover all 64 banks; a DMA piece = 1 KiB = 16 / 8 consecutive rows.
+// Ragged steps (the last of an image) and rows beyond the matrix: the piece is fetched from a clamped, valid address (finite values)
+// and the feature fragment is zeroed in registers - as are the channels Dropout2d removed (per image and channel = per lane).
+// grid = channel tiles x splits, the tiles of a split on one XCD (they share the 512 rows).
+#define W3_DH_BYTES (384 * 64)
+#define W3_B_BYTES (128 * 128)
+__device__ __forceinline__ void w3_wait_barrier(const int n) {
+    switch (n) {
+#define W3_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        W3_W(1) W3_W(2) W3_W(3) W3_W(4) W3_W(5) W3_W(6) W3_W(7)
+#undef W3_W
+        default: asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;    // (over-waits, never under-waits)
+    }
+}
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char w3sm[];     // [NSTAGE][d hidden 384 rows | features 128 rows | d code 8 g8 rows]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = (a.N + 127) / 128;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = xcd + 8 * (slot / tn), n0 = (slot % tn) * 128;
+    const int steps_img = (a.P + 31) / 32, total = a.B * steps_img;
+    const int s0 = (int)((long long)total * split / a.splits), s1 = (int)((long long)total * (split + 1) / a.splits), ns = s1 - s0;
+    const int wm = wid >> 1, wn = wid & 1, r32 = lane & 31, kg = lane >> 5;
+    const int g8 = (a.M2 + 7) >> 3;                                   // 1-KiB pieces of the d code part
+    const int stage_bytes = W3_DH_BYTES + W3_B_BYTES + g8 * 1024;
+    const uint32_t lds0 = lds_addr(w3sm);
+    // ---- the wave's DMA pieces (d hidden: wid, wid + 8, wid + 16; features: wid, wid + 8; d code: wid, wid + 8 where below g8).  A lane's
+    //      16 bytes: LDS slot (row, physical piece) = the lane's place in the KiB; it fetches the LOGICAL piece physical ^ swizzle(row).
+    //      The per-lane offsets are recomputed at every step from the lane number (a dozen VALU operations under 16 MFMAs) - held in
+    //      registers across the loop they were spilled, and a scratch reload is a vector-memory load hipcc waits for with vmcnt(0):
+    //      it drains the DMA queue
+    const int npw = 5 + (wid < g8 ? 1 : 0) + (wid + 8 < g8 ? 1 : 0);   // DMA instructions of this wave per step
+    auto issue = [&](const int b, const int p0, const int st) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                   // (opaque: no hoisting out of the step loop)
+        const int v = a.P - p0;                                        // valid positions from p0 on (>= 8)
+        const uint32_t dst = lds0 + st * stage_bytes + wid * 1024;
+        // d hidden: row = 16 piece + lane / 4, swizzle (row >> 2) & 3 = (lane >> 4) & 3 for every piece
+        const int pd = 8 * ((ln & 3) ^ ((ln >> 4) & 3)), pdv = pd + 8 <= v ? pd : 0;
+        const __bf16* Ab = static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0 + pdv;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int row = 16 * (wid + 8 * u) + (ln >> 2);
+            dma16(Ab + (row < a.M ? row : a.M - 1) * a.P, dst + u * 8192);
+        }
+        // fp32 rows: row = 8 piece + lane / 8, swizzle (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7, piece & 1 = wid & 1
+        const int pf = 4 * ((ln & 7) ^ ((4 * (wid & 1) + (ln >> 4)) & 7)), pfv = pf + 4 <= v ? pf : 0;
+        const float* Bb = static_cast<const float*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + p0 + pfv;
+        const float* Gb = static_cast<const float*>(a.A2) + dg_img_off(b, (long long)a.M2 * a.P, a.Bs, a.dA2) + p0 + pfv;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 8 * (wid + 8 * u) + (ln >> 3);
+            dma16(Bb + (n0 + row < a.N ? n0 + row : a.N - 1) * a.P, dst + W3_DH_BYTES + u * 8192);
+            if (wid + 8 * u < g8) dma16(Gb + (row < a.M2 ? row : a.M2 - 1) * a.P, dst + W3_DH_BYTES + W3_B_BYTES + u * 8192);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // fragment addresses inside a stage (bytes).  d hidden and feature rows: row and swizzle are fixed per lane and the wave's row blocks
+    // lie 32 rows apart (an immediate offset); d code rows (waves 6, 7): clamped to the rows the stage holds (rows >= M2 feed
+    // accumulator rows that are never stored)
+    const int asw = (r32 >> 2) & 3, a_l = (wm * 128 + r32) * 64;
+    const int a_off[2] = {a_l + ((kg ^ asw) << 4), a_l + (((2 + kg) ^ asw) << 4)};
+    const int bsw = (r32 >> 1) & 7, b_l = W3_DH_BYTES + (wn * 64 + r32) * 128;
+    const int gmax = 8 * g8 - 1;
+    const float* const kmask = wm == 3 ? a.keep_2 : a.keep;
+    unsigned kbits[2] = {~0u, ~0u};         // all-ones / zero per feature channel of this lane: Dropout2d and channels beyond N
+    int bcur = -1;
+    auto load_b = [&](const char* base, const int ks, const int v, bf16x8 (&bfr)[2]) __attribute__((always_inline)) {
+        const int L0 = 4 * ks + 2 * kg;
+        const unsigned live = (16 * ks + 8 * kg + 8 > v) ? 0u : ~0u;   // positions beyond the image
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(base + b_l + j * 4096 + ((L0 ^ bsw) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(base + b_l + j * 4096 + (((L0 + 1) ^ bsw) << 4));
+            u32x4 t = __builtin_bit_cast(u32x4, pack8(lo, hi));
+            t &= (kbits[j] & live);
+            bfr[j] = __builtin_bit_cast(bf16x8, t);
+        }
+    };
+    auto load_a = [&](const char* base, const int ks, bf16x8 (&af)[4]) __attribute__((always_inline)) {
+        if (wm < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + i * 2048);
+        } else {
+            const int L0 = 4 * ks + 2 * kg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 32 + r32 < gmax ? i * 32 + r32 : gmax, sw = (row >> 1) & 7;
+                const char* rp = base + W3_DH_BYTES + W3_B_BYTES + row * 128;
+                af[i] = pack8(*reinterpret_cast<const f32x4*>(rp + ((L0 ^ sw) << 4)), *reinterpret_cast<const f32x4*>(rp + (((L0 + 1) ^ sw) << 4)));
+            }
+        }
+    };
+    constexpr int DIST = NSTAGE - 1;
+    // (image, first position) of the step being issued and of the step being multiplied: advanced, not divided
+    int bi = s0 / steps_img, pi = (s0 - bi * steps_img) * 32, bm = bi, pm = pi;
+#pragma unroll
+    for (int k = 0; k < DIST; ++k)
+        if (k < ns) { issue(bi, pi, k); pi += 32; if (pi >= a.P) { pi = 0; ++bi; } }
+    int st = 0, stn = DIST % NSTAGE;        // stage of step k; stage step k + DIST goes to
+    for (int k = 0; k < ns; ++k) {
+        const int newer = ns - 1 - k < DIST - 1 ? ns - 1 - k : DIST - 1;       // steps issued behind step k
+        w3_wait_barrier(newer * npw);        // step k has landed (every wave's pieces) and nobody reads the stage step k + DIST overwrites
+        if (k + DIST < ns) { issue(bi, pi, stn); pi += 32; if (pi >= a.P) { pi = 0; ++bi; } }
+        if (bm != bcur) {
+            bcur = bm;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nj = n0 + wn * 64 + j * 32 + r32;
+                const float kv = (kmask && nj < a.N) ? kmask[(size_t)bm * a.N + nj] : 1.f;
+                kbits[j] = (nj < a.N && kv != 0.f) ? ~0u : 0u;
+            }
+        }
+        const int v = a.P - pm;
+        const char* base = w3sm + st * stage_bytes;
+        // feature fragments of both k-steps first (fp32 in LDS: eight temporaries each on the way to bf16), then - d hidden waves - the
+        // A fragments of both k-steps requested before the first MFMA: the reads of the second run under the products of the first
+        bf16x8 b0[2], b1[2], a0[4], a1[4];
+        load_b(base, 0, v, b0);
+        load_b(base, 1, v, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(base, 0, a0);
+        load_a(base, 1, a1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        pm += 32; if (pm >= a.P) { pm = 0; ++bm; }
+        st = st + 1 == NSTAGE ? 0 : st + 1;
+        stn = stn + 1 == NSTAGE ? 0 : stn + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no DMA piece outlives the block's LDS; all have landed by the last step anyway)
+    const int Mo = wm == 3 ? a.M2 : a.M;
+    float* out = (wm == 3 ? a.part2 : a.part) + (size_t)split * Mo * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (wm == 3 ? 0 : wm * 128) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                if (m < Mo && n < a.N) out[(size_t)m * a.N + n] = acc[i][j][e];
+            }
+        }
+}
+// (what the plan asks before it sizes the partial sums: dg_api.hip head_splits)
+bool dg_head_wgrad_one_pass(int M, int N, int M2, int P) {
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_HEAD_WGRAD3")) if (e[0] == '0') return false;
+#endif
+    return M > 256 && M <= 384 && M2 > 0 && M2 <= 128 && (P & 7) == 0;
+}
+
 template <typename TA, typename TB, typename TA2 = TA>
 static hipError_t launch_wgrad(const DgHeadWgradArgs& a, hipStream_t s) {
+    if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TB, float>::value && std::is_same<TA2, float>::value) {
+        if (dg_head_wgrad_one_pass(a.M, a.N, a.M2, a.P) && (a.splits & 7) == 0) {
+            const int stage = W3_DH_BYTES + W3_B_BYTES + ((a.M2 + 7) >> 3) * 1024;
+            const bool three = 3 * stage <= 160 * 1024;              // (d code of more than 80 channels: one step of look-ahead)
+            const int smem = (three ? 3 : 2) * stage;
+            auto kern = three ? k_head_wgrad3<3> : k_head_wgrad3<2>;
+            hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(((a.N + 127) / 128) * a.splits), dim3(512), smem, s, a);
+            return hipGetLastError();
+        }
+    }
     const int tiles = ((a.N + 127) / 128) * ((a.M + 127) / 128 + (a.M2 + 127) / 128);
     if ((a.P & 7) == 0 && (a.splits & 7) == 0) {
         const int smem = 4 * 128 * (32 * 2 + 16);
