@@ -1288,7 +1288,7 @@ static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P, int32_t M2 = 
     s = (s + 7) & ~7;                                       // a multiple of 8: k_head_wgrad2 keeps the tiles of a split on one XCD
     return s > steps ? steps : s;
 }
-struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, total; int s2a, s1, s2b, tiles; };
+struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, gbf, total; int s2a, s1, s2b, tiles; bool one_pass; };
 static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     HeadPlan h;
     size_t off = 0;
@@ -1302,6 +1302,9 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     h.p2b = take((size_t)h.s2b * D * C * 4);
     h.pbd = take((size_t)B * h.tiles * D * 4);
     h.pb2a = take((size_t)B * h.tiles * C * 4);
+    // k_head_wgrad3 (d W2a and d W1 in one pass over the features) reads d code as the bf16 copy k_head_dh leaves
+    h.one_pass = dg_head_wgrad_one_pass(C, C, D, P) && (h.s2a & 7) == 0;
+    h.gbf = h.one_pass ? take((size_t)B * D * P * 2) : 0;
     h.total = off;
     return h;
 }
@@ -1407,6 +1410,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
     const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + (size_t)2 * D * C + (size_t)C * C;
     DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P, Bs, d_g};
+    d.gcode_bf = h.one_pass ? reinterpret_cast<__bf16*>(ws + h.gbf) : nullptr;
     // d W2b = d code x hidden^T needs nothing of k_head_dh: it runs BESIDE it on the library's second stream where there is one (fork
     // / join by events, capturable): two launches that each leave most of the chip idle (27 and 37 us at the paired headline shape)
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
@@ -1425,6 +1429,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
     DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
     wa.Bs = Bs; wa.dA = 0; wa.dB = d_feat; wa.dA2 = d_g;
+    wa.A2h = d.gcode_bf;
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);

@@ -813,6 +813,7 @@ struct DgHeadDhArgs {
     float* part_b2a;         // [B * tiles][C] per-block row sums of d hidden_pre
     int32_t B, C, D, P;
     int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
+    __bf16* gcode_bf;                // (B,D,P) out or null: d code rounded to bf16, the A2h operand of k_head_wgrad3 (P a multiple of 4)
     int32_t staged;                  // (set by the launcher) 1: hidden / d hidden through an LDS image of whole rows (P a multiple of 8)
 };
 
@@ -823,6 +824,7 @@ struct DgHeadWgradArgs {
     int32_t B, M, N, P, splits;
     // optional second product with the same Bm in the same launch (M2 > 0): A2 (B, M2, P) fp32, its keep mask and partial sums
     const void* A2; const float* keep_2; float* part2; int32_t M2;
+    const void* A2h;                   // (B, M2, P) bf16 copy of A2 in ONE tensor (k_head_dh) or null; with it the two products run as k_head_wgrad3
     int32_t Bs; long long dA, dB, dA2;   // (pair: images Bs.. of A / Bm / A2 in second tensors, offsets in their elements; 0: one tensor)
 };
 

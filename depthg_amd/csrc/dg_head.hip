@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float x = ok ? v[u][e] : 0.f; rs += x; o[e] = (__bf16)x; }
                 *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
+                if (a.gcode_bf && ok) *reinterpret_cast<bf16x4*>(a.gcode_bf + ((size_t)b * D + d) * P + p) = o;     // (for k_head_wgrad3: its d code rows, as rounded here)
 #pragma unroll
                 for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
                 if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
@@ -772,19 +773,23 @@ __global__ __launch_bounds__(256, 2) void k_head_wgrad2(const DgHeadWgradArgs a)
 }
 
 // Round 6: the two products that share the feature operand in ONE pass over it.  A block owns ALL rows of both products - 384 rows of
-// d hidden (bf16) and up to 128 rows of d code (fp32) = a 512-row tile - and 128 feature channels; its eight waves sit 4 x 2 on the
-// 512 x 128 tile (128 x 64 each: 128 accumulator registers).  The fp32 feature rows of a step are read ONCE per block, where
-// k_head_wgrad2 reads them once per 128-row tile: four times (308 of its 451 MB at the paired headline shape, 77 here).
+// d hidden and up to 128 rows of d code (bf16 both: k_head_dh leaves a bf16 copy of d code, the rounding this product applied anyway) =
+// a 512-row tile - and 128 feature channels; its eight waves sit 4 x 2 on the 512 x 128 tile (128 x 64 each: 128 accumulator
+// registers).  The fp32 feature rows of a step are read ONCE per block, where k_head_wgrad2 reads them once per 128-row tile: four
+// times (308 of its 451 MB at the paired headline shape, 77 here).
 // One block per CU: nothing but the block's own look-ahead covers the memory round trip, and registers cannot (two sets of a step's
-// pieces spill).  So every operand goes global -> LDS by DMA (global_load_lds_dwordx4: no registers), NSTAGE - 1 steps ahead, as it
-// lies in memory - fp32 rows stay fp32 in LDS and are rounded to bf16 on the way into the fragments (the same rounding, later).
+// pieces spill).  So every operand goes global -> LDS by DMA (global_load_lds_dwordx4: no registers), two steps ahead, as it lies in
+// memory - the fp32 feature rows stay fp32 in LDS and are rounded to bf16 on the way into the fragments (the same rounding, later).
 // LDS image of a step (32 positions): rows of 64 (bf16) / 128 (fp32) bytes, the 16-byte pieces of a row XORed with row bits so that the
-// 16 rows one ds_read_b128 pass touches cover all 64 banks; a DMA piece = 1 KiB = 16 / 8 consecutive rows.
+// lane groups of a ds_read_b128 cover all 64 banks; a DMA piece = 1 KiB = 16 / 8 consecutive rows.
 // Ragged steps (the last of an image) and rows beyond the matrix: the piece is fetched from a clamped, valid address (finite values)
-// and the feature fragment is zeroed in registers - as are the channels Dropout2d removed (per image and channel = per lane).
+// and the feature fragment is zeroed in registers - as are the channels Dropout2d removed (per image and channel = per lane); rows of
+// the tile beyond M2 are never filled: they feed accumulator rows that are never stored.
 // grid = channel tiles x splits, the tiles of a split on one XCD (they share the 512 rows).
-#define W3_DH_BYTES (384 * 64)
+#define W3_A_BYTES (512 * 64)
 #define W3_B_BYTES (128 * 128)
+#define W3_STAGE (W3_A_BYTES + W3_B_BYTES)
+#define W3_NSTAGE 3
 __device__ __forceinline__ void w3_wait_barrier(const int n) {
     switch (n) {
 #define W3_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
@@ -793,9 +798,13 @@ __device__ __forceinline__ void w3_wait_barrier(const int n) {
         default: asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;    // (over-waits, never under-waits)
     }
 }
-template <int NSTAGE>
+// one DMA piece: 64 lanes x 16 bytes from base + the lane's byte offset to the KiB at the LDS address (M0 is not restored: nothing
+// else in this kernel reads it)
+__device__ __forceinline__ void w3_dma(const void* sbase, const uint32_t voff, const uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char w3sm[];     // [NSTAGE][d hidden 384 rows | features 128 rows | d code 8 g8 rows]
+    extern __shared__ __attribute__((aligned(1024))) char w3sm[];     // [3 stages][A: d hidden 384 rows, d code 128 rows | features 128 rows]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = (a.N + 127) / 128;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -803,38 +812,41 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
     const int steps_img = (a.P + 31) / 32, total = a.B * steps_img;
     const int s0 = (int)((long long)total * split / a.splits), s1 = (int)((long long)total * (split + 1) / a.splits), ns = s1 - s0;
     const int wm = wid >> 1, wn = wid & 1, r32 = lane & 31, kg = lane >> 5;
-    const int g8 = (a.M2 + 7) >> 3;                                   // 1-KiB pieces of the d code part
-    const int stage_bytes = W3_DH_BYTES + W3_B_BYTES + g8 * 1024;
+    const int g16 = (a.M2 + 15) >> 4;                                 // 1-KiB pieces of the d code rows
     const uint32_t lds0 = lds_addr(w3sm);
-    // ---- the wave's DMA pieces (d hidden: wid, wid + 8, wid + 16; features: wid, wid + 8; d code: wid, wid + 8 where below g8).  A lane's
-    //      16 bytes: LDS slot (row, physical piece) = the lane's place in the KiB; it fetches the LOGICAL piece physical ^ swizzle(row).
-    //      The per-lane offsets are recomputed at every step from the lane number (a dozen VALU operations under 16 MFMAs) - held in
-    //      registers across the loop they were spilled, and a scratch reload is a vector-memory load hipcc waits for with vmcnt(0):
-    //      it drains the DMA queue
-    const int npw = 5 + (wid < g8 ? 1 : 0) + (wid + 8 < g8 ? 1 : 0);   // DMA instructions of this wave per step
-    auto issue = [&](const int b, const int p0, const int st) __attribute__((always_inline)) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));                                   // (opaque: no hoisting out of the step loop)
+    // ---- the wave's DMA pieces.  A lane's 16 bytes: LDS slot (row, physical piece) = the lane's place in the KiB; it fetches the LOGICAL
+    //      piece physical ^ swizzle(row).  A rows (64 bytes): pieces wid, wid + 8, wid + 16 of d hidden, piece wid of d code (below g16);
+    //      feature rows (128 bytes): pieces wid, wid + 8.  Per lane: the byte offset of its row inside an image (one register per piece)
+    //      and of its logical piece inside the row; per step: a scalar base (image, first position) per tensor
+    //      d hidden: row = 16 piece + lane / 4, swizzle (row >> 2) & 3 = (lane >> 4) & 3 for every piece
+    const int pos_a = 8 * ((lane & 3) ^ ((lane >> 4) & 3));          // first position of the lane's piece (bf16 rows)
+    //      fp32 rows: row = 8 piece + lane / 8, swizzle (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7, piece & 1 = wid & 1
+    const int pos_f = 4 * ((lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7));
+    uint32_t ro_dh[3], ro_g, ro_f[2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int row = 16 * (wid + 8 * u) + (lane >> 2); ro_dh[u] = (uint32_t)(row < a.M ? row : a.M - 1) * a.P * 2; }
+    { const int row = 16 * wid + (lane >> 2); ro_g = (uint32_t)(row < a.M2 ? row : a.M2 - 1) * a.P * 2; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int row = n0 + 8 * (wid + 8 * u) + (lane >> 3); ro_f[u] = (uint32_t)(row < a.N ? row : a.N - 1) * a.P * 4; }
+    const bool has_g = wid < g16;
+    const int npw = 5 + (has_g ? 1 : 0);                               // DMA instructions of this wave per step
+    auto issue = [&](int b, int p0, const int st) __attribute__((always_inline)) {
+#ifdef W3_ABL_NODMA
+        if (b >= 0) return;                              // (developer ablation, WRONG results: nothing is fetched)
+#endif
+#ifdef W3_ABL_SAMESTEP
+        b = s0 / steps_img; p0 = 32 * (st & 1);          // (developer ablation, WRONG results: the block re-reads two steps - every piece an L2 hit)
+#endif
         const int v = a.P - p0;                                        // valid positions from p0 on (>= 8)
-        const uint32_t dst = lds0 + st * stage_bytes + wid * 1024;
-        // d hidden: row = 16 piece + lane / 4, swizzle (row >> 2) & 3 = (lane >> 4) & 3 for every piece
-        const int pd = 8 * ((ln & 3) ^ ((ln >> 4) & 3)), pdv = pd + 8 <= v ? pd : 0;
-        const __bf16* Ab = static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0 + pdv;
+        const uint32_t dst = lds0 + st * W3_STAGE + wid * 1024;
+        const uint32_t pa = (pos_a + 8 <= v ? pos_a : 0) * 2, pf = (pos_f + 4 <= v ? pos_f : 0) * 4;
+        const __bf16* Ab = static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int row = 16 * (wid + 8 * u) + (ln >> 2);
-            dma16(Ab + (row < a.M ? row : a.M - 1) * a.P, dst + u * 8192);
-        }
-        // fp32 rows: row = 8 piece + lane / 8, swizzle (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7, piece & 1 = wid & 1
-        const int pf = 4 * ((ln & 7) ^ ((4 * (wid & 1) + (ln >> 4)) & 7)), pfv = pf + 4 <= v ? pf : 0;
-        const float* Bb = static_cast<const float*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + p0 + pfv;
-        const float* Gb = static_cast<const float*>(a.A2) + dg_img_off(b, (long long)a.M2 * a.P, a.Bs, a.dA2) + p0 + pfv;
+        for (int u = 0; u < 3; ++u) w3_dma(Ab, ro_dh[u] + pa, dst + u * 8192);
+        if (has_g) w3_dma(static_cast<const __bf16*>(a.A2h) + (size_t)b * a.M2 * a.P + p0, ro_g + pa, dst + 24 * 1024);
+        const float* Bb = static_cast<const float*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + p0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int row = 8 * (wid + 8 * u) + (ln >> 3);
-            dma16(Bb + (n0 + row < a.N ? n0 + row : a.N - 1) * a.P, dst + W3_DH_BYTES + u * 8192);
-            if (wid + 8 * u < g8) dma16(Gb + (row < a.M2 ? row : a.M2 - 1) * a.P, dst + W3_DH_BYTES + W3_B_BYTES + u * 8192);
-        }
+        for (int u = 0; u < 2; ++u) w3_dma(Bb, ro_f[u] + pf, dst + W3_A_BYTES + u * 8192);
     };
     f32x16 acc[4][2];
 #pragma unroll
@@ -843,13 +855,11 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // fragment addresses inside a stage (bytes).  d hidden and feature rows: row and swizzle are fixed per lane and the wave's row blocks
-    // lie 32 rows apart (an immediate offset); d code rows (waves 6, 7): clamped to the rows the stage holds (rows >= M2 feed
-    // accumulator rows that are never stored)
+    // fragment addresses inside a stage (bytes): row and swizzle are fixed per lane, the wave's row blocks lie 32 rows apart (an
+    // immediate offset)
     const int asw = (r32 >> 2) & 3, a_l = (wm * 128 + r32) * 64;
     const int a_off[2] = {a_l + ((kg ^ asw) << 4), a_l + (((2 + kg) ^ asw) << 4)};
-    const int bsw = (r32 >> 1) & 7, b_l = W3_DH_BYTES + (wn * 64 + r32) * 128;
-    const int gmax = 8 * g8 - 1;
+    const int bsw = (r32 >> 1) & 7, b_l = W3_A_BYTES + (wn * 64 + r32) * 128;
     const float* const kmask = wm == 3 ? a.keep_2 : a.keep;
     unsigned kbits[2] = {~0u, ~0u};         // all-ones / zero per feature channel of this lane: Dropout2d and channels beyond N
     int bcur = -1;
@@ -866,26 +876,18 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
         }
     };
     auto load_a = [&](const char* base, const int ks, bf16x8 (&af)[4]) __attribute__((always_inline)) {
-        if (wm < 3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + i * 2048);
-        } else {
-            const int L0 = 4 * ks + 2 * kg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = i * 32 + r32 < gmax ? i * 32 + r32 : gmax, sw = (row >> 1) & 7;
-                const char* rp = base + W3_DH_BYTES + W3_B_BYTES + row * 128;
-                af[i] = pack8(*reinterpret_cast<const f32x4*>(rp + ((L0 ^ sw) << 4)), *reinterpret_cast<const f32x4*>(rp + (((L0 + 1) ^ sw) << 4)));
-            }
-        }
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + i * 2048);
     };
-    constexpr int DIST = NSTAGE - 1;
+    constexpr int NSTAGE = W3_NSTAGE, DIST = NSTAGE - 1;
     // (image, first position) of the step being issued and of the step being multiplied: advanced, not divided
     int bi = s0 / steps_img, pi = (s0 - bi * steps_img) * 32, bm = bi, pm = pi;
 #pragma unroll
     for (int k = 0; k < DIST; ++k)
         if (k < ns) { issue(bi, pi, k); pi += 32; if (pi >= a.P) { pi = 0; ++bi; } }
     int st = 0, stn = DIST % NSTAGE;        // stage of step k; stage step k + DIST goes to
+    const bool late = wid >= 4;
+    bf16x8 b0[2] = {}, b1[2] = {}, a0[4] = {}, a1[4] = {};
     for (int k = 0; k < ns; ++k) {
         const int newer = ns - 1 - k < DIST - 1 ? ns - 1 - k : DIST - 1;       // steps issued behind step k
         w3_wait_barrier(newer * npw);        // step k has landed (every wave's pieces) and nobody reads the stage step k + DIST overwrites
@@ -900,15 +902,16 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
             }
         }
         const int v = a.P - pm;
-        const char* base = w3sm + st * stage_bytes;
-        // feature fragments of both k-steps first (fp32 in LDS: eight temporaries each on the way to bf16), then - d hidden waves - the
-        // A fragments of both k-steps requested before the first MFMA: the reads of the second run under the products of the first
-        bf16x8 b0[2], b1[2], a0[4], a1[4];
-        load_b(base, 0, v, b0);
-        load_b(base, 1, v, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(base, 0, a0);
-        load_a(base, 1, a1);
+        const char* base = w3sm + st * W3_STAGE;
+        // Waves 0-3 read the step's fragments and multiply; waves 4-7 (the SECOND wave of each SIMD) multiply the fragments they read in
+        // the previous step and then read this step's: behind the barrier one wave of a SIMD is on the LDS pipe while the other is on the
+        // matrix core.  The MFMAs stay unconditional (a condition around them makes hipcc shuffle the accumulators): the late waves'
+        // first product is on zeros
+#ifdef W3_ABL_NOMUL
+        if (v == -12345)                                 // (developer ablation, WRONG results: no fragment reads, no products)
+#endif
+        {
+        if (!late) { load_b(base, 0, v, b0); load_b(base, 1, v, b1); load_a(base, 0, a0); load_a(base, 1, a1); }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -917,11 +920,26 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        if (late) { load_b(base, 0, v, b0); load_b(base, 1, v, b1); load_a(base, 0, a0); load_a(base, 1, a1); }
+        }
         pm += 32; if (pm >= a.P) { pm = 0; ++bm; }
         st = st + 1 == NSTAGE ? 0 : st + 1;
         stn = stn + 1 == NSTAGE ? 0 : stn + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (no DMA piece outlives the block's LDS; all have landed by the last step anyway)
+    // the late waves' last step (the others: once more on zeros)
+    if (!late) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { b0[j] = bf16x8{}; b1[j] = bf16x8{}; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
     const int Mo = wm == 3 ? a.M2 : a.M;
     float* out = (wm == 3 ? a.part2 : a.part) + (size_t)split * Mo * a.N;
 #pragma unroll
@@ -932,6 +950,9 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = (wm == 3 ? 0 : wm * 128) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+#ifdef W3_ABL_NOSTORE
+                if (acc[i][j][e] == 1.2345f)             // (developer ablation, WRONG results: no partial sums written)
+#endif
                 if (m < Mo && n < a.N) out[(size_t)m * a.N + n] = acc[i][j][e];
             }
         }
@@ -947,14 +968,11 @@ bool dg_head_wgrad_one_pass(int M, int N, int M2, int P) {
 template <typename TA, typename TB, typename TA2 = TA>
 static hipError_t launch_wgrad(const DgHeadWgradArgs& a, hipStream_t s) {
     if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TB, float>::value && std::is_same<TA2, float>::value) {
-        if (dg_head_wgrad_one_pass(a.M, a.N, a.M2, a.P) && (a.splits & 7) == 0) {
-            const int stage = W3_DH_BYTES + W3_B_BYTES + ((a.M2 + 7) >> 3) * 1024;
-            const bool three = 3 * stage <= 160 * 1024;              // (d code of more than 80 channels: one step of look-ahead)
-            const int smem = (three ? 3 : 2) * stage;
-            auto kern = three ? k_head_wgrad3<3> : k_head_wgrad3<2>;
-            hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        if (a.A2h && dg_head_wgrad_one_pass(a.M, a.N, a.M2, a.P) && (a.splits & 7) == 0) {
+            const int smem = W3_NSTAGE * W3_STAGE;
+            hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_head_wgrad3), smem);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(((a.N + 127) / 128) * a.splits), dim3(512), smem, s, a);
+            hipLaunchKernelGGL(k_head_wgrad3, dim3(((a.N + 127) / 128) * a.splits), dim3(512), smem, s, a);
             return hipGetLastError();
         }
     }
