@@ -1295,6 +1295,9 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     auto take = [&](size_t bytes) { size_t o = off; off += up(bytes, 256); return o; };
     // cluster2: d W2a and d W1 share the feature operand and one launch (same splits); cluster1 alone (linear head): d W1 by itself
     h.s2a = head_splits(B, C, C, P, D); h.s1 = head_splits(B, D, C, P); h.s2b = h.s1;
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_HEAD_S2B")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= h.s2b) h.s2b = v; }
+#endif
     h.tiles = (P + 63) / 64;
     h.dh = take((size_t)B * C * P * 2);
     h.p2a = take((size_t)h.s2a * C * C * 4);

@@ -814,6 +814,7 @@ struct DgHeadDhArgs {
     int32_t B, C, D, P;
     int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
     __bf16* gcode_bf;                // (B,D,P) out or null: d code rounded to bf16, the A2h operand of k_head_wgrad3 (P a multiple of 4)
+    unsigned long long* stamps;      // developer timing stamps (null in production)
     int32_t staged;                  // (set by the launcher) 1: hidden / d hidden through an LDS image of whole rows (P a multiple of 8)
 };
 

@@ -371,10 +371,11 @@ hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s) {
 // Round 4: the ReLU mask (`hidden`) and the result go through an LDS image [channel][64 positions] - rows of 128 contiguous bytes
 // in memory, read and written by eight lanes of 16 bytes each.  The accumulator layout alone gives every lane 8 bytes of 16
 // different channel rows per instruction: 32-byte runs, 1.8 TB/s on this kernel's 91 MB.
-template <int MB>
+// NKS > 0: the weight fragments of all NKS k-steps (D <= 32 NKS) requested with the tile; 0: fetched inside the k-loop
+template <int MB, int NKS = 0>
 __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
-    constexpr int NT = 64, FROW = NT * 2 + 32, DPMAX = 128, HROW = NT * 2 + 16, CP = 16 * MB * 4;
-    extern __shared__ __attribute__((aligned(16))) char dh_sm[];
+    constexpr int NT = 64, FROW = NT * 2 + 32, DPMAX = 128, HROW = NT * 2, CP = 16 * MB * 4;
+    extern __shared__ __attribute__((aligned(1024))) char dh_sm[];
     char* const Dt = dh_sm;                                            // [DPMAX][FROW]: [d][position] bf16, zero padded to a multiple of 32 rows
     char* const Ht = dh_sm + DPMAX * FROW;                             // [CP][HROW]: hidden tile in, d hidden tile out (staged form only)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c16 = lane & 15;
@@ -382,15 +383,34 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
     const int C = a.C, D = a.D, P = a.P, DP = (D + 31) / 32 * 32;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     const bool staged = a.staged != 0;                                 // (P a multiple of 8: every 16-byte piece of a row is whole)
+#ifdef DG_DEVTOOLS
+    // two blocks' phase stamps: an early one and one of the second round (blocks 3 and 700 of the 13 x 64 grid)
+#define DSTAMP(k) if (a.stamps && tid == 0 && (blk == 3 || blk == 700)) a.stamps[(blk == 3 ? 0 : 8) + k] = __builtin_amdgcn_s_memtime();
+#else
+#define DSTAMP(k)
+#endif
+    DSTAMP(0)
     // hidden rows of the tile: all of a thread's 16-byte pieces requested up front, next to the d code pieces below (one round trip)
-    constexpr int HPCS = CP * (NT / 8) / 256;                          // pieces per thread
-    u32x4 hv[HPCS];
+    // Round 6: by LDS-DMA (no registers: 48 of them held the pieces until the d code tile was converted), rows of 128 bytes, the
+    // 16-byte pieces of row m XORed with m & 7 - the epilogue's 8-byte cells of 16 different rows and the row copies are both conflict-free
+    constexpr int HPCS = CP * (NT / 8) / 256;                          // pieces per thread (the copy-out)
     if (staged) {
+        const uint32_t hdst = lds_addr(Ht);
 #pragma unroll
-        for (int u = 0; u < HPCS; ++u) {
-            const int idx = tid + 256 * u, m = idx >> 3, pc = idx & 7, p = p0 + 8 * pc;
-            hv[u] = *reinterpret_cast<const u32x4*>(a.hidden + ((size_t)b * C + (m < C ? m : C - 1)) * P + (p + 7 < P ? p : P - 8));
+        for (int u = 0; u < CP / 32; ++u) {                            // KiB pieces of 8 rows: wid, wid + 4, ...
+            const int k = __builtin_amdgcn_readfirstlane(wid) + 4 * u, m = 8 * k + (lane >> 3), pcl = (lane & 7) ^ (m & 7), p = p0 + 8 * pcl;
+            dma16(a.hidden + ((size_t)b * C + (m < C ? m : C - 1)) * P + (p + 7 < P ? p : P - 8), hdst + k * 1024);
         }
+    }
+    // the weight fragments of every k-step (B[d][channel m] = W2bT[m][d]; C <= 384, D <= 96: up to 3 x 6 16-byte pieces per lane), requested
+    // with the tile: inside the k-loop each step waited an L2 round trip of its own (7.7 k cycles for 72 MFMAs, stamps of round 6)
+    const int nbase = wid * 16 * MB;
+    u32x4 wpre[NKS > 0 ? NKS : 1][NKS > 0 ? MB : 1];
+    if constexpr (NKS > 0) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) wpre[ks][j] = wraw(a.w2bT, DP, nbase + 16 * j + c16, C, 32 * (ks < DP / 32 ? ks : 0), DP, lane);
     }
     // d code tile -> LDS; its row sums over the tile are the block's share of d b1 (= d b2b): 16 consecutive lanes hold one row
     if ((P & 3) == 0) {
@@ -436,21 +456,31 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
             if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)blk * D + d] = rs;
         }
     }
-    if (staged) {
-#pragma unroll
-        for (int u = 0; u < HPCS; ++u) {
-            const int idx = tid + 256 * u, m = idx >> 3, pc = idx & 7;
-            *reinterpret_cast<u32x4*>(Ht + m * HROW + pc * 16) = hv[u];
-        }
-    }
+    DSTAMP(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the DMA pieces: hipcc does not count them)
     __syncthreads();
+    DSTAMP(2)
     f32x4 acc[4][MB];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nbase = wid * 16 * MB;
     const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if constexpr (NKS > 0) {
+        // (weight fragments: requested with the tile, above)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks < DP / 32) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = tr_frag(Dt, FROW, 32 * ks, 16 * i, lane);     // A[position][d]: the same transposing read
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wfrag(wpre[ks][j], ones, lane), acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
     for (int ks = 0; ks < DP / 32; ++ks) {
         bf16x8 af[4], bfr[MB];
 #pragma unroll
@@ -463,7 +493,9 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 #pragma unroll
             for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    }
     const bool vec = (P & 3) == 0;
+    DSTAMP(3)
     if (staged) {
         // mask and result in place in the LDS image (the lane that reads a piece is the one that overwrites it), then whole rows out
 #pragma unroll
@@ -473,7 +505,7 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = p0 + 16 * i + 4 * g;
-                bf16x4* cell = reinterpret_cast<bf16x4*>(Ht + m * HROW + (16 * i + 4 * g) * 2);
+                bf16x4* cell = reinterpret_cast<bf16x4*>(Ht + m * HROW + (((2 * i + (g >> 1)) ^ (m & 7)) << 4) + 8 * (g & 1));
                 const bf16x4 h4 = *cell;
                 bf16x4 o4;
 #pragma unroll
@@ -489,11 +521,13 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
             if (g == 0 && m < C) a.part_b2a[(size_t)blk * C + m] = bs;
         }
         __syncthreads();
+        DSTAMP(4)
 #pragma unroll
         for (int u = 0; u < HPCS; ++u) {
             const int idx = tid + 256 * u, m = idx >> 3, pc = idx & 7, p = p0 + 8 * pc;
-            if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = *reinterpret_cast<const u32x4*>(Ht + m * HROW + pc * 16);
+            if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = *reinterpret_cast<const u32x4*>(Ht + m * HROW + ((pc ^ (m & 7)) << 4));
         }
+        DSTAMP(5)
         return;
     }
 #pragma unroll
@@ -535,18 +569,33 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s) {
     dim3 grid((a.P + 63) / 64, a.B);
     DgHeadDhArgs a2 = a;
+#ifdef DG_DEVTOOLS
+    static unsigned long long* sbuf = nullptr;
+    const char* sfile = getenv("DG_DH_STAMPS");
+    if (sfile) { if (!sbuf && hipMalloc(&sbuf, 128) != hipSuccess) return hipErrorOutOfMemory; a2.stamps = sbuf; }
+#endif
     a2.staged = ((a.P & 7) == 0 && a.C <= 384) ? 1 : 0;     // (ViT-B width: 130 KB of LDS would leave one block per CU)
-#define DG_DH(MB_) {                                                                                             \
-        const int smem = 128 * (64 * 2 + 32) + (a2.staged ? 16 * MB_ * 4 * (64 * 2 + 16) : 0);                   \
-        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_head_dh<MB_>), smem);                     \
+#ifdef DG_DEVTOOLS
+#define DH_STAMP_DUMP if (sfile) { unsigned long long hs[16];                                                    \
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hs, sbuf, 128, hipMemcpyDeviceToHost) == hipSuccess)     \
+            if (FILE* fp = fopen(sfile, "w")) { for (int q = 0; q < 2; ++q) for (int i = 1; i < 6; ++i)          \
+                fprintf(fp, "block %d phase %d: %llu cycles (starts %llu after block 3)\n", q ? 700 : 3, i, hs[8 * q + i] - hs[8 * q + i - 1], hs[8 * q + i - 1] - hs[0]); fclose(fp); } }
+#else
+#define DH_STAMP_DUMP
+#endif
+#define DG_DH(MB_, NKS_) {                                                                                       \
+        const int smem = 128 * (64 * 2 + 32) + (a2.staged ? 16 * MB_ * 4 * (64 * 2) : 0);                        \
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(k_head_dh<MB_, NKS_>), smem);               \
         if (e != hipSuccess) return e;                                                                           \
-        hipLaunchKernelGGL(k_head_dh<MB_>, grid, dim3(256), smem, s, a2);                                        \
+        hipLaunchKernelGGL((k_head_dh<MB_, NKS_>), grid, dim3(256), smem, s, a2);                                \
+        DH_STAMP_DUMP                                                                                            \
         return hipGetLastError(); }
-    if (a.C <= 64) DG_DH(1)
-    if (a.C <= 128) DG_DH(2)
-    if (a.C <= 192) DG_DH(3)
-    if (a.C <= 384) DG_DH(6)
-    if (a.C <= 768) DG_DH(12)
+    const bool pre3 = a.D <= 96;        // (all weight fragments in registers: 72 of them at C = 384; a fourth k-step would leave one wave per SIMD)
+    if (a.C <= 64) { if (pre3) DG_DH(1, 3) else DG_DH(1, 4) }
+    if (a.C <= 128) { if (pre3) DG_DH(2, 3) else DG_DH(2, 4) }
+    if (a.C <= 192) { if (pre3) DG_DH(3, 3) else DG_DH(3, 4) }
+    if (a.C <= 384) { if (pre3) DG_DH(6, 3) else DG_DH(6, 0) }
+    if (a.C <= 768) DG_DH(12, 0)
 #undef DG_DH
     return hipErrorInvalidValue;
 }

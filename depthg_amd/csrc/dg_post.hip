@@ -1207,7 +1207,12 @@ __global__ __launch_bounds__(256) void k_rand_coords_state(unsigned long long* _
     }
 }
 hipError_t dg_launch_rand_coords_state(unsigned long long* state, float* out, int n, hipStream_t s, float keep_p) {
-    const int blocks = n >= 256 * 256 ? 256 : (n + 255) / 256;     // (ten Philox rounds per value: one block was 15 us for the 74 k mask flags of a step)
+    // (ten Philox rounds per value: one block was 15 us for the 74 k mask flags of a step; 256 blocks 8.2 us - every block ends with
+    //  a ticket on ONE address, and 256 of those in a row are most of it; DG_RAND_BLOCKS in developer builds)
+    int blocks = n >= 64 * 256 ? 64 : (n + 255) / 256;
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_RAND_BLOCKS")) blocks = atoi(e) > 0 ? atoi(e) : blocks;
+#endif
     hipLaunchKernelGGL(k_rand_coords_state, dim3(blocks), dim3(256), 0, s, state, out, n, keep_p);
     return hipGetLastError();
 }
