@@ -271,6 +271,9 @@ static SideStream* side_stream_for(hipStream_t caller) {
     static std::map<int, SideStream> table;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_SIDE_STREAM")) if (e[0] == '0') return nullptr;       // (developer A/B: every call launches in sequence)
+#endif
     std::lock_guard<std::mutex> lk(mu);
     auto it = table.find(dev);
     if (it != table.end()) return &it->second;
@@ -1288,7 +1291,7 @@ static int head_splits(int32_t B, int32_t M, int32_t N, int32_t P, int32_t M2 = 
     s = (s + 7) & ~7;                                       // a multiple of 8: k_head_wgrad2 keeps the tiles of a split on one XCD
     return s > steps ? steps : s;
 }
-struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, gbf, total; int s2a, s1, s2b, tiles; bool one_pass; };
+struct HeadPlan { size_t dh, p2a, p1, p2b, pbd, pb2a, gbf, total; int s2a, s1, s2b, tiles, dh_blocks; bool one_pass; };
 static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     HeadPlan h;
     size_t off = 0;
@@ -1298,6 +1301,9 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
 #ifdef DG_DEVTOOLS
     if (const char* e = getenv("DG_HEAD_S2B")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= h.s2b) h.s2b = v; }
 #endif
+    // k_head_dh2 (the headline widths) forms d W2b beside d hidden: one partial sum per block of its launch
+    h.dh_blocks = dg_head_dh_fused_blocks(B, C, D, P);
+    if (h.dh_blocks > 0) h.s2b = h.dh_blocks;
     h.tiles = (P + 63) / 64;
     h.dh = take((size_t)B * C * P * 2);
     h.p2a = take((size_t)h.s2a * C * C * 4);
@@ -1419,16 +1425,20 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
     wb.A2 = nullptr; wb.keep_2 = nullptr; wb.part2 = nullptr; wb.M2 = 0;
     wb.Bs = Bs; wb.dA = d_g; wb.dB = 0; wb.dA2 = 0;
-    SideRegion side(s);
+    const bool w2b_fused = h.dh_blocks > 0;              // (k_head_dh2: the product rides in the d hidden launch - no second launch, no second stream)
+    if (w2b_fused) d.part_w2b = F32(h.p2b);
+    std::optional<SideRegion> side_o;
+    if (!w2b_fused) side_o.emplace(s);
+    const bool side = side_o && *side_o;
     if (side) {
-        DG_HIP(side.fork());
-        DG_HIP(dg_launch_head_wgrad(wb, false, true, side.stream()));
-        DG_HIP(side.record_join());
+        DG_HIP(side_o->fork());
+        DG_HIP(dg_launch_head_wgrad(wb, false, true, side_o->stream()));
+        DG_HIP(side_o->record_join());
     }
     DG_HIP(dg_launch_head_dh(d, s));
     reduce(F32(h.pbd), grad_b1, grad_b2b, D, B * h.tiles, 1.f);       // d b1 = d b2b = row sums of d code
     reduce(F32(h.pb2a), grad_b2a, nullptr, C, B * h.tiles, 1.f);
-    if (!side) DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
+    if (!side && !w2b_fused) DG_HIP(dg_launch_head_wgrad(wb, false, true, s));
     reduce(F32(h.p2b), grad_w2b, nullptr, D * C, h.s2b, 1.f);
     DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
     wa.Bs = Bs; wa.dA = 0; wa.dB = d_feat; wa.dA2 = d_g;
@@ -1436,7 +1446,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);
-    if (side) DG_HIP(side.join());
+    if (side) DG_HIP(side_o->join());
     DG_HIP(dg_launch_head_reduce(red, s));         // all five reductions in one launch
     return DG_OK;
 }

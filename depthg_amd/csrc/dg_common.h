@@ -139,6 +139,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// ... from a wave-uniform base + a 32-bit byte offset per lane (one VGPR instead of an address pair; M0 is NOT restored: for kernels
+// in which nothing else reads it)
+__device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -814,6 +819,7 @@ struct DgHeadDhArgs {
     int32_t B, C, D, P;
     int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
     __bf16* gcode_bf;                // (B,D,P) out or null: d code rounded to bf16, the A2h operand of k_head_wgrad3 (P a multiple of 4)
+    float* part_w2b;                 // [blocks][D][C] or null: k_head_dh2 also forms d W2b = d code x hidden^T (both tiles are in its LDS), one partial sum per block
     unsigned long long* stamps;      // developer timing stamps (null in production)
     int32_t staged;                  // (set by the launcher) 1: hidden / d hidden through an LDS image of whole rows (P a multiple of 8)
 };
@@ -832,6 +838,7 @@ struct DgHeadWgradArgs {
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);
+int dg_head_dh_fused_blocks(int B, int C, int D, int P);      // > 0: k_head_dh2 runs this shape with that many blocks and can form d W2b on the way
 hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s);
 bool dg_head_wgrad_one_pass(int M, int N, int M2, int P);      // the two products over the features as k_head_wgrad3 (one block = all rows x 128 channels)
 struct DgHeadReduceJob { const float* part; float* out; float* out2; int32_t n, splits; float scale; };

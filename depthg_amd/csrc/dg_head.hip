@@ -566,9 +566,199 @@ __global__ __launch_bounds__(256) void k_head_dh(const DgHeadDhArgs a) {
     }
 }
 
+// Round 6, the headline widths (192 < C <= 384, D <= 96, P a multiple of 8): persistent blocks, the next tile's loads under the
+// current tile's work.  k_head_dh is load -> multiply -> mask -> store per block with two blocks per CU to overlap them: its load
+// phase alone is 10-15 us of a block's 18-25 (stamps, experiments/r06.md).  Here a block of eight waves walks tiles bid, bid + grid, ...:
+// at the top of tile t the hidden rows of tile t + 1 go global -> LDS by DMA into the second image and its d code pieces into
+// registers; the weight fragments (36 registers at 48 channels per wave) are loaded once per block.
+#define DH2_HT (384 * 128)
+#define DH2_DT (96 * 160)
+// ND: 16-row blocks of d code in the fused d W2b product (5: D <= 80, 6: D <= 96; 72 accumulator registers at 6 leave the kernel
+// four registers short), 0: not formed
+template <int ND>
+__global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
+    constexpr bool W2B = ND > 0;
+    constexpr int NT = 64, FROW = NT * 2 + 32, HROW = NT * 2, MB = 3, NKS = 3;
+    extern __shared__ __attribute__((aligned(1024))) char dh2_sm[];    // [2][hidden tile 384 x 128 B] [2][d code tile 96 x 160 B]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
+    const int C = a.C, D = a.D, P = a.P, DP = (D + 31) / 32 * 32;
+    const int tiles_img = (P + NT - 1) / NT, ntiles = a.B * tiles_img;
+    const uint32_t ht0 = lds_addr(dh2_sm);
+    // the weight fragments of every k-step: B[d][channel m] = W2bT[m][d], wave `wid` owns channels [48 wid, 48 wid + 48)
+    const int nbase = wid * 16 * MB;
+    u32x4 wpre[NKS][MB];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) wpre[ks][j] = wraw(a.w2bT, DP, nbase + 16 * j + c16, C, 32 * (ks < DP / 32 ? ks : 0), DP, lane);
+    const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    constexpr int NP = 96 * (NT / 4) / 512;                // d code pieces (4 positions, fp32) per thread: 3
+    f32x4 v[NP];
+    auto fetch = [&](const int t, const int buf) __attribute__((always_inline)) {
+        const int b = t / tiles_img, p0 = (t - b * tiles_img) * NT;
+        // hidden rows: KiB pieces of 8 rows (wid, wid + 8, ...: six per wave), the 16-byte pieces of row m XORed with m & 7
+        const __bf16* hb = a.hidden + (size_t)b * C * P;               // (scalar base + one 32-bit offset per lane and piece)
+        const int m0 = 8 * wid + (lane >> 3), pl = p0 + 8 * ((lane & 7) ^ (m0 & 7)), pc = pl + 7 < P ? pl : P - 8;    // (m & 7 is the same for every piece)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int m = m0 + 64 * u;
+            dma16_s(hb, (uint32_t)((m < C ? m : C - 1) * P + pc) * 2, ht0 + buf * DH2_HT + (wid + 8 * u) * 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int idx = tid + 512 * u, d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
+            v[u] = *reinterpret_cast<const f32x4*>(a.gcode + dg_img_off(b, (long long)D * P, a.Bs, a.d_gcode) + (size_t)(d < D ? d : D - 1) * P + (p < P ? p : P - 4));
+        }
+    };
+    // d W2b[d][m] = sum over positions of d code[d][p] hidden[m][p] for the wave's 48 channels m: both tiles are in LDS anyway (the
+    // product had a launch of its own, k_head_wgrad2 beside this kernel on the second stream, re-reading both tensors); accumulated
+    // over the block's tiles, one partial sum per block
+    f32x4 wacc[W2B ? ND : 1][MB];
+#pragma unroll
+    for (int i = 0; i < (W2B ? ND : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < MB; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (rows DP .. 95 of the d code images are never written: zero, the d W2b product reads all 96)
+    for (int i = tid; i < 2 * DH2_DT / 16; i += 512) {
+        const int bufi = i / (DH2_DT / 16), o = i - bufi * (DH2_DT / 16);
+        if (o * 16 >= DP * FROW) *reinterpret_cast<u32x4*>(dh2_sm + 2 * DH2_HT + bufi * DH2_DT + o * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    int t = blockIdx.x, buf = 0;
+    if (t < ntiles) fetch(t, 0);
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        const int b = t / tiles_img, p0 = (t - b * tiles_img) * NT;
+        char* const Ht = dh2_sm + buf * DH2_HT;
+        char* const Dt = dh2_sm + 2 * DH2_HT + buf * DH2_DT;
+        // d code tile -> LDS (bf16), its row sums = the tile's share of d b1 (= d b2b), the bf16 copy for k_head_wgrad3
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int idx = tid + 512 * u, d = idx / (NT / 4), q4 = idx - d * (NT / 4), p = p0 + 4 * q4;
+            if (d < DP) {                                     // (uniform per wave: 16 consecutive lanes hold one row)
+                const bool ok = d < D && p < P;
+                bf16x4 o;
+                float rs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float x = ok ? v[u][e] : 0.f; rs += x; o[e] = (__bf16)x; }
+                *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
+                if (a.gcode_bf && ok) *reinterpret_cast<bf16x4*>(a.gcode_bf + ((size_t)b * D + d) * P + p) = o;
+#pragma unroll
+                for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
+                if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)t * D + d] = rs;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the DMA pieces of this tile: hipcc does not count them)
+        __syncthreads();                                               // tile t in LDS; every wave is done with the other images (tile t - 1)
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x, buf ^ 1);
+        f32x4 acc[4][MB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks < DP / 32) {
+                bf16x8 af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = tr_frag(Dt, FROW, 32 * ks, 16 * i, lane);     // A[position][d]
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wfrag(wpre[ks][j], ones, lane), acc[i][j], 0, 0, 0);
+            }
+        }
+        if constexpr (W2B) {
+            // A[d][k = position] rows of the d code image, B[k][m] = hidden[m][k] rows of the hidden image (before the mask pass below
+            // overwrites them): 16-byte reads, natural k order on both sides.  Positions beyond the image: the d code image holds zeros
+#pragma unroll
+            for (int ks = 0; ks < NT / 32; ++ks) {
+                bf16x8 hb[MB];
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const int m = nbase + 16 * j + c16;
+                    hb[j] = *reinterpret_cast<const bf16x8*>(Ht + m * HROW + (((4 * ks + g) ^ (m & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Dt + (16 * i + c16) * FROW + (32 * ks + 8 * g) * 2);
+#pragma unroll
+                    for (int j = 0; j < MB; ++j) wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, hb[j], wacc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        // mask and result in place in the LDS image (the lane that reads a cell is the one that overwrites it); row sums of the result
+        float bs[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = nbase + 16 * j + c16;
+            bs[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = p0 + 16 * i + 4 * g;
+                bf16x4* cell = reinterpret_cast<bf16x4*>(Ht + m * HROW + (((2 * i + (g >> 1)) ^ (m & 7)) << 4) + 8 * (g & 1));
+                const bf16x4 h4 = *cell;
+                bf16x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = ((float)h4[r] > 0.f && m < C && p + r < P) ? acc[i][j][r] : 0.f;
+                    bs[j] += x;
+                    o4[r] = (__bf16)x;
+                }
+                *cell = o4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) bs[j] += __shfl_xor(bs[j], 16, 64);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) bs[j] += __shfl_xor(bs[j], 32, 64);
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const int m = nbase + 16 * j + c16;
+            if (g == 0 && m < C) a.part_b2a[(size_t)t * C + m] = bs[j];
+        }
+        __syncthreads();
+        // whole rows out: 384 rows x 8 pieces of 16 bytes = six per thread
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int idx = tid + 512 * u, m = idx >> 3, pc = idx & 7, p = p0 + 8 * pc;
+            if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = *reinterpret_cast<const u32x4*>(Ht + m * HROW + ((pc ^ (m & 7)) << 4));
+        }
+    }
+    if constexpr (W2B) {
+        float* out = a.part_w2b + (size_t)blockIdx.x * D * C;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const int m = nbase + 16 * j + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * i + 4 * g + r;
+                    if (d < D && m < C) out[(size_t)d * C + m] = wacc[i][j][r];
+                }
+            }
+    }
+}
+
+int dg_head_dh_fused_blocks(int B, int C, int D, int P) {
+#ifdef DG_DEVTOOLS
+    if (const char* e = getenv("DG_HEAD_DH2")) if (e[0] == '0') return 0;
+#endif
+    if (!(C > 192 && C <= 384 && D <= 96 && (P & 7) == 0)) return 0;
+    const int ntiles = B * ((P + 63) / 64);
+    return ntiles < 256 ? ntiles : 256;
+}
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s) {
     dim3 grid((a.P + 63) / 64, a.B);
     DgHeadDhArgs a2 = a;
+    if (const int nblk = dg_head_dh_fused_blocks(a.B, a.C, a.D, a.P)) {
+        const int smem = 2 * DH2_HT + 2 * DH2_DT;
+        auto kern = !a.part_w2b ? k_head_dh2<0> : (a.D <= 80 ? k_head_dh2<5> : k_head_dh2<6>);
+        hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, s, a2);
+        return hipGetLastError();
+    }
+    if (a.part_w2b) return hipErrorInvalidValue;           // (only k_head_dh2 forms d W2b: the plan asks dg_head_dh_fused_blocks first)
 #ifdef DG_DEVTOOLS
     static unsigned long long* sbuf = nullptr;
     const char* sfile = getenv("DG_DH_STAMPS");
@@ -847,11 +1037,6 @@ __device__ __forceinline__ void w3_wait_barrier(const int n) {
         default: asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;    // (over-waits, never under-waits)
     }
 }
-// one DMA piece: 64 lanes x 16 bytes from base + the lane's byte offset to the KiB at the LDS address (M0 is not restored: nothing
-// else in this kernel reads it)
-__device__ __forceinline__ void w3_dma(const void* sbase, const uint32_t voff, const uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
 __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char w3sm[];     // [3 stages][A: d hidden 384 rows, d code 128 rows | features 128 rows]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -891,11 +1076,11 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
         const uint32_t pa = (pos_a + 8 <= v ? pos_a : 0) * 2, pf = (pos_f + 4 <= v ? pos_f : 0) * 4;
         const __bf16* Ab = static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) w3_dma(Ab, ro_dh[u] + pa, dst + u * 8192);
-        if (has_g) w3_dma(static_cast<const __bf16*>(a.A2h) + (size_t)b * a.M2 * a.P + p0, ro_g + pa, dst + 24 * 1024);
+        for (int u = 0; u < 3; ++u) dma16_s(Ab, ro_dh[u] + pa, dst + u * 8192);
+        if (has_g) dma16_s(static_cast<const __bf16*>(a.A2h) + (size_t)b * a.M2 * a.P + p0, ro_g + pa, dst + 24 * 1024);
         const float* Bb = static_cast<const float*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + p0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) w3_dma(Bb, ro_f[u] + pf, dst + W3_A_BYTES + u * 8192);
+        for (int u = 0; u < 2; ++u) dma16_s(Bb, ro_f[u] + pf, dst + W3_A_BYTES + u * 8192);
     };
     f32x16 acc[4][2];
 #pragma unroll
