@@ -141,6 +141,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
 }
 // ... from a wave-uniform base + a 32-bit byte offset per lane (one VGPR instead of an address pair; M0 is NOT restored: for kernels
 // in which nothing else reads it)
+__device__ __forceinline__ const void* dg_uniform_ptr(const void* p) {      // a wave-uniform pointer hipcc holds in VGPRs -> an SGPR pair
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ void dma16_s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }

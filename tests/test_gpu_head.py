@@ -47,12 +47,15 @@ def test_head_eval_matches_reference_vectors(proj, dev):
 @pytest.mark.parametrize("B,C,D,hw,proj", [(4, 384, 70, 28, "nonlinear"), (2, 768, 100, 28, "nonlinear"), (3, 384, 90, 14, "nonlinear"),
                                             (2, 384, 70, 15, "nonlinear"), (3, 384, 70, 28, "linear"), (2, 64, 16, 9, "nonlinear"),
                                             (2, 256, 70, 28, "nonlinear"), (2, 320, 33, 28, "nonlinear"), (1, 384, 70, 56, "nonlinear"),
-                                            (2, 200, 24, 28, "linear")])
+                                            (2, 200, 24, 28, "linear"), (2, 384, 90, 28, "nonlinear"), (2, 384, 70, 20, "nonlinear"),
+                                            (3, 352, 96, 24, "nonlinear"), (1, 384, 70, 8, "nonlinear")])
 def test_head_train_forward_backward_vs_oracle(B, C, D, hw, proj, dev):
     """training pass with given Dropout2d draws: code, the returned feats and the six parameter gradients against the oracle;
     28x28 (the recipes), 14x14 / 15x15 / 9x9 (position counts that are not multiples of 8 or 4: the guarded paths), ViT-B width;
     widths below 384 on 28x28 / 56x56 maps (the 112-position, eight-wave forward with padded channel groups; the paired weight-gradient
-    launch with partial tiles)."""
+    launch with partial tiles).  Round 6 - the backward of the headline widths (k_head_dh2 with d W2b inside, k_head_wgrad3): D = 90 /
+    96 (six row blocks of d code, four-piece d code rows), 20 x 20 (400 positions: a ragged last step of 16 and a ragged last tile),
+    C = 352 (clamped rows of both tiles), 8 x 8 at B = 1 (two steps per image: fewer steps than eight splits, the launches of round 5)."""
     from depthg_amd.head import ProjectionHead, draw_keep_masks
     from oracle import head_oracle as HO
     g = torch.Generator().manual_seed(100 * C + hw)
