@@ -1256,6 +1256,13 @@ __global__ __launch_bounds__(256) void k_head_reduce(const DgHeadReduceArgs a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(k + 4 * u) * n];
     }
+    for (; k + 12 < J.splits; k += 16) {                   // (the remainder four at a time: one split per round trip was 4 round trips behind
+        float v[4];                                        //  the 80 splits of k_head_wgrad3 - same sums in the same order: acc[0] takes them one by one)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(k + 4 * u) * n];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[0] += v[u];
+    }
     for (; k < J.splits; k += 4) acc[0] += part[(size_t)k * n];
     red[w][o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();

@@ -24,8 +24,8 @@ cp $out/stats/*/*kernel_stats.csv $out/${tag}_kernel_stats.csv
 ( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
 ( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
 ( cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $out/pmc_sq -- python3 /root/repo/bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline > /dev/null 2>&1 )
-# per-kernel tables of the small-grid configurations (round 5: regenerated every round)
-for c in C2 C3 C4shard; do
+# per-kernel tables of the small-grid configurations (round 5: regenerated every round) and of the step with the head (round 6)
+for c in C2 C3 C4shard headline+head; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$c -- python3 /root/repo/bench.py --config $c --steps 50 --warmup 5 --clock-warmup-s 0.25 --no-cpu-baseline > /dev/null 2>&1 )
   cp $out/stats_$c/*/*kernel_stats.csv $out/${tag}_kernel_stats_$c.csv
 done
