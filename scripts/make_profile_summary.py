@@ -70,7 +70,7 @@ for f in sorted(glob.glob(os.path.join(src, f"{tag}_bench_*.json"))):
     o.append(f"| {name} | {c['ms_per_step']} | {c['value']} | `{rf['kernel']}` | {rf['kernel_ms']*1e3:.1f} | "
              f"{frac} | {c.get('cpu_baseline', {}).get('value', float('nan')):.3f} |".replace("| nan |", "| - |"))
 # per-kernel tables of the small-grid configurations (kernel trace of `bench.py --config <c> --steps 50`)
-for c in ("C2", "C3", "C4shard"):
+for c in ("C2", "C3", "C4shard", "headline+head"):
     f = os.path.join(src, f"{tag}_kernel_stats_{c}.csv")
     if not os.path.exists(f):
         continue
@@ -88,5 +88,16 @@ for extra in (f"{tag}_kernel_stats_headline.csv", f"{tag}_gputests.txt"):
         shutil.copy(os.path.join(src, extra), dst)
 if os.path.exists(os.path.join(src, f"{tag}_parity.md")):
     shutil.copy(os.path.join(src, f"{tag}_parity.md"), dst)
+# a headline line of the same code taken on another box earlier in the round, where one is kept (box-to-box spread: the held clock)
+other = os.path.join(dst, f"{tag}_bench_box_1p93GHz.json")
+if os.path.exists(other):
+    ob = json.loads(last_json(other))
+    o += ["\n## The same headline command on another box of the pool\n",
+          f"`{os.path.basename(other)}` (the round's earlier profile run; the loss path's code is the same - the head's kernels and the random-draw "
+          f"launch changed in between): {ob['ms_per_step']} ms per step, `{ob['roofline']['kernel']}` {ob['roofline']['kernel_ms']*1e3:.1f} µs = "
+          f"{ob['roofline']['frac']} of the peak at {ob['roofline'].get('held_clock_ghz')} GHz held ({ob['roofline'].get('frac_at_held_clock')} at that clock, "
+          f"{ob['roofline'].get('kernel_mcycles')} M cycles per launch).  This run: {b['ms_per_step']} ms, {b['roofline']['frac']} at "
+          f"{b['roofline'].get('held_clock_ghz')} GHz ({b['roofline'].get('frac_at_held_clock')}, {b['roofline'].get('kernel_mcycles')} M cycles): the cycles per launch "
+          "agree, the clock the box holds under the kernel's power draw does not."]
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))
