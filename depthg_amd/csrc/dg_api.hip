@@ -94,7 +94,9 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (d->C > 768 && !p.small)
         return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels are supported on sample grids of at most 160 positions "
                                         "(feature_samples <= 12) only; this call has %d positions%s", d->C, p.P,
-                    (d->flags & DG_IDENTITY_GRID) ? " on the dense identity grid" : "");
+                    (d->flags & DG_IDENTITY_GRID) ? " on the dense identity grid (wider maps go there in channel chunks: dg_normalize_split + DG_FEATS_UNIT)" : "");
+    if ((d->flags & DG_FEATS_UNIT) && !(d->flags & DG_IDENTITY_GRID))
+        return fail(DG_ERR_INVALID, "DG_FEATS_UNIT needs DG_IDENTITY_GRID: on sampled coordinates the reference normalises BEHIND sample()");
     p.C4 = (int)up(d->C, 4); p.D4 = (int)up(d->D, 4);
     p.T = 2 + p.N;
     p.shared = (d->flags & DG_SHARED_COORDS) != 0;
@@ -628,6 +630,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
         g.B = p.B; g.K = p.C; g.D = p.D; g.KF = p.KF; g.KD = p.KD; g.h = p.h; g.w = p.w; g.P = p.P; g.Ppad = p.Ppad;
         g.dH = desc->depth_h; g.dW = desc->depth_w;
         g.code_split = p.pointwise ? 1 : 0;        // (the code column sums then ride in the k_rowmean launch, which only pointwise has)
+        g.unit = (desc->flags & DG_FEATS_UNIT) ? 1 : 0;
         if (fk) { g.fkeep[0] = fk->keep[0]; g.fkeep[1] = fk->keep[1]; g.fscale = fk->scale; }
         if (draw && p.N > 0) { g.draw_out = draw->out; g.draw_state = draw->state; g.draw_seed = draw->seed; g.draw_count = p.N; }
         if (split) {
@@ -1376,6 +1379,16 @@ extern "C" int dg_head_forward_pair(int32_t B, int32_t C, int32_t D, int32_t P, 
     if (B < 1 || B > (1 << 20)) return fail(DG_ERR_INVALID, "bad head dimensions");
     return head_forward_impl(2 * B, B, C, D, P, feat, feat_pos, w1, b1, w2a, b2a, w2b, b2b, keep1, keep2, keep3, keep_scale, code, code_pos,
                              feats_out, feats_out_pos, hidden, wscratch, stream_);
+}
+
+extern "C" int dg_normalize_split(int32_t B, int32_t C, int32_t h, int32_t w, const float* src, int32_t nchunks, int32_t chunk_c,
+                                  float* const* dst, dg_stream_t stream_) {
+    if (B < 1 || C < 1 || h < 1 || w < 1 || !src || !dst) return fail(DG_ERR_INVALID, "dg_normalize_split: bad arguments");
+    if (nchunks < 1 || nchunks > 16 || chunk_c < 1 || (long long)chunk_c * (nchunks - 1) >= C || (long long)chunk_c * nchunks < C)
+        return fail(DG_ERR_INVALID, "dg_normalize_split: %d chunks of %d channels do not tile C=%d (at most 16 chunks)", nchunks, chunk_c, C);
+    for (int k = 0; k < nchunks; ++k) if (!dst[k]) return fail(DG_ERR_INVALID, "dg_normalize_split: null destination %d", k);
+    DG_HIP(dg_launch_normalize_split(src, B, C, h * w, nchunks, chunk_c, dst, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
 }
 
 extern "C" size_t dg_head_workspace_bytes(int32_t B, int32_t C, int32_t D, int32_t P) {

@@ -518,6 +518,7 @@ struct DgDenseArgs {        // identity-grid operand preparation (k_prep_dense)
     // 1 / 0 of source o or null, the kept channels scaled by fscale = 1/(1-p) - the product the producer would have written
     const float* fkeep[2];
     float fscale;
+    int32_t unit;            // DG_FEATS_UNIT: the feature rows are written as they are (unit vectors, or a channel chunk of them)
     int32_t roles;           // 0: every role; else a mask of the roles THIS launch runs - 1 feats, 2 code, 4 depth indicators, 8 the draw
                              // (the launch split in two that run on two streams: dg_api.hip, exact clamp masks on the dense grid)
 };
@@ -840,6 +841,7 @@ struct DgHeadWgradArgs {
     int32_t Bs; long long dA, dB, dA2;   // (pair: images Bs.. of A / Bm / A2 in second tensors, offsets in their elements; 0: one tensor)
 };
 
+hipError_t dg_launch_normalize_split(const float* src, int B, int C, int P, int nchunks, int chunk_c, float* const* dst, hipStream_t s);
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);

@@ -712,7 +712,7 @@ __device__ __forceinline__ void prep_dense_feats(const DgDenseArgs& a, float* sl
     ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += red[j * 32 + xl];
-    const float inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
+    const float inv = a.unit ? 1.f : 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);     // (DG_FEATS_UNIT: a chunk of a vector normalised over all of its channels)
     if (x < w) {
 #pragma unroll
         for (int u = 0; u < MAXU; ++u)
@@ -974,6 +974,38 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad, true);
     }
+}
+
+// norm() over all C channels of an NCHW map, written as channel chunks (dg_normalize_split: the operands of DG_FEATS_UNIT calls).
+// Block = 64 pixels x 4 channel slices (slice q sums channels q, q + 4, ... in order; the four partial sums are added in slice order).
+struct DgNormSplitArgs { const float* src; float* dst[16]; int32_t B, C, P, nchunks, chunk_c; };
+__global__ __launch_bounds__(256) void k_normalize_split(const DgNormSplitArgs a) {
+    __shared__ float part[4][64];
+    const int px = threadIdx.x & 63, q = threadIdx.x >> 6, p = blockIdx.x * 64 + px, b = blockIdx.y;
+    const float* s = a.src + (size_t)b * a.C * a.P + (p < a.P ? p : a.P - 1);
+    float ss = 0.f;
+    for (int c0 = q; c0 < a.C; c0 += 32) {               // eight loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c0 + 4 * u < a.C ? s[(size_t)(c0 + 4 * u) * a.P] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ss = fmaf(v[u], v[u], ss);
+    }
+    part[q][px] = ss;
+    __syncthreads();
+    const float inv = 1.f / fmaxf(sqrtf((part[0][px] + part[1][px]) + (part[2][px] + part[3][px])), DG_EPS_NORM);
+    if (p >= a.P) return;
+    for (int c = q; c < a.C; c += 4) {
+        const int k = c / a.chunk_c, ck = min(a.chunk_c, a.C - k * a.chunk_c);
+        a.dst[k][((size_t)b * ck + (c - k * a.chunk_c)) * a.P + p] = s[(size_t)c * a.P] * inv;
+    }
+}
+hipError_t dg_launch_normalize_split(const float* src, int B, int C, int P, int nchunks, int chunk_c, float* const* dst, hipStream_t s) {
+    DgNormSplitArgs a = {};
+    a.src = src; a.B = B; a.C = C; a.P = P; a.nchunks = nchunks; a.chunk_c = chunk_c;
+    for (int k = 0; k < nchunks; ++k) a.dst[k] = dst[k];
+    hipLaunchKernelGGL(k_normalize_split, dim3((P + 63) / 64, B), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t dg_launch_prep_dense(const DgDenseArgs& a, hipStream_t s) {

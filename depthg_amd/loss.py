@@ -315,23 +315,59 @@ class ContrastiveCorrelationLoss(nn.Module):
             perms_t = perms_t.contiguous()
             assert perms_t.shape == (N, B), f"perms shape {tuple(perms_t.shape)} != {(N, B)}"
         need_grad = torch.is_grad_enabled() and (orig_code.requires_grad or orig_code_pos.requires_grad)
-        desc = ops.make_desc(B, C, D, h, w, S, N, pointwise=bool(cfg.pointwise), zero_clamp=bool(cfg.zero_clamp),
-                             stabalize=bool(cfg.stabalize), depth_term=depth_term, need_grad=need_grad,
-                             shared_coords=bool(shared_coords),
-                             shifts=(cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift,
-                                     cfg.depth_feat_shift if depth_term else 0.0),
-                             depth_hw=tuple(depth_c.shape[-2:]) if depth_c is not None else (0, 0),
-                             identity_grid=bool(identity_grid), weights=self._total_weights(depth_term),
-                             line_grid=line_grid, code_hw=None if same_maps else (hc, wc),
-                             exact_masks=bool(getattr(cfg, "dg_exact_masks", False)))
-        holder = {"draw_state": draw_state, "feat_keep": feat_keep}
         code_in = orig_code if orig_code.dtype == torch.float32 else orig_code.float()
         code_pos_in = orig_code_pos if orig_code_pos.dtype == torch.float32 else orig_code_pos.float()
-        out, total = _CorrLossFunction.apply(code_in.contiguous(), code_pos_in.contiguous(), feats, feats_pos, depth_c,
-                                             coords1, coords2, perms_t, desc, holder)
-        ws = holder["workspace"]
-        if perms_t is None:
-            perms_t = holder["perms"]
+        code_in, code_pos_in = code_in.contiguous(), code_pos_in.contiguous()
+        all_shifts = (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift, cfg.depth_feat_shift if depth_term else 0.0)
+
+        def run(f_a, f_b, perms_in, first=True, unit=False, keep=feat_keep):
+            """one launch set of the C ABI on feature maps of the width the operand kernels hold (`first`: the recipe's shifts and
+            depth term; else a further channel chunk of a wider map: zero shifts, no depth term - see below)"""
+            dt = depth_term and first
+            desc_ = ops.make_desc(B, f_a.shape[1], D, h, w, S, N, pointwise=bool(cfg.pointwise), zero_clamp=bool(cfg.zero_clamp),
+                                  stabalize=bool(cfg.stabalize), depth_term=dt, need_grad=need_grad,
+                                  shared_coords=bool(shared_coords),
+                                  shifts=all_shifts if first else (0.0, 0.0, 0.0, 0.0),
+                                  depth_hw=tuple(depth_c.shape[-2:]) if (depth_c is not None and dt) else (0, 0),
+                                  identity_grid=bool(identity_grid), weights=self._total_weights(dt),
+                                  line_grid=line_grid, code_hw=None if same_maps else (hc, wc),
+                                  exact_masks=bool(getattr(cfg, "dg_exact_masks", False)), feats_unit=unit)
+            holder_ = {"draw_state": draw_state, "feat_keep": keep}
+            out_, total_ = _CorrLossFunction.apply(code_in, code_pos_in, f_a, f_b, depth_c if dt else None,
+                                                   coords1, coords2, perms_in, desc_, holder_)
+            return out_, total_, desc_, holder_["workspace"], (holder_["perms"] if perms_in is None else perms_in)
+
+        wide = identity_grid and C > ops.BLOB_MAX_C
+        if not wide:
+            out, total, desc, ws, perms_t = run(feats, feats_pos, perms_t)
+            chunks = None
+        else:
+            # Feature maps wider than the operand kernels hold, on the dense identity grid: the loss is LINEAR in the feature
+            # correlation fd = sum over channels (src/modules.py:797-809; helper(), :1231-1254: the centering of fd, the shift and
+            # -clamp(cd) * (fd - shift)), and on this grid sample() is a transposition, so norm() can run in front of it.  The maps are
+            # normalised over all C channels once (dg_normalize_split) and evaluated chunk by chunk (DG_FEATS_UNIT): the first chunk
+            # with the recipe's shifts and depth term, the others with zero shifts and without it; the loss means and the code
+            # gradients add up, the cd means (and everything of the depth term) are the first chunk's.
+            if feat_keep is not None:          # (deferred Dropout2d: formed here, in front of the normalisation - same values)
+                ka, kb, kscale = feat_keep
+                if ka is not None:
+                    feats = feats * (ka * kscale)[:, :, None, None]
+                if kb is not None:
+                    feats_pos = feats_pos * (kb * kscale)[:, :, None, None]
+            nch = (C + ops.BLOB_MAX_C - 1) // ops.BLOB_MAX_C
+            chunk_c = ((C + nch - 1) // nch + 7) // 8 * 8
+            fa, fb = ops.normalize_split(feats, chunk_c), ops.normalize_split(feats_pos, chunk_c)
+            chunks = []
+            for k in range(len(fa)):
+                o_k, t_k, desc_k, ws_k, perms_t = run(fa[k], fb[k], perms_t, first=(k == 0), unit=True, keep=None)
+                chunks.append((o_k, t_k, desc_k, ws_k))
+            lossmask = torch.zeros(ops._lib.DG_OUT_COUNT, device=dev)
+            lossmask[[0, 1, 2, ops._lib.DG_OUT_TOTAL]] = 1.0
+            out, total = chunks[0][0], chunks[0][1]
+            for o_k, t_k, _, _ in chunks[1:]:
+                out = out + o_k * lossmask
+                total = total + t_k
+            desc, ws = chunks[0][2], chunks[0][3]
         d = self.__dict__                      # plain attributes: nn.Module.__setattr__ costs microseconds per assignment
         d["last_scalars"] = out.detach()
         d["scalars"] = out                     # the fused output vector with its grad_fn (DG_OUT_* order)
@@ -354,6 +390,9 @@ class ContrastiveCorrelationLoss(nn.Module):
         neg_cd, neg_loss = [], []
         for k in range(N):
             c, l = ops.corr_materialize(desc, 2 + k, ws, want_cd=True, want_loss=True, perms=perms_t)
+            if chunks is not None:             # (a wide map in channel chunks: the un-reduced loss is the sum of the chunks' too)
+                for _, _, desc_j, ws_j in chunks[1:]:
+                    l = l + ops.corr_materialize(desc_j, 2 + k, ws_j, want_cd=False, want_loss=True, perms=perms_t)[1]
             neg_cd.append(c)
             neg_loss.append(l)
         if N > 0:

@@ -49,7 +49,7 @@ def _f32c(t, name):
 
 def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, depth_term, need_grad, shared_coords,
               shifts, depth_hw=(0, 0), identity_grid=False, weights=(0.0, 0.0, 0.0, 0.0), line_grid=False, code_hw=None,
-              exact_masks=False):
+              exact_masks=False, feats_unit=False):
     """dg_corr_desc.  (h, w): the feature maps; code_hw: the code maps' size when it differs (None: the same)."""
     flags = 0
     flags |= _lib.DG_POINTWISE if pointwise else 0
@@ -61,10 +61,26 @@ def make_desc(B, C, D, h, w, S, n_neg, *, pointwise, zero_clamp, stabalize, dept
     flags |= _lib.DG_IDENTITY_GRID if identity_grid else 0
     flags |= _lib.DG_LINE_GRID if line_grid else 0
     flags |= _lib.DG_EXACT_MASKS if exact_masks else 0
+    flags |= _lib.DG_FEATS_UNIT if feats_unit else 0
     ch, cw = (int(code_hw[0]), int(code_hw[1])) if code_hw is not None and tuple(code_hw) != (h, w) else (0, 0)
     return CorrDesc(B, C, D, h, w, S, n_neg, int(depth_hw[0]), int(depth_hw[1]), flags,
                     float(shifts[0]), float(shifts[1]), float(shifts[2]), float(shifts[3]),
                     float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]), ch, cw)
+
+
+BLOB_MAX_C = 768          # feature channels the blob kernels (grids above 160 positions, the identity grid) hold per call
+
+
+def normalize_split(feats, chunk_c):
+    """norm() of the reference over all channels of (B,C,h,w), returned as contiguous channel chunks of `chunk_c` (the last: the
+    rest) - the operands of DG_FEATS_UNIT calls (dg_normalize_split)."""
+    feats = _f32c(feats, "feats")
+    B, C, h, w = feats.shape
+    n = (C + chunk_c - 1) // chunk_c
+    outs = [_empty((B, min(chunk_c, C - k * chunk_c), h, w), torch.float32, feats.device) for k in range(n)]
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.load().dg_normalize_split(B, C, h, w, _ptr(feats), n, chunk_c, ptrs, _stream(feats.device)), "dg_normalize_split")
+    return outs
 
 
 def workspace_bytes(desc):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 116   /* 116: dg_prof_main_span takes FOUR words (+ the workgroups' lifetimes in shader cycles and wall ticks: the clock the CUs held); 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 117   /* 117: DG_FEATS_UNIT, dg_normalize_split (feature maps wider than 768 channels on the dense identity grid, in chunks of the width the operand kernels hold: the loss is linear in the feature correlation); 116: dg_prof_main_span takes FOUR words (+ the workgroups' lifetimes in shader cycles and wall ticks: the clock the CUs held); 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -51,6 +51,13 @@ extern "C" {
                                         compute is too close to zero to be trusted; without the flag the fp16 cd decides on the
                                         dense grids (the small sample grids always take exact masks) */
 
+#define DG_FEATS_UNIT     (1u << 9)  /* with DG_IDENTITY_GRID: the channel vectors of orig_feats / orig_feats_pos are used as they are, not
+                                        normalised - they are unit vectors already, or ONE CHANNEL CHUNK of unit vectors
+                                        (dg_normalize_split).  The loss and its gradients are linear in the feature correlation
+                                        fd (src/modules.py:797-809, 1231-1254: centering, shift and clamp(cd) * (fd - shift)), and fd is
+                                        a sum over channels: a map of C > 768 channels is evaluated as one call per chunk - the first
+                                        with the recipe's shifts and depth term, the others with zero shifts and no depth term - and
+                                        the loss means (not the cd means) and code gradients add up (depthg_amd/loss.py does that). */
 #define DG_MAX_NEG 8
 
 /* error codes */
@@ -65,7 +72,8 @@ typedef void* dg_stream_t; /* hipStream_t */
 /* Shape/cfg descriptor of one loss call (one `ContrastiveCorrelationLoss.forward`). */
 typedef struct dg_corr_desc {
     int32_t B;        /* batch (per rank) */
-    int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 */
+    int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 per call on grids above 160 positions and the identity grid
+                         (wider maps on the identity grid: one call per channel chunk, DG_FEATS_UNIT), <= 8192 on smaller grids */
     int32_t D;        /* code channels = cfg.dim; <= 128 */
     int32_t h, w;     /* feature-map size of orig_feats / orig_feats_pos (and of the code maps unless code_h / code_w say otherwise) */
     int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated (P = S with DG_LINE_GRID) */
@@ -367,6 +375,16 @@ int dg_rand_coords_state(uint64_t* state, int64_t n, float* out, dg_stream_t str
  * keep1 / keep2 / keep3 take; the reference draws them with nn.Dropout2d, src/modules.py:122-132).  One launch for all the masks of a
  * step; advances the state; not torch's stream.  (version 112) */
 int dg_rand_keep_state(uint64_t* state, int64_t n, float p_keep, float* out, dg_stream_t stream);
+
+/*
+ * norm() of the reference (F.normalize(t, dim=1, eps=1e-10), src/modules.py:789-790) over ALL C channels of an NCHW map, written as
+ * `nchunks` maps of `chunk_c` channels each (the last one: the rest), every one contiguous (B, c_k, h, w): the operands of
+ * DG_FEATS_UNIT calls.  On the identity grid sample() is a transposition (reference quirk Q3), so normalising the map in front of it
+ * is what the reference computes behind it.
+ *   src (B,C,h,w) fp32; dst[k] (B, min(chunk_c, C - k chunk_c), h, w) fp32; 1 <= nchunks <= 16, chunk_c * (nchunks - 1) < C <= chunk_c * nchunks
+ */
+int dg_normalize_split(int32_t B, int32_t C, int32_t h, int32_t w, const float* src, int32_t nchunks, int32_t chunk_c,
+                       float* const* dst, dg_stream_t stream);
 
 /*
  * The segmentation head of DinoFeaturizer (replaces `cluster1(dropout(f)) + cluster2(dropout(f))` and the third

@@ -142,6 +142,44 @@ def test_dense_grid_is_not_taken_for_maps_of_two_sizes(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["full", "reduced"])
+def test_wide_dense_grid_reference_vectors(mode, dev):
+    """Reference-pinned vectors of a dense grid whose feature maps are WIDER than the operand kernels hold (C = 1024, D = 70, 16 x 16
+    maps, S = 16: 256 positions, B = 2, three negatives; tests/golden/make_round6_fixtures.py): the call runs as two channel chunks of
+    unit vectors (dg_normalize_split + DG_FEATS_UNIT; the loss is linear in the feature correlation - depthg_amd/loss.py).  Loss means
+    and the weighted total within 1e-4 relative, the un-reduced tensors (mode `full`) at the dense path's tolerances, the code
+    gradients within the dense path's fp16-mask bound."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    fx = load_golden_seeded("forward_wide1024_ident.npz")
+    cfg = cfg_from_fixture(fx, dg_outputs=mode)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    code, code_pos = T(fx["code"]).requires_grad_(True), T(fx["code_pos"]).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]),
+                                                       T(fx["coords1"]), T(fx["coords2"]), T(fx["perms"]),
+                                                       shared_coords=True, identity_grid=True)
+    total = O.total_loss(cfg, out)
+    total.backward()
+    errs = {k: _relerr(out[i].mean(), fx[k]) for i, k in ((0, "pos_intra_loss"), (2, "pos_inter_loss"), (4, "neg_inter_loss_mean"),
+                                                          (6, "depth_feat_loss"))}
+    errs["total"] = _relerr(total, fx["total"])
+    print(mode, {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 1e-4, (k, v)
+    if mode == "full":
+        sub = int(fx["sub"])
+        for i, k, tol in ((1, "pos_intra_cd", 1e-3), (3, "pos_inter_cd", 1e-3), (5, "neg_inter_cd", 1e-3), (4, "neg_inter_loss", 4e-3)):
+            assert tuple(out[i].shape)[-4:] == (16, 16, 16, 16)
+            assert np.abs(out[i].detach().reshape(-1)[::sub].cpu().numpy() - fx[k]).max() < tol, k
+    for got, want, name in ((code.grad, fx["grad_code"], "code"), (code_pos.grad, fx["grad_code_pos"], "code_pos")):
+        got, want = got.cpu().double(), torch.from_numpy(want).double()
+        rel = float((got - want).norm() / want.norm())
+        worst = float((got - want).abs().max() / want.abs().max())
+        print(mode, name, f"grad rel-l2 {rel:.2e} worst {worst:.2e}")
+        assert rel < 2e-2 and worst < 1e-1, (name, rel, worst)         # (the identity grid's bound: clamp-mask flips of the fp16 cd, DESIGN.md section 6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident"])
 def test_headline_width_reference_vectors(case, dev):
     """Reference-pinned vectors at the headline width (C=384, D=70, 28x28 maps, S=28, B=2; tests/golden/make_round4_fixtures.py):

@@ -637,3 +637,63 @@ def test_main_kernel_span_reports_the_held_clock(dev):
         assert ms2 != ms2 and ghz2 != ghz2               # nan: nothing stamped
     finally:
         timer.arm(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,D,hw,N,mode", [(2, 1536, 24, 14, 1, "full"), (3, 800, 90, 20, 3, "reduced"), (1, 2048, 70, 13, 2, "reduced")])
+def test_dense_grid_of_any_width_against_the_oracle(B, C, D, hw, N, mode, dev):
+    """Dense identity grids above 160 positions with feature maps wider than 768 channels (round 6: channel chunks of unit vectors,
+    dg_normalize_split + DG_FEATS_UNIT): two and three chunks, a chunk that is not a multiple of 128 (800 = 2 x 400), D = 90, B = 1,
+    the un-reduced outputs.  Tolerances of the randomised sweep (scripts/fuzz_parity.py)."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(C + hw)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float()
+    perms = [torch.randint(0, B, (B,), generator=g) for _ in range(N)] if B == 1 else [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=hw, neg_samples=N, dim=D, dg_outputs=mode, dg_dense_grid=True)
+    co = O.identity_coords(B, hw)
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=co, coords2=co, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), co.to(dev), co.to(dev),
+                                                       [p.to(dev) for p in perms], shared_coords=True, identity_grid=True)
+    O.total_loss(cfg, out).backward()
+    for i in range(len(ref)):
+        a, b = float(out[i].detach().mean()), float(ref[i].detach().mean())
+        assert abs(a - b) <= 3e-3 * abs(b) + 3e-5, (i, a, b)
+        if mode == "full" and out[i].dim() > 0:
+            assert tuple(out[i].shape) == tuple(ref[i].shape), i
+            assert float((out[i].detach().cpu() - ref[i].detach()).abs().max()) <= 4e-3, i
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        rel = float((got.cpu() - want).norm() / want.norm())
+        assert rel < 4e-2, (name, rel)
+
+
+@pytest.mark.gpu
+def test_normalize_split_and_the_unit_flag_through_the_abi(dev):
+    """dg_normalize_split against F.normalize over all channels (chunks of 400 + 400 + 224), its argument checks, and DG_FEATS_UNIT
+    refused off the identity grid (on sampled coordinates the reference normalises BEHIND sample())."""
+    import ctypes
+    from depthg_amd import _lib, ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1024, 9, 7, generator=g)
+    x[0, :, 1, 2] = 0.0                                    # a zero vector: the eps path
+    x[1, :, 0, 0] *= 1e-12
+    outs = ops.normalize_split(x.to(dev), 400)
+    assert [tuple(o.shape) for o in outs] == [(2, 400, 9, 7), (2, 400, 9, 7), (2, 224, 9, 7)]
+    want = torch.nn.functional.normalize(x, dim=1, eps=1e-10)
+    got = torch.cat([o.cpu() for o in outs], dim=1)
+    assert float((got - want).abs().max()) <= 2e-7
+    assert torch.count_nonzero(got[0, :, 1, 2]) == 0
+    lib = _lib.load()
+    ptrs = (ctypes.c_void_p * 3)(*[o.data_ptr() for o in outs])
+    xd = x.to(dev)
+    assert lib.dg_normalize_split(2, 1024, 9, 7, ctypes.c_void_p(xd.data_ptr()), 3, 300, ptrs, ops._stream(dev)) == -1   # DG_ERR_INVALID: 3 x 300 < 1024
+    assert lib.dg_normalize_split(2, 1024, 9, 7, ctypes.c_void_p(xd.data_ptr()), 3, 600, ptrs, ops._stream(dev)) == -1   # 2 x 600 >= 1024
+    desc = ops.make_desc(2, 384, 70, 14, 14, 14, 1, pointwise=True, zero_clamp=True, stabalize=False, depth_term=False, need_grad=False,
+                         shared_coords=False, shifts=(0.1, 0.1, 0.1, 0.0), feats_unit=True)
+    assert lib.dg_corr_workspace_bytes(ctypes.byref(desc)) == 0
+    assert b"DG_FEATS_UNIT" in lib.dg_last_error()
