@@ -110,9 +110,20 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 
     // ---- stage the feature tile: fp32 (C, NT) -> bf16 LDS image, drop3(f) written on the way.  Eight rows' loads in flight per
     //      thread (one block per CU: nothing else hides the latency)
-    for (int k = tid; k < CP; k += NTH) {
-        km1[k] = (k < C && (!a.keep1 || a.keep1[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
-        km2[k] = (k < C && (!a.keep2 || a.keep2[(size_t)b * C + k] != 0.f)) ? 0xffffu : 0u;
+    // keep flags of the two dropouts: requested here, unconditionally (a null mask reads any valid word), and turned into the bit masks
+    // BEHIND the tile's loads - under `!keep || keep[k] != 0` each was a branch with a load and its own wait: two memory round trips
+    // (2-4 us under load) before the tile's first load was issued
+    constexpr int KIT = (CP + NTH - 1) / NTH;
+    float rk1[KIT], rk2[KIT];
+    {
+        const float* const p1 = a.keep1 ? a.keep1 + (size_t)b * C : a.feat;
+        const float* const p2 = a.keep2 ? a.keep2 + (size_t)b * C : a.feat;
+#pragma unroll
+        for (int u = 0; u < KIT; ++u) {
+            const int k = tid + NTH * u, kc = k < C ? k : C - 1;
+            rk1[u] = p1[kc];
+            rk2[u] = p2[kc];
+        }
     }
     {
         constexpr int Q = NT / 4, NIT = (CP * Q + NTH - 1) / NTH;        // 16-byte pieces per row; pieces per thread
@@ -158,6 +169,14 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                 }
                 *reinterpret_cast<bf16x4*>(Ft + k * FROW + q4 * 8) = o4;
             }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < KIT; ++u) {
+        const int k = tid + NTH * u;
+        if (k < CP) {
+            km1[k] = (k < C && (!a.keep1 || rk1[u] != 0.f)) ? 0xffffu : 0u;
+            km2[k] = (k < C && (!a.keep2 || rk2[u] != 0.f)) ? 0xffffu : 0u;
         }
     }
     __syncthreads();
