@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
         const int rr = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         invd[i] = (a.xinv_dest[dest] && rr < a.P) ? a.xinv_dest[dest][(size_t)n * a.Ppad + rr] : 0.f;
     }
+    const _Float16 __attribute__((address_space(1)))* const hdummy = reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.xinv));
     // up to eight half tiles at a time (HB: sixteen 16-byte loads in flight, what four fp32 tiles are), every load of the batch in flight before the first is used (one at a time the launch was
     // bound by the latency of its loads: the fp32 form's 28 us came back as 24 instead of 17)
     auto add_half4 = [&](const _Float16 __attribute__((address_space(1)))* const (&hb)[HB], const float (&sc)[HB], const bool raw) __attribute__((always_inline)) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
             t0[u] = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(hb[u]);
-            t1[u] = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(hb[u] + ((ok && sc[u] != 0.f) ? 512 : 0));
+            t1[u] = *reinterpret_cast<const f16x8 __attribute__((address_space(1)))*>(hb[u] + ((ok && hb[u] != hdummy) ? 512 : 0));
         }
 #pragma unroll
         for (int u = 0; u < HB; ++u) {
@@ -233,7 +234,6 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
             }
         }
     };
-    const _Float16 __attribute__((address_space(1)))* const hdummy = reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(a.xinv));
     auto add_sources_half = [&](const int8_t* list, const int nsrc_, const bool raw) __attribute__((always_inline)) {
         for (int k0 = 0; k0 < nsrc_; k0 += HB) {
             const _Float16 __attribute__((address_space(1)))* hb[HB];
@@ -243,8 +243,10 @@ __global__ __launch_bounds__(64 * NDF) void k_combine_out(const DgScatterArgs a)
                 const bool live = k0 + u < nsrc_;
                 const DgScatterSrc& q = a.src[(int)list[live ? k0 + u : k0]];
                 sc[u] = live ? dg_src_factor(q) * dg_pick(gs, q.gidx) : 0.f;
-                hb[u] = sc[u] != 0.f ? reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(q.buf)) + (size_t)n * a.Ppad * DP + in_img_h
-                                     : hdummy;
+                // (the address does not wait for the weight - the upstream gradients are a load of their own: a tile whose weight turns
+                //  out zero is fetched and dropped by the select in add_half4, never multiplied: it may be unwritten)
+                hb[u] = live ? reinterpret_cast<const _Float16 __attribute__((address_space(1)))*>(reinterpret_cast<uintptr_t>(q.buf)) + (size_t)n * a.Ppad * DP + in_img_h
+                             : hdummy;
             }
             add_half4(hb, sc, raw);
         }

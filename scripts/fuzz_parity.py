@@ -28,7 +28,7 @@ def one(seed):
     dense = pick(g, 0, 2) == 0
     if EDGE:
         B = [1, 2, 7, 8, 9, 16, 33, 64, 65][pick(g, 0, 8)]
-        C = [31, 33, 127, 128, 129, 383, 384, 385, 767, 768][pick(g, 0, 9)]
+        C = [31, 33, 127, 128, 129, 383, 384, 385, 767, 768, 769, 1024, 1600][pick(g, 0, 12)]     # (> 768: channel chunks on the dense grid, the small-grid kernel on <= 160 positions, refused elsewhere)
         D = [1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 79, 80, 81, 95, 96, 97, 127, 128][pick(g, 0, 17)]
         N = [1, 2, 5, 7, 8][pick(g, 0, 4)]
         if dense:
