@@ -85,7 +85,7 @@ def one(seed):
         out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
                                                            [p.to(dev) for p in perms], **kw)
     except RuntimeError as e:
-        if "not supported" in str(e) or "unsupported" in str(e).lower():
+        if "not supported" in str(e) or "unsupported" in str(e).lower() or "are supported on" in str(e):     # (the stated limits: a refusal, not a result)
             return "skip", desc + f"  [{str(e)[-80:]}]"
         raise
     bad = []
