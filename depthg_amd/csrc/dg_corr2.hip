@@ -639,9 +639,16 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #else
     for (int f = 0; f < RF; ++f) gstepb[f] = fo[f] ? (size_t)0 : gstep * sizeof(v4i_t);
 #endif
-    // running store pointers (the tile index times the tile stride as 64-bit scalar multiplies in front of every store cost three
-    // s_mul and two adds each): gp[0] points at S tile t, gp[1] at S tile t - 1 (fragment 1 runs one phase behind)
-    uintptr_t gp[RF] = {reinterpret_cast<uintptr_t>(gbase[0]), reinterpret_cast<uintptr_t>(gbase[1]) - gstepb[1]};
+    // running store addresses: a scalar base per fragment (advanced by scalar adds; the tile index times the tile stride as 64-bit scalar
+    // multiplies in front of every store cost three s_mul and two adds each) + ONE 32-bit lane offset for every store - half the address
+    // bytes of the vaddr form and no 64-bit VALU add (round 6: -0.5 % of the kernel, -2 us of the step).  gsb[0] points at S tile t,
+    // gsb[1] at S tile t - 1 (fragment 1 runs one phase behind).  (dg_uniform_ptr: readfirstlane returns int - the halves go through
+    // uint32_t, or the low one is sign-extended over the high one)
+    uint64_t gsb[RF];
+#pragma unroll
+    for (int f = 0; f < RF; ++f)
+        gsb[f] = reinterpret_cast<uint64_t>(dg_uniform_ptr(reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(gbase[f] - lane) - (f == 1 ? gstepb[1] : 0))));
+    const uint32_t goff = lane * 16;
     auto g_store = [&](const int f, const int sp, int t) {
         // (asm: the store must be ISSUED here - the counted vmcnt waits at the tile barrier rely on it; hipcc is free to sink
         //  an ordinary store past the barrier, after which the wait lets the youngest DMA pieces of the next tile slip)
@@ -649,10 +656,14 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
 #ifdef C2_ABL_NOGSTORE     // (developer ablation, WRONG results: no G store is issued)
         return;
 #endif
-        v4i_t* g = reinterpret_cast<v4i_t*>(gp[f]) + 64 * sp;
         // (non-temporal: with the default cache policy on these stores / k_gs's loads the step is 1-6 % slower, profiles/r03_SUMMARY.md)
-        if (FOLD && __builtin_expect(fo[f], 0)) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(g), "v"(ga[f][sp]) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(g), "v"(ga[f][sp]) : "memory");
+        if (sp == 0) {
+            if (FOLD && __builtin_expect(fo[f], 0)) asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(goff), "v"(ga[f][sp]), "s"(gsb[f]) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2 nt" :: "v"(goff), "v"(ga[f][sp]), "s"(gsb[f]) : "memory");
+        } else {
+            if (FOLD && __builtin_expect(fo[f], 0)) asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024" :: "v"(goff), "v"(ga[f][sp]), "s"(gsb[f]) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 nt" :: "v"(goff), "v"(ga[f][sp]), "s"(gsb[f]) : "memory");
+        }
     };
     // FOLD: the B fragment of the extra chain step - k = 0: 1, k = 1: 2^-11 (lanes of half 0 hold k 0..7), zero for a fragment that is
     // not folded.  It borrows ga[f][0]: free between the gradient product that read it and the next epilogue of the fragment.
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(256) void k_corr2(const DgCorrArgs args_k) {
             STAMP(t, 5);
             bcur = bnext;
 #pragma unroll
-            for (int f = 0; f < RF; ++f) { gp[f] += gstepb[f]; asm volatile("" : "+v"(gp[f])); }
+            for (int f = 0; f < RF; ++f) { gsb[f] += gstepb[f]; asm volatile("" : "+s"(gsb[f])); }
         }
         // ---- tail: fragment 1 of the last tile (epilogue, G store, gradient product)
         if constexpr (ACT1) {
