@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("DEPTHG_LIB") or os.path.join(_HERE, "lib", "libdepthg
 
 DG_OUT_COUNT = 9
 DG_OUT_TOTAL = 8
-DG_VERSION = 117                     # must match include/depthg_corr.h: a stale library is refused
+DG_VERSION = 118                     # must match include/depthg_corr.h: a stale library is refused
 DG_POINTWISE, DG_ZERO_CLAMP, DG_STABALIZE, DG_DEPTH_TERM, DG_NEED_GRAD, DG_SHARED_COORDS, DG_IDENTITY_GRID, DG_LINE_GRID, \
     DG_EXACT_MASKS, DG_FEATS_UNIT = (1 << i for i in range(10))
 
@@ -20,7 +20,8 @@ EXPORTS = ["dg_version", "dg_last_error", "dg_corr_workspace_bytes", "dg_corr_fo
            "dg_head_forward", "dg_head_workspace_bytes", "dg_head_weights_bytes", "dg_head_backward", "dg_head_forward_pair",
            "dg_head_backward_pair", "dg_cluster_lookup_forward",
            "dg_cluster_lookup_backward", "dg_probe_ce_forward", "dg_probe_ce_backward", "dg_knn_similarities",
-           "dg_prof_main_span", "dg_corr_materialize_shared", "dg_normalize_split"]
+           "dg_prof_main_span", "dg_corr_materialize_shared", "dg_normalize_split", "dg_sampled_sumsq",
+           "dg_corr_forward_extnorm"]
 
 
 class CorrDesc(ctypes.Structure):
@@ -99,6 +100,10 @@ def load():
     lib.dg_fps_workspace_bytes.argtypes = [ctypes.c_int32] * 3
     lib.dg_fps_coords.restype = ctypes.c_int
     lib.dg_fps_coords.argtypes = [vp] + [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dg_sampled_sumsq.restype = ctypes.c_int
+    lib.dg_sampled_sumsq.argtypes = [ctypes.c_int32] * 6 + [vp, vp, vp, ctypes.c_int32, vp, vp]
+    lib.dg_corr_forward_extnorm.restype = ctypes.c_int
+    lib.dg_corr_forward_extnorm.argtypes = [cp] + [vp] * 11 + [ctypes.c_size_t, vp]
     lib.dg_normalize_split.restype = ctypes.c_int
     lib.dg_normalize_split.argtypes = [ctypes.c_int32] * 4 + [vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), vp]
     lib.dg_rand_coords_state.restype = ctypes.c_int

@@ -94,7 +94,8 @@ static int make_plan(const dg_corr_desc* d, Plan& p) {
     if (d->C > 768 && !p.small)
         return fail(DG_ERR_UNSUPPORTED, "C=%d > 768 feature channels are supported on sample grids of at most 160 positions "
                                         "(feature_samples <= 12) only; this call has %d positions%s", d->C, p.P,
-                    (d->flags & DG_IDENTITY_GRID) ? " on the dense identity grid (wider maps go there in channel chunks: dg_normalize_split + DG_FEATS_UNIT)" : "");
+                    (d->flags & DG_IDENTITY_GRID) ? " on the dense identity grid (wider maps go there in channel chunks: dg_normalize_split + DG_FEATS_UNIT)"
+                                                   : " (wider maps go there in channel chunks: dg_sampled_sumsq + dg_corr_forward_extnorm)");
     if ((d->flags & DG_FEATS_UNIT) && !(d->flags & DG_IDENTITY_GRID))
         return fail(DG_ERR_INVALID, "DG_FEATS_UNIT needs DG_IDENTITY_GRID: on sampled coordinates the reference normalises BEHIND sample()");
     p.C4 = (int)up(d->C, 4); p.D4 = (int)up(d->D, 4);
@@ -552,7 +553,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
                              const float* orig_code, const float* orig_code_pos, const float* depth,
                              const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
                              float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_,
-                             const FeatKeep* fk = nullptr);
+                             const FeatKeep* fk = nullptr, const float* feat_inv = nullptr);
 
 extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                                const float* orig_code, const float* orig_code_pos, const float* depth,
@@ -560,6 +561,22 @@ extern "C" int dg_corr_forward(const dg_corr_desc* desc, const float* orig_feats
                                float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
     return corr_forward_impl(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms, nullptr,
                              out_scalars, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int dg_corr_forward_extnorm(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                                       const float* orig_code, const float* orig_code_pos, const float* depth,
+                                       const float* coords1, const float* coords2, const int64_t* perms, const float* feat_inv,
+                                       float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_) {
+    if (!feat_inv) return fail(DG_ERR_INVALID, "dg_corr_forward_extnorm: feat_inv is null");
+    return corr_forward_impl(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2, perms, nullptr,
+                             out_scalars, workspace, workspace_bytes, stream_, nullptr, feat_inv);
+}
+
+extern "C" int dg_sampled_sumsq(int32_t B, int32_t C, int32_t h, int32_t w, int32_t S, int32_t line_grid, const float* feats,
+                                const float* coords, const int64_t* srcidx, int32_t accumulate, float* out, dg_stream_t stream_) {
+    if (B < 1 || C < 1 || h < 1 || w < 1 || S < 1 || !feats || !coords || !out) return fail(DG_ERR_INVALID, "dg_sampled_sumsq: bad arguments");
+    DG_HIP(dg_launch_sampled_sumsq(feats, coords, srcidx, out, B, C, h, w, S, line_grid ? 1 : S, accumulate ? 1 : 0, static_cast<hipStream_t>(stream_)));
+    return DG_OK;
 }
 
 extern "C" int dg_corr_forward_draw(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
@@ -590,10 +607,14 @@ extern "C" int dg_corr_forward_masked(const dg_corr_desc* desc, const float* ori
 static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
                              const float* orig_code, const float* orig_code_pos, const float* depth,
                              const float* coords1, const float* coords2, const int64_t* perms, const DrawArgs* draw,
-                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_, const FeatKeep* fk) {
+                             float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream_, const FeatKeep* fk,
+                             const float* feat_inv) {
     Plan p;
     int rc = make_plan(desc, p);
     if (rc != DG_OK) return rc;
+    if (feat_inv && (p.ident || p.small))
+        return fail(DG_ERR_INVALID, "dg_corr_forward_extnorm is the sampled-coordinate path above 160 positions: the identity grid takes "
+                                    "DG_FEATS_UNIT, smaller grids any width as they are");
     if (fk && (fk->keep[0] || fk->keep[1]) && !p.ident)
         return fail(DG_ERR_UNSUPPORTED, "deferred feature dropout (feat_keep) is built for the identity grid only: "
                                         "with sampled coordinates hand the dropped features in");
@@ -714,6 +735,7 @@ static int corr_forward_impl(const dg_corr_desc* desc, const float* orig_feats, 
             DgGatherJob& f = g.jobs[nj++];
             f.src = p.rows ? F32(p.rows_f[o]) : F32(p.nhwc_f[srcsel]); f.coords = coords; f.srcidx = p.rows ? nullptr : idx;
             f.blob = ws + p.op[o]; f.inv_norm = nullptr; f.colpart = F32(p.colpart[o]);
+            f.ext_inv = feat_inv ? feat_inv + (size_t)o * p.B * p.P : nullptr;
             f.K = p.C; f.K4 = p.C4; f.Kpad = p.KF; f.is_code = 0; f.h = p.h; f.w = p.w;
             DgGatherJob& c = g.jobs[nj++];
             c.src = p.rows ? F32(p.rows_c[o]) : F32(p.nhwc_c[srcsel]); c.coords = coords; c.srcidx = p.rows ? nullptr : idx;

@@ -305,6 +305,7 @@ struct DgGatherJob {
     int32_t K, K4, Kpad;
     int32_t is_code;         // 1: fp16 code (C and P parts), 0: bf16 feats (F part)
     int32_t h, w;            // size of the map `src` holds (not read in direct mode)
+    const float* ext_inv;    // [B][P] or null: 1 / norm of the sampled vector over ALL channels, of which this job holds a chunk (dg_corr_forward_extnorm)
 };
 #define DG_MAX_GATHER 20
 // the jobs of a call with general coordinates that depend on nothing but its inputs (k_pre_general; dg_post.hip)
@@ -841,6 +842,7 @@ struct DgHeadWgradArgs {
     int32_t Bs; long long dA, dB, dA2;   // (pair: images Bs.. of A / Bm / A2 in second tensors, offsets in their elements; 0: one tensor)
 };
 
+hipError_t dg_launch_sampled_sumsq(const float* feats, const float* coords, const int64_t* srcidx, float* out, int B, int C, int h, int w, int S, int Sh, int accumulate, hipStream_t s);
 hipError_t dg_launch_normalize_split(const float* src, int B, int C, int P, int nchunks, int chunk_c, float* const* dst, hipStream_t s);
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);

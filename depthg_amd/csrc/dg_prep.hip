@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void k_gather_norm(const DgGatherArgs a) {
             for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
             inv = 1.f / fmaxf(sqrtf(ss), DG_EPS_NORM);
         }
+        // (a channel chunk of a wider map: the norm of the whole sampled vector, formed over all chunks in front of this call)
+        if (J.ext_inv && p < a.P) inv = J.ext_inv[(size_t)n * a.P + p];
         // normalise, convert, store (zero rows for p >= P, zero columns for k >= K4)
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
@@ -974,6 +976,53 @@ __global__ __launch_bounds__(256) void k_prep_dense(const DgDenseArgs a) {
     } else if (x == 0 && !(DG_DBG(a.debug) & 4)) {
         depth_nz_image(a.depth, a.nz, a.nzsum, n, a.dH, a.dW, a.h, a.h, a.Ppad, true);
     }
+}
+
+// sum over the channels of sample(feats, coords)^2 per position (sample(): src/modules.py:822-825, the arithmetic of k_gather_norm
+// above: align_corners, border clamp, output position (i, j) reads coords[n][j][i]) from the NCHW map directly - the norm-only pass of a
+// call whose feature maps are wider than the operand kernels hold (dg_sampled_sumsq): out[n][p] (+)= the chunk's share.
+// Block = 64 positions x 4 channel slices (slice q walks channels q, q + 4, ...; the four shares are added in slice order).
+struct DgSumsqArgs { const float* feats; const float* coords; const int64_t* srcidx; float* out; int32_t B, C, h, w, S, Sh, P, accumulate; };
+__global__ __launch_bounds__(256) void k_sampled_sumsq(const DgSumsqArgs a) {
+    __shared__ float part[4][64];
+    const int px = threadIdx.x & 63, q = threadIdx.x >> 6, p = blockIdx.x * 64 + px, n = blockIdx.y;
+    const int pc = p < a.P ? p : a.P - 1, i = pc / a.S, j = pc - i * a.S;
+    const float* c = a.coords + (((size_t)n * a.S + j) * a.Sh + i) * 2;
+    float x = ((c[0] + 1.f) / 2.f) * (float)(a.w - 1);
+    float y = ((c[1] + 1.f) / 2.f) * (float)(a.h - 1);
+    x = fminf(fmaxf(x, 0.f), (float)(a.w - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(a.h - 1));
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float wx1 = x - x0f, wy1 = y - y0f, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool inx = x0 + 1 <= a.w - 1, iny = y0 + 1 <= a.h - 1;
+    const float w00 = wy0 * wx0, w01 = (inx ? wy0 * wx1 : 0.f), w10 = (iny ? wy1 * wx0 : 0.f), w11 = (inx && iny) ? wy1 * wx1 : 0.f;
+    const int o00 = y0 * a.w + x0, o01 = o00 + (inx ? 1 : 0), o10 = o00 + (iny ? a.w : 0), o11 = o10 + (inx ? 1 : 0);
+    const int ns = a.srcidx ? (int)a.srcidx[n] : n;
+    const float* img = a.feats + (size_t)ns * a.C * a.h * a.w;
+    const int HW = a.h * a.w;
+    float ss = 0.f;
+    for (int ch = q; ch < a.C; ch += 4) {
+        const float* pl = img + (size_t)ch * HW;
+        float v = pl[o00] * w00;
+        if (w01 != 0.f) v += pl[o01] * w01;
+        if (w10 != 0.f) v += pl[o10] * w10;
+        if (w11 != 0.f) v += pl[o11] * w11;
+        ss = fmaf(v, v, ss);
+    }
+    part[q][px] = ss;
+    __syncthreads();
+    if (q == 0 && p < a.P) {
+        const float t = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
+        float* o = a.out + (size_t)n * a.P + p;
+        *o = a.accumulate ? *o + t : t;
+    }
+}
+hipError_t dg_launch_sampled_sumsq(const float* feats, const float* coords, const int64_t* srcidx, float* out, int B, int C, int h, int w,
+                                   int S, int Sh, int accumulate, hipStream_t s) {
+    const DgSumsqArgs a{feats, coords, srcidx, out, B, C, h, w, S, Sh, S * Sh, accumulate};
+    hipLaunchKernelGGL(k_sampled_sumsq, dim3((S * Sh + 63) / 64, B), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // norm() over all C channels of an NCHW map, written as channel chunks (dg_normalize_split: the operands of DG_FEATS_UNIT calls).

@@ -60,7 +60,10 @@ class _CorrLossFunction(torch.autograd.Function):
     def forward(ctx, orig_code, orig_code_pos, orig_feats, orig_feats_pos, depth, coords1, coords2, perms, desc, holder):
         ws = ops.alloc_workspace(desc, orig_feats.device)
         fk = holder.get("feat_keep")
-        if fk is not None:                 # Dropout2d of the feature maps applied inside the operand preparation (identity grid)
+        if holder.get("feat_inv") is not None:     # one channel chunk of wider maps on sampled coordinates (forward_with: `wide`)
+            out = ops.corr_forward_extnorm(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
+                                           perms, holder["feat_inv"], ws)
+        elif fk is not None:               # Dropout2d of the feature maps applied inside the operand preparation (identity grid)
             drew = perms is None
             out, perms = ops.corr_forward_masked(desc, orig_feats, orig_feats_pos, orig_code, orig_code_pos, depth, coords1, coords2,
                                                  perms, ws, holder.get("draw_state"), fk[0], fk[1], fk[2])
@@ -320,7 +323,7 @@ class ContrastiveCorrelationLoss(nn.Module):
         code_in, code_pos_in = code_in.contiguous(), code_pos_in.contiguous()
         all_shifts = (cfg.pos_intra_shift, cfg.pos_inter_shift, cfg.neg_inter_shift, cfg.depth_feat_shift if depth_term else 0.0)
 
-        def run(f_a, f_b, perms_in, first=True, unit=False, keep=feat_keep):
+        def run(f_a, f_b, perms_in, first=True, unit=False, keep=feat_keep, feat_inv=None):
             """one launch set of the C ABI on feature maps of the width the operand kernels hold (`first`: the recipe's shifts and
             depth term; else a further channel chunk of a wider map: zero shifts, no depth term - see below)"""
             dt = depth_term and first
@@ -332,13 +335,47 @@ class ContrastiveCorrelationLoss(nn.Module):
                                   identity_grid=bool(identity_grid), weights=self._total_weights(dt),
                                   line_grid=line_grid, code_hw=None if same_maps else (hc, wc),
                                   exact_masks=bool(getattr(cfg, "dg_exact_masks", False)), feats_unit=unit)
-            holder_ = {"draw_state": draw_state, "feat_keep": keep}
+            holder_ = {"draw_state": draw_state, "feat_keep": keep, "feat_inv": feat_inv}
             out_, total_ = _CorrLossFunction.apply(code_in, code_pos_in, f_a, f_b, depth_c if dt else None,
                                                    coords1, coords2, perms_in, desc_, holder_)
             return out_, total_, desc_, holder_["workspace"], (holder_["perms"] if perms_in is None else perms_in)
 
         wide = identity_grid and C > ops.BLOB_MAX_C
-        if not wide:
+        P_pos = int(coords1.shape[1]) * int(coords1.shape[2])
+        wide_sampled = (not identity_grid) and C > ops.BLOB_MAX_C and P_pos > SMALL_GRID_POSITIONS
+        if wide_sampled:
+            # ... and on SAMPLED coordinates above 160 positions: the reference normalises behind sample(), so the norm of every sampled
+            # vector is formed over all channel chunks first (dg_sampled_sumsq per operand: feats at coords1, feats_pos at coords2 and,
+            # with coordinates per image, feats through every negative's batch map at coords2), then each chunk runs with those norms
+            # (dg_corr_forward_extnorm) - shifts, depth term and the sums as on the dense grid below
+            if feat_keep is not None:
+                raise RuntimeError("depthg_amd: deferred feature dropout is the identity grid's")       # (forward_with formed the tensors above)
+            if perms_t is None:
+                perms_t = super_perms(N, B, dev) if N > 0 else torch.zeros(0, B, dtype=torch.long, device=dev)
+            nops = 2 if (shared_coords or N == 0) else 2 + N
+            nch = (C + ops.BLOB_MAX_C - 1) // ops.BLOB_MAX_C
+            chunk_c = ((C + nch - 1) // nch + 7) // 8 * 8
+            fa = [feats[:, k:k + chunk_c].contiguous() for k in range(0, C, chunk_c)]
+            fb = [feats_pos[:, k:k + chunk_c].contiguous() for k in range(0, C, chunk_c)]
+            sumsq = torch.empty(nops, B, P_pos, device=dev, dtype=torch.float32)
+            for k in range(len(fa)):
+                ops.sampled_sumsq(fa[k], coords1, None, sumsq[0], k > 0)
+                ops.sampled_sumsq(fb[k], coords2, None, sumsq[1], k > 0)
+                for j in range(2, nops):
+                    ops.sampled_sumsq(fa[k], coords2, perms_t[j - 2], sumsq[j], k > 0)     # (the negatives are orig_feats[perm] at coords2, src/modules.py:1341-1345)
+            feat_inv = (1.0 / sumsq.sqrt().clamp_min(1e-10)).contiguous()
+            chunks = []
+            for k in range(len(fa)):
+                o_k, t_k, desc_k, ws_k, perms_t = run(fa[k], fb[k], perms_t, first=(k == 0), keep=None, feat_inv=feat_inv)
+                chunks.append((o_k, t_k, desc_k, ws_k))
+            lossmask = torch.zeros(ops._lib.DG_OUT_COUNT, device=dev)
+            lossmask[[0, 1, 2, ops._lib.DG_OUT_TOTAL]] = 1.0
+            out, total = chunks[0][0], chunks[0][1]
+            for o_k, t_k, _, _ in chunks[1:]:
+                out = out + o_k * lossmask
+                total = total + t_k
+            desc, ws = chunks[0][2], chunks[0][3]
+        elif not wide:
             out, total, desc, ws, perms_t = run(feats, feats_pos, perms_t)
             chunks = None
         else:

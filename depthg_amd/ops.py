@@ -83,6 +83,27 @@ def normalize_split(feats, chunk_c):
     return outs
 
 
+def sampled_sumsq(feats_chunk, coords, srcidx, out, accumulate):
+    """out[n][p] (+)= sum over the chunk's channels of sample(feats_chunk[srcidx[n]], coords[n])^2 (dg_sampled_sumsq)."""
+    B, C, h, w = feats_chunk.shape
+    S, line = coords.shape[1], coords.shape[2] == 1 and coords.shape[1] != 1
+    _lib.check(_lib.load().dg_sampled_sumsq(B, C, h, w, S, 1 if line else 0, _ptr(feats_chunk), _ptr(coords), _ptr(srcidx),
+                                            1 if accumulate else 0, _ptr(out), _stream(feats_chunk.device)), "dg_sampled_sumsq")
+
+
+def corr_forward_extnorm(desc, feats, feats_pos, code, code_pos, depth, coords1, coords2, perms, feat_inv, workspace):
+    """dg_corr_forward on ONE channel chunk of wider feature maps, normalised by `feat_inv` (nops, B, P): 1 / the norm of the whole
+    sampled vector (sampled coordinates above 160 positions; see include/depthg_corr.h)."""
+    lib = _lib.load()
+    dev = feats.device
+    out = _empty(_lib.DG_OUT_COUNT, torch.float32, dev)
+    rc = lib.dg_corr_forward_extnorm(ctypes.byref(desc), _ptr(feats), _ptr(feats_pos), _ptr(code), _ptr(code_pos), _ptr(depth),
+                                     _ptr(coords1), _ptr(coords2), _ptr(perms), _ptr(feat_inv), _ptr(out), _ptr(workspace),
+                                     workspace.numel(), _stream(dev))
+    _lib.check(rc, "dg_corr_forward_extnorm")
+    return out
+
+
 def workspace_bytes(desc):
     n = _lib.load().dg_corr_workspace_bytes(ctypes.byref(desc))
     if n == 0:

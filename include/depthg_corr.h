@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DG_VERSION 117   /* 117: DG_FEATS_UNIT, dg_normalize_split (feature maps wider than 768 channels on the dense identity grid, in chunks of the width the operand kernels hold: the loss is linear in the feature correlation); 116: dg_prof_main_span takes FOUR words (+ the workgroups' lifetimes in shader cycles and wall ticks: the clock the CUs held); 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
+#define DG_VERSION 118   /* 118: dg_sampled_sumsq, dg_corr_forward_extnorm (feature maps wider than 768 channels on SAMPLED grids above 160 positions, in channel chunks); 117: DG_FEATS_UNIT, dg_normalize_split (feature maps wider than 768 channels on the dense identity grid, in chunks of the width the operand kernels hold: the loss is linear in the feature correlation); 116: dg_prof_main_span takes FOUR words (+ the workgroups' lifetimes in shader cycles and wall ticks: the clock the CUs held); 115: dg_corr_intra_folded; 114: dg_fps_coords_pair takes a workspace (dg_fps_workspace_bytes(2 B, h, w): the pooled depth maps, written by a launch over the whole chip in front of the sampler), dg_corr_materialize_shared, dg_prof_main_span (the fused correlation launch's execution span inside a replayed step), sample grids of <= 160 positions at any feature width (fused small-grid kernel); 113: dg_corr_forward_masked; 112: dg_rand_coords_state; 111: dg_head_forward_pair / dg_head_backward_pair; 110: dg_fps_coords_pair; 109: dg_knn_similarities; 108: dg_corr_desc.code_h / code_w (code maps of another resolution than the feature maps: the FeaturePyramidNet producer, src/modules.py:732-766), dg_corr_desc.flags DG_EXACT_MASKS; 107: dg_head_*, dg_cluster_lookup_*, dg_probe_ce_*; 106: dg_corr_main_kernel_name; 105: dg_corr_forward_draw; 104: dg_lhp_map_forward / dg_lhp_map_backward; 103: dg_super_perms_state; 102: DG_LINE_GRID, dg_salience_coords, dg_simple_depth_coords; 101: total weights, DG_OUT_TOTAL */
 
 /* flags of dg_corr_desc.flags (names follow the cfg keys read at src/modules.py:1236-1352) */
 #define DG_POINTWISE      (1u << 0)  /* cfg.pointwise: spatial centering of fd (modules.py:1236-1239) */
@@ -73,7 +73,8 @@ typedef void* dg_stream_t; /* hipStream_t */
 typedef struct dg_corr_desc {
     int32_t B;        /* batch (per rank) */
     int32_t C;        /* feature channels of orig_feats (384 ViT-S, 768 ViT-B); <= 768 per call on grids above 160 positions and the identity grid
-                         (wider maps on the identity grid: one call per channel chunk, DG_FEATS_UNIT), <= 8192 on smaller grids */
+                         (wider maps: one call per channel chunk - DG_FEATS_UNIT on the identity grid, dg_corr_forward_extnorm on sampled
+                         coordinates), <= 8192 on smaller grids */
     int32_t D;        /* code channels = cfg.dim; <= 128 */
     int32_t h, w;     /* feature-map size of orig_feats / orig_feats_pos (and of the code maps unless code_h / code_w say otherwise) */
     int32_t S;        /* cfg.feature_samples; P = S*S positions are correlated (P = S with DG_LINE_GRID) */
@@ -385,6 +386,25 @@ int dg_rand_keep_state(uint64_t* state, int64_t n, float p_keep, float* out, dg_
  */
 int dg_normalize_split(int32_t B, int32_t C, int32_t h, int32_t w, const float* src, int32_t nchunks, int32_t chunk_c,
                        float* const* dst, dg_stream_t stream);
+
+/*
+ * Feature maps wider than 768 channels on SAMPLED coordinates above 160 positions (the reference normalises behind sample(),
+ * src/modules.py:789-790, 822-825: the norm of a sampled vector is over all of its channels).  Two calls per channel chunk:
+ *   dg_sampled_sumsq: out[n][p] (+)= sum over the chunk's channels of sample(feats[srcidx ? srcidx[n] : n], coords[n])[c][p]^2
+ *     feats (B,C_k,h,w) fp32 - ONE chunk, contiguous; coords (B,S,S,2) or (B,S,1,2) with line_grid; out (B,P) fp32; accumulate 0 / 1.
+ *     Once per operand: orig_feats at coords1, orig_feats_pos at coords2 and - coordinates per image (no DG_SHARED_COORDS) - orig_feats
+ *     through every negative's batch map at coords2 (src/modules.py:1341-1345).
+ *   dg_corr_forward_extnorm: dg_corr_forward on the chunk with feat_inv = 1 / max(sqrt(sum over ALL chunks), 1e-10), (nops, B, P) fp32,
+ *     operand-major (nops = 2, or 2 + n_neg without DG_SHARED_COORDS), used instead of the chunk's own norms.
+ * As with DG_FEATS_UNIT the first chunk carries the recipe's shifts and depth term, the others zero shifts and none; loss means and code
+ * gradients add up (dg_corr_backward* per chunk, unchanged).
+ */
+int dg_sampled_sumsq(int32_t B, int32_t C, int32_t h, int32_t w, int32_t S, int32_t line_grid, const float* feats,
+                     const float* coords, const int64_t* srcidx, int32_t accumulate, float* out, dg_stream_t stream);
+int dg_corr_forward_extnorm(const dg_corr_desc* desc, const float* orig_feats, const float* orig_feats_pos,
+                            const float* orig_code, const float* orig_code_pos, const float* depth,
+                            const float* coords1, const float* coords2, const int64_t* perms, const float* feat_inv,
+                            float* out_scalars, void* workspace, size_t workspace_bytes, dg_stream_t stream);
 
 /*
  * The segmentation head of DinoFeaturizer (replaces `cluster1(dropout(f)) + cluster2(dropout(f))` and the third

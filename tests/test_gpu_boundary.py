@@ -142,28 +142,31 @@ def test_dense_grid_is_not_taken_for_maps_of_two_sizes(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["full", "reduced"])
-def test_wide_dense_grid_reference_vectors(mode, dev):
+@pytest.mark.parametrize("case,mode", [("ident", "full"), ("ident", "reduced"), ("rand", "full"), ("rand", "reduced")])
+def test_wide_maps_reference_vectors(case, mode, dev):
     """Reference-pinned vectors of a dense grid whose feature maps are WIDER than the operand kernels hold (C = 1024, D = 70, 16 x 16
     maps, S = 16: 256 positions, B = 2, three negatives; tests/golden/make_round6_fixtures.py): the call runs as two channel chunks of
     unit vectors (dg_normalize_split + DG_FEATS_UNIT; the loss is linear in the feature correlation - depthg_amd/loss.py).  Loss means
     and the weighted total within 1e-4 relative, the un-reduced tensors (mode `full`) at the dense path's tolerances, the code
-    gradients within the dense path's fp16-mask bound."""
+    gradients within the dense path's fp16-mask bound.  `rand`: the same width on the reference's own random coordinates (20 x 20
+    maps, S = 16, two negatives): the norms of the sampled vectors over both chunks first (dg_sampled_sumsq), then every chunk with them
+    (dg_corr_forward_extnorm)."""
     from depthg_amd import ContrastiveCorrelationLoss
     from oracle import depthg_oracle as O
-    fx = load_golden_seeded("forward_wide1024_ident.npz")
+    fx = load_golden_seeded(f"forward_wide1024_{case}.npz")
+    ident = case == "ident"
     cfg = cfg_from_fixture(fx, dg_outputs=mode)
     T = lambda a: torch.from_numpy(a).to(dev)
     code, code_pos = T(fx["code"]).requires_grad_(True), T(fx["code_pos"]).requires_grad_(True)
     out = ContrastiveCorrelationLoss(cfg).forward_with(T(fx["feats"]), T(fx["feats_pos"]), code, code_pos, T(fx["depth"]),
                                                        T(fx["coords1"]), T(fx["coords2"]), T(fx["perms"]),
-                                                       shared_coords=True, identity_grid=True)
+                                                       shared_coords=ident, identity_grid=ident)
     total = O.total_loss(cfg, out)
     total.backward()
     errs = {k: _relerr(out[i].mean(), fx[k]) for i, k in ((0, "pos_intra_loss"), (2, "pos_inter_loss"), (4, "neg_inter_loss_mean"),
                                                           (6, "depth_feat_loss"))}
     errs["total"] = _relerr(total, fx["total"])
-    print(mode, {k: f"{v:.2e}" for k, v in errs.items()})
+    print(case, mode, {k: f"{v:.2e}" for k, v in errs.items()})
     for k, v in errs.items():
         assert v <= 1e-4, (k, v)
     if mode == "full":

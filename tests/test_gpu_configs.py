@@ -697,3 +697,76 @@ def test_normalize_split_and_the_unit_flag_through_the_abi(dev):
                          shared_coords=False, shifts=(0.1, 0.1, 0.1, 0.0), feats_unit=True)
     assert lib.dg_corr_workspace_bytes(ctypes.byref(desc)) == 0
     assert b"DG_FEATS_UNIT" in lib.dg_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,D,hw,S,N,shared,mode", [(2, 1024, 70, 20, 16, 2, False, "reduced"), (3, 1536, 24, 18, 14, 1, True, "full"),
+                                                     (2, 800, 90, 24, 13, 3, False, "reduced")])
+def test_sampled_grid_of_any_width_against_the_oracle(B, C, D, hw, S, N, shared, mode, dev):
+    """Sampled coordinates above 160 positions with feature maps wider than 768 channels (round 6: dg_sampled_sumsq over all channel
+    chunks, then dg_corr_forward_extnorm per chunk): coordinates per image (the negatives are operands of their own), one shared grid,
+    169 positions (the exact-mask launches) and 256 (the blob kernels' fp16 masks).  Tolerances of the randomised sweep."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(C + hw)
+    f, fp = torch.randn(B, C, hw, hw, generator=g), torch.randn(B, C, hw, hw, generator=g)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), generator=g).float()
+    perms = [O.super_perm(B, g) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs=mode)
+    if shared:
+        c1 = c2 = torch.rand(1, S, S, 2, generator=g).expand(B, S, S, 2).contiguous() * 2.2 - 1.1
+    else:
+        c1, c2 = torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1, torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1
+    cr, cpr = c.clone().requires_grad_(True), cp.clone().requires_grad_(True)
+    ref = O.forward(cfg, f, fp, cr, cpr, d, d, coords1=c1, coords2=c2, perms=perms)
+    O.total_loss(cfg, ref).backward()
+    cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+    out = ContrastiveCorrelationLoss(cfg).forward_with(f.to(dev), fp.to(dev), cg, cpg, d.to(dev), c1.to(dev), c2.to(dev),
+                                                       [p.to(dev) for p in perms], shared_coords=shared)
+    O.total_loss(cfg, out).backward()
+    for i in range(len(ref)):
+        a, b = float(out[i].detach().mean()), float(ref[i].detach().mean())
+        assert abs(a - b) <= 3e-3 * abs(b) + 3e-5, (i, a, b)
+        if mode == "full" and out[i].dim() > 0:
+            assert tuple(out[i].shape) == tuple(ref[i].shape), i
+            assert float((out[i].detach().cpu() - ref[i].detach()).abs().max()) <= 4e-3, i
+    for got, want, name in ((cg.grad, cr.grad, "code"), (cpg.grad, cpr.grad, "code_pos")):
+        rel = float((got.cpu() - want).norm() / want.norm())
+        assert rel < 4e-2, (name, rel)
+
+
+@pytest.mark.gpu
+def test_sampled_sumsq_and_the_external_norms_through_the_abi(dev):
+    """dg_sampled_sumsq against the oracle's sample() (with a batch map, accumulating over two chunks, coordinates beyond [-1, 1]), and
+    dg_corr_forward_extnorm refused where it does not apply (the identity grid, sample grids of <= 160 positions)."""
+    import ctypes
+    from depthg_amd import _lib, ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(9)
+    B, C, h, w, S = 3, 40, 9, 11, 6
+    x = torch.randn(B, C, h, w, generator=g)
+    co = torch.rand(B, S, S, 2, generator=g) * 2.4 - 1.2
+    idx = torch.tensor([2, 0, 0])
+    want = O.sample(x[idx], co).square().sum(1).reshape(B, -1)       # (B, C, S, S) -> (B, P), position order of sample()
+    out = torch.empty(B, S * S, device=dev)
+    xa, xb = x[:, :24].contiguous().to(dev), x[:, 24:].contiguous().to(dev)
+    ops.sampled_sumsq(xa, co.to(dev), idx.to(dev), out, False)
+    ops.sampled_sumsq(xb, co.to(dev), idx.to(dev), out, True)
+    assert float((out.cpu() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    lib = _lib.load()
+    for kw in (dict(identity_grid=True, shared_coords=True, S=14), dict(S=11)):
+        S_ = kw.pop("S")
+        desc = ops.make_desc(2, 384, 70, 14, 14, S_, 1, pointwise=True, zero_clamp=True, stabalize=False, depth_term=False, need_grad=False,
+                             shifts=(0.1, 0.1, 0.1, 0.0), **{"shared_coords": False, **kw})
+        ws = ops.alloc_workspace(desc, dev)
+        t = torch.zeros(2, 384, 14, 14, device=dev)
+        cc = torch.zeros(2, 70, 14, 14, device=dev)
+        coords = torch.zeros(2, S_, S_, 2, device=dev)
+        perms = torch.zeros(1, 2, dtype=torch.long, device=dev)
+        inv = torch.ones(3, 2, S_ * S_, device=dev)
+        outv = torch.empty(_lib.DG_OUT_COUNT, device=dev)
+        P = lambda v: ctypes.c_void_p(v.data_ptr())
+        rc = lib.dg_corr_forward_extnorm(ctypes.byref(desc), P(t), P(t), P(cc), P(cc), None, P(coords), P(coords), P(perms), P(inv), P(outv),
+                                         P(ws), ws.numel(), ops._stream(dev))
+        assert rc == -1 and b"dg_corr_forward_extnorm" in lib.dg_last_error()

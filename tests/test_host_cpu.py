@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/depthg_corr.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.dg_version() == _lib.DG_VERSION == 117
+    assert lib.dg_version() == _lib.DG_VERSION == 118
 
 
 def test_descriptor_validation_and_workspace():

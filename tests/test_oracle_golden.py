@@ -142,11 +142,11 @@ def test_forward_fps_coords_regenerated(case):
     assert np.array_equal(c2.numpy(), fx["coords2"])
 
 
-@pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident", "fpn2048_none", "fpn2048_fps", "wide1024_ident"])
+@pytest.mark.parametrize("case", ["hl28_rand", "hl28_ident", "fpn2048_none", "fpn2048_fps", "wide1024_ident", "wide1024_rand"])
 def test_forward_headline_width_against_reference(case):
     """The headline width (C=384, D=70, 28x28, S=28) at B=2, vectors from the imported reference with its own torch.rand
     coordinates (`rand`) and on the pixel-centre grid (`ident`); inputs re-drawn from the stored seed.  `wide1024_ident` (round 6):
-    1024 feature channels on a dense 16 x 16 grid (tests/golden/make_round6_fixtures.py)."""
+    1024 feature channels on a dense 16 x 16 grid / on 256 sampled positions of 20 x 20 maps (tests/golden/make_round6_fixtures.py)."""
     from conftest import load_golden_seeded
     fx = load_golden_seeded(f"forward_{case}.npz")
     cfg = cfg_from_fixture(fx)
