@@ -770,3 +770,42 @@ def test_sampled_sumsq_and_the_external_norms_through_the_abi(dev):
         rc = lib.dg_corr_forward_extnorm(ctypes.byref(desc), P(t), P(t), P(cc), P(cc), None, P(coords), P(coords), P(perms), P(inv), P(outv),
                                          P(ws), ws.numel(), ops._stream(dev))
         assert rc == -1 and b"dg_corr_forward_extnorm" in lib.dg_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dense", [True, False])
+def test_channel_chunks_equal_the_single_call(dense, dev, monkeypatch):
+    """The chunked evaluation against the SAME library's single call where both exist: C = 768 as one call and - with the module's
+    chunk limit lowered to 384 - as two chunks (dense 20 x 20 grid; 196 sampled positions).  Same loss means to 1e-5 relative, same
+    code gradients to 2e-3 relative L2 (the chunks round their operands separately).  Without zero_clamp: with it the two forms run
+    on kernels whose clamp masks differ in kind (384-channel chunks take k_corr2, whose fp16 cd decides the mask: 6.6e-3 against the
+    oracle where the 768-channel call, on exact masks at 196 positions, has 2.8e-4 - DESIGN.md section 6), which is not what this test
+    is about."""
+    from depthg_amd import ContrastiveCorrelationLoss, ops
+    from oracle import depthg_oracle as O
+    g = torch.Generator().manual_seed(77)
+    B, C, D, hw, N = 3, 768, 70, 20, 2
+    S = hw if dense else 14
+    f, fp = torch.randn(B, C, hw, hw, generator=g).to(dev), torch.randn(B, C, hw, hw, generator=g).to(dev)
+    c, cp = torch.randn(B, D, hw, hw, generator=g), torch.randn(B, D, hw, hw, generator=g)
+    d = torch.randint(0, 256, (B, 1, 80, 80), generator=g).float().to(dev)
+    perms = [O.super_perm(B, g).to(dev) for _ in range(N)]
+    cfg = O.default_cfg(feature_samples=S, neg_samples=N, dim=D, dg_outputs="reduced", dg_dense_grid=dense, zero_clamp=False)
+    if dense:
+        c1 = c2 = O.identity_coords(B, hw).to(dev)
+        kw = dict(shared_coords=True, identity_grid=True)
+    else:
+        c1, c2 = (torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1).to(dev), (torch.rand(B, S, S, 2, generator=g) * 2.2 - 1.1).to(dev)
+        kw = {}
+    res = []
+    for limit in (768, 384):
+        monkeypatch.setattr(ops, "BLOB_MAX_C", limit)
+        cg, cpg = c.to(dev).requires_grad_(True), cp.to(dev).requires_grad_(True)
+        out = ContrastiveCorrelationLoss(cfg).forward_with(f, fp, cg, cpg, d, c1, c2, perms, **kw)
+        O.total_loss(cfg, out).backward()
+        res.append(([float(o.detach().mean()) for o in out], cg.grad.clone(), cpg.grad.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-5 * abs(a) + 2e-8, (a, b)
+    for k in (1, 2):
+        rel = float((res[0][k] - res[1][k]).norm() / res[0][k].norm())
+        assert rel < 2e-3, (k, rel)
