@@ -809,3 +809,25 @@ def test_channel_chunks_equal_the_single_call(dense, dev, monkeypatch):
     for k in (1, 2):
         rel = float((res[0][k] - res[1][k]).norm() / res[0][k].norm())
         assert rel < 2e-3, (k, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dense,S,hw", [(True, 16, 16), (False, 14, 20)])
+def test_forward_draws_and_chunks_on_wide_maps(dense, S, hw, dev):
+    """ContrastiveCorrelationLoss.forward (its own coordinate and batch-map draws) on maps of 1024 channels: the chunked evaluation
+    behind the reference's call signature - the first chunk's draws are every chunk's."""
+    from depthg_amd import ContrastiveCorrelationLoss
+    from oracle import depthg_oracle as O
+    torch.manual_seed(3)
+    B, C, D = 3, 1024, 70
+    f, fp = torch.randn(B, C, hw, hw, device=dev), torch.randn(B, C, hw, hw, device=dev)
+    c, cp = torch.randn(B, D, hw, hw, device=dev, requires_grad=True), torch.randn(B, D, hw, hw, device=dev, requires_grad=True)
+    d = torch.randint(0, 256, (B, 1, 4 * hw, 4 * hw), device=dev).float()
+    cfg = O.default_cfg(feature_samples=S, neg_samples=3, dim=D, dg_outputs="reduced", dg_dense_grid=dense)
+    loss = ContrastiveCorrelationLoss(cfg)
+    out = loss(f, fp, None, None, c, cp, d, d)
+    loss.total.backward()
+    assert len(out) == 8 and all(bool(torch.isfinite(o).all()) for o in out)
+    assert float(out[7].mean()) == pytest.approx(1.0)          # (mean of dd on a depth map without zeros)
+    for g_ in (c.grad, cp.grad):
+        assert g_ is not None and bool(torch.isfinite(g_).all()) and float(g_.norm()) > 0.0
