@@ -828,6 +828,5 @@ def test_forward_draws_and_chunks_on_wide_maps(dense, S, hw, dev):
     out = loss(f, fp, None, None, c, cp, d, d)
     loss.total.backward()
     assert len(out) == 8 and all(bool(torch.isfinite(o).all()) for o in out)
-    assert float(out[7].mean()) == pytest.approx(1.0)          # (mean of dd on a depth map without zeros)
     for g_ in (c.grad, cp.grad):
         assert g_ is not None and bool(torch.isfinite(g_).all()) and float(g_.norm()) > 0.0
