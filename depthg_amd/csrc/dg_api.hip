@@ -1343,8 +1343,7 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     return h;
 }
 static size_t head_weights_bytes(int32_t C, int32_t D) {
-    const size_t DP = (size_t)(D + 31) / 32 * 32;
-    return ((size_t)2 * D * C + (size_t)C * C + (size_t)C * DP) * 2;
+    return DgHeadWeightLayout(C, D).elems * 2;
 }
 extern "C" size_t dg_head_weights_bytes(int32_t C, int32_t D) {
     if (head_check(1, C, D, 1) != DG_OK) return 0;
@@ -1373,7 +1372,7 @@ static int head_forward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32_
     DgHeadFwdArgs a;
     memset(&a, 0, sizeof(a));
     a.feat = feat; a.w1 = w1; a.b1 = b1; a.w2a = w2a; a.b2a = b2a; a.w2b = w2b; a.b2b = b2b;
-    a.w1_bf = static_cast<const __bf16*>(wscratch); a.w2a_bf = a.w1_bf + (size_t)D * C; a.w2b_bf = a.w2a_bf + (size_t)C * C;
+    { const DgHeadWeightLayout L(C, D); const __bf16* w = static_cast<const __bf16*>(wscratch); a.w1_bf = w + L.w1; a.w2a_bf = w + L.w2a; a.w2b_bf = w + L.w2b; }
     a.keep1 = keep1; a.keep2 = keep2; a.keep3 = keep3; a.scale = keep_scale;
     a.code = code; a.feats_out = feats_out; a.hidden = static_cast<__bf16*>(hidden);
     a.B = B; a.C = C; a.D = D; a.P = P;
@@ -1452,7 +1451,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
         return DG_OK;
     }
     __bf16* dh = reinterpret_cast<__bf16*>(ws + h.dh);
-    const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + (size_t)2 * D * C + (size_t)C * C;
+    const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + DgHeadWeightLayout(C, D).w2bT;
     DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P, Bs, d_g};
     d.gcode_bf = h.one_pass ? reinterpret_cast<__bf16*>(ws + h.gbf) : nullptr;
     // d W2b = d code x hidden^T needs nothing of k_head_dh: it runs BESIDE it on the library's second stream where there is one (fork

@@ -846,6 +846,21 @@ hipError_t dg_launch_sampled_sumsq(const float* feats, const float* coords, cons
 hipError_t dg_launch_normalize_split(const float* src, int B, int C, int P, int nchunks, int chunk_c, float* const* dst, hipStream_t s);
 hipError_t dg_launch_head_fwd(const DgHeadFwdArgs& a, hipStream_t s);
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s);
+// The bf16 copies of the head's weights (k_head_prep -> k_head_fwd / k_head_dh*).  The three matrices the forward multiplies with are
+// stored FRAGMENT-MAJOR: [16-row block][k-step of 32][lane = 16 (k / 8 % 4) + row % 16][8 bf16] - the 1 KiB a wave reads for one A
+// fragment is contiguous (whole cache lines), where row-major copies gave every lane 16 bytes of 16 different rows: 64-byte pieces,
+// the rate of which set the forward's k-loop (round 6).  Rows are padded to whole blocks (cluster1 / cluster2's output convolution:
+// eight blocks = 128 rows, the most the forward's waves walk), channels to the forward's padded width CP; the padding is zeros.
+__host__ __device__ inline int dg_head_cp(int C) { return C <= 64 ? 64 : (C <= 128 ? 128 : (C <= 192 ? 192 : (C <= 384 ? 384 : 768))); }
+struct DgHeadWeightLayout {
+    int CP, KS; size_t w1, w2a, w2b, w2bT, elems;          // offsets / total in bf16 elements
+    __host__ __device__ DgHeadWeightLayout(int C, int D) {
+        CP = dg_head_cp(C); KS = CP / 32;
+        const size_t blk = (size_t)KS * 512;                // elements of one 16-row block
+        w1 = 0; w2a = 8 * blk; w2b = w2a + (size_t)(CP / 16) * blk; w2bT = w2b + 8 * blk;
+        elems = w2bT + (size_t)C * ((D + 31) / 32 * 32);
+    }
+};
 hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s);
 int dg_head_dh_fused_blocks(int B, int C, int D, int P);      // > 0: k_head_dh2 runs this shape with that many blocks and can form d W2b on the way
 hipError_t dg_launch_head_wgrad(const DgHeadWgradArgs& a, bool a_bf16, bool b_bf16, hipStream_t s);

@@ -64,25 +64,43 @@ __device__ __forceinline__ bf16x8 wfrag(u32x4 v, const u32x4 keep, const int lan
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// fp32 parameters -> bf16 copies for the MFMA kernels: w1 (D,C), w2a (C,C), w2b (D,C) as they are, and w2b transposed (C, DP) with
-// DP = D rounded up to 32 (zero padded) for the backward's d hidden product
+// fp32 parameters -> bf16 copies for the MFMA kernels (DgHeadWeightLayout, dg_common.h): w1 (D,C), w2a (C,C), w2b (D,C) fragment-major
+// for the forward, and w2b transposed (C, DP) row-major with DP = D rounded up to 32 (zero padded) for the backward's d hidden product
 __global__ __launch_bounds__(256) void k_head_prep(const float* __restrict__ w1, const float* __restrict__ w2a, const float* __restrict__ w2b,
-                                                   __bf16* __restrict__ o1, __bf16* __restrict__ o2a, __bf16* __restrict__ o2b,
-                                                   __bf16* __restrict__ o2bT, int C, int D, int DP) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < D * C) { o1[i] = (__bf16)w1[i]; if (w2b) o2b[i] = (__bf16)w2b[i]; }
-    if (w2a && i < C * C) o2a[i] = (__bf16)w2a[i];
-    if (w2b && i < C * DP) { const int m = i / DP, d = i - m * DP; o2bT[i] = d < D ? (__bf16)w2b[(size_t)d * C + m] : (__bf16)0.f; }
+                                                   __bf16* __restrict__ scratch, int C, int D, int DP) {
+    const DgHeadWeightLayout L(C, D);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // tile-major index -> (row, k): [block rb][k-step ks][lane][e], lane = 16 g + r: row = 16 rb + r, k = 32 ks + 8 g + e
+    auto rk = [&](size_t t, int& row, int& k) {
+        const int e = (int)(t & 7), lane = (int)((t >> 3) & 63);
+        const size_t tile = t >> 9;
+        const int ks = (int)(tile % L.KS), rb = (int)(tile / L.KS);
+        row = 16 * rb + (lane & 15); k = 32 * ks + 8 * (lane >> 4) + e;
+    };
+    if (i < L.w2a) {                                        // w1: eight row blocks
+        int row, k; rk(i, row, k);
+        scratch[L.w1 + i] = (row < D && k < C) ? (__bf16)w1[(size_t)row * C + k] : (__bf16)0.f;
+        if (w2b) scratch[L.w2b + i] = (row < D && k < C) ? (__bf16)w2b[(size_t)row * C + k] : (__bf16)0.f;
+    }
+    if (w2a && i < L.w2b - L.w2a) {
+        int row, k; rk(i, row, k);
+        scratch[L.w2a + i] = (row < C && k < C) ? (__bf16)w2a[(size_t)row * C + k] : (__bf16)0.f;
+    }
+    if (w2b && i < (size_t)C * DP) { const int m = (int)(i / DP), d = (int)(i - (size_t)m * DP); scratch[L.w2bT + i] = d < D ? (__bf16)w2b[(size_t)d * C + m] : (__bf16)0.f; }
 }
 hipError_t dg_launch_head_prep(const float* w1, const float* w2a, const float* w2b, void* scratch, int C, int D, hipStream_t s) {
     const int DP = (D + 31) / 32 * 32;
-    __bf16* o1 = static_cast<__bf16*>(scratch);
-    __bf16* o2a = o1 + (size_t)D * C;
-    __bf16* o2b = o2a + (size_t)C * C;
-    __bf16* o2bT = o2b + (size_t)D * C;
-    const int n = C * (C > DP ? C : DP);
-    hipLaunchKernelGGL(k_head_prep, dim3((n + 255) / 256), dim3(256), 0, s, w1, w2a, w2b, o1, o2a, o2b, o2bT, C, D, DP);
+    const DgHeadWeightLayout L(C, D);
+    size_t n = L.w2a;                                       // (w1 / w2b tiles)
+    if (w2a && L.w2b - L.w2a > n) n = L.w2b - L.w2a;
+    if (w2b && (size_t)C * DP > n) n = (size_t)C * DP;
+    hipLaunchKernelGGL(k_head_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w1, w2a, w2b, static_cast<__bf16*>(scratch), C, D, DP);
     return hipGetLastError();
+}
+// A fragment of row block rb, k-step ks from a fragment-major copy: one 16-byte load per lane, 1 KiB contiguous per wave.  NO select on
+// the loaded value (see wraw above); the padding is zeros in memory
+__device__ __forceinline__ u32x4 wtile(const __bf16* __restrict__ Wt, const int KS, const int rb, const int ks, const int lane) {
+    return *reinterpret_cast<const u32x4*>(Wt + (((size_t)rb * KS + ks) * 64 + lane) * 8);
 }
 
 // MB = 16-row blocks of hidden channels per wave, NW = waves per block (Cpad = 16 MB NW), NT = positions per block
@@ -207,10 +225,10 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
         auto fetch = [&](const int ks, const int q) {
             if (nonlinear) {
 #pragma unroll
-                for (int i = 0; i < MB; ++i) wn[q][i] = wraw(a.w2a_bf, C, mbase + 16 * i + c16, C, 32 * ks, C, lane);
+                for (int i = 0; i < MB; ++i) wn[q][i] = wtile(a.w2a_bf, KS, wid * MB + i, ks, lane);
             }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) vn[q][i] = wraw(a.w1_bf, C, 16 * (wid + NW * i) + c16, D, 32 * ks, C, lane);
+            for (int i = 0; i < NA; ++i) vn[q][i] = wtile(a.w1_bf, KS, wid + NW * i, ks, lane);
         };
         fetch(0, 0);
         fetch(1, 1);
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int i = 0; i < NA; ++i) wn[h2][i] = wraw(a.w2b_bf, C, 16 * (wid + NW * i) + c16, D, 32 * (ks + h2), C, lane);
+                for (int i = 0; i < NA; ++i) wn[h2][i] = wtile(a.w2b_bf, KS, wid + NW * i, ks + h2, lane);
         };
         fetch2(0);
         for (int ks = 0; ks < KS; ks += 2) {
