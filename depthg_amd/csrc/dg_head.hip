@@ -106,6 +106,9 @@ __device__ __forceinline__ u32x4 wtile(const __bf16* __restrict__ Wt, const int 
 // MB = 16-row blocks of hidden channels per wave, NW = waves per block (Cpad = 16 MB NW), NT = positions per block
 // (head_frow(NT): an odd number of 32-byte pieces per row, what tr_frag's bank pattern needs)
 __host__ __device__ constexpr int head_frow(int NT) { return ((NT * 2 / 32) & 1) ? NT * 2 : NT * 2 + 32; }
+#ifndef HEAD_FWD_PD
+#define HEAD_FWD_PD 3
+#endif
 template <int MB, int NT, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
     constexpr int NTH = 64 * NW, CP = 16 * MB * NW, NB = NT / 16, FROW = head_frow(NT), DBMAX = 8, KS = CP / 32;
@@ -213,15 +216,17 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { acc2a[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2b[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < NB; ++j) acc2a[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        // weight fragments two k-steps ahead: one step of 28 MFMAs (0.2 us) does not cover an L2 round trip
-        static_assert(KS % 2 == 0, "two k-steps per iteration");
-        u32x4 wn[2][MB], vn[2][NA];
+        // weight fragments PD k-steps ahead: one step of 28 MFMAs (0.2 us) does not cover an L2 round trip (~1 us) - three ahead where the
+        // k-steps divide by three (the 384-channel forms: 96 KB of fragments in flight per CU instead of 64), two elsewhere
+        constexpr int PD = HEAD_FWD_PD > 2 && KS % 3 == 0 ? 3 : 2;
+        static_assert(KS % PD == 0, "PD k-steps per iteration");
+        u32x4 wn[PD][MB], vn[PD][NA];
         auto fetch = [&](const int ks, const int q) {
             if (nonlinear) {
 #pragma unroll
@@ -230,18 +235,18 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) vn[q][i] = wtile(a.w1_bf, KS, wid + NW * i, ks, lane);
         };
-        fetch(0, 0);
-        fetch(1, 1);
-        for (int ks0 = 0; ks0 < KS; ks0 += 2) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < PD; ++q) fetch(q, q);
+        for (int ks0 = 0; ks0 < KS; ks0 += PD) {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
                 const int ks = ks0 + q;
                 u32x4 wc[MB], vc[NA];
 #pragma unroll
                 for (int i = 0; i < MB; ++i) wc[i] = wn[q][i];
 #pragma unroll
                 for (int i = 0; i < NA; ++i) vc[i] = vn[q][i];
-                if (ks + 2 < KS) fetch(ks + 2, q);
+                if (ks + PD < KS) fetch(ks + PD, q);
                 const u32x4 keep2 = *reinterpret_cast<const u32x4*>(km2 + 32 * ks + 8 * g);
                 const u32x4 keep1 = *reinterpret_cast<const u32x4*>(km1 + 32 * ks + 8 * g);
                 bf16x8 bfr[NB];
@@ -266,8 +271,24 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
         }
     }
     HSTAMP(2)
+    // the output convolution's weight fragments, all k-steps, where they fit (the hidden accumulators die in the next phase): requested
+    // here, they arrive under the bias / ReLU / hidden-image phases
+    constexpr bool W2B_ALL = NA * KS <= 12;
+    u32x4 w2all[W2B_ALL ? KS : 1][NA];
+    if constexpr (W2B_ALL) {
+        if (nonlinear) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) w2all[ks][i] = wtile(a.w2b_bf, KS, wid + NW * i, ks, lane);
+        }
+    }
     __syncthreads();                                       // every wave is done reading the f tile
     HSTAMP(3)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc2b[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};     // (first touched here: not live during the k-loop above)
     if (nonlinear) {
         // bias + ReLU in the accumulators; hidden tile -> the channel-major image the f tile occupied (the next product reads it
         // with the same transposing fragment reads; it is also what goes to HBM)
@@ -290,8 +311,24 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
         __syncthreads();
         HSTAMP(4)
         // ---- cluster2's output convolution: W2b hidden
-        static_assert(KS % 2 == 0, "two k-steps per iteration");
         const u32x4 ones = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if constexpr (W2B_ALL) {
+            // (every k-step's fragment was requested behind the first k-loop, w2all: this loop is MFMAs and LDS reads only - one
+            //  fragment per wave and k-step two steps ahead was a chain of L2 round trips, 7 k cycles for 84 MFMAs)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 bfr[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bfr[j] = tr_frag(Ft, FROW, 32 * ks, 16 * j, lane);
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const bf16x8 af = wfrag(w2all[ks][i], ones, lane);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc2b[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2b[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+        static_assert(KS % 2 == 0, "two k-steps per iteration");
         u32x4 wn[2][NA];
         auto fetch2 = [&](const int ks) {
 #pragma unroll
@@ -319,6 +356,7 @@ __global__ __launch_bounds__(64 * NW) void k_head_fwd(const DgHeadFwdArgs a) {
                     for (int j = 0; j < NB; ++j) acc2b[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc2b[i][j], 0, 0, 0);
                 }
             }
+        }
         }
     }
     HSTAMP(5)
