@@ -1330,7 +1330,7 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     h.dh_blocks = dg_head_dh_fused_blocks(B, C, D, P);
     if (h.dh_blocks > 0) h.s2b = h.dh_blocks;
     h.tiles = (P + 63) / 64;
-    h.dh = take((size_t)B * C * P * 2);
+    h.dh = take((size_t)B * C * ((P + 31) / 32 * 32) * 2);      // (+ the padding of the last step: the step-major form of k_head_dh2 / k_head_wgrad3)
     h.p2a = take((size_t)h.s2a * C * C * 4);
     h.p1 = take((size_t)(h.s1 > h.s2a ? h.s1 : h.s2a) * D * C * 4);
     h.p2b = take((size_t)h.s2b * D * C * 4);
@@ -1338,7 +1338,7 @@ static HeadPlan head_plan(int32_t B, int32_t C, int32_t D, int32_t P) {
     h.pb2a = take((size_t)B * h.tiles * C * 4);
     // k_head_wgrad3 (d W2a and d W1 in one pass over the features) reads d code as the bf16 copy k_head_dh leaves
     h.one_pass = dg_head_wgrad_one_pass(C, C, D, P) && (h.s2a & 7) == 0;
-    h.gbf = h.one_pass ? take((size_t)B * D * P * 2) : 0;
+    h.gbf = h.one_pass ? take((size_t)B * D * ((P + 31) / 32 * 32) * 2) : 0;
     h.total = off;
     return h;
 }
@@ -1454,6 +1454,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     const __bf16* w2bT = static_cast<const __bf16*>(wscratch) + DgHeadWeightLayout(C, D).w2bT;
     DgHeadDhArgs d{grad_code, w2bT, static_cast<const __bf16*>(hidden), dh, F32(h.pbd), F32(h.pb2a), B, C, D, P, Bs, d_g};
     d.gcode_bf = h.one_pass ? reinterpret_cast<__bf16*>(ws + h.gbf) : nullptr;
+    d.step_major = (h.one_pass && h.dh_blocks > 0) ? 1 : 0;          // (both ends are this round's kernels: k_head_dh2 writes what k_head_wgrad3 reads)
     // d W2b = d code x hidden^T needs nothing of k_head_dh: it runs BESIDE it on the library's second stream where there is one (fork
     // / join by events, capturable): two launches that each leave most of the chip idle (27 and 37 us at the paired headline shape)
     DgHeadWgradArgs wb{grad_code, hidden, nullptr, F32(h.p2b), B, D, C, P, h.s2b};
@@ -1477,6 +1478,7 @@ static int head_backward_impl(int32_t B, int32_t Bs, int32_t C, int32_t D, int32
     DgHeadWgradArgs wa{dh, feat, keep2, F32(h.p2a), B, C, C, P, h.s2a, grad_code, keep1, F32(h.p1), D};
     wa.Bs = Bs; wa.dA = 0; wa.dB = d_feat; wa.dA2 = d_g;
     wa.A2h = d.gcode_bf;
+    wa.a_step_major = d.step_major;
     DG_HIP(dg_launch_head_wgrad(wa, true, false, s));
     reduce(F32(h.p2a), grad_w2a, nullptr, C * C, h.s2a, keep2 ? keep_scale : 1.f);
     reduce(F32(h.p1), grad_w1, nullptr, D * C, h.s2a, keep1 ? keep_scale : 1.f);

@@ -826,6 +826,8 @@ struct DgHeadDhArgs {
     int32_t B, C, D, P;
     int32_t Bs; long long d_gcode;   // (pair: images Bs.. of gcode in a second tensor, as DgHeadFwdArgs)
     __bf16* gcode_bf;                // (B,D,P) out or null: d code rounded to bf16, the A2h operand of k_head_wgrad3 (P a multiple of 4)
+    int32_t step_major;              // 1 (k_head_dh2 in front of k_head_wgrad3): dh and gcode_bf as [image][step of 32 positions][row][32] - the rows of a step
+                                     //    contiguous, what k_head_wgrad3's DMA pieces read (row-major gave them 64-byte pieces of 16 rows: 54 against 45 us)
     float* part_w2b;                 // [blocks][D][C] or null: k_head_dh2 also forms d W2b = d code x hidden^T (both tiles are in its LDS), one partial sum per block
     unsigned long long* stamps;      // developer timing stamps (null in production)
     int32_t staged;                  // (set by the launcher) 1: hidden / d hidden through an LDS image of whole rows (P a multiple of 8)
@@ -839,6 +841,7 @@ struct DgHeadWgradArgs {
     // optional second product with the same Bm in the same launch (M2 > 0): A2 (B, M2, P) fp32, its keep mask and partial sums
     const void* A2; const float* keep_2; float* part2; int32_t M2;
     const void* A2h;                   // (B, M2, P) bf16 copy of A2 in ONE tensor (k_head_dh) or null; with it the two products run as k_head_wgrad3
+    int32_t a_step_major;              // k_head_wgrad3: A and A2h are [image][step of 32 positions][row][32] (k_head_dh2 wrote them so)
     int32_t Bs; long long dA, dB, dA2;   // (pair: images Bs.. of A / Bm / A2 in second tensors, offsets in their elements; 0: one tensor)
 };
 

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char dh2_sm[];    // [2][hidden tile 384 x 128 B] [2][d code tile 96 x 160 B]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, c16 = lane & 15;
     const int C = a.C, D = a.D, P = a.P, DP = (D + 31) / 32 * 32;
-    const int tiles_img = (P + NT - 1) / NT, ntiles = a.B * tiles_img;
+    const int tiles_img = (P + NT - 1) / NT, ntiles = a.B * tiles_img, steps_img = (P + 31) / 32;
     const uint32_t ht0 = lds_addr(dh2_sm);
     // the weight fragments of every k-step: B[d][channel m] = W2bT[m][d], wave `wid` owns channels [48 wid, 48 wid + 48)
     const int nbase = wid * 16 * MB;
@@ -715,7 +715,10 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float x = ok ? v[u][e] : 0.f; rs += x; o[e] = (__bf16)x; }
                 *reinterpret_cast<bf16x4*>(Dt + d * FROW + q4 * 8) = o;
-                if (a.gcode_bf && ok) *reinterpret_cast<bf16x4*>(a.gcode_bf + ((size_t)b * D + d) * P + p) = o;
+                if (a.gcode_bf && ok) {
+                    if (a.step_major) *reinterpret_cast<bf16x4*>(a.gcode_bf + (((size_t)b * steps_img + (p >> 5)) * D + d) * 32 + (p & 31)) = o;
+                    else *reinterpret_cast<bf16x4*>(a.gcode_bf + ((size_t)b * D + d) * P + p) = o;
+                }
 #pragma unroll
                 for (int sh = 8; sh > 0; sh >>= 1) rs += __shfl_xor(rs, sh, 64);
                 if ((tid & 15) == 0 && d < D) a.part_bd[(size_t)t * D + d] = rs;
@@ -795,7 +798,12 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int idx = tid + 512 * u, m = idx >> 3, pc = idx & 7, p = p0 + 8 * pc;
-            if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = *reinterpret_cast<const u32x4*>(Ht + m * HROW + ((pc ^ (m & 7)) << 4));
+            const u32x4 val = *reinterpret_cast<const u32x4*>(Ht + m * HROW + ((pc ^ (m & 7)) << 4));
+            if (a.step_major) {
+                // [image][step][row][32 positions]: the tile is steps 2 tile, 2 tile + 1; positions beyond the image hold zeros (masked above)
+                const int stp = (p0 >> 5) + (pc >> 2);
+                if (m < C && stp < steps_img) *reinterpret_cast<u32x4*>(a.dh + (((size_t)b * steps_img + stp) * C + m) * 32 + 8 * (pc & 3)) = val;
+            } else if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = val;
         }
     }
     if constexpr (W2B) {
@@ -1132,9 +1140,10 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
     //      fp32 rows: row = 8 piece + lane / 8, swizzle (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7, piece & 1 = wid & 1
     const int pos_f = 4 * ((lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7));
     uint32_t ro_dh[3], ro_g, ro_f[2];
+    const int arow = a.a_step_major ? 64 : a.P * 2;                    // bytes between two rows of A inside a step
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int row = 16 * (wid + 8 * u) + (lane >> 2); ro_dh[u] = (uint32_t)(row < a.M ? row : a.M - 1) * a.P * 2; }
-    { const int row = 16 * wid + (lane >> 2); ro_g = (uint32_t)(row < a.M2 ? row : a.M2 - 1) * a.P * 2; }
+    for (int u = 0; u < 3; ++u) { const int row = 16 * (wid + 8 * u) + (lane >> 2); ro_dh[u] = (uint32_t)(row < a.M ? row : a.M - 1) * arow; }
+    { const int row = 16 * wid + (lane >> 2); ro_g = (uint32_t)(row < a.M2 ? row : a.M2 - 1) * arow; }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { const int row = n0 + 8 * (wid + 8 * u) + (lane >> 3); ro_f[u] = (uint32_t)(row < a.N ? row : a.N - 1) * a.P * 4; }
     const bool has_g = wid < g16;
@@ -1149,10 +1158,14 @@ __global__ __launch_bounds__(512) void k_head_wgrad3(const DgHeadWgradArgs a) {
         const int v = a.P - p0;                                        // valid positions from p0 on (>= 8)
         const uint32_t dst = lds0 + st * W3_STAGE + wid * 1024;
         const uint32_t pa = (pos_a + 8 <= v ? pos_a : 0) * 2, pf = (pos_f + 4 <= v ? pos_f : 0) * 4;
-        const __bf16* Ab = static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0;
+        // (step-major A: [image][step][row][32 positions] - a piece = 16 rows x 64 bytes = one contiguous KiB)
+        const size_t sidx = (size_t)b * steps_img + (p0 >> 5);
+        const __bf16* Ab = a.a_step_major ? static_cast<const __bf16*>(a.A) + sidx * a.M * 32
+                                          : static_cast<const __bf16*>(a.A) + dg_img_off(b, (long long)a.M * a.P, a.Bs, a.dA) + p0;
 #pragma unroll
         for (int u = 0; u < 3; ++u) dma16_s(Ab, ro_dh[u] + pa, dst + u * 8192);
-        if (has_g) dma16_s(static_cast<const __bf16*>(a.A2h) + (size_t)b * a.M2 * a.P + p0, ro_g + pa, dst + 24 * 1024);
+        if (has_g) dma16_s(a.a_step_major ? static_cast<const __bf16*>(a.A2h) + sidx * a.M2 * 32 : static_cast<const __bf16*>(a.A2h) + (size_t)b * a.M2 * a.P + p0,
+                           ro_g + pa, dst + 24 * 1024);
         const float* Bb = static_cast<const float*>(a.Bm) + dg_img_off(b, (long long)a.N * a.P, a.Bs, a.dB) + p0;
 #pragma unroll
         for (int u = 0; u < 2; ++u) dma16_s(Bb, ro_f[u] + pf, dst + W3_A_BYTES + u * 8192);
