@@ -92,8 +92,8 @@ if os.path.exists(os.path.join(src, f"{tag}_parity.md")):
 others = sorted(glob.glob(os.path.join(dst, f"{tag}_bench_box_*.json")))
 if others:
     o += ["\n## The same headline command on other boxes of the pool\n",
-          "(earlier runs of this round; the loss path's code is the same in all of them - the head's kernels, the random-draw launch and two "
-          "load-ordering changes came in between)\n",
+          "(earlier runs of this round; between them and this run: the head's kernels, the random-draw launch, two load-ordering changes and - "
+          "from the 1.98-GHz run to this one - the G stores of k_corr2 in the scalar-base form)\n",
           "| file | ms per step | kernel µs | fraction of MFMA peak | held GHz | fraction at the held clock | M cycles per launch |\n|---|---|---|---|---|---|---|"]
     for f in others + [None]:
         ob = b if f is None else json.loads(last_json(f))
