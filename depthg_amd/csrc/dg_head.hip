@@ -699,9 +699,16 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
         if (o * 16 >= DP * FROW) *reinterpret_cast<u32x4*>(dh2_sm + 2 * DH2_HT + bufi * DH2_DT + o * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     int t = blockIdx.x, buf = 0;
+#ifdef DG_DEVTOOLS
+    int tix = 0;
+#define D2STAMP(k) if (a.stamps && tid == 0 && blockIdx.x == 3 && tix < 2) a.stamps[8 * tix + k] = __builtin_amdgcn_s_memtime();
+#else
+#define D2STAMP(k)
+#endif
     if (t < ntiles) fetch(t, 0);
     for (; t < ntiles; t += gridDim.x, buf ^= 1) {
         const int b = t / tiles_img, p0 = (t - b * tiles_img) * NT;
+        D2STAMP(0)
         char* const Ht = dh2_sm + buf * DH2_HT;
         char* const Dt = dh2_sm + 2 * DH2_HT + buf * DH2_DT;
         // d code tile -> LDS (bf16), its row sums = the tile's share of d b1 (= d b2b), the bf16 copy for k_head_wgrad3
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the DMA pieces of this tile: hipcc does not count them)
         __syncthreads();                                               // tile t in LDS; every wave is done with the other images (tile t - 1)
+        D2STAMP(1)
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x, buf ^ 1);
         f32x4 acc[4][MB];
 #pragma unroll
@@ -744,6 +752,7 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
                     for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wfrag(wpre[ks][j], ones, lane), acc[i][j], 0, 0, 0);
             }
         }
+        D2STAMP(2)
         if constexpr (W2B) {
             // A[d][k = position] rows of the d code image, B[k][m] = hidden[m][k] rows of the hidden image (before the mask pass below
             // overwrites them): 16-byte reads, natural k order on both sides.  Positions beyond the image: the d code image holds zeros
@@ -763,6 +772,7 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
                 }
             }
         }
+        D2STAMP(3)
         // mask and result in place in the LDS image (the lane that reads a cell is the one that overwrites it); row sums of the result
         float bs[MB];
 #pragma unroll
@@ -794,6 +804,7 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
             if (g == 0 && m < C) a.part_b2a[(size_t)t * C + m] = bs[j];
         }
         __syncthreads();
+        D2STAMP(4)
         // whole rows out: 384 rows x 8 pieces of 16 bytes = six per thread
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -805,6 +816,10 @@ __global__ __launch_bounds__(512) void k_head_dh2(const DgHeadDhArgs a) {
                 if (m < C && stp < steps_img) *reinterpret_cast<u32x4*>(a.dh + (((size_t)b * steps_img + stp) * C + m) * 32 + 8 * (pc & 3)) = val;
             } else if (m < C && p + 7 < P) *reinterpret_cast<u32x4*>(a.dh + ((size_t)b * C + m) * P + p) = val;
         }
+        D2STAMP(5)
+#ifdef DG_DEVTOOLS
+        ++tix;
+#endif
     }
     if constexpr (W2B) {
         float* out = a.part_w2b + (size_t)blockIdx.x * D * C;
@@ -838,6 +853,20 @@ hipError_t dg_launch_head_dh(const DgHeadDhArgs& a, hipStream_t s) {
         auto kern = !a.part_w2b ? k_head_dh2<0> : (a.D <= 80 ? k_head_dh2<5> : k_head_dh2<6>);
         hipError_t e = dg_set_max_smem(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) return e;
+#ifdef DG_DEVTOOLS
+        if (const char* sf = getenv("DG_DH_STAMPS")) {
+            static unsigned long long* sb2 = nullptr;
+            if (!sb2 && hipMalloc(&sb2, 128) != hipSuccess) return hipErrorOutOfMemory;
+            a2.stamps = sb2;
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, s, a2);
+            unsigned long long hs[16];
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(hs, sb2, 128, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* fp = fopen(sf, "w")) { for (int q = 0; q < 2; ++q) for (int i = 1; i < 6; ++i)
+                    fprintf(fp, "k_head_dh2 block 3 tile %d phase %d: %llu cycles\n", q, i, hs[8 * q + i] - hs[8 * q + i - 1]);
+                    fprintf(fp, "tile 0 start -> tile 1 start: %llu cycles\n", hs[8] - hs[0]); fclose(fp); }
+            return hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), smem, s, a2);
         return hipGetLastError();
     }
