@@ -60,6 +60,13 @@ CONFIGS = {
                          pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
                what="config 5: 56x56 maps (ViT-S/8 at 448 input), B=32/GPU, C=384, D=70, dense grid (P=3136), positives = a "
                     "different random tensor (kNN positive), 5 negatives, depth term on; fwd + bwd", cpu_B=1),
+    # not a BASELINE.json configuration: the headline's dense 28x28 grid at the ViT-B width (VERDICT r05 item 6 asks for the line) -
+    # 768-channel vectors do not fit k_corr2's accumulation registers, the step runs on the round-1 kernel k_corr_main
+    "denseB": dict(H=dict(B=32, C=768, D=70, h=28, w=28, S=28, n_neg=5, depth_hw=224), sampling="none", dense=True, pointwise=True,
+                   scal=dict(pos_intra_shift=0.07, pos_inter_shift=0.025, neg_inter_shift=0.761, depth_feat_shift=0.03,
+                             pos_intra_weight=0.58, pos_inter_weight=0.36, neg_inter_weight=0.7, depth_feat_weight=0.19),
+                   what="dense 28x28 grid at the ViT-B width: B=32/GPU, C=768, D=70, P=784, 5 negatives, depth term on, pointwise, "
+                        "zero_clamp; fwd + bwd (not a BASELINE configuration)", cpu_B=8),
 }
 HEAD_GRAD_ELEMS = 201_740          # cluster1 (26,950) + cluster2 (174,790) parameters, reference src/modules.py:75-88
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16/f16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
